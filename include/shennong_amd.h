@@ -1,0 +1,247 @@
+/*
+ * shennong_amd.h — C ABI of libshennong_hip.so, the MI355X (gfx950) speech-features backend.
+ *
+ * This is the drop-in boundary for the hot path of bootphon/shennong: the seam where the
+ * reference's Python processors hand one utterance to pykaldi/Kaldi
+ *   - MelFeaturesProcessor._process:  cls(options).compute(SubVector(int16 wave), vtln_warp)
+ *         (reference shennong/processor/base.py:408-436; filterbank.py:84; mfcc.py:86)
+ *   - SpectrogramProcessor.process:   Spectrogram(options).compute(wave, 1.0)
+ *         (reference shennong/processor/spectrogram.py:134-140)
+ *   - PlpProcessor._compute:          per-frame Python loop over pykaldi primitives
+ *         (reference shennong/processor/plp.py:510-626)
+ *   - KaldiPitchProcessor.process:    compute_kaldi_pitch(options, wave)
+ *         (reference shennong/processor/pitch_kaldi.py:296-299)
+ *   - KaldiPitchPostProcessor.process: process_pitch(options, matrix)
+ *         (reference shennong/processor/pitch_kaldi.py:535-537)
+ *   - DeltaPostProcessor.process:     compute_deltas(options, matrix)
+ *         (reference shennong/postprocessor/delta.py:129-131)
+ *   - EnergyProcessor.process:        per-frame extract_window + sum of squares
+ *         (reference shennong/processor/energy.py:148-186)
+ *   - Frames.nframes / window():      num_frames / FeatureWindowFunction
+ *         (reference shennong/frames.py:137; shennong/window.py:107-114)
+ *
+ * The ABI is batch-first: one call covers N utterances given as one concatenated int16 buffer
+ * plus an offsets table (the reference's process_all / joblib loop, base.py:56-107, becomes a
+ * single launch).  Plain pointers and sizes only; no torch/numpy types.
+ *
+ * Threading: a plan is immutable after creation; run calls on the same plan serialise on an
+ * internal mutex, calls on different plans may run concurrently.  The library never keeps a
+ * caller pointer after a call returns.  Errors: every entry point returns 0 on success and a
+ * negative SNF_E_* code otherwise; snf_last_error() returns a thread-local message.
+ *
+ * Option-struct field meanings and defaults are exactly Kaldi's FrameExtractionOptions /
+ * MelBanksOptions / FbankOptions / MfccOptions / PlpOptions / SpectrogramOptions /
+ * PitchExtractionOptions / ProcessPitchOptions / DeltaFeaturesOptions, which the reference
+ * wraps one-to-one (reference shennong/processor/base.py:122-374, filterbank.py:48-55,
+ * mfcc.py:48-56, plp.py:265-273, pitch_kaldi.py:86-91,321-327, delta.py:54).
+ */
+#ifndef SHENNONG_AMD_H_
+#define SHENNONG_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes ------------------------------------------------------------------------- */
+#define SNF_OK 0
+#define SNF_E_INVALID (-1)  /* bad argument (Python raises ValueError before reaching here)   */
+#define SNF_E_RUNTIME (-2)  /* Kaldi-class option error (KALDI_ERR) -> Python RuntimeError     */
+#define SNF_E_HIP (-3)      /* HIP runtime failure                                             */
+#define SNF_E_NODEVICE (-4) /* no usable gfx950 device                                         */
+
+/* ---- plan kinds --------------------------------------------------------------------------- */
+#define SNF_KIND_SPECTROGRAM 0
+#define SNF_KIND_FBANK 1
+#define SNF_KIND_MFCC 2
+#define SNF_KIND_PLP 3
+#define SNF_KIND_PITCH 4
+#define SNF_KIND_PITCH_POST 5
+#define SNF_KIND_DELTA 6
+#define SNF_KIND_ENERGY 7
+
+/* ---- window types (reference shennong/processor/base.py:215-221) --------------------------- */
+#define SNF_WINDOW_HAMMING 0
+#define SNF_WINDOW_HANNING 1
+#define SNF_WINDOW_POVEY 2
+#define SNF_WINDOW_RECTANGULAR 3
+#define SNF_WINDOW_BLACKMAN 4
+
+/* energy compression of EnergyProcessor (reference shennong/processor/energy.py:81-84) */
+#define SNF_COMPRESS_OFF 0
+#define SNF_COMPRESS_LOG 1
+#define SNF_COMPRESS_SQRT 2
+
+/* Kaldi FrameExtractionOptions (reference shennong/processor/base.py:122-262). */
+typedef struct snf_frame_options {
+  float samp_freq;               /* 16000 */
+  float frame_shift_ms;          /* 10    */
+  float frame_length_ms;         /* 25    */
+  float dither;                  /* 1.0 (0 = off; != 0 uses a counter-based GPU RNG)           */
+  float preemph_coeff;           /* 0.97  */
+  int32_t remove_dc_offset;      /* 1     */
+  int32_t window_type;           /* SNF_WINDOW_POVEY */
+  int32_t round_to_power_of_two; /* 1     */
+  float blackman_coeff;          /* 0.42  */
+  int32_t snip_edges;            /* 1     */
+} snf_frame_options;
+
+/* Kaldi MelBanksOptions (reference shennong/processor/base.py:288-374). */
+typedef struct snf_mel_options {
+  int32_t num_bins; /* 23 */
+  float low_freq;   /* 20 */
+  float high_freq;  /* 0 => Nyquist, <0 => offset from Nyquist */
+  float vtln_low;   /* 100 */
+  float vtln_high;  /* -500 */
+} snf_mel_options;
+
+/* Kaldi PitchExtractionOptions (reference shennong/processor/pitch_kaldi.py:86-91). */
+typedef struct snf_pitch_options {
+  float samp_freq;               /* 16000 */
+  float frame_shift_ms;          /* 10 */
+  float frame_length_ms;         /* 25 */
+  float preemph_coeff;           /* 0 */
+  float min_f0;                  /* 50 */
+  float max_f0;                  /* 400 */
+  float soft_min_f0;             /* 10 */
+  float penalty_factor;          /* 0.1 */
+  float lowpass_cutoff;          /* 1000 */
+  float resample_freq;           /* 4000 */
+  float delta_pitch;             /* 0.005 */
+  float nccf_ballast;            /* 7000 */
+  int32_t lowpass_filter_width;  /* 1 */
+  int32_t upsample_filter_width; /* 5 */
+  int32_t recompute_frame;       /* 500 (not exposed by the reference; Kaldi default)           */
+  int32_t snip_edges;            /* 1   (not exposed by the reference; Kaldi default)           */
+} snf_pitch_options;
+
+/* Kaldi ProcessPitchOptions (reference shennong/processor/pitch_kaldi.py:321-327). */
+typedef struct snf_pitch_post_options {
+  float pitch_scale;                   /* 2.0 */
+  float pov_scale;                     /* 2.0 */
+  float pov_offset;                    /* 0.0 */
+  float delta_pitch_scale;             /* 10.0 */
+  float delta_pitch_noise_stddev;      /* 0.005 (0 = deterministic)                             */
+  int32_t normalization_left_context;  /* 75 */
+  int32_t normalization_right_context; /* 75 */
+  int32_t delta_window;                /* 2 */
+  int32_t delay;                       /* 0 */
+  int32_t add_pov_feature;             /* 1 */
+  int32_t add_normalized_log_pitch;    /* 1 */
+  int32_t add_delta_pitch;             /* 1 */
+  int32_t add_raw_log_pitch;           /* 0 */
+} snf_pitch_post_options;
+
+/* One flat options record; `kind` selects which fields are read. */
+typedef struct snf_options {
+  int32_t kind; /* SNF_KIND_* */
+  snf_frame_options frame;
+  snf_mel_options mel;
+  /* FbankOptions / MfccOptions / PlpOptions / SpectrogramOptions / EnergyProcessor */
+  int32_t use_energy;
+  float energy_floor;
+  int32_t raw_energy;
+  int32_t htk_compat;
+  int32_t use_log_fbank; /* fbank only */
+  int32_t use_power;     /* fbank only */
+  int32_t num_ceps;      /* mfcc, plp */
+  float cepstral_lifter; /* mfcc, plp */
+  int32_t lpc_order;     /* plp */
+  float compress_factor; /* plp */
+  float cepstral_scale;  /* plp */
+  int32_t rasta;         /* plp (shennong extension, reference plp.py:64-146) */
+  int32_t compression;   /* energy: SNF_COMPRESS_* */
+  /* DeltaFeaturesOptions */
+  int32_t delta_order;  /* 2 */
+  int32_t delta_window; /* 2 */
+  snf_pitch_options pitch;
+  snf_pitch_post_options pitch_post;
+  uint64_t seed; /* RNG seed for dither / delta-pitch noise */
+} snf_options;
+
+typedef struct snf_plan snf_plan; /* opaque */
+
+/* ---- library / device --------------------------------------------------------------------- */
+const char* snf_version(void);
+const char* snf_last_error(void);
+int snf_device_count(void);
+int snf_set_device(int device_id);
+int snf_device_name(int device_id, char* buf, int buflen);
+int snf_device_synchronize(void);
+
+/* ---- host-side helpers that replace pykaldi free functions -------------------------------- */
+/* kaldi.feat.window.num_frames(nsamples, opts, flush=True)   (reference frames.py:137) */
+int64_t snf_num_frames(const snf_frame_options* o, int64_t num_samples);
+/* kaldi.feat.window.first_sample_of_frame(frame, opts)        (reference plp.py:218) */
+int64_t snf_first_sample_of_frame(const snf_frame_options* o, int64_t frame);
+int32_t snf_window_size(const snf_frame_options* o);
+int32_t snf_window_shift(const snf_frame_options* o);
+int32_t snf_padded_window_size(const snf_frame_options* o);
+/* FeatureWindowFunction.from_options(opts).window             (reference window.py:107-114);
+   writes snf_window_size() floats. */
+int snf_window_function(const snf_frame_options* o, float* out);
+/* Number of frames Kaldi's pitch extractor emits for `num_samples` input samples. */
+int64_t snf_pitch_num_frames(const snf_pitch_options* o, int64_t num_samples);
+
+/* ---- plans ---------------------------------------------------------------------------------- */
+/* Precomputes window, mel banks (per distinct vtln warp, on demand), DCT, lifter, IDFT bases,
+   resampler taps... and uploads them to `device_id`.  Immutable afterwards. */
+int snf_plan_create(const snf_options* opts, int device_id, snf_plan** out);
+void snf_plan_destroy(snf_plan* plan);
+/* output dimension (columns); for DELTA/PITCH_POST/ENERGY see the dedicated entry points */
+int32_t snf_plan_ndims(const snf_plan* plan);
+/* rows produced for an utterance of `num_samples` samples (bit-exact Kaldi NumFrames) */
+int64_t snf_plan_num_frames(const snf_plan* plan, int64_t num_samples);
+
+/*
+ * Audio -> Features for a batch of utterances (kinds SPECTROGRAM, FBANK, MFCC, PLP, PITCH, ENERGY).
+ *   wave            concatenated int16 PCM of all utterances            [sample_offsets[n_utts]]
+ *   sample_offsets  n_utts+1 offsets into `wave`
+ *   vtln_warp       n_utts warp factors or NULL (=1.0; ignored by SPECTROGRAM/PITCH/ENERGY)
+ *   out             concatenated row-major float32 [frame_offsets[n_utts], ndims]
+ *   frame_offsets   n_utts+1 row offsets; frame_offsets[u+1]-frame_offsets[u] must equal
+ *                   snf_plan_num_frames(plan, samples of u)
+ * Host-pointer variant: stages through device memory owned by the plan (H2D, kernels, D2H).
+ */
+int snf_plan_run_batch(snf_plan* plan, const int16_t* wave, const int64_t* sample_offsets,
+                       int64_t n_utts, const float* vtln_warp, float* out,
+                       const int64_t* frame_offsets);
+
+/* Device-pointer variant: `d_wave`/`d_out` are device buffers on the plan's device; the offsets
+   tables and vtln_warp stay host pointers (they are small and are uploaded by the call).
+   `stream` is a hipStream_t (NULL = the plan's own stream).  Asynchronous w.r.t. the host when
+   `stream` != NULL; with NULL the call returns after the plan's stream has been synchronised. */
+int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64_t* sample_offsets,
+                              int64_t n_utts, const float* vtln_warp, float* d_out,
+                              const int64_t* frame_offsets, void* stream);
+
+/*
+ * Features -> Features post-processors (kinds DELTA, PITCH_POST).
+ *   in   concatenated row-major float32 [frame_offsets[n_utts], in_cols]
+ *   out  concatenated row-major float32 [frame_offsets[n_utts], snf_post_ndims(plan, in_cols)]
+ */
+int32_t snf_post_ndims(const snf_plan* plan, int32_t in_cols);
+int snf_post_run_batch(snf_plan* plan, const float* in, int32_t in_cols,
+                       const int64_t* frame_offsets, int64_t n_utts, float* out);
+int snf_post_run_batch_device(snf_plan* plan, const float* d_in, int32_t in_cols,
+                              const int64_t* frame_offsets, int64_t n_utts, float* d_out,
+                              void* stream);
+
+/* ---- device memory + timing (so hosts without torch can keep data resident in HBM) ---------- */
+int snf_malloc(void** dptr, uint64_t bytes);
+int snf_free(void* dptr);
+int snf_memcpy_h2d(void* dst, const void* src, uint64_t bytes);
+int snf_memcpy_d2h(void* dst, const void* src, uint64_t bytes);
+int snf_memset(void* dst, int value, uint64_t bytes);
+/* Duration in milliseconds of the kernels launched by the last run call on this plan, measured
+   with HIP events on the stream the kernels were launched on.  `which` selects a kernel slot:
+   0 = whole call, 1.. = per-kernel; returns <0 if the slot was not recorded. */
+float snf_plan_last_kernel_ms(const snf_plan* plan, int which);
+/* Name of the kernel recorded in slot `which` (NULL if none). */
+const char* snf_plan_kernel_name(const snf_plan* plan, int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHENNONG_AMD_H_ */
