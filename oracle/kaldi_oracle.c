@@ -63,6 +63,19 @@ static float vecsum(const float* a, int n) {
   for (int i = 0; i < n; i++) s += a[i];
   return s;
 }
+/* Whole-signal sums (tens of thousands of terms): Kaldi hands these to BLAS sdot, whose blocked
+ * SIMD accumulation is far more accurate than a sequential float loop; a double accumulator
+ * rounded to float is the closest portable stand-in. */
+static float vecvec_long(const float* a, const float* b, int64_t n) {
+  double s = 0.0;
+  for (int64_t i = 0; i < n; i++) s += (double)a[i] * (double)b[i];
+  return (float)s;
+}
+static float vecsum_long(const float* a, int64_t n) {
+  double s = 0.0;
+  for (int64_t i = 0; i < n; i++) s += (double)a[i];
+  return (float)s;
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* Framing  [KALDI-UPSTREAM feature-window.h/.cc: FrameExtractionOptions, NumFrames,           */
@@ -1023,9 +1036,9 @@ ORC_API int orc_pitch(const snf_pitch_options* o, const int16_t* wave16, int64_t
   linres_apply(&lr, wave, n, down, n_down);
   /* signal statistics: phase 1 sees down[0:n_down_p1], phase 2 everything (double accumulators
      += float VecVec / Sum of each chunk) */
-  double sumsq1 = (double)vecvec(down, down, (int)n_down_p1), sum1 = (double)vecsum(down, (int)n_down_p1);
-  double sumsq2 = sumsq1 + (double)vecvec(down + n_down_p1, down + n_down_p1, (int)(n_down - n_down_p1));
-  double sum2 = sum1 + (double)vecsum(down + n_down_p1, (int)(n_down - n_down_p1));
+  double sumsq1 = (double)vecvec_long(down, down, n_down_p1), sum1 = (double)vecsum_long(down, n_down_p1);
+  double sumsq2 = sumsq1 + (double)vecvec_long(down + n_down_p1, down + n_down_p1, n_down - n_down_p1);
+  double sum2 = sum1 + (double)vecsum_long(down + n_down_p1, n_down - n_down_p1);
 
   int S = c.num_states, L = c.num_lags;
   float* window = (float*)malloc(sizeof(float) * (size_t)c.full_len);
@@ -1161,10 +1174,10 @@ static float nccf_to_pov_feature(float n) {
 static float nccf_to_pov(float n) {
   float ndash = fabsf(n);
   if (ndash > 1.0f) ndash = 1.0f;
-  float r = (float)(-5.2 + 5.4 * (double)expf((float)(7.5 * ((double)ndash - 1.0))) + 4.8 * (double)ndash -
-                    2.0 * (double)expf((float)(-10.0 * (double)ndash)) +
-                    4.2 * (double)expf((float)(20.0 * ((double)ndash - 1.0))));
-  return (float)(1.0 / (1.0 + (double)expf((float)(-1.0 * (double)r))));
+  /* Exp() is called with double arguments here, so Kaldi takes the double overload */
+  float r = (float)(-5.2 + 5.4 * exp(7.5 * ((double)ndash - 1.0)) + 4.8 * (double)ndash -
+                    2.0 * exp(-10.0 * (double)ndash) + 4.2 * exp(20.0 * ((double)ndash - 1.0)));
+  return (float)(1.0 / (1.0 + exp(-1.0 * (double)r)));
 }
 
 ORC_API int32_t orc_process_pitch_ndims(const snf_pitch_post_options* o) {

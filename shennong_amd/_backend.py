@@ -1,0 +1,338 @@
+"""ctypes loader and thin call layer over ``libshennong_hip.so`` (the C ABI in
+``include/shennong_amd.h``).
+
+There is no CPU fallback: if the HIP library is missing or no MI355X is visible, every compute
+call raises.  Host-only helpers (frame counts, window function) work without a GPU.
+"""
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+from shennong_amd import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, 'libshennong_hip.so')
+_LIB = None
+_LOCK = threading.Lock()
+_PLANS = {}
+_DEVICE = int(os.environ.get('SHENNONG_AMD_DEVICE', '0'))
+
+# every entry point declared in include/shennong_amd.h (checked by tests/test_abi.py)
+EXPORTS = [
+    'snf_version', 'snf_last_error', 'snf_device_count', 'snf_set_device',
+    'snf_device_name', 'snf_device_synchronize', 'snf_num_frames',
+    'snf_first_sample_of_frame', 'snf_window_size', 'snf_window_shift',
+    'snf_padded_window_size', 'snf_window_function', 'snf_pitch_num_frames',
+    'snf_plan_create', 'snf_plan_destroy', 'snf_plan_ndims',
+    'snf_plan_num_frames', 'snf_plan_run_batch', 'snf_plan_run_batch_device',
+    'snf_post_ndims', 'snf_post_run_batch', 'snf_post_run_batch_device',
+    'snf_malloc', 'snf_free', 'snf_memcpy_h2d', 'snf_memcpy_d2h', 'snf_memset',
+    'snf_plan_last_kernel_ms', 'snf_plan_kernel_name']
+
+
+def lib():
+    """Loads the HIP library once; raises loudly when it has not been built"""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    with _LOCK:
+        if _LIB is not None:
+            return _LIB
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f'{_LIB_PATH} not found: build it with `make -C '
+                f'{os.path.join(_HERE, "csrc")}` (or python -c "import '
+                f'__graft_entry__ as g; g.build()"). shennong_amd has no CPU '
+                f'fallback.')
+        L = C.CDLL(_LIB_PATH)
+        i64, i32, f32, vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
+        pf, pi64 = C.POINTER(C.c_float), C.POINTER(C.c_int64)
+        pi16 = C.POINTER(C.c_int16)
+        FO, PO = C.POINTER(_abi.FrameOptions), C.POINTER(_abi.PitchOptions)
+        OP = C.POINTER(_abi.Options)
+        L.snf_version.restype = C.c_char_p
+        L.snf_last_error.restype = C.c_char_p
+        L.snf_device_name.argtypes = [i32, C.c_char_p, i32]
+        L.snf_set_device.argtypes = [i32]
+        L.snf_num_frames.argtypes = [FO, i64]
+        L.snf_num_frames.restype = i64
+        L.snf_first_sample_of_frame.argtypes = [FO, i64]
+        L.snf_first_sample_of_frame.restype = i64
+        L.snf_window_size.argtypes = [FO]
+        L.snf_window_shift.argtypes = [FO]
+        L.snf_padded_window_size.argtypes = [FO]
+        L.snf_window_function.argtypes = [FO, pf]
+        L.snf_pitch_num_frames.argtypes = [PO, i64]
+        L.snf_pitch_num_frames.restype = i64
+        L.snf_plan_create.argtypes = [OP, i32, C.POINTER(vp)]
+        L.snf_plan_destroy.argtypes = [vp]
+        L.snf_plan_destroy.restype = None
+        L.snf_plan_ndims.argtypes = [vp]
+        L.snf_plan_num_frames.argtypes = [vp, i64]
+        L.snf_plan_num_frames.restype = i64
+        L.snf_plan_run_batch.argtypes = [vp, pi16, pi64, i64, pf, pf, pi64]
+        L.snf_plan_run_batch_device.argtypes = [
+            vp, vp, pi64, i64, pf, vp, pi64, vp]
+        L.snf_post_ndims.argtypes = [vp, i32]
+        L.snf_post_run_batch.argtypes = [vp, pf, i32, pi64, i64, pf]
+        L.snf_post_run_batch_device.argtypes = [vp, vp, i32, pi64, i64, vp, vp]
+        L.snf_malloc.argtypes = [C.POINTER(vp), C.c_uint64]
+        L.snf_free.argtypes = [vp]
+        L.snf_memcpy_h2d.argtypes = [vp, vp, C.c_uint64]
+        L.snf_memcpy_d2h.argtypes = [vp, vp, C.c_uint64]
+        L.snf_memset.argtypes = [vp, i32, C.c_uint64]
+        L.snf_plan_last_kernel_ms.argtypes = [vp, i32]
+        L.snf_plan_last_kernel_ms.restype = f32
+        L.snf_plan_kernel_name.argtypes = [vp, i32]
+        L.snf_plan_kernel_name.restype = C.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    """Maps an ABI return code to the exception class the reference raises"""
+    if rc == _abi.SNF_OK:
+        return
+    msg = lib().snf_last_error().decode(errors='replace')
+    if rc == _abi.SNF_E_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def device_count():
+    return int(lib().snf_device_count())
+
+
+def set_device(device_id):
+    """Selects the GPU used by plans created afterwards (one process per GPU)"""
+    global _DEVICE
+    _DEVICE = int(device_id)
+
+
+def get_device():
+    return _DEVICE
+
+
+def device_name(device_id=None):
+    buf = C.create_string_buffer(256)
+    check(lib().snf_device_name(
+        _DEVICE if device_id is None else device_id, buf, 256))
+    return buf.value.decode()
+
+
+# ---- host-only helpers -------------------------------------------------------
+def num_frames(frame_opts, nsamples):
+    return int(lib().snf_num_frames(C.byref(frame_opts), int(nsamples)))
+
+
+def first_sample_of_frame(frame_opts, frame):
+    return int(lib().snf_first_sample_of_frame(C.byref(frame_opts), int(frame)))
+
+
+def window_size(frame_opts):
+    return int(lib().snf_window_size(C.byref(frame_opts)))
+
+
+def window_shift(frame_opts):
+    return int(lib().snf_window_shift(C.byref(frame_opts)))
+
+
+def padded_window_size(frame_opts):
+    return int(lib().snf_padded_window_size(C.byref(frame_opts)))
+
+
+def window_function(frame_opts):
+    out = np.zeros(max(window_size(frame_opts), 0), dtype=np.float32)
+    check(lib().snf_window_function(
+        C.byref(frame_opts), out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out
+
+
+def pitch_num_frames(pitch_opts, nsamples):
+    return int(lib().snf_pitch_num_frames(C.byref(pitch_opts), int(nsamples)))
+
+
+# ---- plans -------------------------------------------------------------------
+class Plan:
+    """An immutable device-resident feature plan (window, mel banks, DCT... in HBM)"""
+    def __init__(self, opts, device=None):
+        self.opts = _abi.Options.from_buffer_copy(bytes(opts))
+        self.device = _DEVICE if device is None else int(device)
+        handle = C.c_void_p()
+        check(lib().snf_plan_create(
+            C.byref(self.opts), self.device, C.byref(handle)))
+        self.handle = handle
+
+    def __del__(self):
+        handle = getattr(self, 'handle', None)
+        if handle and _LIB is not None:
+            try:
+                _LIB.snf_plan_destroy(handle)
+            except Exception:  # pragma: nocover
+                pass
+            self.handle = None
+
+    @property
+    def ndims(self):
+        return int(lib().snf_plan_ndims(self.handle))
+
+    def num_frames(self, nsamples):
+        return int(lib().snf_plan_num_frames(self.handle, int(nsamples)))
+
+    def post_ndims(self, in_cols):
+        return int(lib().snf_post_ndims(self.handle, int(in_cols)))
+
+    def last_kernel_ms(self, which=0):
+        return float(lib().snf_plan_last_kernel_ms(self.handle, which))
+
+    def kernel_name(self, which):
+        name = lib().snf_plan_kernel_name(self.handle, which)
+        return name.decode() if name else None
+
+    # -- Audio -> Features --
+    def run(self, waves, vtln_warps=None):
+        """`waves`: list of 1-D int16 arrays -> list of float32 [nframes, ndims]"""
+        n = len(waves)
+        lengths = np.fromiter((w.shape[0] for w in waves), np.int64, n)
+        soff = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lengths, out=soff[1:])
+        nfr = np.fromiter(
+            (self.num_frames(x) for x in lengths), np.int64, n)
+        foff = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(nfr, out=foff[1:])
+        if n == 1:
+            wave = np.ascontiguousarray(waves[0], dtype=np.int16)
+        else:
+            wave = np.concatenate(
+                [np.asarray(w, dtype=np.int16) for w in waves]) \
+                if n else np.zeros(0, np.int16)
+        d = self.ndims
+        out = np.empty((int(foff[-1]), d), dtype=np.float32)
+        warp = None
+        if vtln_warps is not None:
+            warp = np.ascontiguousarray(vtln_warps, dtype=np.float32)
+            if warp.shape[0] != n:
+                raise ValueError('one vtln_warp per utterance is required')
+            if np.all(warp == 1.0):
+                warp = None
+        check(lib().snf_plan_run_batch(
+            self.handle, wave.ctypes.data_as(C.POINTER(C.c_int16)),
+            soff.ctypes.data_as(C.POINTER(C.c_int64)), n,
+            warp.ctypes.data_as(C.POINTER(C.c_float)) if warp is not None
+            else None,
+            out.ctypes.data_as(C.POINTER(C.c_float)),
+            foff.ctypes.data_as(C.POINTER(C.c_int64))))
+        res = []
+        for u in range(n):
+            if nfr[u] == 0:
+                # Kaldi returns an empty (0, 0) matrix when no frame fits
+                res.append(np.zeros((0, 0), dtype=np.float32))
+            elif n == 1:
+                res.append(out)
+            else:
+                res.append(out[foff[u]:foff[u + 1]].copy())
+        return res
+
+    # -- Features -> Features --
+    def run_post(self, mats):
+        """`mats`: list of float32 [nframes, cols] -> list of float32 [nframes, out_cols]"""
+        n = len(mats)
+        if n == 0:
+            return []
+        cols = mats[0].shape[1]
+        nfr = np.fromiter((m.shape[0] for m in mats), np.int64, n)
+        foff = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(nfr, out=foff[1:])
+        if n == 1:
+            data = np.ascontiguousarray(mats[0], dtype=np.float32)
+        else:
+            data = np.ascontiguousarray(
+                np.concatenate(mats, axis=0), dtype=np.float32)
+        ocols = self.post_ndims(cols)
+        if ocols <= 0:
+            raise ValueError('bad column count for this post-processor')
+        out = np.empty((int(foff[-1]), ocols), dtype=np.float32)
+        check(lib().snf_post_run_batch(
+            self.handle, data.ctypes.data_as(C.POINTER(C.c_float)), cols,
+            foff.ctypes.data_as(C.POINTER(C.c_int64)), n,
+            out.ctypes.data_as(C.POINTER(C.c_float))))
+        if n == 1:
+            return [out]
+        return [out[foff[u]:foff[u + 1]].copy() for u in range(n)]
+
+    # -- device-resident variants (benchmark / pipelines that keep data in HBM) --
+    def run_device(self, d_wave, soff, foff, d_out, vtln_warps=None, stream=None):
+        n = soff.shape[0] - 1
+        warp = None
+        if vtln_warps is not None:
+            warp = np.ascontiguousarray(vtln_warps, dtype=np.float32)
+        check(lib().snf_plan_run_batch_device(
+            self.handle, C.c_void_p(d_wave),
+            soff.ctypes.data_as(C.POINTER(C.c_int64)), n,
+            warp.ctypes.data_as(C.POINTER(C.c_float)) if warp is not None
+            else None,
+            C.c_void_p(d_out), foff.ctypes.data_as(C.POINTER(C.c_int64)),
+            C.c_void_p(stream) if stream else None))
+
+    def run_post_device(self, d_in, in_cols, foff, d_out, stream=None):
+        n = foff.shape[0] - 1
+        check(lib().snf_post_run_batch_device(
+            self.handle, C.c_void_p(d_in), in_cols,
+            foff.ctypes.data_as(C.POINTER(C.c_int64)), n, C.c_void_p(d_out),
+            C.c_void_p(stream) if stream else None))
+
+
+def get_plan(opts, device=None):
+    """Plan cache keyed by (options bytes, device): options are copied by value at every
+    ``process`` call like the reference does (processor/base.py:421-425)"""
+    key = (_abi.options_key(opts), _DEVICE if device is None else int(device))
+    with _LOCK:
+        plan = _PLANS.get(key)
+    if plan is None:
+        plan = Plan(opts, device)
+        with _LOCK:
+            if len(_PLANS) > 64:
+                _PLANS.clear()
+            _PLANS.setdefault(key, plan)
+            plan = _PLANS[key]
+    return plan
+
+
+def clear_plans():
+    with _LOCK:
+        _PLANS.clear()
+
+
+# ---- raw device memory (for hosts that keep batches resident in HBM) ----------
+class DeviceBuffer:
+    def __init__(self, nbytes):
+        ptr = C.c_void_p()
+        check(lib().snf_malloc(C.byref(ptr), int(max(nbytes, 16))))
+        self.ptr = ptr.value
+        self.nbytes = int(nbytes)
+
+    def upload(self, array):
+        array = np.ascontiguousarray(array)
+        check(lib().snf_memcpy_h2d(
+            C.c_void_p(self.ptr), array.ctypes.data_as(C.c_void_p),
+            array.nbytes))
+
+    def download(self, array):
+        check(lib().snf_memcpy_d2h(
+            array.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
+            array.nbytes))
+        return array
+
+    def free(self):
+        if self.ptr:
+            lib().snf_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # pragma: nocover
+            pass

@@ -1,0 +1,144 @@
+"""Audio container: the input of every features processor
+
+Only what the hot path needs from reference shennong/audio.py: ``data / sample_rate / nchannels /
+nsamples / dtype``, ``astype`` (int16 <-> float scaling by 2**15, audio.py:469-518), ``segment``
+(audio.py:520-561) and wav loading through scipy (audio.py:243-286 without the pydub fallback,
+resampling and sox scanning, which are file-format plumbing and out of scope here).
+"""
+
+import warnings
+
+import numpy as np
+import scipy.io.wavfile
+
+
+class Audio:
+    """An audio signal with the given `data` and `sample_rate`"""
+    def __init__(self, data, sample_rate, validate=True):
+        self._sample_rate = int(sample_rate)
+        # force shape (n, 1) to be (n,)
+        self._data = (
+            data[:, 0] if data.ndim > 1 and data.shape[1] == 1 else data)
+        if validate and not self.is_valid():
+            raise ValueError(f'invalid audio data for type {self.dtype}')
+
+    def __eq__(self, other):
+        if self.sample_rate != other.sample_rate:
+            return False
+        return np.array_equal(self.data, other.data)
+
+    @property
+    def data(self):
+        return self._data
+
+    @property
+    def sample_rate(self):
+        return self._sample_rate
+
+    @property
+    def duration(self):
+        return self.nsamples / self.sample_rate
+
+    @property
+    def nchannels(self):
+        if self.data.ndim == 1:
+            return 1
+        return self.data.shape[1]
+
+    @property
+    def nsamples(self):
+        return self.data.shape[0]
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def precision(self):
+        return self.dtype.itemsize * 8
+
+    @classmethod
+    def load(cls, filename):
+        """Loads a wav file (16/32 bits PCM or float) with scipy"""
+        try:
+            sample_rate, data = scipy.io.wavfile.read(filename)
+        except Exception as err:  # noqa
+            raise ValueError(f'{filename}: cannot read file: {err}') from None
+        return cls(data, sample_rate, validate=False)
+
+    @staticmethod
+    def _is_valid_dtype(dtype):
+        return dtype in (np.dtype(t) for t in (
+            np.int16, np.int32, np.float32, np.float64))
+
+    def is_valid(self):
+        """True if dtype is supported and samples are within the type's range"""
+        if not self._is_valid_dtype(self.dtype):
+            warnings.warn(f'unsupported audio data type: {self.dtype}')
+            return False
+        if self.dtype is np.dtype(np.int16):
+            emin, emax = -2**15, 2**15 - 1
+        elif self.dtype is np.dtype(np.int32):
+            emin, emax = -2**31, 2**31 - 1
+        else:
+            emin, emax = -1, 1
+        if self.data.size == 0:
+            return True
+        dmin, dmax = np.amin(self.data), np.amax(self.data)
+        if dmin < emin or dmax > emax:
+            warnings.warn(
+                f'invalid audio for type {self.dtype}: boundaries must be in '
+                f'({emin}, {emax}) but are ({dmin}, {dmax})')
+            return False
+        return True
+
+    def astype(self, dtype):
+        """Returns the signal converted to `dtype` (reference audio.py:469-518)"""
+        if self.dtype is np.dtype(dtype):
+            return self
+        if not self._is_valid_dtype(dtype):
+            raise ValueError(f'unsupported audio data type: {dtype}')
+        if self.dtype is np.dtype(np.int16):
+            if dtype is np.int32:
+                data = self.data * 2**15
+            else:
+                data = self.data / 2**15
+        elif self.dtype is np.dtype(np.int32):
+            if dtype is np.int16:
+                data = self.data / 2**15
+            else:
+                data = self.data / 2**30
+        else:
+            if dtype is np.int16:
+                data = self.data * 2**15
+            elif dtype is np.int32:
+                data = self.data * 2**30
+            else:
+                data = self.data
+        with np.errstate(invalid='ignore'):
+            # out-of-range floats wrap exactly like the reference's C cast
+            return Audio(data.astype(dtype), self.sample_rate, validate=False)
+
+    def segment(self, segments):
+        """Returns audio chunks for a list of (tstart, tstop) pairs in seconds"""
+        if not isinstance(segments, list):
+            raise ValueError('segments must be a list')
+        for segment in segments:
+            try:
+                if not len(segment) == 2:
+                    raise ValueError('segments elements must be pairs')
+            except TypeError:
+                raise ValueError('segments elements must be pairs')
+            if segment[0] >= segment[1]:
+                raise ValueError('time indices in segments must be sorted')
+        chunks = []
+        for segment in segments:
+            istart = int(segment[0] * self.sample_rate)
+            istop = int(segment[1] * self.sample_rate)
+            chunks.append(Audio(
+                self.data[istart:istop], self.sample_rate, validate=False))
+        return chunks

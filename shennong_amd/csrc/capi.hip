@@ -1,0 +1,830 @@
+// C ABI of libshennong_hip.so (include/shennong_amd.h): plans, device tables, batch orchestration.
+//
+// A plan owns (a) the immutable tables Kaldi would rebuild per utterance (window, FFT twiddles, mel
+// banks per VTLN warp, DCT, lifter, IDFT bases, resampler taps), resident in HBM, (b) grow-only
+// device scratch for the host-pointer entry points, (c) one HIP stream and the events that time the
+// kernels on that stream.
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "snf_internal.h"
+
+using namespace snf;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return SNF_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    SNF_HIP_CHECK(hipMalloc(&p, want));
+    cap = want;
+    return SNF_OK;
+  }
+  template <typename T>
+  int upload(const std::vector<T>& v, hipStream_t s) {
+    const size_t bytes = sizeof(T) * v.size();
+    int rc = ensure(bytes > 0 ? bytes : 16);
+    if (rc) return rc;
+    if (bytes) {
+      // the source is a short-lived pageable host vector: finish the copy before returning
+      SNF_HIP_CHECK(hipMemcpyAsync(p, v.data(), bytes, hipMemcpyHostToDevice, s));
+      SNF_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    return SNF_OK;
+  }
+  template <typename T>
+  T* as() const { return static_cast<T*>(p); }
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+};
+
+constexpr int kMaxSlots = 6;
+
+}  // namespace
+
+struct snf_plan {
+  snf_options o{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  int kind = 0, ndims = 0;
+
+  // mel family
+  MelParams mp{};
+  DevBuf d_window, d_tw_fft, d_tw_unpack, d_tw_dft, d_dct, d_lifter, d_idft;
+  std::vector<float> warps;  // distinct VTLN warp factors seen so far (index = warp id)
+  std::vector<MelBanksHost> banks;
+  DevBuf d_mel_first, d_mel_size, d_mel_off, d_mel_w, d_eql;
+  bool warps_dirty = true;
+  PlpParams pp{};
+
+  // delta
+  DeltaParams dp{};
+  DevBuf d_scales, d_dims;
+
+  // pitch
+  PitchTablesHost pt;
+  PitchDevTables pd{};
+  DevBuf d_lags, d_ar_first, d_ar_n, d_ar_w, d_rs_first, d_rs_ntaps, d_rs_w;
+  PitchPostParams ppost{};
+
+  // scratch (host-pointer entry points and intermediates)
+  DevBuf s_wave, s_out, s_in, s_soff, s_foff, s_uwarp, s_mel, s_energy;
+  DevBuf s_down, s_stats, s_bp, s_doff, s_dp1, s_fp1, s_states;
+
+  // last uploaded offsets tables (re-validated / re-uploaded only when they change)
+  std::vector<int64_t> h_soff, h_foff;
+
+  // timing
+  hipEvent_t ev[kMaxSlots + 1] = {};
+  const char* slot_name[kMaxSlots + 1] = {};
+  int n_slots = 0;
+  bool events_valid = false;
+
+  ~snf_plan() {
+    for (auto& e : ev)
+      if (e) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+int guard_device(const snf_plan* plan) {
+  SNF_HIP_CHECK(hipSetDevice(plan->device));
+  return SNF_OK;
+}
+
+int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+// ---- mel-family plan -----------------------------------------------------------------------------
+int build_mel_plan(snf_plan* plan) {
+  const snf_options& o = plan->o;
+  const snf_frame_options& fo = o.frame;
+  MelParams& p = plan->mp;
+  p.win_len = window_size(fo);
+  p.win_shift = window_shift(fo);
+  p.padded = padded_window_size(fo);
+  if (p.win_shift <= 0) return set_error(SNF_E_RUNTIME, "frame shift is shorter than one sample");
+  if (p.win_len < 2) return set_error(SNF_E_RUNTIME, "frame length must be at least 2 samples");
+  if (p.padded % 2 != 0)
+    return set_error(SNF_E_RUNTIME, "padded window size must be even (real FFT)");
+  p.half = p.padded / 2;
+  p.pow2 = (p.padded & (p.padded - 1)) == 0;
+  p.log2_half = p.pow2 ? ilog2(p.half) : 0;
+  p.snip_edges = fo.snip_edges;
+  p.remove_dc = fo.remove_dc_offset;
+  p.preemph = fo.preemph_coeff;
+  p.dither = fo.dither;
+  p.seed = o.seed;
+  p.kind = plan->kind;
+
+  std::vector<float> window;
+  int rc = make_window(fo, &window);
+  if (rc) return rc;
+  if ((rc = plan->d_window.upload(window, plan->stream))) return rc;
+  p.window = plan->d_window.as<float>();
+
+  constexpr double kTwoPi = 6.283185307179586476925286766559005;
+  std::vector<float2> tw;
+  if (p.pow2) {
+    tw.resize(p.half / 2 > 0 ? p.half / 2 : 1);
+    for (int k = 0; k < static_cast<int>(tw.size()); ++k) {
+      const double a = -kTwoPi * k / p.half;
+      tw[k] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
+    }
+    if ((rc = plan->d_tw_fft.upload(tw, plan->stream))) return rc;
+    tw.resize(p.half / 2 + 1);
+    for (int k = 0; k < static_cast<int>(tw.size()); ++k) {
+      const double a = -kTwoPi * k / p.padded;
+      tw[k] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
+    }
+    if ((rc = plan->d_tw_unpack.upload(tw, plan->stream))) return rc;
+    p.tw_fft = plan->d_tw_fft.as<float2>();
+    p.tw_unpack = plan->d_tw_unpack.as<float2>();
+    p.tw_dft = nullptr;
+  } else {
+    tw.resize(p.padded);
+    for (int k = 0; k < p.padded; ++k) {
+      const double a = -kTwoPi * k / p.padded;
+      tw[k] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(std::sin(a)));
+    }
+    if ((rc = plan->d_tw_dft.upload(tw, plan->stream))) return rc;
+    p.tw_dft = plan->d_tw_dft.as<float2>();
+    p.tw_fft = nullptr;
+    p.tw_unpack = nullptr;
+  }
+
+  p.use_energy = o.use_energy;
+  p.raw_energy = o.raw_energy;
+  p.htk_compat = o.htk_compat;
+  p.use_log = o.use_log_fbank;
+  p.use_power = o.use_power;
+  p.num_bins = o.mel.num_bins;
+  p.num_ceps = o.num_ceps;
+  p.compression = o.compression;
+  p.has_floor = o.energy_floor > 0.0f;
+  p.log_energy_floor = p.has_floor ? logf(o.energy_floor) : 0.0f;
+  p.dct = nullptr;
+  p.lifter = nullptr;
+
+  switch (plan->kind) {
+    case SNF_KIND_SPECTROGRAM:
+      plan->ndims = p.half + 1;
+      p.need_raw = o.raw_energy ? 1 : 0;
+      p.need_post = o.raw_energy ? 0 : 1;
+      p.num_bins = 0;
+      break;
+    case SNF_KIND_FBANK:
+      plan->ndims = o.mel.num_bins + (o.use_energy ? 1 : 0);
+      break;
+    case SNF_KIND_MFCC:
+      plan->ndims = o.num_ceps;
+      break;
+    case SNF_KIND_PLP:
+      plan->ndims = o.num_ceps;
+      break;
+    default:
+      return set_error(SNF_E_INVALID, "not a mel-family kind");
+  }
+  if (plan->kind != SNF_KIND_SPECTROGRAM) {
+    p.need_raw = (o.use_energy && o.raw_energy) ? 1 : 0;
+    p.need_post = (o.use_energy && !o.raw_energy) ? 1 : 0;
+    // Kaldi builds the warp-1.0 banks in the computer's constructor: option errors surface here
+    MelBanksHost mb;
+    if ((rc = make_mel_banks(o.mel, fo, 1.0f, &mb))) return rc;
+    plan->warps.assign(1, 1.0f);
+    plan->banks.assign(1, mb);
+    plan->warps_dirty = true;
+  }
+  if (plan->kind == SNF_KIND_MFCC) {
+    if (o.num_ceps > o.mel.num_bins)
+      return set_error(SNF_E_RUNTIME, "num-ceps cannot be larger than num-mel-bins. It should be "
+                                      "smaller or equal. You provided num-ceps: " +
+                                          std::to_string(o.num_ceps) + "  and num-mel-bins: " +
+                                          std::to_string(o.mel.num_bins));
+    if (o.num_ceps <= 0) return set_error(SNF_E_RUNTIME, "num-ceps must be strictly positive");
+    std::vector<float> dct, lifter;
+    make_dct_matrix(o.num_ceps, o.mel.num_bins, &dct);
+    if ((rc = plan->d_dct.upload(dct, plan->stream))) return rc;
+    p.dct = plan->d_dct.as<float>();
+    if (o.cepstral_lifter != 0.0f) {
+      make_lifter(o.cepstral_lifter, o.num_ceps, &lifter);
+      if ((rc = plan->d_lifter.upload(lifter, plan->stream))) return rc;
+      p.lifter = plan->d_lifter.as<float>();
+    }
+  }
+  if (plan->kind == SNF_KIND_PLP) {
+    if (o.num_ceps <= 0 || o.num_ceps > o.lpc_order + 1)
+      return set_error(SNF_E_INVALID, "We must have 0 < num_ceps <= lpc_order+1");
+    PlpParams& q = plan->pp;
+    q.num_bins = o.mel.num_bins;
+    q.lpc_order = o.lpc_order;
+    q.num_ceps = o.num_ceps;
+    q.use_energy = o.use_energy;
+    q.htk_compat = o.htk_compat;
+    q.has_floor = o.energy_floor > 0.0f;
+    q.log_energy_floor = q.has_floor ? std::log(static_cast<double>(o.energy_floor)) : 0.0;
+    q.rasta = o.rasta;
+    q.compress_factor = o.compress_factor;
+    q.cepstral_scale = o.cepstral_scale;
+    std::vector<float> idft, lifter;
+    make_idft_bases(o.lpc_order + 1, o.mel.num_bins + 2, &idft);
+    if ((rc = plan->d_idft.upload(idft, plan->stream))) return rc;
+    q.idft = plan->d_idft.as<float>();
+    q.lifter = nullptr;
+    if (o.cepstral_lifter != 0.0f) {
+      make_lifter(o.cepstral_lifter, o.num_ceps, &lifter);
+      if ((rc = plan->d_lifter.upload(lifter, plan->stream))) return rc;
+      q.lifter = plan->d_lifter.as<float>();
+    }
+  }
+  p.ndims = plan->ndims;
+  return SNF_OK;
+}
+
+// (re)upload the per-warp mel tables after a new warp factor appeared
+int sync_warp_tables(snf_plan* plan) {
+  if (!plan->warps_dirty || plan->kind == SNF_KIND_SPECTROGRAM) return SNF_OK;
+  const int nb = plan->o.mel.num_bins;
+  std::vector<int> first, size, off;
+  std::vector<float> w, eql;
+  for (const MelBanksHost& mb : plan->banks) {
+    const int base = static_cast<int>(w.size());
+    for (int b = 0; b < nb; ++b) {
+      first.push_back(mb.first[b]);
+      size.push_back(mb.size[b]);
+      off.push_back(base + mb.offset[b]);
+    }
+    w.insert(w.end(), mb.w.begin(), mb.w.end());
+    if (plan->kind == SNF_KIND_PLP) {
+      std::vector<float> e;
+      make_equal_loudness(mb, &e);
+      eql.insert(eql.end(), e.begin(), e.end());
+    }
+  }
+  int rc;
+  if ((rc = plan->d_mel_first.upload(first, plan->stream))) return rc;
+  if ((rc = plan->d_mel_size.upload(size, plan->stream))) return rc;
+  if ((rc = plan->d_mel_off.upload(off, plan->stream))) return rc;
+  if ((rc = plan->d_mel_w.upload(w, plan->stream))) return rc;
+  plan->mp.mel_first = plan->d_mel_first.as<int>();
+  plan->mp.mel_size = plan->d_mel_size.as<int>();
+  plan->mp.mel_offset = plan->d_mel_off.as<int>();
+  plan->mp.mel_w = plan->d_mel_w.as<float>();
+  if (plan->kind == SNF_KIND_PLP) {
+    if ((rc = plan->d_eql.upload(eql, plan->stream))) return rc;
+    plan->pp.eql = plan->d_eql.as<float>();
+  }
+  // the uploads read from host vectors that die at scope exit
+  SNF_HIP_CHECK(hipStreamSynchronize(plan->stream));
+  plan->warps_dirty = false;
+  return SNF_OK;
+}
+
+// map per-utterance warp factors to table ids, creating tables on demand
+int resolve_warps(snf_plan* plan, const float* vtln_warp, int64_t n_utts,
+                  std::vector<int32_t>* ids, bool* any) {
+  *any = false;
+  if (!vtln_warp || plan->kind == SNF_KIND_SPECTROGRAM) return SNF_OK;
+  ids->assign(n_utts, 0);
+  for (int64_t u = 0; u < n_utts; ++u) {
+    const float wf = vtln_warp[u];
+    int id = -1;
+    for (size_t k = 0; k < plan->warps.size(); ++k)
+      if (plan->warps[k] == wf) {
+        id = static_cast<int>(k);
+        break;
+      }
+    if (id < 0) {
+      MelBanksHost mb;
+      int rc = make_mel_banks(plan->o.mel, plan->o.frame, wf, &mb);
+      if (rc) return rc;
+      plan->warps.push_back(wf);
+      plan->banks.push_back(mb);
+      plan->warps_dirty = true;
+      id = static_cast<int>(plan->warps.size()) - 1;
+    }
+    (*ids)[u] = id;
+    if (id != 0) *any = true;
+  }
+  return SNF_OK;
+}
+
+int build_delta_plan(snf_plan* plan) {
+  const snf_options& o = plan->o;
+  if (o.delta_order < 0 || o.delta_order >= 1000)
+    return set_error(SNF_E_RUNTIME, "delta order must be in [0, 999]");
+  if (o.delta_window <= 0 || o.delta_window >= 1000)
+    return set_error(SNF_E_INVALID, "window must be in [1, 999]");
+  std::vector<float> scales;
+  std::vector<int> dims;
+  make_delta_scales(o.delta_order, o.delta_window, &scales, &dims);
+  int rc;
+  if ((rc = plan->d_scales.upload(scales, plan->stream))) return rc;
+  if ((rc = plan->d_dims.upload(dims, plan->stream))) return rc;
+  plan->dp.order = o.delta_order;
+  plan->dp.window = o.delta_window;
+  plan->dp.n_scales = static_cast<int>(scales.size());
+  plan->dp.scales = plan->d_scales.as<float>();
+  plan->dp.dims = plan->d_dims.as<int>();
+  plan->ndims = -1;
+  return SNF_OK;
+}
+
+int build_pitch_plan(snf_plan* plan) {
+  const snf_pitch_options& o = plan->o.pitch;
+  int rc = make_pitch_tables(o, &plan->pt);
+  if (rc) return rc;
+  const PitchTablesHost& t = plan->pt;
+  if ((rc = plan->d_lags.upload(t.lags, plan->stream))) return rc;
+  if ((rc = plan->d_ar_first.upload(t.ar_first, plan->stream))) return rc;
+  if ((rc = plan->d_ar_n.upload(t.ar_n, plan->stream))) return rc;
+  if ((rc = plan->d_ar_w.upload(t.ar_w, plan->stream))) return rc;
+  if ((rc = plan->d_rs_first.upload(t.resample.first, plan->stream))) return rc;
+  if ((rc = plan->d_rs_ntaps.upload(t.resample.ntaps, plan->stream))) return rc;
+  if ((rc = plan->d_rs_w.upload(t.resample.weights, plan->stream))) return rc;
+  PitchDevTables& d = plan->pd;
+  d.first_lag = t.first_lag;
+  d.last_lag = t.last_lag;
+  d.num_lags = t.num_lags;
+  d.num_states = t.num_states;
+  d.win_size = t.win_size;
+  d.win_shift = t.win_shift;
+  d.full_len = t.full_len;
+  d.ar_max_taps = t.max_taps;
+  d.rs_in_unit = t.resample.in_unit;
+  d.rs_out_unit = t.resample.out_unit;
+  d.rs_max_taps = t.resample.max_taps;
+  d.snip_edges = o.snip_edges;
+  d.recompute_frame = o.recompute_frame;
+  d.soft_min_f0 = o.soft_min_f0;
+  const float delta_pitch_sq =
+      static_cast<float>(std::pow(static_cast<double>(logf(static_cast<float>(1.0 + o.delta_pitch))), 2.0));
+  d.inter_frame_factor = delta_pitch_sq * o.penalty_factor;
+  d.nccf_ballast = o.nccf_ballast;
+  d.lags = plan->d_lags.as<float>();
+  d.ar_first = plan->d_ar_first.as<int>();
+  d.ar_n = plan->d_ar_n.as<int>();
+  d.ar_w = plan->d_ar_w.as<float>();
+  d.rs_first = plan->d_rs_first.as<int>();
+  d.rs_ntaps = plan->d_rs_ntaps.as<int>();
+  d.rs_w = plan->d_rs_w.as<float>();
+  plan->ndims = 2;
+  return SNF_OK;
+}
+
+int64_t pitch_frames_for(const snf_plan* plan, int64_t n, int64_t* n_down, int64_t* n_down_p1,
+                         int64_t* frames_p1) {
+  const PitchTablesHost& t = plan->pt;
+  const int64_t nd = t.resample.num_output(n, true), nd1 = t.resample.num_output(n, false);
+  const bool snip = plan->o.pitch.snip_edges != 0;
+  const int64_t T = t.frames_available(nd, true, snip);
+  int64_t T1 = t.frames_available(nd1, false, snip);
+  if (T1 > T) T1 = T;
+  if (n_down) *n_down = nd;
+  if (n_down_p1) *n_down_p1 = nd1;
+  if (frames_p1) *frames_p1 = T1;
+  return T;
+}
+
+void begin_timing(snf_plan* plan) {
+  plan->n_slots = 0;
+  plan->events_valid = false;
+  (void)hipEventRecord(plan->ev[0], plan->stream);
+}
+void mark_kernel(snf_plan* plan, const char* name) {
+  if (plan->n_slots >= kMaxSlots) return;
+  ++plan->n_slots;
+  plan->slot_name[plan->n_slots] = name;
+  (void)hipEventRecord(plan->ev[plan->n_slots], plan->stream);
+  plan->events_valid = true;
+}
+
+int check_offsets(const snf_plan* plan, const int64_t* sample_offsets, const int64_t* frame_offsets,
+                  int64_t n_utts) {
+  if (n_utts < 0) return set_error(SNF_E_INVALID, "n_utts < 0");
+  if (n_utts == 0) return SNF_OK;
+  if (!sample_offsets || !frame_offsets) return set_error(SNF_E_INVALID, "null offsets table");
+  for (int64_t u = 0; u < n_utts; ++u) {
+    const int64_t n = sample_offsets[u + 1] - sample_offsets[u];
+    const int64_t f = frame_offsets[u + 1] - frame_offsets[u];
+    if (n < 0 || f < 0) return set_error(SNF_E_INVALID, "offsets tables must be non-decreasing");
+    if (f != snf_plan_num_frames(plan, n))
+      return set_error(SNF_E_INVALID, "frame_offsets do not match snf_plan_num_frames for utterance " +
+                                          std::to_string(u));
+  }
+  return SNF_OK;
+}
+
+int run_pitch_device(snf_plan* plan, const int16_t* d_wave, const int64_t* sample_offsets,
+                     int64_t n_utts, float* d_out, const int64_t* frame_offsets, hipStream_t s) {
+  const int64_t total_frames = frame_offsets[n_utts];
+  if (total_frames == 0) return SNF_OK;
+  std::vector<int64_t> doff(n_utts + 1, 0), dp1(n_utts, 0), fp1(n_utts, 0);
+  for (int64_t u = 0; u < n_utts; ++u) {
+    int64_t nd, nd1, t1;
+    pitch_frames_for(plan, sample_offsets[u + 1] - sample_offsets[u], &nd, &nd1, &t1);
+    doff[u + 1] = doff[u] + nd;
+    dp1[u] = nd1;
+    fp1[u] = t1;
+  }
+  const int64_t total_down = doff[n_utts];
+  int rc;
+  std::vector<int64_t> soff(sample_offsets, sample_offsets + n_utts + 1);
+  std::vector<int64_t> foff(frame_offsets, frame_offsets + n_utts + 1);
+  if ((rc = plan->s_soff.upload(soff, s))) return rc;
+  if ((rc = plan->s_foff.upload(foff, s))) return rc;
+  if ((rc = plan->s_doff.upload(doff, s))) return rc;
+  if ((rc = plan->s_dp1.upload(dp1, s))) return rc;
+  if ((rc = plan->s_fp1.upload(fp1, s))) return rc;
+  if ((rc = plan->s_down.ensure(sizeof(float) * static_cast<size_t>(total_down > 0 ? total_down : 1)))) return rc;
+  if ((rc = plan->s_stats.ensure(sizeof(double) * 4 * static_cast<size_t>(n_utts)))) return rc;
+  if ((rc = plan->s_bp.ensure(sizeof(int16_t) * static_cast<size_t>(total_frames) * plan->pd.num_states))) return rc;
+  if ((rc = plan->s_states.ensure(sizeof(int32_t) * static_cast<size_t>(total_frames)))) return rc;
+  SNF_HIP_CHECK(hipStreamSynchronize(s));  // host vectors above go out of scope after launch setup
+  PitchBatch b{};
+  b.wave = d_wave;
+  b.sample_offsets = plan->s_soff.as<int64_t>();
+  b.frame_offsets = plan->s_foff.as<int64_t>();
+  b.down_offsets = plan->s_doff.as<int64_t>();
+  b.down_phase1 = plan->s_dp1.as<int64_t>();
+  b.frames_phase1 = plan->s_fp1.as<int64_t>();
+  b.n_utts = n_utts;
+  b.total_frames = total_frames;
+  b.total_down = total_down;
+  return launch_pitch(plan->pd, b, plan->s_down.as<float>(), plan->s_stats.as<double>(),
+                      plan->s_bp.as<int16_t>(), plan->s_states.as<int32_t>(), d_out, s);
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* snf_version(void) { return "shennong_amd 0.1 (gfx950)"; }
+const char* snf_last_error(void) { return last_error(); }
+
+int snf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+int snf_set_device(int device_id) {
+  SNF_HIP_CHECK(hipSetDevice(device_id));
+  return SNF_OK;
+}
+int snf_device_name(int device_id, char* buf, int buflen) {
+  hipDeviceProp_t prop;
+  SNF_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+  snprintf(buf, buflen, "%s (%s)", prop.name, prop.gcnArchName);
+  return SNF_OK;
+}
+int snf_device_synchronize(void) {
+  SNF_HIP_CHECK(hipDeviceSynchronize());
+  return SNF_OK;
+}
+
+int64_t snf_num_frames(const snf_frame_options* o, int64_t n) { return num_frames(*o, n); }
+int64_t snf_first_sample_of_frame(const snf_frame_options* o, int64_t f) {
+  return first_sample_of_frame(*o, f);
+}
+int32_t snf_window_size(const snf_frame_options* o) { return window_size(*o); }
+int32_t snf_window_shift(const snf_frame_options* o) { return window_shift(*o); }
+int32_t snf_padded_window_size(const snf_frame_options* o) { return padded_window_size(*o); }
+int snf_window_function(const snf_frame_options* o, float* out) {
+  std::vector<float> w;
+  int rc = make_window(*o, &w);
+  if (rc) return rc;
+  std::memcpy(out, w.data(), sizeof(float) * w.size());
+  return SNF_OK;
+}
+int64_t snf_pitch_num_frames(const snf_pitch_options* o, int64_t n) {
+  PitchTablesHost t;
+  if (make_pitch_tables(*o, &t)) return -1;
+  return t.frames_available(t.resample.num_output(n, true), true, o->snip_edges != 0);
+}
+
+int snf_plan_create(const snf_options* opts, int device_id, snf_plan** out) {
+  if (!opts || !out) return set_error(SNF_E_INVALID, "null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return set_error(SNF_E_NODEVICE, "no HIP device visible: libshennong_hip needs an MI355X (gfx950)");
+  if (device_id < 0 || device_id >= ndev) return set_error(SNF_E_INVALID, "bad device id");
+  SNF_HIP_CHECK(hipSetDevice(device_id));
+  std::unique_ptr<snf_plan> plan(new snf_plan);
+  plan->o = *opts;
+  plan->device = device_id;
+  plan->kind = opts->kind;
+  SNF_HIP_CHECK(hipStreamCreateWithFlags(&plan->stream, hipStreamNonBlocking));
+  for (auto& e : plan->ev) SNF_HIP_CHECK(hipEventCreate(&e));
+  int rc;
+  switch (opts->kind) {
+    case SNF_KIND_SPECTROGRAM:
+    case SNF_KIND_FBANK:
+    case SNF_KIND_MFCC:
+    case SNF_KIND_PLP:
+      rc = build_mel_plan(plan.get());
+      break;
+    case SNF_KIND_DELTA:
+      rc = build_delta_plan(plan.get());
+      break;
+    case SNF_KIND_PITCH:
+      rc = build_pitch_plan(plan.get());
+      break;
+    case SNF_KIND_PITCH_POST: {
+      const snf_pitch_post_options& q = opts->pitch_post;
+      plan->ppost.o = q;
+      plan->ppost.seed = opts->seed;
+      plan->ppost.ndims = (q.add_pov_feature ? 1 : 0) + (q.add_normalized_log_pitch ? 1 : 0) +
+                          (q.add_delta_pitch ? 1 : 0) + (q.add_raw_log_pitch ? 1 : 0);
+      plan->ndims = plan->ppost.ndims;
+      rc = SNF_OK;
+      if (plan->ndims <= 0)
+        rc = set_error(SNF_E_INVALID, "at least one of the pitch post-processing features must be selected");
+      else if (q.delay != 0)
+        rc = set_error(SNF_E_RUNTIME, "pitch post-processing delay != 0 is not supported");
+      else if (q.delta_window <= 0 || q.delta_window >= 1000)
+        rc = set_error(SNF_E_RUNTIME, "delta_window must be in [1, 999]");
+      break;
+    }
+    default:
+      rc = set_error(SNF_E_INVALID, "unknown or unsupported plan kind");
+  }
+  if (rc) return rc;
+  SNF_HIP_CHECK(hipStreamSynchronize(plan->stream));
+  *out = plan.release();
+  return SNF_OK;
+}
+
+void snf_plan_destroy(snf_plan* plan) {
+  if (!plan) return;
+  (void)hipSetDevice(plan->device);
+  (void)hipStreamSynchronize(plan->stream);
+  delete plan;
+}
+
+int32_t snf_plan_ndims(const snf_plan* plan) { return plan ? plan->ndims : -1; }
+
+int64_t snf_plan_num_frames(const snf_plan* plan, int64_t n) {
+  if (!plan) return -1;
+  switch (plan->kind) {
+    case SNF_KIND_SPECTROGRAM:
+    case SNF_KIND_FBANK:
+    case SNF_KIND_MFCC:
+    case SNF_KIND_PLP:
+      return num_frames(plan->o.frame, n);
+    case SNF_KIND_PITCH:
+      return pitch_frames_for(plan, n, nullptr, nullptr, nullptr);
+    default:
+      return -1;
+  }
+}
+
+int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64_t* sample_offsets,
+                              int64_t n_utts, const float* vtln_warp, float* d_out,
+                              const int64_t* frame_offsets, void* stream) {
+  if (!plan) return set_error(SNF_E_INVALID, "null plan");
+  std::lock_guard<std::mutex> lock(plan->mu);
+  int rc = guard_device(plan);
+  if (rc) return rc;
+  if (n_utts < 0) return set_error(SNF_E_INVALID, "n_utts < 0");
+  if (n_utts == 0) return SNF_OK;
+  if (!sample_offsets || !frame_offsets) return set_error(SNF_E_INVALID, "null offsets table");
+  const bool same_tables =
+      plan->h_soff.size() == static_cast<size_t>(n_utts + 1) &&
+      std::memcmp(plan->h_soff.data(), sample_offsets, sizeof(int64_t) * (n_utts + 1)) == 0 &&
+      std::memcmp(plan->h_foff.data(), frame_offsets, sizeof(int64_t) * (n_utts + 1)) == 0;
+  if (!same_tables) {
+    plan->h_soff.clear();
+    if ((rc = check_offsets(plan, sample_offsets, frame_offsets, n_utts))) return rc;
+  }
+  const int64_t total_frames = frame_offsets[n_utts];
+  if (total_frames == 0) return SNF_OK;
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : plan->stream;
+  const bool own_stream = (stream == nullptr);
+
+  if (plan->kind == SNF_KIND_PITCH) {
+    plan->h_soff.clear();
+    if (own_stream) begin_timing(plan);
+    rc = run_pitch_device(plan, d_wave, sample_offsets, n_utts, d_out, frame_offsets, s);
+    if (rc) return rc;
+    if (own_stream) {
+      mark_kernel(plan, "pitch");
+      SNF_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    return SNF_OK;
+  }
+  if (plan->kind != SNF_KIND_SPECTROGRAM && plan->kind != SNF_KIND_FBANK &&
+      plan->kind != SNF_KIND_MFCC && plan->kind != SNF_KIND_PLP)
+    return set_error(SNF_E_INVALID, "plan kind does not take audio input");
+
+  std::vector<int32_t> warp_ids;
+  bool any_warp = false;
+  if ((rc = resolve_warps(plan, vtln_warp, n_utts, &warp_ids, &any_warp))) return rc;
+  if ((rc = sync_warp_tables(plan))) return rc;
+
+  if (!same_tables) {
+    std::vector<int64_t> soff(sample_offsets, sample_offsets + n_utts + 1);
+    std::vector<int64_t> foff(frame_offsets, frame_offsets + n_utts + 1);
+    if ((rc = plan->s_soff.upload(soff, s))) return rc;
+    if ((rc = plan->s_foff.upload(foff, s))) return rc;
+    plan->h_soff.swap(soff);
+    plan->h_foff.swap(foff);
+  }
+  if (any_warp && (rc = plan->s_uwarp.upload(warp_ids, s))) return rc;
+  BatchArgs b{};
+  b.wave = d_wave;
+  b.sample_offsets = plan->s_soff.as<int64_t>();
+  b.frame_offsets = plan->s_foff.as<int64_t>();
+  b.utt_warp = any_warp ? plan->s_uwarp.as<int32_t>() : nullptr;
+  b.n_utts = n_utts;
+  b.total_frames = total_frames;
+
+  if (plan->kind == SNF_KIND_PLP) {
+    const int nb = plan->o.mel.num_bins;
+    if ((rc = plan->s_mel.ensure(sizeof(float) * static_cast<size_t>(total_frames) * nb))) return rc;
+    if ((rc = plan->s_energy.ensure(sizeof(double) * static_cast<size_t>(total_frames)))) return rc;
+  }
+  if (own_stream) begin_timing(plan);
+  if (plan->kind == SNF_KIND_PLP) {
+    const int nb = plan->o.mel.num_bins;
+    if ((rc = launch_mel_features(plan->mp, b, plan->s_mel.as<float>(), nb,
+                                  plan->s_energy.as<double>(), s)))
+      return rc;
+    if (own_stream) mark_kernel(plan, "mel_features_generic_kernel");
+    if (plan->o.rasta) {
+      if ((rc = launch_rasta(plan->s_mel.as<float>(), b, nb, s))) return rc;
+      if (own_stream) mark_kernel(plan, "rasta_kernel");
+    }
+    if ((rc = launch_plp_tail(plan->pp, b, plan->s_mel.as<float>(), plan->s_energy.as<double>(),
+                              d_out, s)))
+      return rc;
+    if (own_stream) mark_kernel(plan, "plp_tail_kernel");
+  } else {
+    if ((rc = launch_mel_features(plan->mp, b, d_out, plan->ndims, nullptr, s))) return rc;
+    if (own_stream) mark_kernel(plan, "mel_features_generic_kernel");
+  }
+  if (own_stream) SNF_HIP_CHECK(hipStreamSynchronize(s));
+  return SNF_OK;
+}
+
+int snf_plan_run_batch(snf_plan* plan, const int16_t* wave, const int64_t* sample_offsets,
+                       int64_t n_utts, const float* vtln_warp, float* out,
+                       const int64_t* frame_offsets) {
+  if (!plan) return set_error(SNF_E_INVALID, "null plan");
+  if (n_utts <= 0) return n_utts == 0 ? SNF_OK : set_error(SNF_E_INVALID, "n_utts < 0");
+  if (!sample_offsets || !frame_offsets) return set_error(SNF_E_INVALID, "null offsets table");
+  const int64_t total_samples = sample_offsets[n_utts] - sample_offsets[0];
+  const int64_t total_frames = frame_offsets[n_utts];
+  if (sample_offsets[0] != 0 || frame_offsets[0] != 0)
+    return set_error(SNF_E_INVALID, "offsets tables must start at 0");
+  int16_t* d_wave;
+  float* d_out;
+  {
+    std::lock_guard<std::mutex> lock(plan->mu);
+    int rc = guard_device(plan);
+    if (rc) return rc;
+    if ((rc = plan->s_wave.ensure(sizeof(int16_t) * static_cast<size_t>(total_samples > 0 ? total_samples : 1)))) return rc;
+    if ((rc = plan->s_out.ensure(sizeof(float) * static_cast<size_t>(total_frames > 0 ? total_frames : 1) *
+                                 (plan->ndims > 0 ? plan->ndims : 1))))
+      return rc;
+    d_wave = plan->s_wave.as<int16_t>();
+    d_out = plan->s_out.as<float>();
+    if (total_samples > 0)
+      SNF_HIP_CHECK(hipMemcpy(d_wave, wave, sizeof(int16_t) * total_samples, hipMemcpyHostToDevice));
+  }
+  int rc = snf_plan_run_batch_device(plan, d_wave, sample_offsets, n_utts, vtln_warp, d_out,
+                                     frame_offsets, nullptr);
+  if (rc) return rc;
+  if (total_frames > 0) {
+    std::lock_guard<std::mutex> lock(plan->mu);
+    SNF_HIP_CHECK(hipMemcpy(out, d_out, sizeof(float) * total_frames * plan->ndims,
+                            hipMemcpyDeviceToHost));
+  }
+  return SNF_OK;
+}
+
+int32_t snf_post_ndims(const snf_plan* plan, int32_t in_cols) {
+  if (!plan) return -1;
+  if (plan->kind == SNF_KIND_DELTA) return in_cols * (plan->o.delta_order + 1);
+  if (plan->kind == SNF_KIND_PITCH_POST) return plan->ndims;
+  return -1;
+}
+
+int snf_post_run_batch_device(snf_plan* plan, const float* d_in, int32_t in_cols,
+                              const int64_t* frame_offsets, int64_t n_utts, float* d_out,
+                              void* stream) {
+  if (!plan) return set_error(SNF_E_INVALID, "null plan");
+  if (n_utts <= 0) return n_utts == 0 ? SNF_OK : set_error(SNF_E_INVALID, "n_utts < 0");
+  if (!frame_offsets) return set_error(SNF_E_INVALID, "null offsets table");
+  for (int64_t u = 0; u < n_utts; ++u)
+    if (frame_offsets[u + 1] < frame_offsets[u])
+      return set_error(SNF_E_INVALID, "offsets tables must be non-decreasing");
+  std::lock_guard<std::mutex> lock(plan->mu);
+  int rc = guard_device(plan);
+  if (rc) return rc;
+  const int64_t total_frames = frame_offsets[n_utts];
+  if (total_frames == 0) return SNF_OK;
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : plan->stream;
+  const bool own_stream = (stream == nullptr);
+  std::vector<int64_t> foff(frame_offsets, frame_offsets + n_utts + 1);
+  if ((rc = plan->s_foff.upload(foff, s))) return rc;
+  SNF_HIP_CHECK(hipStreamSynchronize(s));
+  if (own_stream) begin_timing(plan);
+  if (plan->kind == SNF_KIND_DELTA) {
+    if (in_cols <= 0) return set_error(SNF_E_INVALID, "in_cols must be positive");
+    if ((rc = launch_deltas(plan->dp, d_in, in_cols, plan->s_foff.as<int64_t>(), n_utts,
+                            total_frames, d_out, s)))
+      return rc;
+    if (own_stream) mark_kernel(plan, "delta_kernel");
+  } else if (plan->kind == SNF_KIND_PITCH_POST) {
+    if (in_cols != 2)
+      return set_error(SNF_E_INVALID, "data shape must be (_, 2), but it is (_, " +
+                                          std::to_string(in_cols) + ")");
+    if ((rc = launch_pitch_post(plan->ppost, d_in, plan->s_foff.as<int64_t>(), n_utts,
+                                total_frames, d_out, s)))
+      return rc;
+    if (own_stream) mark_kernel(plan, "pitch_post_kernel");
+  } else {
+    return set_error(SNF_E_INVALID, "plan kind is not a post-processor");
+  }
+  if (own_stream) SNF_HIP_CHECK(hipStreamSynchronize(s));
+  return SNF_OK;
+}
+
+int snf_post_run_batch(snf_plan* plan, const float* in, int32_t in_cols,
+                       const int64_t* frame_offsets, int64_t n_utts, float* out) {
+  if (!plan) return set_error(SNF_E_INVALID, "null plan");
+  if (n_utts <= 0) return n_utts == 0 ? SNF_OK : set_error(SNF_E_INVALID, "n_utts < 0");
+  if (!frame_offsets) return set_error(SNF_E_INVALID, "null offsets table");
+  const int64_t total_frames = frame_offsets[n_utts];
+  const int32_t out_cols = snf_post_ndims(plan, in_cols);
+  if (out_cols <= 0 || in_cols <= 0) return set_error(SNF_E_INVALID, "bad column count");
+  if (total_frames == 0) return SNF_OK;
+  float *d_in, *d_out;
+  {
+    std::lock_guard<std::mutex> lock(plan->mu);
+    int rc = guard_device(plan);
+    if (rc) return rc;
+    if ((rc = plan->s_in.ensure(sizeof(float) * static_cast<size_t>(total_frames) * in_cols))) return rc;
+    if ((rc = plan->s_out.ensure(sizeof(float) * static_cast<size_t>(total_frames) * out_cols))) return rc;
+    d_in = plan->s_in.as<float>();
+    d_out = plan->s_out.as<float>();
+    SNF_HIP_CHECK(hipMemcpy(d_in, in, sizeof(float) * total_frames * in_cols, hipMemcpyHostToDevice));
+  }
+  int rc = snf_post_run_batch_device(plan, d_in, in_cols, frame_offsets, n_utts, d_out, nullptr);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(plan->mu);
+  SNF_HIP_CHECK(hipMemcpy(out, d_out, sizeof(float) * total_frames * out_cols, hipMemcpyDeviceToHost));
+  return SNF_OK;
+}
+
+int snf_malloc(void** dptr, uint64_t bytes) {
+  SNF_HIP_CHECK(hipMalloc(dptr, bytes));
+  return SNF_OK;
+}
+int snf_free(void* dptr) {
+  SNF_HIP_CHECK(hipFree(dptr));
+  return SNF_OK;
+}
+int snf_memcpy_h2d(void* dst, const void* src, uint64_t bytes) {
+  SNF_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return SNF_OK;
+}
+int snf_memcpy_d2h(void* dst, const void* src, uint64_t bytes) {
+  SNF_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return SNF_OK;
+}
+int snf_memset(void* dst, int value, uint64_t bytes) {
+  SNF_HIP_CHECK(hipMemset(dst, value, bytes));
+  return SNF_OK;
+}
+
+float snf_plan_last_kernel_ms(const snf_plan* plan, int which) {
+  if (!plan || !plan->events_valid || which < 0 || which > plan->n_slots) return -1.0f;
+  float ms = -1.0f;
+  if (hipEventSynchronize(plan->ev[plan->n_slots]) != hipSuccess) return -1.0f;
+  hipError_t e = which == 0 ? hipEventElapsedTime(&ms, plan->ev[0], plan->ev[plan->n_slots])
+                            : hipEventElapsedTime(&ms, plan->ev[which - 1], plan->ev[which]);
+  return e == hipSuccess ? ms : -1.0f;
+}
+const char* snf_plan_kernel_name(const snf_plan* plan, int which) {
+  if (!plan || which <= 0 || which > plan->n_slots) return nullptr;
+  return plan->slot_name[which];
+}
+
+}  // extern "C"

@@ -1,0 +1,284 @@
+// Generic fused speech-feature kernel for gfx950 (MI355X).
+//
+// One wavefront (64 lanes) owns one frame at a time; its whole pipeline
+//   ExtractWindow (+reflection) -> dither -> DC removal -> raw log-energy -> pre-emphasis -> window
+//   -> zero-pad -> real FFT (packed complex radix-2 in LDS) -> power spectrum
+//   -> {log spectrogram | mel filterbank (+log) | MFCC DCT+lifter | raw mel for PLP}
+// runs out of a wave-private LDS region, so a frame makes exactly one trip from HBM (int16 samples
+// in, float32 features out) and no workgroup barrier is ever needed.  This kernel handles every
+// option combination (any window length / FFT size / window type / snip_edges / VTLN warp);
+// kernels_fbank512.hip specialises the headline 25 ms / 16 kHz (512-point) configuration.
+//
+// Restates [KALDI-UPSTREAM] feature-window.cc (ExtractWindow / ProcessWindow), feature-fbank.cc,
+// feature-mfcc.cc, feature-spectrogram.cc, mel-computations.cc (MelBanks::Compute), which the
+// reference reaches through pykaldi at shennong/processor/base.py:429-431 and
+// spectrogram.py:138-140; the in-tree restatements of the per-frame recipe are plp.py:171-260.
+#include <float.h>
+
+#include "snf_internal.h"
+
+namespace snf {
+
+namespace {
+
+constexpr int kWaves = 4;  // wavefronts per workgroup (independent of each other)
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // make this wave's LDS writes visible to its own later reads (all 64 lanes run in lock-step;
+  // only compiler reordering and outstanding lgkm counters have to be fenced)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// largest u with offsets[u] <= g (offsets[n] > g): the utterance that owns global row g
+__device__ __forceinline__ int64_t find_utt(const int64_t* __restrict__ offsets, int64_t n,
+                                            int64_t g) {
+  int64_t lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (offsets[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+// counter-based N(0,1): statistical stand-in for Kaldi's RandGauss() dither (not reproducible
+// against C rand(); parity tests run with dither = 0 exactly like the reference's own tests)
+__device__ __forceinline__ float gauss(uint64_t seed, uint64_t frame, uint32_t i) {
+  const uint64_t h = mix64(seed ^ mix64(frame * 0x100000001B3ull + i));
+  const float u1 = (static_cast<float>((h >> 40) & 0xFFFFFF) + 1.0f) * (1.0f / 16777216.0f);
+  const float u2 = static_cast<float>((h >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+__device__ __forceinline__ int bit_reverse(int v, int bits) {
+  return bits == 0 ? 0 : static_cast<int>(__brev(static_cast<unsigned>(v)) >> (32 - bits));
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kWaves * 64) void mel_features_generic_kernel(
+    const MelParams p, const BatchArgs b, float* __restrict__ out, const int out_cols,
+    double* __restrict__ energy_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int N = p.padded, M = p.half, L = p.win_len;
+  // wave-private LDS: xs[N+2] (samples, later power spectrum), zs[N] (complex FFT data), mel[nb]
+  const int xs_floats = (N + 2 + 1) & ~1;
+  const int mel_floats = (p.num_bins + 1) & ~1;
+  const size_t per_wave = static_cast<size_t>(xs_floats + N + mel_floats);
+  float* xs = reinterpret_cast<float*>(smem) + per_wave * wid;
+  float* zsf = xs + xs_floats;
+  float2* zs = reinterpret_cast<float2*>(zsf);
+  float* melbuf = zsf + N;
+  float* ps = xs;
+
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kWaves;
+  for (int64_t g = static_cast<int64_t>(blockIdx.x) * kWaves + wid; g < b.total_frames;
+       g += stride) {
+    // ---- which utterance / which frame ---------------------------------------------------------
+    const int64_t u = find_utt(b.frame_offsets, b.n_utts, g);
+    const int64_t f = g - b.frame_offsets[u];
+    const int64_t s0 = b.sample_offsets[u];
+    const int64_t n = b.sample_offsets[u + 1] - s0;
+    const int warp_id = b.utt_warp ? b.utt_warp[u] : 0;
+    const int64_t start = p.snip_edges
+                              ? f * p.win_shift
+                              : f * p.win_shift + p.win_shift / 2 - p.win_len / 2;
+    const int16_t* __restrict__ w = b.wave + s0;
+
+    // ---- ExtractWindow: copy L samples, reflecting at the utterance edges ------------------------
+    float part = 0.0f;
+    for (int i = lane; i < L; i += 64) {
+      int64_t k = start + i;
+      while (k < 0 || k >= n) k = k < 0 ? -k - 1 : 2 * n - 1 - k;
+      float v = static_cast<float>(w[k]);
+      if (p.dither != 0.0f) v += p.dither * gauss(p.seed, static_cast<uint64_t>(g), i);
+      xs[i] = v;
+      part += v;
+    }
+    // ---- ProcessWindow: DC removal, raw energy ---------------------------------------------------
+    float neg_mean = 0.0f;
+    if (p.remove_dc) neg_mean = -wave_sum(part) / static_cast<float>(L);
+    float e_part = 0.0f;
+    for (int i = lane; i < L; i += 64) {
+      const float v = xs[i] + neg_mean;
+      xs[i] = v;
+      e_part += v * v;
+    }
+    float raw_energy = 0.0f;
+    if (p.need_raw) raw_energy = wave_sum(e_part);
+    wave_lds_sync();
+    // ---- pre-emphasis (needs the left neighbour), window, zero-pad, bit-reversed packing ---------
+    float e2_part = 0.0f;
+    for (int i = lane; i < N; i += 64) {
+      float y = 0.0f;
+      if (i < L) {
+        const float x = xs[i];
+        const float xm = xs[i > 0 ? i - 1 : 0];
+        y = (x - p.preemph * xm) * p.window[i];
+      }
+      e2_part += y * y;
+      if (p.pow2) zsf[2 * bit_reverse(i >> 1, p.log2_half) + (i & 1)] = y;
+      else zsf[i] = y;
+    }
+    float post_energy = 0.0f;
+    if (p.need_post) post_energy = wave_sum(e2_part);
+
+    if (p.pow2) {
+      // ---- complex FFT of size M = N/2 on the packed frame (radix-2 DIT, data stays in LDS) -------
+      for (int s = 0; s < p.log2_half; ++s) {
+        wave_lds_sync();
+        const int half = 1 << s;
+        const int tw_stride = M >> (s + 1);
+        for (int j = lane; j < (M >> 1); j += 64) {
+          const int k = j & (half - 1);
+          const int i0 = ((j >> s) << (s + 1)) + k, i1 = i0 + half;
+          const float2 a = zs[i0], c = zs[i1];
+          const float2 t = p.tw_fft[k * tw_stride];
+          const float xr = c.x * t.x - c.y * t.y, xi = c.x * t.y + c.y * t.x;
+          zs[i0] = make_float2(a.x + xr, a.y + xi);
+          zs[i1] = make_float2(a.x - xr, a.y - xi);
+        }
+      }
+      wave_lds_sync();
+      // ---- real-FFT unpack + ComputePowerSpectrum (Nyquist bin kept like Kaldi) -------------------
+      if (lane == 0) {
+        const float2 z0 = zs[0];
+        const float dc = z0.x + z0.y, ny = z0.x - z0.y;
+        ps[0] = dc * dc;
+        ps[M] = ny * ny;
+      }
+      for (int k = 1 + lane; 2 * k <= M; k += 64) {
+        const float2 zk = zs[k], zm = zs[M - k];
+        const float2 t = p.tw_unpack[k];
+        const float c_re = 0.5f * (zk.x + zm.x), c_im = 0.5f * (zk.y - zm.y);
+        const float d_re = 0.5f * (zk.y + zm.y), d_im = -0.5f * (zk.x - zm.x);
+        const float t_re = d_re * t.x - d_im * t.y, t_im = d_re * t.y + d_im * t.x;
+        const float a_re = c_re + t_re, a_im = c_im + t_im;
+        ps[k] = a_re * a_re + a_im * a_im;
+        if (M - k != k) {
+          const float b_re = c_re - t_re, b_im = t_im - c_im;
+          ps[M - k] = b_re * b_re + b_im * b_im;
+        }
+      }
+    } else {
+      // ---- direct DFT for non power-of-two frames (round_to_power_of_two = False) -----------------
+      wave_lds_sync();
+      for (int k = lane; k <= M; k += 64) {
+        float re = 0.0f, im = 0.0f;
+        int idx = 0;
+        for (int t = 0; t < N; ++t) {
+          const float2 wv = p.tw_dft[idx];
+          const float x = zsf[t];
+          re += x * wv.x;
+          im += x * wv.y;
+          idx += k;
+          if (idx >= N) idx -= N;
+        }
+        ps[k] = (k == 0 || k == M) ? re * re : re * re + im * im;
+      }
+    }
+    wave_lds_sync();
+
+    // ---- log energy column -----------------------------------------------------------------------
+    const float e_lin = p.need_raw ? raw_energy : post_energy;
+    float log_energy = 0.0f;
+    if (p.kind == SNF_KIND_PLP) {
+      // shennong's PLP floors with float64 eps and takes a double log (reference plp.py:191-193)
+      if ((p.need_raw || p.need_post) && lane == 0)
+        energy_out[g] = log(fmax(static_cast<double>(e_lin), DBL_EPSILON));
+    } else if (p.need_raw || p.need_post) {
+      log_energy = logf(fmaxf(e_lin, FLT_EPSILON));
+      if (p.has_floor && log_energy < p.log_energy_floor) log_energy = p.log_energy_floor;
+    }
+
+    float* __restrict__ row = out + g * static_cast<int64_t>(out_cols);
+    if (p.kind == SNF_KIND_SPECTROGRAM) {
+      for (int k = lane; k <= M; k += 64) {
+        float v = logf(fmaxf(ps[k], FLT_EPSILON));
+        if (k == 0) v = log_energy;
+        row[k] = v;
+      }
+    } else {
+      const int nb = p.num_bins;
+      const int* __restrict__ mfirst = p.mel_first + warp_id * nb;
+      const int* __restrict__ msize = p.mel_size + warp_id * nb;
+      const int* __restrict__ moff = p.mel_offset + warp_id * nb;
+      if (p.kind == SNF_KIND_FBANK && !p.use_power) {
+        for (int k = lane; k <= M; k += 64) ps[k] = sqrtf(ps[k]);
+        wave_lds_sync();
+      }
+      const int mel_col = (p.kind == SNF_KIND_FBANK && p.use_energy && !p.htk_compat) ? 1 : 0;
+      for (int m = lane; m < nb; m += 64) {
+        const int first = mfirst[m], size = msize[m];
+        const float* __restrict__ wt = p.mel_w + moff[m];
+        float acc = 0.0f;
+        for (int j = 0; j < size; ++j) acc += wt[j] * ps[first + j];
+        if (p.kind == SNF_KIND_FBANK) {
+          row[mel_col + m] = p.use_log ? logf(fmaxf(acc, FLT_EPSILON)) : acc;
+        } else if (p.kind == SNF_KIND_MFCC) {
+          melbuf[m] = logf(fmaxf(acc, FLT_EPSILON));
+        } else {  // PLP: linear mel energies, the recipe continues in plp_tail_kernel
+          row[m] = acc;
+        }
+      }
+      if (p.kind == SNF_KIND_FBANK && p.use_energy && lane == 0)
+        row[p.htk_compat ? nb : 0] = log_energy;
+      if (p.kind == SNF_KIND_MFCC) {
+        wave_lds_sync();
+        for (int c = lane; c < p.num_ceps; c += 64) {
+          const float* __restrict__ d = p.dct + c * nb;
+          float v = 0.0f;
+          for (int m = 0; m < nb; ++m) v += d[m] * melbuf[m];
+          if (p.lifter) v *= p.lifter[c];
+          if (c == 0 && p.use_energy) v = log_energy;
+          int oc = c;
+          if (p.htk_compat) {
+            oc = c == 0 ? p.num_ceps - 1 : c - 1;
+            if (c == 0 && !p.use_energy)
+              v = static_cast<float>(static_cast<double>(v) * 1.4142135623730950488016887);
+          }
+          row[oc] = v;
+        }
+      }
+    }
+    wave_lds_sync();  // the next frame reuses xs/zs
+  }
+}
+
+int launch_mel_features(const MelParams& p, const BatchArgs& b, float* out, int out_cols,
+                        double* energy_out, hipStream_t stream) {
+  if (b.total_frames <= 0) return SNF_OK;
+  const int xs_floats = (p.padded + 2 + 1) & ~1;
+  const int mel_floats = (p.num_bins + 1) & ~1;
+  const size_t lds = sizeof(float) * kWaves * static_cast<size_t>(xs_floats + p.padded + mel_floats);
+  if (lds > 160 * 1024)
+    return set_error(SNF_E_RUNTIME, "frame too long for the LDS-resident FFT (padded window > 4096)");
+  if (lds > 64 * 1024)
+    SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mel_features_generic_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(lds)));
+  int64_t blocks = (b.total_frames + kWaves - 1) / kWaves;
+  const int64_t max_blocks = 256 * 8;  // 256 CUs x 8 resident workgroups of 4 waves
+  if (blocks > max_blocks) blocks = max_blocks;
+  hipLaunchKernelGGL(mel_features_generic_kernel, dim3(static_cast<unsigned>(blocks)),
+                     dim3(kWaves * 64), lds, stream, p, b, out, out_cols, energy_out);
+  SNF_HIP_CHECK(hipGetLastError());
+  return SNF_OK;
+}
+
+}  // namespace snf

@@ -1,0 +1,348 @@
+// Kaldi pitch tracker on gfx950: the reference reaches it through
+// kaldi.feat.pitch.compute_kaldi_pitch (shennong/processor/pitch_kaldi.py:296-299).
+//
+// Restates [KALDI-UPSTREAM] pitch-functions.cc (OnlinePitchFeatureImpl::AcceptWaveform /
+// InputFinished / RecomputeBacktraces, ComputeCorrelation, ComputeNccf, ComputeLocalCost,
+// PitchFrameInfo::ComputeBacktraces) and resample.cc (LinearResample, ArbitraryResample) for the
+// offline single-chunk call the reference makes (frames_per_chunk = 0).
+//
+// Pipeline (three launches per batch):
+//   1. pitch_resample_kernel   one thread per downsampled sample: 16 kHz -> 4 kHz windowed-sinc FIR
+//   2. pitch_stats_kernel      one workgroup per utterance: signal sum / sum of squares (ballast)
+//   3. pitch_track_kernel      one workgroup per utterance: per frame NCCF at the integer lags
+//      (batched-lag correlation in LDS) -> sinc resampling to the log-spaced lags -> Viterbi forward
+//      step over all states in parallel; then traceback and the POV NCCF of the chosen lags.
+// The Viterbi recursion is sequential in time, so an utterance stays on one CU; utterances are the
+// parallel axis (10 000+ per launch).
+#include <float.h>
+
+#include "snf_internal.h"
+
+namespace snf {
+
+namespace {
+
+__device__ __forceinline__ int64_t find_utt(const int64_t* __restrict__ offsets, int64_t n,
+                                            int64_t g) {
+  int64_t lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (offsets[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+constexpr int kTrackThreads = 512;
+
+}  // namespace
+
+// ---- 1. LinearResample ---------------------------------------------------------------------------
+__global__ void pitch_resample_kernel(const PitchDevTables t, const PitchBatch b,
+                                      float* __restrict__ down) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= b.total_down) return;
+  const int64_t u = find_utt(b.down_offsets, b.n_utts, idx);
+  const int64_t k = idx - b.down_offsets[u];
+  const int64_t s0 = b.sample_offsets[u], n = b.sample_offsets[u + 1] - s0;
+  const int16_t* __restrict__ w = b.wave + s0;
+  const int64_t unit = k / t.rs_out_unit;
+  const int wrapped = static_cast<int>(k - unit * t.rs_out_unit);
+  const int64_t first_in = t.rs_first[wrapped] + unit * t.rs_in_unit;
+  const float* __restrict__ wt = t.rs_w + wrapped * t.rs_max_taps;
+  const int ntaps = t.rs_ntaps[wrapped];
+  float s = 0.0f;
+  for (int i = 0; i < ntaps; ++i) {
+    const int64_t j = first_in + i;
+    if (j >= 0 && j < n) s += wt[i] * static_cast<float>(w[j]);
+  }
+  down[idx] = s;
+}
+
+// ---- 2. signal statistics for the NCCF ballast -----------------------------------------------------
+// stats[u] = {sumsq_phase1, sum_phase1, sumsq_all, sum_all}: Kaldi accumulates float BLAS dot/sum of
+// each chunk into doubles; phase 1 = what the resampler emitted before the flush.
+__global__ void pitch_stats_kernel(const PitchBatch b, const float* __restrict__ down,
+                                   double* __restrict__ stats) {
+  const int64_t u = blockIdx.x;
+  const int64_t d0 = b.down_offsets[u], nd = b.down_offsets[u + 1] - d0, nd1 = b.down_phase1[u];
+  const float* __restrict__ x = down + d0;
+  double sq1 = 0, s1 = 0, sq2 = 0, s2 = 0;
+  for (int64_t i = threadIdx.x; i < nd; i += blockDim.x) {
+    const double v = x[i];
+    if (i < nd1) { sq1 += v * v; s1 += v; } else { sq2 += v * v; s2 += v; }
+  }
+  __shared__ double red[4][16];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  sq1 = wave_sum_d(sq1); s1 = wave_sum_d(s1); sq2 = wave_sum_d(sq2); s2 = wave_sum_d(s2);
+  if (lane == 0) { red[0][wid] = sq1; red[1][wid] = s1; red[2][wid] = sq2; red[3][wid] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, c = 0, d = 0, e = 0;
+    for (int i = 0; i < nw; ++i) { a += red[0][i]; c += red[1][i]; d += red[2][i]; e += red[3][i]; }
+    // each chunk's BLAS result is a float that is then added to a double accumulator
+    const double fsq1 = static_cast<float>(a), fs1 = static_cast<float>(c);
+    const double fsq2 = static_cast<float>(d), fs2 = static_cast<float>(e);
+    stats[u * 4 + 0] = fsq1;
+    stats[u * 4 + 1] = fs1;
+    stats[u * 4 + 2] = fsq1 + fsq2;
+    stats[u * 4 + 3] = fs1 + fs2;
+  }
+}
+
+// ---- 3. NCCF + Viterbi ------------------------------------------------------------------------------
+namespace {
+
+struct TrackShared {
+  float* win;      // [full_len]
+  float* nccf;     // [num_lags]      nccf_pitch at the integer lags
+  float* norm;     // [num_lags]      e1*e2 (for avg_norm_prod in the recompute pass)
+  float* fwd;      // [num_states]
+  float* nxt;      // [num_states]
+  float* red;      // [16]
+};
+
+__device__ __forceinline__ float block_min(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float m = red[0];
+  for (int i = 1; i < nw; ++i) m = fminf(m, red[i]);
+  return m;
+}
+
+// loads frame t of the utterance into sh.win, removes the mean of its first win_size samples and
+// returns e1 = sum of squares of those samples (every wave computes the two reductions redundantly)
+__device__ __forceinline__ float load_frame(const PitchDevTables& t, const float* __restrict__ x,
+                                            int64_t nd, int64_t frame, float* win) {
+  int64_t start;
+  if (t.snip_edges) start = frame * t.win_shift;
+  else start = static_cast<int64_t>((static_cast<double>(frame) + 0.5) * t.win_shift) - t.full_len / 2;
+  __syncthreads();
+  for (int i = threadIdx.x; i < t.full_len; i += blockDim.x) {
+    const int64_t k = start + i;
+    win[i] = (k >= 0 && k < nd) ? x[k] : 0.0f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  float s = 0.0f;
+  for (int i = lane; i < t.win_size; i += 64) s += win[i];
+  const float neg_mean = -wave_sum_f(s) / static_cast<float>(t.win_size);
+  __syncthreads();
+  for (int i = threadIdx.x; i < t.full_len; i += blockDim.x) win[i] += neg_mean;
+  __syncthreads();
+  float e = 0.0f;
+  for (int i = lane; i < t.win_size; i += 64) e += win[i] * win[i];
+  return wave_sum_f(e);
+}
+
+// one forward (Viterbi) pass over all frames; returns with sh.fwd = final normalised forward cost
+__device__ void forward_pass(const PitchDevTables& t, const float* __restrict__ x, int64_t nd,
+                             int64_t T, int64_t T1, double ms1, double ms2, bool rescale,
+                             float new_ballast, int16_t* __restrict__ bp, const TrackShared& sh) {
+  const int S = t.num_states, L = t.num_lags, W = t.win_size;
+  for (int s = threadIdx.x; s < S; s += blockDim.x) sh.fwd[s] = 0.0f;
+  for (int64_t frame = 0; frame < T; ++frame) {
+    const double ms = frame < T1 ? ms1 : ms2;
+    const float ballast = static_cast<float>(pow(ms * W, 2.0) * static_cast<double>(t.nccf_ballast));
+    const float e1 = load_frame(t, x, nd, frame, sh.win);
+    // batched-lag correlation: one thread per integer lag
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+      const float* __restrict__ a = sh.win;
+      const float* __restrict__ c = sh.win + t.first_lag + l;
+      float e2 = 0.0f, ip = 0.0f;
+      for (int i = 0; i < W; ++i) {
+        e2 += c[i] * c[i];
+        ip += a[i] * c[i];
+      }
+      const float norm = e1 * e2;
+      const float den = static_cast<float>(sqrt(static_cast<double>(norm + ballast)));
+      sh.nccf[l] = den != 0.0f ? ip / den : 0.0f;
+      sh.norm[l] = norm;
+    }
+    __syncthreads();
+    float scale = 1.0f;
+    if (rescale) {
+      float sum = 0.0f;
+      for (int l = 0; l < L; ++l) sum += sh.norm[l];
+      const float avg_norm_prod = sum / static_cast<float>(L);
+      const float old_ms = static_cast<float>(ms);
+      const float old_ballast =
+          static_cast<float>(pow(static_cast<double>(old_ms) * W, 2.0) * static_cast<double>(t.nccf_ballast));
+      scale = powf((old_ballast + avg_norm_prod) / (new_ballast + avg_norm_prod), 0.5f);
+    }
+    // sinc-resample the NCCF to the log-spaced lags, local cost, Viterbi step
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+      const float* __restrict__ wt = t.ar_w + s * t.ar_max_taps;
+      const float* __restrict__ src = sh.nccf + t.ar_first[s];
+      const int n = t.ar_n[s];
+      float v = 0.0f;
+      for (int j = 0; j < n; ++j) v += src[j] * wt[j];
+      if (rescale) v *= scale;
+      float local = 1.0f - v;
+      local += t.soft_min_f0 * t.lags[s] * v;
+      // exact argmin_j (j-s)^2 * factor + fwd[j]; lowest index wins ties (what Kaldi's bounded
+      // two-sweep search converges to).  No FMA contraction: costs must round like Kaldi's.
+      const float fs = static_cast<float>(s);
+      float best = __fadd_rn(__fmul_rn(fs * fs, t.inter_frame_factor), sh.fwd[0]);
+      int best_j = 0;
+      for (int j = 1; j < S; ++j) {
+        const float d = static_cast<float>(j) - fs;
+        const float c = __fadd_rn(__fmul_rn(d * d, t.inter_frame_factor), sh.fwd[j]);
+        if (c < best) { best = c; best_j = j; }
+      }
+      sh.nxt[s] = __fadd_rn(best, local);
+      bp[frame * S + s] = static_cast<int16_t>(best_j);
+    }
+    float m = FLT_MAX;
+    __syncthreads();
+    for (int s = threadIdx.x; s < S; s += blockDim.x) m = fminf(m, sh.nxt[s]);
+    m = block_min(m, sh.red);
+    for (int s = threadIdx.x; s < S; s += blockDim.x) sh.fwd[s] = sh.nxt[s] + (-m);
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kTrackThreads) void pitch_track_kernel(
+    const PitchDevTables t, const PitchBatch b, const float* __restrict__ down,
+    const double* __restrict__ stats, int16_t* __restrict__ backptr, int32_t* __restrict__ states,
+    float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int64_t u = blockIdx.x;
+  const int64_t f0 = b.frame_offsets[u], T = b.frame_offsets[u + 1] - f0;
+  if (T <= 0) return;
+  const int64_t T1 = b.frames_phase1[u];
+  const int64_t d0 = b.down_offsets[u], nd = b.down_offsets[u + 1] - d0, nd1 = b.down_phase1[u];
+  const float* __restrict__ x = down + d0;
+  const int S = t.num_states, L = t.num_lags, W = t.win_size;
+  TrackShared sh;
+  sh.win = reinterpret_cast<float*>(smem);
+  sh.nccf = sh.win + ((t.full_len + 3) & ~3);
+  sh.norm = sh.nccf + ((L + 3) & ~3);
+  sh.fwd = sh.norm + ((L + 3) & ~3);
+  sh.nxt = sh.fwd + ((S + 3) & ~3);
+  sh.red = sh.nxt + ((S + 3) & ~3);
+  int16_t* __restrict__ bp = backptr + f0 * S;
+
+  const double sq1 = stats[u * 4 + 0], s1 = stats[u * 4 + 1], sq2 = stats[u * 4 + 2],
+               s2 = stats[u * 4 + 3];
+  const double n1 = static_cast<double>(nd1), n2 = static_cast<double>(nd);
+  const double ms1 = nd1 > 0 ? sq1 / n1 - pow(s1 / n1, 2.0) : 0.0;
+  const double ms2 = sq2 / n2 - pow(s2 / n2, 2.0);
+
+  forward_pass(t, x, nd, T, T1, ms1, ms2, false, 0.0f, bp, sh);
+
+  // InputFinished(): RecomputeBacktraces when the utterance is shorter than recompute_frame and some
+  // frame saw a mean-square energy more than 1 % away from the final one
+  if (T < t.recompute_frame && T1 > 0) {
+    const double mean = s2 / n2;
+    const float ms_final = static_cast<float>(sq2 / n2 - mean * mean);
+    const float a = static_cast<float>(ms1);
+    const bool approx_equal = (a == ms_final) || (fabsf(a - ms_final) <= 0.01f * (fabsf(a) + fabsf(ms_final)));
+    if (!approx_equal) {
+      const float new_ballast =
+          static_cast<float>(pow(static_cast<double>(ms_final) * W, 2.0) * static_cast<double>(t.nccf_ballast));
+      __syncthreads();
+      forward_pass(t, x, nd, T, T1, ms1, ms2, true, new_ballast, bp, sh);
+    }
+  }
+
+  // traceback (sequential chain of dependent loads; L2-resident)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int best = 0;
+    float bv = sh.fwd[0];
+    for (int s = 1; s < S; ++s)
+      if (sh.fwd[s] < bv) { bv = sh.fwd[s]; best = s; }
+    for (int64_t frame = T - 1; frame >= 0; --frame) {
+      states[f0 + frame] = best;
+      best = bp[frame * S + best];
+    }
+  }
+  __syncthreads();
+  __threadfence_block();
+
+  // output rows: (POV NCCF resampled at the chosen lag, 1 / lag); the POV NCCF (ballast 0) is only
+  // needed at the chosen state, so it is recomputed here instead of being stored for all states
+  for (int64_t frame = threadIdx.x; frame < T; frame += blockDim.x) {
+    const int s = states[f0 + frame];
+    int64_t start;
+    if (t.snip_edges) start = frame * t.win_shift;
+    else start = static_cast<int64_t>((static_cast<double>(frame) + 0.5) * t.win_shift) - t.full_len / 2;
+    float sum = 0.0f;
+    for (int i = 0; i < W; ++i) {
+      const int64_t k = start + i;
+      sum += (k >= 0 && k < nd) ? x[k] : 0.0f;
+    }
+    const float neg_mean = -sum / static_cast<float>(W);
+    float e1 = 0.0f;
+    for (int i = 0; i < W; ++i) {
+      const int64_t k = start + i;
+      const float v = ((k >= 0 && k < nd) ? x[k] : 0.0f) + neg_mean;
+      e1 += v * v;
+    }
+    const float* __restrict__ wt = t.ar_w + s * t.ar_max_taps;
+    const int first = t.ar_first[s], n = t.ar_n[s];
+    float pov = 0.0f;
+    for (int j = 0; j < n; ++j) {
+      const int lag = t.first_lag + first + j;
+      float e2 = 0.0f, ip = 0.0f;
+      for (int i = 0; i < W; ++i) {
+        const int64_t ka = start + i, kc = ka + lag;
+        const float va = ((ka >= 0 && ka < nd) ? x[ka] : 0.0f) + neg_mean;
+        const float vc = ((kc >= 0 && kc < nd && i + lag < t.full_len) ? x[kc] : 0.0f) + neg_mean;
+        e2 += vc * vc;
+        ip += va * vc;
+      }
+      const float norm = e1 * e2;
+      const float den = static_cast<float>(sqrt(static_cast<double>(norm + 0.0f)));
+      const float nccf = den != 0.0f ? ip / den : 0.0f;
+      pov += nccf * wt[j];
+    }
+    out[(f0 + frame) * 2 + 0] = pov;
+    out[(f0 + frame) * 2 + 1] = 1.0f / t.lags[s];
+  }
+}
+
+int launch_pitch(const PitchDevTables& t, const PitchBatch& b, float* down, double* stats,
+                 int16_t* backptr, int32_t* states, float* out, hipStream_t stream) {
+  if (b.total_frames <= 0) return SNF_OK;
+  if (t.num_states > 32767) return set_error(SNF_E_RUNTIME, "too many pitch states (delta_pitch too small)");
+  if (b.total_down > 0) {
+    const int threads = 256;
+    hipLaunchKernelGGL(pitch_resample_kernel,
+                       dim3(static_cast<unsigned>((b.total_down + threads - 1) / threads)),
+                       dim3(threads), 0, stream, t, b, down);
+    SNF_HIP_CHECK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(pitch_stats_kernel, dim3(static_cast<unsigned>(b.n_utts)), dim3(256), 0, stream,
+                     b, down, stats);
+  SNF_HIP_CHECK(hipGetLastError());
+  const size_t lds = sizeof(float) * (((t.full_len + 3) & ~3) + 2 * ((t.num_lags + 3) & ~3) +
+                                      2 * ((t.num_states + 3) & ~3) + 16);
+  if (lds > 160 * 1024) return set_error(SNF_E_RUNTIME, "pitch state space does not fit in LDS");
+  if (lds > 64 * 1024)
+    SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pitch_track_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+  hipLaunchKernelGGL(pitch_track_kernel, dim3(static_cast<unsigned>(b.n_utts)), dim3(kTrackThreads),
+                     lds, stream, t, b, down, stats, backptr, states, out);
+  SNF_HIP_CHECK(hipGetLastError());
+  return SNF_OK;
+}
+
+}  // namespace snf

@@ -1,0 +1,299 @@
+// Frame-matrix kernels: RASTA filtering and the PLP tail (reference plp.py:64-146, :548-626),
+// delta / delta-delta (reference postprocessor/delta.py:129-131 -> [KALDI-UPSTREAM]
+// feature-functions.cc DeltaFeatures) and pitch post-processing (reference
+// processor/pitch_kaldi.py:535-537 -> [KALDI-UPSTREAM] pitch-functions.cc OnlineProcessPitch).
+//
+// These are pure HBM-streaming kernels over [frames, cols] float32 matrices: each row is read once
+// (plus an edge-clamped halo that stays in L2) and each output row written once.
+#include <float.h>
+
+#include "snf_internal.h"
+
+namespace snf {
+
+namespace {
+
+__device__ __forceinline__ int64_t find_utt(const int64_t* __restrict__ offsets, int64_t n,
+                                            int64_t g) {
+  int64_t lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (offsets[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ float gauss(uint64_t seed, uint64_t idx) {
+  const uint64_t h = mix64(seed ^ mix64(idx));
+  const float u1 = (static_cast<float>((h >> 40) & 0xFFFFFF) + 1.0f) * (1.0f / 16777216.0f);
+  const float u2 = static_cast<float>((h >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+constexpr int kMaxBins = 126;
+constexpr int kMaxLpc = 63;
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// RASTA: one thread per (utterance, mel bin), sequential over the utterance's frames.  Log domain,
+// float64 IIR state, direct form II transposed exactly like scipy.signal.lfilter, first four frames
+// emit exp(0) = 1 and prime the FIR state with zi * x[0] (reference plp.py:87-88, :121-146).
+// ------------------------------------------------------------------------------------------------
+__global__ void rasta_kernel(float* __restrict__ mel, const BatchArgs b, const int nb) {
+  const int64_t tid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (tid >= b.n_utts * nb) return;
+  const int64_t u = tid / nb;
+  const int bin = static_cast<int>(tid - u * nb);
+  const int64_t f0 = b.frame_offsets[u], f1 = b.frame_offsets[u + 1];
+  const double b0 = 0.2, b1 = 0.1, b2 = 0.0, b3 = -0.1, b4 = -0.2, a1 = -0.94;
+  double zi3 = b4, zi2 = b3 + zi3, zi1 = b2 + zi2, zi0 = b1 + zi1;
+  double z0 = 0, z1 = 0, z2 = 0, z3 = 0;
+  float first[4];
+  int count = 0;
+  for (int64_t t = f0; t < f1; ++t, ++count) {
+    float* cell = mel + t * nb + bin;
+    const float x = logf(*cell + FLT_EPSILON);
+    double y = 0.0;
+    if (count < 4) {
+      first[count] = x;
+      if (count == 3) {
+        const double x0 = first[0];
+        z0 = zi0 * x0; z1 = zi1 * x0; z2 = zi2 * x0; z3 = zi3 * x0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double xt = first[k];
+          z0 = z1 + xt * b1;
+          z1 = z2 + xt * b2;
+          z2 = z3 + xt * b3;
+          z3 = xt * b4;
+        }
+      }
+    } else {
+      const double xd = x;
+      y = z0 + b0 * xd;
+      z0 = (z1 + xd * b1) - y * a1;
+      z1 = z2 + xd * b2;
+      z2 = z3 + xd * b3;
+      z3 = xd * b4;
+    }
+    *cell = expf(static_cast<float>(y));
+  }
+}
+
+int launch_rasta(float* mel, const BatchArgs& b, int num_bins, hipStream_t stream) {
+  const int64_t total = b.n_utts * num_bins;
+  if (total <= 0 || b.total_frames <= 0) return SNF_OK;
+  const int threads = 64;
+  hipLaunchKernelGGL(rasta_kernel, dim3(static_cast<unsigned>((total + threads - 1) / threads)),
+                     dim3(threads), 0, stream, mel, b, num_bins);
+  SNF_HIP_CHECK(hipGetLastError());
+  return SNF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PLP tail: equal loudness -> cube-root compression -> IDFT to autocorrelation -> Durbin ->
+// LPC to cepstrum -> lifter/scale -> energy -> HTK reorder.  One thread per frame
+// (reference plp.py:587-626; Durbin / IDFT bases are [KALDI-UPSTREAM] mel-computations.cc /
+// feature-functions.cc wrapped at plp.py:601 and :473).
+// ------------------------------------------------------------------------------------------------
+__global__ void plp_tail_kernel(const PlpParams p, const BatchArgs b,
+                                const float* __restrict__ mel, const double* __restrict__ energy,
+                                float* __restrict__ out) {
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= b.total_frames) return;
+  const int nb = p.num_bins, order = p.lpc_order, nc = p.num_ceps;
+  int warp_id = 0;
+  if (b.utt_warp) warp_id = b.utt_warp[find_utt(b.frame_offsets, b.n_utts, g)];
+  const float* __restrict__ eql = p.eql + warp_id * nb;
+  float m[kMaxBins + 2];
+  for (int i = 0; i < nb; ++i) {
+    float v = mel[g * nb + i] * eql[i];
+    m[i + 1] = powf(v, p.compress_factor);
+  }
+  m[0] = m[1];
+  m[nb + 1] = m[nb];
+  float ac[kMaxLpc + 1], lpc[kMaxLpc], tmp[kMaxLpc], cep[kMaxLpc];
+  for (int i = 0; i <= order; ++i) {
+    const float* __restrict__ basis = p.idft + i * (nb + 2);
+    float s = 0.0f;
+    for (int j = 0; j < nb + 2; ++j) s += basis[j] * m[j];
+    ac[i] = s;
+  }
+  // Durbin recursion
+  float E = ac[0];
+  for (int i = 0; i < order; ++i) lpc[i] = 0.0f;
+  for (int i = 0; i < order; ++i) {
+    float ki = ac[i + 1];
+    for (int j = 0; j < i; ++j) ki += lpc[j] * ac[i - j];
+    ki = ki / E;
+    float c = 1 - ki * ki;
+    if (c < 1.0e-5f) c = 1.0e-5f;
+    E *= c;
+    tmp[i] = -ki;
+    for (int j = 0; j < i; ++j) tmp[j] = lpc[j] - ki * lpc[i - j - 1];
+    for (int j = 0; j <= i; ++j) lpc[j] = tmp[j];
+  }
+  const float res_f = static_cast<float>(-log(1.0 / static_cast<double>(E)));
+  const double res = fmax(static_cast<double>(res_f), DBL_EPSILON);
+  // LPC -> cepstrum: Python-float (double) accumulation, float32 storage (reference plp.py:149-168)
+  for (int i = 0; i < order; ++i) {
+    double sum = 0.0;
+    for (int j = 0; j < i; ++j)
+      sum += static_cast<double>(i - j) * static_cast<double>(lpc[j]) * static_cast<double>(cep[i - j - 1]);
+    cep[i] = static_cast<float>(-static_cast<double>(lpc[i]) - sum / static_cast<double>(i + 1));
+  }
+  float* __restrict__ row = out + g * nc;
+  const bool floor_it = p.has_floor;
+  for (int c = 0; c < nc; ++c) {
+    float v = c == 0 ? static_cast<float>(res) : cep[c - 1];
+    if (p.lifter) v *= p.lifter[c];
+    if (p.cepstral_scale != 1.0f) v *= p.cepstral_scale;
+    if (c == 0 && p.use_energy) {
+      double le = energy[g];
+      if (floor_it && le < p.log_energy_floor) le = p.log_energy_floor;
+      v = static_cast<float>(le);
+    }
+    int oc = c;
+    if (p.htk_compat) oc = c == 0 ? nc - 1 : c - 1;
+    row[oc] = v;
+  }
+}
+
+int launch_plp_tail(const PlpParams& p, const BatchArgs& b, const float* mel, const double* energy,
+                    float* out, hipStream_t stream) {
+  if (b.total_frames <= 0) return SNF_OK;
+  if (p.num_bins > kMaxBins || p.lpc_order > kMaxLpc)
+    return set_error(SNF_E_RUNTIME, "PLP: num_bins > 126 or lpc_order > 63 not supported");
+  const int threads = 64;
+  hipLaunchKernelGGL(plp_tail_kernel,
+                     dim3(static_cast<unsigned>((b.total_frames + threads - 1) / threads)),
+                     dim3(threads), 0, stream, p, b, mel, energy, out);
+  SNF_HIP_CHECK(hipGetLastError());
+  return SNF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Deltas: out[:, i*D:(i+1)*D] = sum_j scales_i[j] * in[clamp(t + j)]; one thread per (row, column).
+// ------------------------------------------------------------------------------------------------
+__global__ void delta_kernel(const DeltaParams p, const float* __restrict__ in, const int D,
+                             const int64_t* __restrict__ frame_offsets, const int64_t n_utts,
+                             const int64_t total_frames, float* __restrict__ out) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= total_frames * D) return;
+  const int64_t g = idx / D;
+  const int c = static_cast<int>(idx - g * D);
+  const int64_t u = find_utt(frame_offsets, n_utts, g);
+  const int64_t f0 = frame_offsets[u], f1 = frame_offsets[u + 1];
+  const int OD = D * (p.order + 1);
+  const float* __restrict__ sc = p.scales;
+  for (int i = 0; i <= p.order; ++i) {
+    const int dim = p.dims[i], max_off = (dim - 1) / 2;
+    float acc = 0.0f;
+    for (int j = -max_off; j <= max_off; ++j) {
+      int64_t t = g + j;
+      t = t < f0 ? f0 : (t >= f1 ? f1 - 1 : t);
+      const float s = sc[j + max_off];
+      if (s != 0.0f) acc += s * in[t * D + c];
+    }
+    out[g * OD + static_cast<int64_t>(i) * D + c] = acc;
+    sc += dim;
+  }
+}
+
+int launch_deltas(const DeltaParams& p, const float* in, int in_cols, const int64_t* frame_offsets,
+                  int64_t n_utts, int64_t total_frames, float* out, hipStream_t stream) {
+  const int64_t total = total_frames * in_cols;
+  if (total <= 0) return SNF_OK;
+  const int threads = 256;
+  hipLaunchKernelGGL(delta_kernel, dim3(static_cast<unsigned>((total + threads - 1) / threads)),
+                     dim3(threads), 0, stream, p, in, in_cols, frame_offsets, n_utts, total_frames,
+                     out);
+  SNF_HIP_CHECK(hipGetLastError());
+  return SNF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pitch post-processing: one thread per frame.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float nccf_to_pov_feature(float n) {
+  n = fminf(fmaxf(n, -1.0f), 1.0f);
+  return static_cast<float>(pow(1.0001 - static_cast<double>(n), 0.15) - 1.0);
+}
+__device__ __forceinline__ float nccf_to_pov(float n) {
+  float a = fabsf(n);
+  if (a > 1.0f) a = 1.0f;
+  const double ad = a;
+  // Kaldi calls Exp() with double arguments here -> double overload
+  const float r = static_cast<float>(-5.2 + 5.4 * exp(7.5 * (ad - 1.0)) + 4.8 * ad -
+                                     2.0 * exp(-10.0 * ad) + 4.2 * exp(20.0 * (ad - 1.0)));
+  return static_cast<float>(1.0 / (1.0 + exp(-1.0 * static_cast<double>(r))));
+}
+
+__global__ void pitch_post_kernel(const PitchPostParams p, const float* __restrict__ in,
+                                  const int64_t* __restrict__ frame_offsets, const int64_t n_utts,
+                                  const int64_t total_frames, float* __restrict__ out) {
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= total_frames) return;
+  const int64_t u = find_utt(frame_offsets, n_utts, g);
+  const int64_t f0 = frame_offsets[u], f1 = frame_offsets[u + 1];
+  const snf_pitch_post_options& o = p.o;
+  float* __restrict__ row = out + g * p.ndims;
+  int idx = 0;
+  const float nccf = in[g * 2], log_pitch = logf(in[g * 2 + 1]);
+  if (o.add_pov_feature) row[idx++] = o.pov_scale * nccf_to_pov_feature(nccf) + o.pov_offset;
+  if (o.add_normalized_log_pitch) {
+    int64_t wb = g - o.normalization_left_context, we = g + o.normalization_right_context + 1;
+    if (wb < f0) wb = f0;
+    if (we > f1) we = f1;
+    double sum_pov = 0.0, sum_lp = 0.0;
+    for (int64_t t = wb; t < we; ++t) {
+      const float pov = nccf_to_pov(in[t * 2]), lp = logf(in[t * 2 + 1]);
+      sum_pov += pov;
+      sum_lp += pov * lp;
+    }
+    const float avg = static_cast<float>(sum_lp / sum_pov);
+    row[idx++] = (log_pitch - avg) * o.pitch_scale;
+  }
+  if (o.add_delta_pitch) {
+    // ComputeDeltas(order 1, window w) over the clamped +-w neighbourhood of log-pitch
+    const int w = o.delta_window;
+    float normalizer = 0.0f;
+    for (int j = -w; j <= w; ++j) normalizer += static_cast<float>(j * j);
+    const float inv = static_cast<float>(1.0 / normalizer);
+    int64_t lo = g - w, hi = g + w;
+    if (lo < f0) lo = f0;
+    if (hi > f1 - 1) hi = f1 - 1;
+    float acc = 0.0f;
+    for (int j = -w; j <= w; ++j) {
+      int64_t t = g + j;
+      t = t < lo ? lo : (t > hi ? hi : t);
+      const float s = static_cast<float>(j) * inv;
+      if (s != 0.0f) acc += s * logf(in[t * 2 + 1]);
+    }
+    float noise = 0.0f;
+    if (o.delta_pitch_noise_stddev != 0.0f)
+      noise = gauss(p.seed, static_cast<uint64_t>(g)) * o.delta_pitch_noise_stddev;
+    row[idx++] = (acc + noise) * o.delta_pitch_scale;
+  }
+  if (o.add_raw_log_pitch) row[idx++] = log_pitch;
+}
+
+int launch_pitch_post(const PitchPostParams& p, const float* in, const int64_t* frame_offsets,
+                      int64_t n_utts, int64_t total_frames, float* out, hipStream_t stream) {
+  if (total_frames <= 0) return SNF_OK;
+  const int threads = 128;
+  hipLaunchKernelGGL(pitch_post_kernel,
+                     dim3(static_cast<unsigned>((total_frames + threads - 1) / threads)),
+                     dim3(threads), 0, stream, p, in, frame_offsets, n_utts, total_frames, out);
+  SNF_HIP_CHECK(hipGetLastError());
+  return SNF_OK;
+}
+
+}  // namespace snf

@@ -1,0 +1,183 @@
+// Internal declarations of libshennong_hip.so (MI355X / gfx950 speech-features backend).
+// Not part of the public ABI (that is include/shennong_amd.h).
+#ifndef SNF_INTERNAL_H_
+#define SNF_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/shennong_amd.h"
+
+namespace snf {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+int set_error(int code, const std::string& msg);
+const char* last_error();
+
+#define SNF_HIP_CHECK(expr)                                                                  \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return snf::set_error(SNF_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));   \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// host-side tables (host_tables.cpp): the product's own restatement of the tables Kaldi
+// precomputes in FeatureWindowFunction / MelBanks / MfccComputer / PlpComputer / LinearResample /
+// ArbitraryResample (called by the reference at processor/base.py:429-431, plp.py:443-508,
+// pitch_kaldi.py:296-299)
+// ---------------------------------------------------------------------------------------------
+int32_t window_shift(const snf_frame_options& o);
+int32_t window_size(const snf_frame_options& o);
+int32_t padded_window_size(const snf_frame_options& o);
+int64_t num_frames(const snf_frame_options& o, int64_t num_samples);
+int64_t first_sample_of_frame(const snf_frame_options& o, int64_t frame);
+int make_window(const snf_frame_options& o, std::vector<float>* w);
+
+struct MelBanksHost {
+  int num_bins = 0, num_fft_bins = 0;
+  std::vector<int> first, size, offset;  // per bin: first fft bin, support length, offset in w
+  std::vector<float> w;                  // concatenated supports
+  std::vector<float> center_freqs;
+};
+int make_mel_banks(const snf_mel_options& mo, const snf_frame_options& fo, float vtln_warp,
+                   MelBanksHost* out);
+void make_dct_matrix(int num_rows, int num_cols, std::vector<float>* m);  // first rows of NxN DCT
+void make_lifter(float q, int n, std::vector<float>* c);
+void make_equal_loudness(const MelBanksHost& mb, std::vector<float>* out);
+void make_idft_bases(int n_bases, int dim, std::vector<float>* m);
+void make_delta_scales(int order, int window, std::vector<float>* scales, std::vector<int>* dims);
+
+struct LinearResampleHost {
+  int rate_in = 0, rate_out = 0, in_unit = 0, out_unit = 0, num_zeros = 0, max_taps = 0;
+  float cutoff = 0;
+  std::vector<int> first;       // [out_unit]
+  std::vector<int> ntaps;       // [out_unit]
+  std::vector<float> weights;   // [out_unit][max_taps] zero padded
+  int64_t num_output(int64_t n_in, bool flush) const;
+};
+void make_linear_resample(int rate_in, int rate_out, float cutoff, int num_zeros,
+                          LinearResampleHost* out);
+
+struct PitchTablesHost {
+  int first_lag = 0, last_lag = 0, num_lags = 0, num_states = 0;
+  int win_size = 0, win_shift = 0, full_len = 0, max_taps = 0;
+  std::vector<float> lags;        // [num_states]
+  std::vector<int> ar_first;      // [num_states]
+  std::vector<int> ar_n;          // [num_states]
+  std::vector<float> ar_w;        // [num_states][max_taps]
+  LinearResampleHost resample;
+  int64_t frames_available(int64_t n_down, bool input_finished, bool snip_edges) const;
+};
+int make_pitch_tables(const snf_pitch_options& o, PitchTablesHost* out);
+
+// ---------------------------------------------------------------------------------------------
+// device parameter blocks (passed by value to kernels)
+// ---------------------------------------------------------------------------------------------
+struct MelParams {
+  // framing
+  int win_len, win_shift, padded, half, log2_half;  // half = padded/2 (complex FFT size)
+  int snip_edges, remove_dc, pow2;
+  float preemph, dither;
+  unsigned long long seed;
+  const float* window;       // [win_len]
+  const float2* tw_fft;      // [half/2]     exp(-2 pi i k / half)
+  const float2* tw_unpack;   // [half/2 + 1] exp(-2 pi i k / padded)
+  const float2* tw_dft;      // [padded]     exp(-2 pi i k / padded) (non power-of-two path)
+  // epilogue
+  int kind, ndims;
+  int use_energy, raw_energy, htk_compat, use_log, use_power, need_raw, need_post;
+  int has_floor;
+  float log_energy_floor;
+  int num_bins, num_ceps, compression;
+  const int* mel_first;      // [n_warps][num_bins]
+  const int* mel_size;       // [n_warps][num_bins]
+  const int* mel_offset;     // [n_warps][num_bins] offset into mel_w
+  const float* mel_w;
+  const float* dct;          // [num_ceps][num_bins]
+  const float* lifter;       // [num_ceps] or nullptr
+};
+
+struct BatchArgs {
+  const int16_t* wave;
+  const int64_t* sample_offsets;  // [n_utts+1]
+  const int64_t* frame_offsets;   // [n_utts+1]
+  const int32_t* utt_warp;        // [n_utts] index into the plan's warp tables, or nullptr
+  int64_t n_utts;
+  int64_t total_frames;
+};
+
+struct PlpParams {
+  int num_bins, lpc_order, num_ceps, use_energy, htk_compat, has_floor, rasta;
+  float compress_factor, cepstral_scale;
+  double log_energy_floor;
+  const float* eql;     // [n_warps][num_bins]
+  const float* idft;    // [lpc_order+1][num_bins+2]
+  const float* lifter;  // [num_ceps] or nullptr
+};
+
+struct DeltaParams {
+  int order, window, n_scales;
+  const float* scales;   // concatenated
+  const int* dims;       // [order+1]
+};
+
+// ---------------------------------------------------------------------------------------------
+// kernel launchers (kernels_*.hip)
+// ---------------------------------------------------------------------------------------------
+// Fused frame extraction -> window -> FFT -> power -> epilogue.  `out` is [total_frames, out_cols];
+// for kind PLP it receives linear mel energies [total_frames, num_bins] and `energy_out`
+// [total_frames] the log energy column (double).
+int launch_mel_features(const MelParams& p, const BatchArgs& b, float* out, int out_cols,
+                        double* energy_out, hipStream_t stream);
+int launch_rasta(float* mel, const BatchArgs& b, int num_bins, hipStream_t stream);
+int launch_plp_tail(const PlpParams& p, const BatchArgs& b, const float* mel, const double* energy,
+                    float* out, hipStream_t stream);
+int launch_deltas(const DeltaParams& p, const float* in, int in_cols, const int64_t* frame_offsets,
+                  int64_t n_utts, int64_t total_frames, float* out, hipStream_t stream);
+
+struct PitchDevTables {
+  int first_lag, last_lag, num_lags, num_states, win_size, win_shift, full_len;
+  int ar_max_taps, rs_in_unit, rs_out_unit, rs_max_taps;
+  int snip_edges, recompute_frame;
+  float soft_min_f0, inter_frame_factor, nccf_ballast;
+  const float* lags;      // [num_states]
+  const int* ar_first;    // [num_states]
+  const int* ar_n;        // [num_states]
+  const float* ar_w;      // [num_states][ar_max_taps]
+  const int* rs_first;    // [rs_out_unit]
+  const int* rs_ntaps;    // [rs_out_unit]
+  const float* rs_w;      // [rs_out_unit][rs_max_taps]
+};
+struct PitchBatch {
+  const int16_t* wave;
+  const int64_t* sample_offsets;  // [n_utts+1]
+  const int64_t* frame_offsets;   // [n_utts+1]
+  const int64_t* down_offsets;    // [n_utts+1] offsets into the downsampled scratch
+  const int64_t* down_phase1;     // [n_utts] samples available before the flush
+  const int64_t* frames_phase1;   // [n_utts] frames processed before the flush
+  int64_t n_utts, total_frames, total_down;
+};
+// resample -> signal statistics -> fused NCCF + Viterbi per utterance -> traceback + POV output.
+// `backptr` is [total_frames, num_states] int16, `states` [total_frames] int32 scratch.
+int launch_pitch(const PitchDevTables& t, const PitchBatch& b, float* down, double* stats,
+                 int16_t* backptr, int32_t* states, float* out, hipStream_t stream);
+
+struct PitchPostParams {
+  snf_pitch_post_options o;
+  int ndims;
+  unsigned long long seed;
+};
+int launch_pitch_post(const PitchPostParams& p, const float* in, const int64_t* frame_offsets,
+                      int64_t n_utts, int64_t total_frames, float* out, hipStream_t stream);
+
+}  // namespace snf
+
+#endif  // SNF_INTERNAL_H_

@@ -1,0 +1,209 @@
+"""Features container: the output of every processor
+
+Mirrors reference shennong/features.py:62-437 (data [nframes, ndims], times [nframes, 2] or
+[nframes], properties dict; validate / __eq__ / is_close / copy / concatenate).  The reference's
+per-frame Python loop in ``validate`` (features.py:342) is replaced by a vectorised check.
+"""
+
+import copy
+
+import numpy as np
+
+from shennong_amd.logger import get_logger
+from shennong_amd.utils import dict_equal
+
+
+class Features:
+    """Features data with attached timestamps and properties"""
+    def __init__(self, data, times, properties=None, validate=True):
+        self._data = data
+        self._times = times
+        self._properties = {} if properties is None else properties
+        if validate is True:
+            self.validate()
+
+    @property
+    def data(self):
+        return self._data
+
+    @property
+    def times(self):
+        return self._times
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    @property
+    def ndims(self):
+        return self.shape[1]
+
+    @property
+    def nframes(self):
+        return self.shape[0]
+
+    @property
+    def properties(self):
+        return self._properties
+
+    def _to_dict(self, with_properties=True):
+        features = {'data': self.data, 'times': self.times}
+        if with_properties:
+            features['properties'] = self.properties
+        return features
+
+    @staticmethod
+    def _from_dict(features, validate=True):
+        missing_keys = {'data', 'times'} - set(features.keys())
+        if missing_keys:
+            raise ValueError(
+                'cannot read features from dict, missing keys: {}'
+                .format(', '.join(missing_keys)))
+        return Features(
+            features['data'], features['times'],
+            properties=features.get('properties', {}), validate=validate)
+
+    def __eq__(self, other):
+        if self is other:
+            return True
+        if self.shape != other.shape or self.dtype != other.dtype:
+            return False
+        if not dict_equal(self.properties, other.properties):
+            return False
+        if not np.array_equal(self.times, other.times):
+            return False
+        return bool(np.array_equal(self.data, other.data))
+
+    def is_close(self, other, rtol=1e-5, atol=1e-8):
+        """True if data is allclose and shape / times / properties are equal"""
+        if self is other:
+            return True
+        if self.shape != other.shape:
+            return False
+        if not dict_equal(self.properties, other.properties):
+            return False
+        if not np.array_equal(self.times, other.times):
+            return False
+        return bool(np.allclose(self.data, other.data, atol=atol, rtol=rtol))
+
+    def copy(self, dtype=None, subsample=None):
+        if subsample is None:
+            subsample = 1
+        elif not isinstance(subsample, int) or subsample <= 0:
+            raise ValueError(
+                f'subsample must be a strictly positive integer, '
+                f'it is: {subsample}')
+        if dtype:
+            return Features(
+                self.data[0:self.nframes:subsample].astype(dtype),
+                self.times[0:self.nframes:subsample].astype(dtype),
+                properties=copy.deepcopy(self.properties), validate=False)
+        return Features(
+            self.data[0:self.nframes:subsample].copy(),
+            self.times[0:self.nframes:subsample].copy(),
+            properties=copy.deepcopy(self.properties), validate=False)
+
+    def is_valid(self):
+        try:
+            self.validate()
+        except ValueError:
+            return False
+        return True
+
+    def validate(self):
+        """Raises a ValueError if the features are not in a valid state"""
+        errors = []
+        if not isinstance(self.data, np.ndarray):
+            errors.append('data must be a numpy array')
+        if not isinstance(self.times, np.ndarray):
+            errors.append('times must be a numpy array')
+        if not isinstance(self.properties, dict):
+            errors.append('properties must be a dictionnary')
+        if errors:
+            raise ValueError(
+                'invalid features data types: {}'.format(', '.join(errors)))
+        if not self.data.ndim == 2:
+            errors.append(
+                'data dimension must be 2 but is {}'.format(self.data.ndim))
+        if self.times.ndim > 2:
+            errors.append('times dimension must be 1 or 2 but is {}'.format(
+                self.times.ndim))
+        if self.times.ndim == 2 and self.times.shape[1] != 2:
+            errors.append('times shape[1] must be 2, it is {}'.format(
+                self.times.shape[1]))
+        nframes1 = self.data.shape[0]
+        nframes2 = self.times.shape[0]
+        if not nframes1 == nframes2:
+            errors.append(
+                'mismatch in number of frames: {} for data but {} '
+                'for times'.format(nframes1, nframes2))
+        if errors:
+            raise ValueError(
+                'invalid features dimensions: {}'.format(', '.join(errors)))
+        # times must be sorted in increasing order (stable sort is identity)
+        index = (np.argsort(self.times, kind='stable')
+                 if self.times.ndim == 1 else np.lexsort(self.times.T))
+        if not np.array_equal(index, np.arange(self.nframes)):
+            raise ValueError('times is not sorted in increasing order')
+        if not np.all(np.isfinite(self.data)):
+            raise ValueError(
+                'data contains non-finite numbers (nan of infinity)')
+
+    def concatenate(self, other, tolerance=0,
+                    log=get_logger('features', 'info')):
+        """Column-wise concatenation with `other` (reference features.py:350-437)"""
+        need_trim = False
+        diff = abs(self.nframes - other.nframes)
+        if diff:
+            if not tolerance:
+                raise ValueError('features have a different number of frames')
+            if tolerance and diff > tolerance:
+                raise ValueError(
+                    'features differs number of frames, and '
+                    'greater than tolerance: |{} - {}| > {}'.format(
+                        self.nframes, other.nframes, tolerance))
+            log.warning(
+                'features differs in number of frames, but '
+                'within tolerance (|%s - %s| <= %s), trim the longest one',
+                self.nframes, other.nframes, tolerance)
+            need_trim = True
+        data1, data2 = self.data, other.data
+        times1, times2 = self.times, other.times
+        if need_trim:
+            if self.nframes > other.nframes:
+                data1, times1 = data1[:-diff], times1[:-diff]
+            else:
+                data2, times2 = data2[:-diff], times2[:-diff]
+        if not np.allclose(times1, times2):
+            raise ValueError('times are not equal')
+        properties = copy.deepcopy(self.properties)
+        other_properties = copy.deepcopy(other.properties)
+        properties.update(
+            {k: v for k, v in other_properties.items() if k != 'pipeline'})
+        if 'pipeline' not in properties:
+            properties['pipeline'] = []
+        if 'pipeline' in other_properties:
+            for k in other_properties['pipeline']:
+                properties['pipeline'].append(k)
+                columns = properties['pipeline'][-1]['columns']
+                properties['pipeline'][-1]['columns'] = [
+                    columns[0] + self.ndims, columns[1] + self.ndims]
+        return Features(
+            np.hstack((data1, data2)), times1, properties=properties)
+
+
+class FeaturesCollection(dict):
+    """A dict of Features indexed by utterance name (return type of process_all;
+    reference shennong/features_collection.py:81 minus the on-disk serializers)"""
+    def is_valid(self):
+        return all(f.is_valid() for f in self.values())
+
+    def is_close(self, other, rtol=1e-5, atol=1e-8):
+        if not self.keys() == other.keys():
+            return False
+        return all(
+            self[k].is_close(other[k], rtol=rtol, atol=atol) for k in self)

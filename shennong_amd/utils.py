@@ -1,0 +1,37 @@
+"""Small host utilities (mirrors reference shennong/utils.py:18-96)"""
+
+import multiprocessing
+
+import numpy as np
+
+from shennong_amd.logger import null_logger
+
+
+def get_njobs(njobs=None, log=null_logger()):
+    """Returns min(njobs, ncpus); ``ValueError`` if `njobs` <= 0 (reference utils.py:18-55)"""
+    max_njobs = multiprocessing.cpu_count()
+    if njobs is None:
+        return max_njobs
+    if njobs <= 0:
+        raise ValueError(
+            'njobs must be strictly positive, it is {}'.format(njobs))
+    if njobs > max_njobs:
+        log.warning(
+            'asking %d CPU cores but reducing to %d (max available)',
+            njobs, max_njobs)
+        return max_njobs
+    return njobs
+
+
+def array2list(seq):
+    """Converts numpy arrays in `seq` into lists"""
+    if isinstance(seq, dict):
+        return {k: array2list(v) for k, v in seq.items()}
+    if isinstance(seq, np.ndarray):
+        return seq.tolist()
+    return seq
+
+
+def dict_equal(dict1, dict2):
+    """True if the two dicts (which may hold numpy arrays) are equal"""
+    return array2list(dict1) == array2list(dict2)

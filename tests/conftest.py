@@ -1,0 +1,70 @@
+"""Shared fixtures.  GPU tests are marked ``@pytest.mark.gpu`` and call the HIP path through the
+C ABI; everything else runs on CPU (oracle pins, host logic, ABI symbol checks)."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+import scipy.io.wavfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line(
+        'markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def wav_file():
+    return os.path.join(GOLDEN, 'test.wav')
+
+
+@pytest.fixture(scope='session')
+def audio(wav_file):
+    """The reference's test clip: 16 kHz int16 mono, 22 713 samples -> 140 frames
+    (reference test/conftest.py:28-35)"""
+    from shennong_amd import Audio
+    return Audio.load(wav_file)
+
+
+@pytest.fixture(scope='session')
+def audio_8k():
+    from shennong_amd import Audio
+    return Audio.load(os.path.join(GOLDEN, 'test.8k.wav'))
+
+
+@pytest.fixture(scope='session')
+def wave(wav_file):
+    return scipy.io.wavfile.read(wav_file)[1]
+
+
+@pytest.fixture(scope='session')
+def synth_waves():
+    from shennong_amd import synth
+    return synth.ragged_utterances(1000, 6, min_s=0.3, max_s=1.2)
+
+
+@pytest.fixture(scope='session')
+def gpu():
+    """Skips when no device is visible; on the GPU box a missing library is an error"""
+    from shennong_amd import _backend
+    if _backend.device_count() < 1:
+        pytest.skip('no HIP device visible')
+    return _backend
+
+
+def assert_close(got, want, rtol=1e-4, atol=2e-3, what=''):
+    """Parity tolerance of the float32 features: 1e-4 relative (BASELINE.json north_star) plus a
+    small absolute term for log outputs near the FLT_EPSILON floor, where float32 FFT round-off of
+    either side dominates (SURVEY.md §7 'Hard parts')."""
+    got = np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert got.dtype == want.dtype == np.float32, (what, got.dtype, want.dtype)
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=what)

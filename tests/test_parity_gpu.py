@@ -1,0 +1,212 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Tolerance: rtol 1e-4 (BASELINE.json north_star) + atol 2e-3 on log-domain outputs, frame counts and
+shapes bit-exact; delta is compared at 1e-5; pitch frame-by-frame (see test_pitch)."""
+
+import itertools
+
+import numpy as np
+import pytest
+
+from conftest import assert_close
+from oracle import oracle as orc
+from shennong_amd import Audio, _abi, synth
+from shennong_amd.processor import (
+    FilterbankProcessor, MfccProcessor, PlpProcessor, SpectrogramProcessor,
+    KaldiPitchProcessor, KaldiPitchPostProcessor)
+from shennong_amd.postprocessor import DeltaPostProcessor
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(proc, wave, warp=1.0):
+    return orc.compute(proc._build_options(), np.asarray(wave, np.int16), warp)
+
+
+@pytest.mark.parametrize('num_bins', [23, 40])
+@pytest.mark.parametrize('use_energy', [False, True])
+def test_fbank_testwav(gpu, audio, wave, num_bins, use_energy):
+    proc = FilterbankProcessor(num_bins=num_bins, use_energy=use_energy, dither=0)
+    got = proc.process(audio)
+    want = _oracle(proc, wave)
+    assert got.shape == (140, num_bins + use_energy)
+    assert_close(got.data, want, what='fbank')
+
+
+@pytest.mark.parametrize('opts', [
+    dict(raw_energy=False, use_energy=True),
+    dict(htk_compat=True, use_energy=True),
+    dict(use_log_fbank=False),
+    dict(use_power=False),
+    dict(energy_floor=1e9, use_energy=True),
+    dict(window_type='hamming'), dict(window_type='hanning'),
+    dict(window_type='rectangular'), dict(window_type='blackman'),
+    dict(preemph_coeff=0.0), dict(remove_dc_offset=False),
+    dict(snip_edges=False),
+    dict(frame_shift=0.02, frame_length=0.05),
+    dict(low_freq=100, high_freq=-200),
+    dict(round_to_power_of_two=False),
+])
+def test_fbank_options(gpu, audio, wave, opts):
+    proc = FilterbankProcessor(dither=0, **opts)
+    got = proc.process(audio)
+    want = _oracle(proc, wave)
+    rtol = 1e-4 if opts.get('use_log_fbank', True) else 2e-4
+    assert_close(got.data, want, rtol=rtol,
+                 atol=2e-3 if opts.get('use_log_fbank', True) else 1.0,
+                 what=str(opts))
+
+
+@pytest.mark.parametrize('opts', [
+    dict(), dict(use_energy=False), dict(raw_energy=False),
+    dict(htk_compat=True), dict(htk_compat=True, use_energy=False),
+    dict(num_ceps=5), dict(num_ceps=23), dict(cepstral_lifter=0.0),
+    dict(num_bins=40, num_ceps=20), dict(snip_edges=False),
+])
+def test_mfcc(gpu, audio, wave, opts):
+    proc = MfccProcessor(dither=0, **opts)
+    got = proc.process(audio)
+    assert_close(got.data, _oracle(proc, wave), what=str(opts))
+
+
+@pytest.mark.parametrize('opts', [dict(), dict(raw_energy=False),
+                                  dict(energy_floor=1e9), dict(snip_edges=False)])
+def test_spectrogram(gpu, audio, wave, opts):
+    proc = SpectrogramProcessor(dither=0, **opts)
+    got = proc.process(audio)
+    want = _oracle(proc, wave)
+    assert got.shape[1] == 257
+    # single-bin log power: deep spectral nulls amplify float32 FFT round-off of both sides
+    assert_close(got.data, want, rtol=1e-4, atol=2e-2, what=str(opts))
+    assert np.mean(np.abs(got.data - want) < 1e-3) > 0.999
+
+
+@pytest.mark.parametrize('opts', [
+    dict(), dict(use_energy=False), dict(raw_energy=False), dict(htk_compat=True),
+    dict(rasta=True), dict(rasta=True, snip_edges=False), dict(num_ceps=5),
+    dict(cepstral_lifter=0, cepstral_scale=0.9), dict(lpc_order=8, num_ceps=9),
+])
+def test_plp(gpu, audio, wave, opts):
+    proc = PlpProcessor(dither=0, **opts)
+    got = proc.process(audio)
+    want = _oracle(proc, wave)
+    assert_close(got.data, want, rtol=2e-4, atol=2e-3, what=str(opts))
+
+
+@pytest.mark.parametrize('warp', [0.85, 1.0, 1.2])
+@pytest.mark.parametrize('cls', [FilterbankProcessor, MfccProcessor, PlpProcessor])
+def test_vtln_warp(gpu, audio, wave, cls, warp):
+    proc = cls(dither=0)
+    got = proc.process(audio, vtln_warp=warp)
+    assert_close(got.data, _oracle(proc, wave, warp), rtol=2e-4, what=f'warp {warp}')
+    assert got.properties[proc.name]['vtln_warp'] == warp
+
+
+@pytest.mark.parametrize('sample_rate, frame_length', [
+    (8000, 0.025), (16000, 0.064), (44100, 0.025), (16000, 0.005)])
+def test_other_fft_sizes(gpu, sample_rate, frame_length):
+    n = int(0.4 * sample_rate)
+    wave = synth.utterances(7, 1, n, sample_rate)[0]
+    proc = MfccProcessor(sample_rate=sample_rate, frame_length=frame_length, dither=0)
+    got = proc.process(Audio(wave, sample_rate))
+    assert_close(got.data, _oracle(proc, wave), what=f'{sample_rate} {frame_length}')
+
+
+def test_batch_ragged(gpu, synth_waves):
+    """process_all = one launch over ragged utterances, including one too short for any frame"""
+    from shennong_amd import Utterances
+    waves = list(synth_waves) + [np.zeros(100, np.int16)]
+    utts = Utterances([(f'u{i}', Audio(w, 16000)) for i, w in enumerate(waves)])
+    warps = {f'u{i}': [1.0, 0.9, 1.1][i % 3] for i in range(len(waves))}
+    proc = FilterbankProcessor(num_bins=40, dither=0)
+    feats = proc.process_all(utts, vtln_warp=warps)
+    assert list(feats.keys()) == [f'u{i}' for i in range(len(waves))]
+    for i, w in enumerate(waves):
+        f = feats[f'u{i}']
+        want = _oracle(proc, w, warps[f'u{i}'])
+        assert f.shape == want.shape
+        if want.size:
+            assert_close(f.data, want, rtol=2e-4, what=f'utt {i}')
+    assert feats[f'u{len(waves) - 1}'].shape == (0, 0)
+
+
+@pytest.mark.parametrize('order, window', itertools.product([0, 1, 2, 5], [1, 2, 5]))
+def test_delta(gpu, audio, order, window):
+    mfcc = MfccProcessor(dither=0).process(audio)
+    got = DeltaPostProcessor(order=order, window=window).process(mfcc)
+    want = orc.deltas(mfcc.data, order, window)
+    assert got.shape == (140, 13 * (order + 1))
+    assert_close(got.data, want, rtol=1e-5, atol=1e-5)
+    assert np.array_equal(got.data[:, :13], mfcc.data)
+
+
+def test_delta_batch_edges(gpu):
+    rng = np.random.default_rng(3)
+    mats = [rng.standard_normal((n, 7)).astype(np.float32) for n in (1, 2, 3, 9, 40)]
+    from shennong_amd import Features
+    feats = [Features(m, np.arange(m.shape[0], dtype=np.float64)) for m in mats]
+    outs = DeltaPostProcessor()._process_batch(feats)
+    for m, o in zip(mats, outs):
+        assert_close(o.data, orc.deltas(m, 2, 2), rtol=1e-5, atol=1e-5)
+
+
+def _pitch_close(got, want):
+    assert got.shape == want.shape
+    same = got[:, 1] == want[:, 1]
+    # frames where the Viterbi path differs must be rare (float round-off near-ties) and one
+    # lag step (0.5 %) apart at most on average
+    assert same.mean() >= 0.97, same.mean()
+    assert np.max(np.abs(got[:, 1] / want[:, 1] - 1)) < 0.05
+    np.testing.assert_allclose(got[same, 0], want[same, 0], rtol=1e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize('opts', [dict(), dict(frame_shift=0.02),
+                                  dict(frame_shift=0.02, frame_length=0.05),
+                                  dict(min_f0=60, max_f0=350, penalty_factor=0.2)])
+def test_pitch(gpu, audio, wave, opts):
+    proc = KaldiPitchProcessor(**opts)
+    got = proc.process(audio)
+    want = orc.pitch(proc._options, wave)
+    _pitch_close(got.data, want)
+
+
+def test_pitch_batch(gpu, synth_waves):
+    proc = KaldiPitchProcessor()
+    outs = proc._process_batch([Audio(w, 16000) for w in synth_waves])
+    for w, o in zip(synth_waves, outs):
+        _pitch_close(o.data, orc.pitch(proc._options, w))
+
+
+@pytest.mark.parametrize('flags', [(1, 1, 1, 1), (1, 1, 1, 0), (0, 0, 1, 1), (0, 1, 0, 0)])
+def test_pitch_post(gpu, wave, flags):
+    raw = orc.pitch(_abi.default_pitch_options(), wave)
+    from shennong_amd import Features
+    proc = KaldiPitchPostProcessor(
+        delta_pitch_noise_stddev=0, add_pov_feature=flags[0],
+        add_normalized_log_pitch=flags[1], add_delta_pitch=flags[2],
+        add_raw_log_pitch=flags[3])
+    times = KaldiPitchProcessor().times(raw.shape[0])
+    feats = Features(raw, times, properties={
+        'pipeline': [{'name': 'pitch', 'columns': [0, 1]}], 'pitch': {}})
+    got = proc.process(feats)
+    want = orc.process_pitch(proc._options, raw)
+    assert_close(got.data, want, rtol=1e-4, atol=1e-5)
+
+
+def test_full_size_properties(gpu):
+    """At BASELINE.json's full utterance size: bit stability run-to-run, batch == single, and
+    linearity of the (linear) mel energies: fbank(2 x) = 4 fbank(x)."""
+    waves = synth.utterances(42, 8, 48000)
+    proc = FilterbankProcessor(num_bins=40, dither=0, use_log_fbank=False,
+                               remove_dc_offset=False)
+    a = proc._process_batch([Audio(w, 16000) for w in waves])
+    b = proc._process_batch([Audio(w, 16000) for w in waves])
+    for x, y in zip(a, b):
+        assert x.shape == (298, 40)
+        assert x == y
+    single = proc.process(Audio(waves[3], 16000))
+    assert np.array_equal(single.data, a[3].data)
+    half = (waves[0] // 2).astype(np.int16)
+    f1 = proc.process(Audio(half, 16000)).data
+    f2 = proc.process(Audio((half * 2).astype(np.int16), 16000)).data
+    np.testing.assert_allclose(f2, 4 * f1, rtol=2e-5)
