@@ -65,6 +65,10 @@ struct snf_plan {
   DevBuf d_mel_first, d_mel_size, d_mel_off, d_mel_w, d_eql;
   bool warps_dirty = true;
   PlpParams pp{};
+  // register-resident fast path for the 512-point configuration
+  bool fast512 = false;
+  Fast512Params fp{};
+  DevBuf d_fast_tables;
 
   // delta
   DeltaParams dp{};
@@ -252,6 +256,17 @@ int build_mel_plan(snf_plan* plan) {
     }
   }
   p.ndims = plan->ndims;
+  if (fast512_eligible(p, false)) {
+    std::vector<float> dct_h, lifter_h, blob;
+    if (plan->kind == SNF_KIND_MFCC) {
+      make_dct_matrix(o.num_ceps, o.mel.num_bins, &dct_h);
+      if (o.cepstral_lifter != 0.0f) make_lifter(o.cepstral_lifter, o.num_ceps, &lifter_h);
+    }
+    if ((rc = fast512_build(p, window, plan->banks[0], dct_h, lifter_h, &blob, &plan->fp))) return rc;
+    if ((rc = plan->d_fast_tables.upload(blob, plan->stream))) return rc;
+    plan->fp.tables = plan->d_fast_tables.as<float>();
+    plan->fast512 = true;
+  }
   return SNF_OK;
 }
 
@@ -659,13 +674,21 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     if ((rc = plan->s_mel.ensure(sizeof(float) * static_cast<size_t>(total_frames) * nb))) return rc;
     if ((rc = plan->s_energy.ensure(sizeof(double) * static_cast<size_t>(total_frames)))) return rc;
   }
+  const bool use_fast = plan->fast512 && !any_warp;
   if (own_stream) begin_timing(plan);
   if (plan->kind == SNF_KIND_PLP) {
     const int nb = plan->o.mel.num_bins;
-    if ((rc = launch_mel_features(plan->mp, b, plan->s_mel.as<float>(), nb,
-                                  plan->s_energy.as<double>(), s)))
-      return rc;
-    if (own_stream) mark_kernel(plan, "mel_features_generic_kernel");
+    if (use_fast) {
+      if ((rc = launch_fbank512(plan->fp, b, plan->s_mel.as<float>(), nb,
+                                plan->s_energy.as<double>(), s)))
+        return rc;
+      if (own_stream) mark_kernel(plan, "fbank512_kernel");
+    } else {
+      if ((rc = launch_mel_features(plan->mp, b, plan->s_mel.as<float>(), nb,
+                                    plan->s_energy.as<double>(), s)))
+        return rc;
+      if (own_stream) mark_kernel(plan, "mel_features_generic_kernel");
+    }
     if (plan->o.rasta) {
       if ((rc = launch_rasta(plan->s_mel.as<float>(), b, nb, s))) return rc;
       if (own_stream) mark_kernel(plan, "rasta_kernel");
@@ -675,8 +698,13 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
       return rc;
     if (own_stream) mark_kernel(plan, "plp_tail_kernel");
   } else {
-    if ((rc = launch_mel_features(plan->mp, b, d_out, plan->ndims, nullptr, s))) return rc;
-    if (own_stream) mark_kernel(plan, "mel_features_generic_kernel");
+    if (use_fast) {
+      if ((rc = launch_fbank512(plan->fp, b, d_out, plan->ndims, nullptr, s))) return rc;
+      if (own_stream) mark_kernel(plan, "fbank512_kernel");
+    } else {
+      if ((rc = launch_mel_features(plan->mp, b, d_out, plan->ndims, nullptr, s))) return rc;
+      if (own_stream) mark_kernel(plan, "mel_features_generic_kernel");
+    }
   }
   if (own_stream) SNF_HIP_CHECK(hipStreamSynchronize(s));
   return SNF_OK;

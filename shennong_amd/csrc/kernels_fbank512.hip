@@ -1,0 +1,457 @@
+// Register-resident fused filterbank / MFCC kernel for the headline configuration
+// (padded frame = 512 samples: 25 ms @ 16 kHz, snip_edges, no VTLN warp) on gfx950.
+//
+// Mapping (wave64 = 4 frames x 16 lanes; lane l of a frame, complex packing z[n] = x[2n] + i x[2n+1]):
+//   A  load: lane l reads samples of z[l + 16 j], j < NJ straight from HBM/L2 (int16 pairs, one dword
+//      per element + the left neighbour for pre-emphasis); DC removal via a 16-lane DPP all-reduce;
+//      pre-emphasis and window in registers (Kaldi op order).
+//   B  pass 1: 16-point FFT over j in registers (radix-4 x radix-4, compile-time twiddles), inter-pass
+//      twiddle W256^(l k2), 16x16 transpose through a padded (conflict-free) wave-private LDS tile.
+//   C  pass 2: 16-point FFT over n1 in registers -> lane l holds Z[l + 16 k1].
+//   D  real-FFT unpack + power: bins k and 256-k are paired; the partner Z[256-k] comes through LDS
+//      (half a tile), twiddles W512^k from an LDS table.  Scaled by 4 (the 1/2 factors of the unpack
+//      are folded into the mel weights as an exact power of two).
+//   E  power spectrum to a wave-private LDS tile; F: sparse mel filterbank (each lane owns bins
+//      l, l+16, l+32..), log, coalesced 64-byte row segments to HBM.  MFCC adds the 13x23 DCT-II and
+//      lifter from LDS tables.
+// Nothing but the int16 samples and the float32 features ever touches HBM; no workgroup barrier.
+//
+// The dense contractions (mel x frame, DCT-II) are NOT mapped to MFMA here: the mel matrix is 95 %
+// zeros (2 non-zeros per FFT bin), f32 MFMA runs at the f32 VALU rate on gfx950, and a 16-frame MFMA
+// tile would cost more LDS traffic than the sparse form saves in VALU.
+//
+// Restates the same [KALDI-UPSTREAM] per-frame recipe as kernels_mel.hip (feature-window.cc
+// ProcessWindow order, feature-fbank.cc, feature-mfcc.cc, MelBanks::Compute), reached by the
+// reference at shennong/processor/base.py:429-431.
+#include <float.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "snf_internal.h"
+
+namespace snf {
+
+namespace {
+
+constexpr int kWaves = 4;                 // wavefronts per workgroup
+constexpr int kTileRow = 17;               // complex per transposed row (16 + 1 pad: conflict-free)
+constexpr int kFrameTileBytes = 16 * kTileRow * 8;  // wave-private LDS per frame (2176 B)
+constexpr int kMaxRounds = kFast512MaxRounds;  // mel bins <= 64
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// sum over the 16 lanes of a DPP row (= one frame), result in every lane of the row
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 1, 64);
+  return v;
+}
+
+__device__ __forceinline__ int64_t find_utt(const int64_t* __restrict__ offsets, int64_t n,
+                                            int64_t g) {
+  int64_t lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (offsets[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// a * (-i)
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }
+
+// 4-point forward DFT
+__device__ __forceinline__ void dft4(float2 a0, float2 a1, float2 a2, float2 a3, float2& o0,
+                                     float2& o1, float2& o2, float2& o3) {
+  const float2 s0 = cadd(a0, a2), s1 = csub(a0, a2), s2 = cadd(a1, a3), s3 = mul_mi(csub(a1, a3));
+  o0 = cadd(s0, s2);
+  o1 = cadd(s1, s3);
+  o2 = csub(s0, s2);
+  o3 = csub(s1, s3);
+}
+
+// 16-point forward FFT in registers, natural order in and out (radix-4 DIF x radix-4)
+__device__ __forceinline__ void fft16(float2 (&v)[16]) {
+  constexpr float c1 = 0.92387953251128675613f;  // cos(pi/8)
+  constexpr float s1 = 0.38268343236508977173f;  // sin(pi/8)
+  constexpr float r2 = 0.70710678118654752440f;  // sqrt(1/2)
+  float2 t[4][4];  // t[m][q]
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dft4(v[q], v[q + 4], v[q + 8], v[q + 12], t[0][q], t[1][q], t[2][q], t[3][q]);
+  // twiddles W16^(q m)
+  t[1][1] = cmul(t[1][1], make_float2(c1, -s1));                                   // W^1
+  t[1][2] = make_float2((t[1][2].x + t[1][2].y) * r2, (t[1][2].y - t[1][2].x) * r2);  // W^2
+  t[1][3] = cmul(t[1][3], make_float2(s1, -c1));                                   // W^3
+  t[2][1] = make_float2((t[2][1].x + t[2][1].y) * r2, (t[2][1].y - t[2][1].x) * r2);  // W^2
+  t[2][2] = mul_mi(t[2][2]);                                                       // W^4
+  t[2][3] = make_float2((t[2][3].y - t[2][3].x) * r2, -(t[2][3].x + t[2][3].y) * r2); // W^6
+  t[3][1] = cmul(t[3][1], make_float2(s1, -c1));                                   // W^3
+  t[3][2] = make_float2((t[3][2].y - t[3][2].x) * r2, -(t[3][2].x + t[3][2].y) * r2); // W^6
+  t[3][3] = cmul(t[3][3], make_float2(-c1, s1));                                   // W^9
+#pragma unroll
+  for (int m = 0; m < 4; ++m) dft4(t[m][0], t[m][1], t[m][2], t[m][3], v[m], v[4 + m], v[8 + m], v[12 + m]);
+}
+
+}  // namespace
+
+template <int NJ, int KIND>
+__global__ __launch_bounds__(kWaves * 64, 2) void fbank512_kernel(const Fast512Params p,
+                                                                   const BatchArgs b,
+                                                                   float* __restrict__ out,
+                                                                   double* __restrict__ energy_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tab = reinterpret_cast<float*>(smem);
+  // ---- stage the tables into LDS (the only workgroup-wide barrier of the kernel) -------------------
+  for (int i = threadIdx.x; i < p.table_floats; i += blockDim.x) tab[i] = p.tables[i];
+  __syncthreads();
+  const float2* __restrict__ t_win = reinterpret_cast<const float2*>(tab);
+  const float2* __restrict__ t_tw16 = t_win + 256;
+  const float2* __restrict__ t_tw512 = t_tw16 + 256;
+  const int* __restrict__ t_first = reinterpret_cast<const int*>(tab + p.off_first);
+  const int* __restrict__ t_count = reinterpret_cast<const int*>(tab + p.off_count);
+  const float* __restrict__ t_w = tab + p.off_w;
+  const float* __restrict__ t_dct = tab + p.off_dct;
+  const float* __restrict__ t_lifter = tab + p.off_lifter;
+
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int l = lane & 15, q = lane >> 4;
+  const int tab_bytes = (p.table_floats * 4 + 255) & ~255;
+  char* wave_base = smem + tab_bytes + (wid * 4 + q) * kFrameTileBytes;
+  float2* tile = reinterpret_cast<float2*>(wave_base);          // 16 rows x 17 complex
+  // power tile aliases the frame tile: 257 floats, skewed by 16 banks for odd frames so that the
+  // two frames of a 32-lane LDS group do not hit the same banks systematically
+  float* ptile = reinterpret_cast<float*>(wave_base) + (q & 1) * 16;
+
+  const int64_t n_sets = (b.total_frames + 3) >> 2;
+  const int64_t set_stride = static_cast<int64_t>(gridDim.x) * kWaves;
+  for (int64_t set = static_cast<int64_t>(blockIdx.x) * kWaves + wid; set < n_sets; set += set_stride) {
+    int64_t g = set * 4 + q;
+    const bool valid = g < b.total_frames;
+    if (!valid) g = b.total_frames - 1;
+    const int64_t u = find_utt(b.frame_offsets, b.n_utts, g);
+    const int64_t f = g - b.frame_offsets[u];
+    const int16_t* __restrict__ wp = b.wave + b.sample_offsets[u] + f * p.win_shift;
+
+    // ---- A: load, DC removal, pre-emphasis, window ------------------------------------------------
+    // A1: one dword (two int16 samples) per element; sum for the DC offset.  Only the last j can
+    // fall outside the window (NJ = ceil(win_len / 32)): every other load is base + constant.
+    typedef int __attribute__((aligned(2))) int_a2;
+    const int16_t* __restrict__ wl = wp + 2 * l;
+    const bool in_last = 2 * (l + 16 * (NJ - 1)) < p.win_len;
+    const int16_t* __restrict__ wlast = in_last ? wl + 32 * (NJ - 1) : wp;
+    int raw[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ - 1; ++j) raw[j] = *reinterpret_cast<const int_a2*>(wl + 32 * j);
+    raw[NJ - 1] = *reinterpret_cast<const int_a2*>(wlast);
+    float part = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float s2 = static_cast<float>(static_cast<short>(raw[j] & 0xffff)) +
+                       static_cast<float>(raw[j] >> 16);
+      part += (j < NJ - 1 || in_last) ? s2 : 0.0f;
+    }
+    float neg_mean = 0.0f;
+    if (p.remove_dc) neg_mean = -row_sum16(part) / static_cast<float>(p.win_len);
+    __builtin_amdgcn_sched_barrier(0);
+    // A2: the left neighbour x[2n-1] is re-read (L1 hit) instead of being kept from A1
+    float2 z[16];
+    float e_raw = 0.0f, e_post = 0.0f;
+    const int16_t* __restrict__ wprev0 = l > 0 ? wl - 1 : wp;  // x[-1] := x[0] (Kaldi Preemphasize)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j < NJ) {
+        const bool in = j < NJ - 1 || in_last;
+        const float xp = static_cast<float>(j == 0 ? wprev0[0]
+                                                   : (j < NJ - 1 ? wl[32 * j - 1] : wlast[in_last ? -1 : 0]));
+        const float xe = static_cast<float>(static_cast<short>(raw[j] & 0xffff));
+        const float xo = static_cast<float>(raw[j] >> 16);
+        const float2 w = t_win[l + 16 * j];  // zero outside the window
+        const float ae = xe + neg_mean, ao = xo + neg_mean, ap = xp + neg_mean;
+        if (p.need_raw && in) e_raw += ae * ae + ao * ao;
+        const float ye = (ae - p.preemph * ap) * w.x;
+        const float yo = (ao - p.preemph * ae) * w.y;
+        z[j] = make_float2(ye, yo);
+        if (p.need_post) e_post += ye * ye + yo * yo;
+      } else {
+        z[j] = make_float2(0.0f, 0.0f);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- B: pass 1 (FFT over j), inter-pass twiddle, transpose -------------------------------------
+    fft16(z);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) z[k2] = cmul(z[k2], t_tw16[k2 * 16 + l]);
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) tile[k2 * kTileRow + l] = z[k2];
+    wave_lds_sync();
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) z[n1] = tile[l * kTileRow + n1];
+    // ---- C: pass 2 (FFT over n1): z[k1] = Z[l + 16 k1] ---------------------------------------------
+    fft16(z);
+    __builtin_amdgcn_sched_barrier(0);
+    wave_lds_sync();
+
+    // ---- D: real-FFT unpack + power (x4) -----------------------------------------------------------
+    // upper half to LDS: xbuf[r][c] = Z[c + 16 (r + 8)], rows 0..7 (+ row 8 scratch for lane 0)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) tile[r * 16 + l] = z[r + 8];
+    wave_lds_sync();
+    float pk[8], pm[8];  // 4 P[k], 4 P[256-k] for k = l + 16 k1
+    const int pbase = l > 0 ? 7 * 16 + (16 - l) : 8 * 16;
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) {
+      const float2 zk = z[k1];
+      const float2 zp = tile[pbase - 16 * k1];
+      const float2 w = t_tw512[l + 16 * k1];
+      const float c_re = zk.x + zp.x, c_im = zk.y - zp.y;
+      const float d_re = zk.y + zp.y, d_im = zp.x - zk.x;
+      const float t_re = d_re * w.x - d_im * w.y, t_im = d_re * w.y + d_im * w.x;
+      const float a_re = c_re + t_re, a_im = c_im + t_im;
+      const float b_re = c_re - t_re, b_im = t_im - c_im;
+      pk[k1] = a_re * a_re + a_im * a_im;
+      pm[k1] = b_re * b_re + b_im * b_im;
+    }
+    if (l == 0) {
+      // k = 0: DC (and Nyquist, unused by the mel banks); pairs (16 k1, 256 - 16 k1) were computed
+      // above with zp = Z[256 - 16 k1] = row (8 - k1); k1 = 0 read scratch -> overwrite
+      const float dc = z[0].x + z[0].y;
+      pk[0] = 4.0f * dc * dc;
+      const float ny = z[0].x - z[0].y;
+      pm[0] = 4.0f * ny * ny;
+    }
+    // k = 128 (self-paired): Z[128] sits in lane 0, register 8
+    const float p128 = 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y);
+    wave_lds_sync();
+    // ---- E: power tile ------------------------------------------------------------------------------
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) {
+      ptile[l + 16 * k1] = pk[k1];
+      ptile[256 - l - 16 * k1] = pm[k1];
+    }
+    if (l == 0) ptile[128] = p128;
+    wave_lds_sync();
+
+    // ---- log-energy column ---------------------------------------------------------------------------
+    float log_energy = 0.0f;
+    if (p.need_raw || p.need_post) {
+      const float e_lin = row_sum16(p.need_raw ? e_raw : e_post);
+      if (KIND == SNF_KIND_PLP) {
+        if (valid && l == 0) energy_out[g] = log(fmax(static_cast<double>(e_lin), DBL_EPSILON));
+      } else {
+        log_energy = logf(fmaxf(e_lin, FLT_EPSILON));
+        if (p.has_floor && log_energy < p.log_energy_floor) log_energy = p.log_energy_floor;
+      }
+    }
+
+    // ---- F: sparse mel filterbank, log, epilogue ------------------------------------------------------
+    float* __restrict__ row = out + g * static_cast<int64_t>(p.out_cols);
+    const int mel_col = (KIND == SNF_KIND_FBANK && p.use_energy && !p.htk_compat) ? 1 : 0;
+    float logmel[kMaxRounds];
+#pragma unroll
+    for (int r = 0; r < kMaxRounds; ++r) {
+      if (r < p.rounds) {
+        const int m = l + 16 * r;
+        const int first = t_first[r * 16 + l], count = t_count[r * 16 + l];
+        const float* __restrict__ wt = t_w + p.mel_woff[r] + l;
+        float acc = 0.0f;
+        for (int t = 0; t < p.mel_maxcount[r]; ++t) {
+          const float pv = ptile[first + (t < count ? t : 0)];
+          acc += wt[16 * t] * pv;
+        }
+        if (KIND == SNF_KIND_FBANK) {
+          const float v = p.use_log ? logf(fmaxf(acc, FLT_EPSILON)) : acc;
+          if (valid && m < p.num_bins) row[mel_col + m] = v;
+        } else if (KIND == SNF_KIND_MFCC) {
+          logmel[r] = logf(fmaxf(acc, FLT_EPSILON));
+        } else {
+          if (valid && m < p.num_bins) row[m] = acc;
+        }
+      }
+    }
+    if (KIND == SNF_KIND_FBANK) {
+      if (p.use_energy && valid && l == 0) row[p.htk_compat ? p.num_bins : 0] = log_energy;
+    }
+    if (KIND == SNF_KIND_MFCC) {
+      // DCT-II + lifter: lane c owns cepstrum c (num_ceps <= 16); log-mel goes through the (now idle)
+      // power tile
+      wave_lds_sync();
+#pragma unroll
+      for (int r = 0; r < kMaxRounds; ++r)
+        if (r < p.rounds && l + 16 * r < p.num_bins) ptile[l + 16 * r] = logmel[r];
+      wave_lds_sync();
+      float v = 0.0f;
+      for (int m = 0; m < p.num_bins; ++m) v += t_dct[m * 16 + l] * ptile[m];
+      v *= t_lifter[l];
+      if (l == 0 && p.use_energy) v = log_energy;
+      int oc = l;
+      if (p.htk_compat) {
+        oc = l == 0 ? p.num_ceps - 1 : l - 1;
+        if (l == 0 && !p.use_energy)
+          v = static_cast<float>(static_cast<double>(v) * 1.4142135623730950488016887);
+      }
+      if (valid && l < p.num_ceps) row[oc] = v;
+    }
+    wave_lds_sync();  // the tile is reused by the next frame set
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+bool fast512_eligible(const MelParams& mp, bool any_warp) {
+  if (getenv("SNF_DISABLE_FAST512")) return false;
+  if (any_warp) return false;
+  if (mp.padded != 512 || !mp.pow2 || !mp.snip_edges || mp.dither != 0.0f) return false;
+  if (mp.win_len & 1) return false;
+  const int nj = (mp.win_len + 31) / 32;  // only the last j may be partially outside the window
+  if (nj != 13 && nj != 16) return false;
+  if (mp.kind != SNF_KIND_FBANK && mp.kind != SNF_KIND_MFCC && mp.kind != SNF_KIND_PLP) return false;
+  if (mp.kind == SNF_KIND_FBANK && !mp.use_power) return false;
+  if (mp.num_bins > 16 * kMaxRounds) return false;
+  if (mp.kind == SNF_KIND_MFCC && mp.num_ceps > 16) return false;
+  return true;
+}
+
+// Builds the packed LDS table blob from the plan's host tables (warp 1.0 mel banks).
+int fast512_build(const MelParams& mp, const std::vector<float>& window, const MelBanksHost& mb,
+                  const std::vector<float>& dct, const std::vector<float>& lifter,
+                  std::vector<float>* blob, Fast512Params* out) {
+  constexpr double kTwoPi = 6.283185307179586476925286766559005;
+  Fast512Params p{};
+  p.win_len = mp.win_len;
+  p.win_shift = mp.win_shift;
+  p.remove_dc = mp.remove_dc;
+  p.preemph = mp.preemph;
+  p.kind = mp.kind;
+  p.use_energy = mp.use_energy;
+  p.need_raw = mp.need_raw;
+  p.need_post = mp.need_post;
+  p.htk_compat = mp.htk_compat;
+  p.use_log = mp.use_log;
+  p.has_floor = mp.has_floor;
+  p.log_energy_floor = mp.log_energy_floor;
+  p.num_bins = mp.num_bins;
+  p.num_ceps = mp.num_ceps;
+  p.rounds = (mp.num_bins + 15) / 16;
+  blob->clear();
+  // window pairs
+  for (int n = 0; n < 256; ++n) {
+    blob->push_back(2 * n < mp.win_len ? window[2 * n] : 0.0f);
+    blob->push_back(2 * n + 1 < mp.win_len ? window[2 * n + 1] : 0.0f);
+  }
+  // inter-pass twiddles T[k2][n1] = exp(-2 pi i n1 k2 / 256)
+  for (int k2 = 0; k2 < 16; ++k2)
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const double a = -kTwoPi * (n1 * k2) / 256.0;
+      blob->push_back(static_cast<float>(std::cos(a)));
+      blob->push_back(static_cast<float>(std::sin(a)));
+    }
+  // unpack twiddles exp(-2 pi i k / 512), k < 128
+  for (int k = 0; k < 128; ++k) {
+    const double a = -kTwoPi * k / 512.0;
+    blob->push_back(static_cast<float>(std::cos(a)));
+    blob->push_back(static_cast<float>(std::sin(a)));
+  }
+  // mel: lane l of round r owns bin l + 16 r
+  p.off_first = static_cast<int>(blob->size());
+  for (int r = 0; r < p.rounds; ++r)
+    for (int l = 0; l < 16; ++l) {
+      const int m = l + 16 * r;
+      const int first = m < mb.num_bins ? mb.first[m] : 0;
+      float as_float;
+      std::memcpy(&as_float, &first, 4);
+      blob->push_back(as_float);
+    }
+  p.off_count = static_cast<int>(blob->size());
+  for (int r = 0; r < p.rounds; ++r) {
+    int mx = 0;
+    for (int l = 0; l < 16; ++l) {
+      const int m = l + 16 * r;
+      const int count = m < mb.num_bins ? mb.size[m] : 0;
+      if (count > mx) mx = count;
+      float as_float;
+      std::memcpy(&as_float, &count, 4);
+      blob->push_back(as_float);
+    }
+    p.mel_maxcount[r] = mx;
+  }
+  p.off_w = static_cast<int>(blob->size());
+  int woff = 0;
+  for (int r = 0; r < p.rounds; ++r) {
+    p.mel_woff[r] = woff;
+    for (int t = 0; t < p.mel_maxcount[r]; ++t)
+      for (int l = 0; l < 16; ++l) {
+        const int m = l + 16 * r;
+        float w = 0.0f;
+        if (m < mb.num_bins && t < mb.size[m]) w = 0.25f * mb.w[mb.offset[m] + t];  // exact scaling
+        blob->push_back(w);
+      }
+    woff += p.mel_maxcount[r] * 16;
+  }
+  p.off_dct = static_cast<int>(blob->size());
+  if (mp.kind == SNF_KIND_MFCC) {
+    for (int m = 0; m < mp.num_bins; ++m)
+      for (int c = 0; c < 16; ++c)
+        blob->push_back(c < mp.num_ceps ? dct[static_cast<size_t>(c) * mp.num_bins + m] : 0.0f);
+  }
+  p.off_lifter = static_cast<int>(blob->size());
+  for (int c = 0; c < 16; ++c)
+    blob->push_back(c < static_cast<int>(lifter.size()) ? lifter[c] : 1.0f);
+  p.table_floats = static_cast<int>(blob->size());
+  *out = p;
+  return SNF_OK;
+}
+
+int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int out_cols,
+                    double* energy_out, hipStream_t stream) {
+  if (b.total_frames <= 0) return SNF_OK;
+  Fast512Params q = p;
+  q.out_cols = out_cols;
+  const int tab_bytes = (p.table_floats * 4 + 255) & ~255;
+  const size_t lds = static_cast<size_t>(tab_bytes) + kWaves * 4 * kFrameTileBytes;
+  if (lds > 80 * 1024) return set_error(SNF_E_RUNTIME, "fast512: tables do not fit in LDS");
+  const int nj = (p.win_len + 31) / 32;
+  const int64_t n_sets = (b.total_frames + 3) / 4;
+  int64_t blocks = (n_sets + kWaves - 1) / kWaves;
+  const int64_t max_blocks = 256 * 2 * 8;  // resident workgroups x grid-stride depth
+  if (blocks > max_blocks) blocks = max_blocks;
+  const dim3 grid(static_cast<unsigned>(blocks)), block(kWaves * 64);
+#define SNF_LAUNCH(NJ_, KIND_)                                                                      \
+  do {                                                                                              \
+    if (lds > 64 * 1024)                                                                            \
+      SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fbank512_kernel<NJ_, KIND_>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,                 \
+                                        static_cast<int>(lds)));                                    \
+    hipLaunchKernelGGL((fbank512_kernel<NJ_, KIND_>), grid, block, lds, stream, q, b, out,           \
+                       energy_out);                                                                 \
+  } while (0)
+  if (nj == 13) {
+    if (p.kind == SNF_KIND_FBANK) SNF_LAUNCH(13, SNF_KIND_FBANK);
+    else if (p.kind == SNF_KIND_MFCC) SNF_LAUNCH(13, SNF_KIND_MFCC);
+    else SNF_LAUNCH(13, SNF_KIND_PLP);
+  } else {
+    if (p.kind == SNF_KIND_FBANK) SNF_LAUNCH(16, SNF_KIND_FBANK);
+    else if (p.kind == SNF_KIND_MFCC) SNF_LAUNCH(16, SNF_KIND_MFCC);
+    else SNF_LAUNCH(16, SNF_KIND_PLP);
+  }
+#undef SNF_LAUNCH
+  SNF_HIP_CHECK(hipGetLastError());
+  return SNF_OK;
+}
+
+}  // namespace snf

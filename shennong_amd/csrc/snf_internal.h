@@ -143,6 +143,32 @@ int launch_plp_tail(const PlpParams& p, const BatchArgs& b, const float* mel, co
 int launch_deltas(const DeltaParams& p, const float* in, int in_cols, const int64_t* frame_offsets,
                   int64_t n_utts, int64_t total_frames, float* out, hipStream_t stream);
 
+
+// ---- register-resident 512-point fast path (kernels_fbank512.hip) ----------------------------------
+constexpr int kFast512MaxRounds = 4;
+struct Fast512Params {
+  int win_len, win_shift, remove_dc;
+  float preemph;
+  int kind, out_cols, use_energy, need_raw, need_post, htk_compat, use_log, has_floor;
+  float log_energy_floor;
+  int num_bins, num_ceps, rounds;
+  int mel_maxcount[kFast512MaxRounds];
+  int mel_woff[kFast512MaxRounds];
+  int table_floats;          // total floats of the packed table blob below
+  // one packed blob, copied to LDS at kernel start:
+  //   float2 win[256] | float2 tw16[256] | float2 tw512[128] | int first[rounds*16] |
+  //   int count[rounds*16] | float w[...] | float dct_t[num_bins*16] | float lifter[16]
+  const float* tables;
+  int off_first, off_count, off_w, off_dct, off_lifter;  // float offsets into the blob
+};
+
+bool fast512_eligible(const MelParams& mp, bool any_warp);
+int fast512_build(const MelParams& mp, const std::vector<float>& window, const MelBanksHost& mb,
+                  const std::vector<float>& dct, const std::vector<float>& lifter,
+                  std::vector<float>* blob, Fast512Params* out);
+int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int out_cols,
+                    double* energy_out, hipStream_t stream);
+
 struct PitchDevTables {
   int first_lag, last_lag, num_lags, num_states, win_size, win_shift, full_len;
   int ar_max_taps, rs_in_unit, rs_out_unit, rs_max_taps;
