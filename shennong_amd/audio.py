@@ -104,7 +104,8 @@ class Audio:
             raise ValueError(f'unsupported audio data type: {dtype}')
         if self.dtype is np.dtype(np.int16):
             if dtype is np.int32:
-                data = self.data * 2**15
+                # `data * 2**15` under the reference's numpy 1.x value-based casting
+                data = self.data.astype(np.int32) * 2**15
             else:
                 data = self.data / 2**15
         elif self.dtype is np.dtype(np.int32):

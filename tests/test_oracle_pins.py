@@ -1,0 +1,281 @@
+"""Pins the CPU oracle (oracle/kaldi_oracle.c) against everything the reference's own tests hold for
+the hot path, against fixtures generated from the reference's runnable numpy
+code (tests/golden/make_golden.py) and against the independent float64 restatement.
+
+Coefficient VALUES of fbank / MFCC / PLP / pitch are "parity unpinned" by the reference (no golden
+files, Kaldi not runnable here); what is pinned is listed test by test below."""
+
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import oracle as orc, spec_f64
+from shennong_amd import _abi
+
+
+@pytest.fixture(scope='module')
+def golden():
+    return np.load(os.path.join(GOLDEN, 'reference_numpy.npz'))
+
+
+def _frame_opts(**kw):
+    o = _abi.default_frame_options()
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+# ---- frame counts: every shape the reference tests assert -----------------------------------------
+@pytest.mark.parametrize('nsamples, shift_ms, length_ms, snip, sr, expected', [
+    (22713, 10, 25, True, 16000, 140),    # test_filterbank.py:61-62, test_mfcc.py:114
+    (22713, 20, 25, True, 16000, 70),     # test_filterbank.py:63-64
+    (22713, 20, 50, True, 16000, 69),     # test_filterbank.py:65-66
+    (22713, 10, 25, False, 16000, 142),   # test_plp.py:70-74
+    (16000, 10, 25, True, 16000, 98),     # test_pipeline.py:302-308 (1 s)
+    (3200, 10, 25, True, 16000, 18),      # test_pipeline.py (0.2 s)
+    (11356, 10, 25, True, 8000, 140),     # test_mfcc.py:131-137 (8 kHz resample of the clip)
+    (10, 10, 25, True, 16000, 0),
+])
+def test_num_frames(nsamples, shift_ms, length_ms, snip, sr, expected):
+    o = _frame_opts(samp_freq=sr, frame_shift_ms=shift_ms, frame_length_ms=length_ms,
+                    snip_edges=int(snip))
+    assert orc.num_frames(o, nsamples) == expected
+
+
+@pytest.mark.parametrize('length, shift, n, snip, expected', [
+    (1, 1, 10, True, 10), (1, 1, 10, False, 10), (2, 1, 10, True, 9), (2, 1, 10, False, 10),
+    (2, 2, 10, True, 5), (2, 2, 10, False, 5), (1, 2, 10, True, 5), (1, 2, 10, False, 5),
+    (3, 1, 10, True, 8), (3, 1, 10, False, 10), (5, 3, 9, True, 2), (5, 3, 9, False, 3)])
+def test_num_frames_frames_literals(length, shift, n, snip, expected):
+    """reference test/test_frames.py:18-138 (sample_rate=1, shift/length in seconds)"""
+    o = _frame_opts(samp_freq=1, frame_shift_ms=shift * 1000.0, frame_length_ms=length * 1000.0,
+                    snip_edges=int(snip))
+    assert orc.num_frames(o, n) == expected
+
+
+def test_first_sample_of_frame():
+    o = _frame_opts()
+    assert [orc.first_sample_of_frame(o, f) for f in range(3)] == [0, 160, 320]
+    o.snip_edges = 0
+    assert [orc.first_sample_of_frame(o, f) for f in range(3)] == [-120, 40, 200]
+
+
+# ---- window known answers (reference shennong/window.py:43-49, test/test_window.py:12-28) ----------
+def test_window_known_answers():
+    o = _frame_opts(samp_freq=1000, frame_length_ms=5,
+                    window_type=_abi.WINDOW_TYPES['hamming'])
+    assert np.array_equal(orc.window_function(o),
+                          np.array([0.08, 0.54, 1.0, 0.54, 0.08], dtype=np.float32))
+    o.window_type = _abi.WINDOW_TYPES['povey']
+    assert orc.window_function(o).tolist() == [
+        0.0, 0.5547847151756287, 1.0, 0.5547847151756287, 0.0]
+    o.window_type = _abi.WINDOW_TYPES['rectangular']
+    assert np.all(orc.window_function(o) == 1.0)
+
+
+@pytest.mark.parametrize('kind', ['hamming', 'hanning', 'povey', 'rectangular', 'blackman'])
+@pytest.mark.parametrize('length', [3, 10, 100, 400])
+def test_window_properties(kind, length):
+    o = _frame_opts(samp_freq=1000, frame_length_ms=length, window_type=_abi.WINDOW_TYPES[kind])
+    win = orc.window_function(o)
+    assert win.shape == (length,) and not np.any(np.isnan(win))
+    assert win.max() <= 1.0 and win.min() >= -1e-7
+    if kind == 'povey':
+        assert win[0] == win[-1] == 0.0
+    np.testing.assert_allclose(win, spec_f64.window_function(length, kind), rtol=1e-6, atol=1e-7)
+
+
+# ---- ExtractWindow reflection (reference plp.py:242-254) --------------------------------------------
+def test_extract_window_reflection():
+    o = _frame_opts(samp_freq=1000, frame_shift_ms=3, frame_length_ms=5, snip_edges=0,
+                    remove_dc_offset=0, preemph_coeff=0.0, dither=0.0,
+                    window_type=_abi.WINDOW_TYPES['rectangular'], round_to_power_of_two=0)
+    wave = np.arange(9, dtype=np.float32)
+    # frame 0 starts at 3*0 + 1 - 2 = -1: reflect -1 -> 0
+    win, _ = orc.extract_window(o, wave, 0)
+    assert win.tolist() == [0, 0, 1, 2, 3]
+    # last frame (2) starts at 5, runs to 9: reflect 9 -> 8
+    win, _ = orc.extract_window(o, wave, 2)
+    assert win.tolist() == [5, 6, 7, 8, 8]
+
+
+# ---- energy identity (reference test/processor/test_energy.py:36-44) --------------------------------
+@pytest.mark.parametrize('raw_energy', [True, False])
+def test_energy_identity(wave, raw_energy):
+    """MFCC[:, 0] == PLP[:, 0] == EnergyProcessor == log sum (x - mean)^2 (raw) computed in numpy"""
+    x = spec_f64.extract_frames(wave, 160, 400)
+    x = x - x.mean(axis=1, keepdims=True)
+    if not raw_energy:
+        y = x.copy()
+        y[:, 1:] = x[:, 1:] - np.float32(0.97) * x[:, :-1]
+        y[:, 0] = x[:, 0] - np.float32(0.97) * x[:, 0]
+        x = y * spec_f64.window_function(400, 'povey')
+    want = np.log((x * x).sum(axis=1))
+    cols = []
+    for kind in (_abi.KIND_MFCC, _abi.KIND_PLP, _abi.KIND_ENERGY):
+        o = _abi.default_options(kind)
+        o.frame.dither = 0
+        o.raw_energy = int(raw_energy)
+        cols.append(orc.compute(o, wave)[:, 0])
+        assert cols[-1].shape == (140,)
+        np.testing.assert_allclose(cols[-1], want, rtol=2e-6)
+    assert np.allclose(cols[0], cols[1]) and np.allclose(cols[0], cols[2])
+
+
+def test_plp_energy_floor_known_answer(wave):
+    """reference test_plp.py:77-81: energy_floor=exp(50), raw_energy=False -> column 0 == 50"""
+    o = _abi.default_options(_abi.KIND_PLP)
+    o.frame.dither = 0
+    o.raw_energy = 0
+    o.energy_floor = np.exp(50)
+    feat = orc.compute(o, wave)
+    assert feat.shape == (140, 13)
+    assert np.all(feat[:, 0] == 50)
+
+
+def test_htk_compat_rules(wave):
+    """reference test_mfcc.py:100-111 and test_plp.py:50-61"""
+    def run(kind, **kw):
+        o = _abi.default_options(kind)
+        o.frame.dither = 0
+        for k, v in kw.items():
+            setattr(o, k, v)
+        return orc.compute(o, wave)
+    for kind, c0_scale in ((_abi.KIND_MFCC, 2 ** 0.5), (_abi.KIND_PLP, 1.0)):
+        a = run(kind, use_energy=1, htk_compat=0)
+        b = run(kind, use_energy=1, htk_compat=1)
+        assert a[:, 0] == pytest.approx(b[:, -1])
+        assert np.array_equal(a[:, 1:], b[:, :-1])
+        a = run(kind, use_energy=0, htk_compat=0)
+        b = run(kind, use_energy=0, htk_compat=1)
+        assert a[:, 0] * c0_scale == pytest.approx(b[:, -1])
+    a = run(_abi.KIND_FBANK, use_energy=1, htk_compat=0)
+    b = run(_abi.KIND_FBANK, use_energy=1, htk_compat=1)
+    assert np.array_equal(a[:, 0], b[:, -1]) and np.array_equal(a[:, 1:], b[:, :-1])
+
+
+def test_option_errors():
+    """Kaldi KALDI_ERR cases surfaced as RuntimeError (reference test_filterbank.py:46-50,
+    test_mfcc.py:72-98)"""
+    wave = np.zeros(16000, dtype=np.int16)
+    for nb in (0, 1, 2):
+        o = _abi.default_options(_abi.KIND_FBANK)
+        o.frame.dither = 0
+        o.mel.num_bins = nb
+        with pytest.raises(RuntimeError):
+            orc.compute(o, wave)
+    o = _abi.default_options(_abi.KIND_MFCC)
+    o.frame.dither = 0
+    o.num_ceps = 25
+    with pytest.raises(RuntimeError):
+        orc.compute(o, wave)
+
+
+# ---- float64 restatement -------------------------------------------------------------------------------
+@pytest.mark.parametrize('kind, code, kw', [
+    ('fbank', _abi.KIND_FBANK, dict(num_bins=40)),
+    ('fbank', _abi.KIND_FBANK, dict(num_bins=23, snip_edges=False)),
+    ('mfcc', _abi.KIND_MFCC, dict()),
+    ('spectrogram', _abi.KIND_SPECTROGRAM, dict()),
+])
+def test_against_float64_spec(wave, kind, code, kw):
+    o = _abi.default_options(code)
+    o.frame.dither = 0
+    o.mel.num_bins = kw.get('num_bins', 23)
+    o.frame.snip_edges = int(kw.get('snip_edges', True))
+    got = orc.compute(o, wave)
+    want = spec_f64.features(
+        wave, kind, num_bins=o.mel.num_bins, snip_edges=bool(o.frame.snip_edges),
+        use_energy=(None if kind == 'mfcc' else False))
+    assert got.shape == want.shape
+    atol = {'fbank': 1e-4, 'mfcc': 5e-4, 'spectrogram': 5e-3}[kind]
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=atol)
+
+
+def test_mel_banks_structure():
+    """strict (left, right) support, Nyquist bin never used, two non-zeros per FFT bin at most"""
+    first, size, w, center = orc.mel_banks(
+        _abi.MelOptions(num_bins=40, low_freq=20, high_freq=0, vtln_low=100, vtln_high=-500),
+        _abi.default_frame_options())
+    assert w.shape == (40, 256)
+    assert np.all((w > 0).sum(axis=0) <= 2)
+    assert np.all(np.diff(center) > 0) and first[0] >= 1
+    for b in range(40):
+        nz = np.nonzero(w[b])[0]
+        assert nz[0] == first[b] and len(nz) == size[b] and w[b].max() <= 1.0
+    np.testing.assert_allclose(w, spec_f64.mel_banks(40, 16000.0, 512), atol=2e-5)
+
+
+# ---- deltas (scales derivable; reference test_delta.py:26-35) -------------------------------------------
+def test_delta_scales():
+    s = orc.delta_scales(2, 2)
+    np.testing.assert_allclose(s[1], np.array([-2, -1, 0, 1, 2]) / 10, rtol=1e-7)
+    np.testing.assert_allclose(
+        s[2], np.array([4, 4, 1, -4, -10, -4, 1, 4, 4]) / 100, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize('order, window', [(0, 1), (1, 2), (2, 2), (5, 5)])
+def test_deltas(order, window):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((30, 4)).astype(np.float32)
+    d = orc.deltas(x, order, window)
+    assert d.shape == (30, 4 * (order + 1))
+    assert np.array_equal(d[:, :4], x)
+    if order >= 1:
+        idx = np.clip(np.arange(30)[:, None] + np.arange(-window, window + 1)[None, :], 0, 29)
+        sc = np.arange(-window, window + 1) / (2 * sum(j * j for j in range(1, window + 1)))
+        want = (x[idx] * sc[None, :, None]).sum(axis=1)
+        np.testing.assert_allclose(d[:, 4:8], want, rtol=1e-5, atol=1e-6)
+
+
+# ---- fixtures generated from the reference's runnable numpy code ----------------------------------------
+def test_rasta_golden(golden):
+    """RastaFilter.filter (reference plp.py:101-146) incl. the 4-frame warm-up"""
+    got = orc.rasta(golden['rasta_in'], do_log=True)
+    np.testing.assert_allclose(got, golden['rasta_out'], rtol=3e-6)
+    assert np.all(got[:4] == 1.0)
+    got = orc.rasta(golden['rasta_in'][:3], do_log=True)
+    assert np.array_equal(got, golden['rasta_short_out'])
+    got = orc.rasta(golden['rasta_nolog_in'], do_log=False)
+    np.testing.assert_allclose(got, golden['rasta_nolog_out'], rtol=1e-6, atol=1e-7)
+
+
+def test_lpc2cepstrum_golden(golden):
+    for lpc, cep in zip(golden['lpc_in'], golden['lpc_out']):
+        assert np.array_equal(orc.lpc2cepstrum(lpc), cep)
+
+
+# ---- pitch: structure pinned by the reference (shapes) and by Kaldi's constants ---------------------------
+def test_pitch_structure(wave):
+    po = _abi.default_pitch_options()
+    lags, first_lag, last_lag = orc.pitch_lags(po)
+    assert (len(lags), first_lag, last_lag) == (417, 8, 82)
+    assert orc.pitch_num_frames(po, 22713) == 140             # test_pitch_kaldi.py:39-47
+    po2 = _abi.default_pitch_options()
+    po2.frame_shift_ms = 20
+    assert orc.pitch_num_frames(po2, 22713) == 70
+    po2.frame_length_ms = 50
+    assert orc.pitch_num_frames(po2, 22713) == 69
+    down = orc.linear_resample(wave.astype(np.float32), 16000, 4000, 1000.0, 1)
+    assert down.shape == (5679,)
+    raw = orc.pitch(po, wave)
+    assert raw.shape == (140, 2)
+    assert np.all((raw[:, 1] >= 50) & (raw[:, 1] <= 400)) and np.all(np.abs(raw[:, 0]) <= 1.01)
+
+
+def test_pitch_tracks_a_tone():
+    """A 5-harmonic 150 Hz tone in light noise must be tracked within one lag step"""
+    from shennong_amd import synth
+    rng = np.random.default_rng(0)
+    t = np.arange(32000) / 16000
+    x = sum(np.sin(2 * np.pi * h * 150.0 * t) / h for h in range(1, 6)) * 6000
+    wave = np.clip(x + rng.normal(0, 200, t.shape), -32767, 32767).astype(np.int16)
+    raw = orc.pitch(_abi.default_pitch_options(), wave)
+    assert np.median(np.abs(raw[5:-5, 1] / 150.0 - 1)) < 0.01
+    assert np.median(raw[5:-5, 0]) > 0.9
+    post = _abi.default_pitch_post_options()
+    post.delta_pitch_noise_stddev = 0
+    feats = orc.process_pitch(post, raw)
+    assert feats.shape == (raw.shape[0], 3) and np.all(np.isfinite(feats))
