@@ -1,0 +1,99 @@
+"""Multi-GPU driver: utterances shard embarrassingly over the ranks of one node, one process per GPU.
+
+The reference's only parallelism is a joblib thread pool over utterances sharing one address space
+(reference shennong/processor/base.py:104-107); its multi-GPU counterpart is:
+  * ``shard_utterances``  - length-balanced static partition (no data-path collective),
+  * ``gather_features``   - the one exchange step: variable-length gather of the float32 Features blocks
+                            to a root rank as point-to-point sends (``gatherv``): every peer uses its own
+                            direct xGMI link to the root instead of a ring.
+``torch.distributed`` (backend "nccl" = RCCL on ROCm, "gloo" on CPU) is plumbing only.
+"""
+
+import numpy as np
+
+
+def shard_utterances(lengths, world_size):
+    """Greedy longest-first partition of utterance indices by sample count.
+
+    Returns `world_size` lists of indices (each sorted ascending); deterministic, every index appears
+    exactly once, the per-rank sample totals differ by at most the longest utterance."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    order = np.argsort(-lengths, kind='stable')
+    totals = np.zeros(world_size, dtype=np.int64)
+    shards = [[] for _ in range(world_size)]
+    for idx in order:
+        r = int(np.argmin(totals))
+        shards[r].append(int(idx))
+        totals[r] += lengths[idx]
+    return [sorted(s) for s in shards]
+
+
+def gather_features(local, dst=0, group=None, device=None):
+    """Gathers per-rank ``{name: float32 [nframes, ndims]}`` dicts on rank `dst`.
+
+    Names and shapes travel as a small all-gathered object; the matrices travel as ONE contiguous
+    float32 buffer per peer, sent point-to-point to `dst`.  Returns the merged dict on `dst`, None
+    elsewhere."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    names = list(local.keys())
+    shapes = [tuple(local[n].shape) for n in names]
+    meta = [None] * world
+    dist.all_gather_object(meta, (names, shapes), group=group)
+    sizes = [sum(int(np.prod(s)) for s in m[1]) for m in meta]
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) \
+            if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+    flat = np.concatenate([np.ascontiguousarray(local[n], dtype=np.float32).reshape(-1)
+                           for n in names]) if names else np.zeros(0, np.float32)
+    send = torch.from_numpy(flat).to(device)
+    if rank == dst:
+        bufs = {r: torch.empty(sizes[r], dtype=torch.float32, device=device)
+                for r in range(world) if r != dst and sizes[r] > 0}
+        ops = [dist.P2POp(dist.irecv, buf, r, group) for r, buf in bufs.items()]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        merged = {}
+        for r in range(world):
+            data = (send if r == dst else bufs.get(r))
+            host = data.cpu().numpy() if data is not None else np.zeros(0, np.float32)
+            pos = 0
+            for name, shape in zip(*meta[r]):
+                n = int(np.prod(shape))
+                merged[name] = host[pos:pos + n].reshape(shape).copy()
+                pos += n
+        return merged
+    if sizes[rank] > 0:
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, send, dst, group)]):
+            req.wait()
+    return None
+
+
+def process_all_sharded(processor, utterances, dst=0, group=None, **kwargs):
+    """``processor.process_all`` over the utterances owned by this rank, then the gather.
+
+    Every rank passes the same `utterances`; rank `dst` gets the full FeaturesCollection (same keys
+    and values as a single-process ``process_all``), the others get None."""
+    import torch.distributed as dist
+    from shennong_amd.features import Features, FeaturesCollection
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    utts = list(utterances)
+    signals = [u.load_audio() for u in utts]
+    shards = shard_utterances([s.nsamples for s in signals], world)
+    mine = shards[rank]
+    per_utt = {k: [v[utts[i].name] for i in mine] for k, v in kwargs.items()}
+    feats = processor._process_batch([signals[i] for i in mine], **per_utt) if mine else []
+    local = {utts[i].name: f.data for i, f in zip(mine, feats)}
+    merged = gather_features(local, dst=dst, group=group)
+    if merged is None:
+        return None
+    out = FeaturesCollection()
+    for i, u in enumerate(utts):
+        data = merged[u.name]
+        extra = {k: v[u.name] for k, v in kwargs.items()}
+        out[u.name] = Features(
+            data, processor.times(data.shape[0]),
+            properties=processor.get_properties(**extra), validate=False)
+    return out
