@@ -108,7 +108,7 @@ __device__ __forceinline__ void fft16(float2 (&v)[16]) {
 }  // namespace
 
 template <int NJ, int KIND>
-__global__ __launch_bounds__(kWaves * 64, 2) void fbank512_kernel(const Fast512Params p,
+__global__ __launch_bounds__(kWaves * 64, 3) void fbank512_kernel(const Fast512Params p,
                                                                    const BatchArgs b,
                                                                    float* __restrict__ out,
                                                                    double* __restrict__ energy_out) {
@@ -141,9 +141,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void fbank512_kernel(const Fast512P
     int64_t g = set * 4 + q;
     const bool valid = g < b.total_frames;
     if (!valid) g = b.total_frames - 1;
-    const int64_t u = find_utt(b.frame_offsets, b.n_utts, g);
-    const int64_t f = g - b.frame_offsets[u];
-    const int16_t* __restrict__ wp = b.wave + b.sample_offsets[u] + f * p.win_shift;
+    // the four frames of a set are consecutive rows: one wave-uniform (scalar) binary search for the
+    // first one, then a short per-frame walk across utterance boundaries
+    const int64_t g0 = __builtin_amdgcn_readfirstlane(static_cast<int>(set & 0x7fffffff)) * 4ll +
+                       ((set >> 31) << 33);
+    int64_t u = find_utt(b.frame_offsets, b.n_utts, g0);
+    while (g >= b.frame_offsets[u + 1]) ++u;
+    const int f = static_cast<int>(g - b.frame_offsets[u]);
+    const int16_t* __restrict__ wp = b.wave + b.sample_offsets[u] + static_cast<int64_t>(f) * p.win_shift;
 
     // ---- A: load, DC removal, pre-emphasis, window ------------------------------------------------
     // A1: one dword (two int16 samples) per element; sum for the DC offset.  Only the last j can
@@ -166,16 +171,19 @@ __global__ __launch_bounds__(kWaves * 64, 2) void fbank512_kernel(const Fast512P
     float neg_mean = 0.0f;
     if (p.remove_dc) neg_mean = -row_sum16(part) / static_cast<float>(p.win_len);
     __builtin_amdgcn_sched_barrier(0);
-    // A2: the left neighbour x[2n-1] is re-read (L1 hit) instead of being kept from A1
+    // A2: the left neighbour x[2n-1] is the odd sample of element n-1 = lane l-1 (same j), or lane 15
+    // of j-1 for lane 0: one DPP row rotate per element instead of a second trip to memory
     float2 z[16];
     float e_raw = 0.0f, e_post = 0.0f;
-    const int16_t* __restrict__ wprev0 = l > 0 ? wl - 1 : wp;  // x[-1] := x[0] (Kaldi Preemphasize)
+    int rot_prev = raw[0] << 16;  // lane 0, j = 0: x[-1] := x[0] (Kaldi Preemphasize)
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       if (j < NJ) {
         const bool in = j < NJ - 1 || in_last;
-        const float xp = static_cast<float>(j == 0 ? wprev0[0]
-                                                   : (j < NJ - 1 ? wl[32 * j - 1] : wlast[in_last ? -1 : 0]));
+        // row_ror:1 -> lane l receives lane (l - 1) mod 16 of its own frame
+        const int rot = __builtin_amdgcn_update_dpp(0, raw[j], 0x121, 0xf, 0xf, false);
+        const float xp = static_cast<float>((l == 0 ? rot_prev : rot) >> 16);
+        rot_prev = rot;
         const float xe = static_cast<float>(static_cast<short>(raw[j] & 0xffff));
         const float xo = static_cast<float>(raw[j] >> 16);
         const float2 w = t_win[l + 16 * j];  // zero outside the window
@@ -266,13 +274,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void fbank512_kernel(const Fast512P
     for (int r = 0; r < kMaxRounds; ++r) {
       if (r < p.rounds) {
         const int m = l + 16 * r;
-        const int first = t_first[r * 16 + l], count = t_count[r * 16 + l];
+        const int first = t_first[r * 16 + l];
         const float* __restrict__ wt = t_w + p.mel_woff[r] + l;
+        const float* __restrict__ pp = ptile + first;
+        // taps beyond `count` carry zero weights and read finite filler inside the frame tile
         float acc = 0.0f;
-        for (int t = 0; t < p.mel_maxcount[r]; ++t) {
-          const float pv = ptile[first + (t < count ? t : 0)];
-          acc += wt[16 * t] * pv;
-        }
+#pragma unroll 4
+        for (int t = 0; t < p.mel_maxcount[r]; ++t) acc += wt[16 * t] * pp[t];
         if (KIND == SNF_KIND_FBANK) {
           const float v = p.use_log ? logf(fmaxf(acc, FLT_EPSILON)) : acc;
           if (valid && m < p.num_bins) row[mel_col + m] = v;
