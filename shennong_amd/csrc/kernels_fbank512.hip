@@ -35,7 +35,7 @@ namespace snf {
 
 namespace {
 
-constexpr int kWaves = 4;                 // wavefronts per workgroup
+constexpr int kWaves = 8;                 // wavefronts per workgroup (2 workgroups per CU)
 constexpr int kTileRow = 17;               // complex per transposed row (16 + 1 pad: conflict-free)
 constexpr int kFrameTileBytes = 16 * kTileRow * 8;  // wave-private LDS per frame (2176 B)
 constexpr int kMaxRounds = kFast512MaxRounds;  // mel bins <= 64
@@ -47,11 +47,16 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // sum over the 16 lanes of a DPP row (= one frame), result in every lane of the row
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_ror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL,
+                                                               0xf, 0xf, false));
+}
 __device__ __forceinline__ float row_sum16(float v) {
-  v += __shfl_xor(v, 8, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 1, 64);
+  v += dpp_row_ror<0x128>(v);  // row_ror:8
+  v += dpp_row_ror<0x124>(v);  // row_ror:4
+  v += dpp_row_ror<0x122>(v);  // row_ror:2
+  v += dpp_row_ror<0x121>(v);  // row_ror:1
   return v;
 }
 
@@ -107,8 +112,9 @@ __device__ __forceinline__ void fft16(float2 (&v)[16]) {
 
 }  // namespace
 
-template <int NJ, int KIND>
-__global__ __launch_bounds__(kWaves * 64, 3) void fbank512_kernel(const Fast512Params p,
+// ENERGY: 0 = no log-energy column, 1 = raw (before pre-emphasis/window), 2 = after the window
+template <int NJ, int KIND, int ENERGY>
+__global__ __launch_bounds__(kWaves * 64, 4) void fbank512_kernel(const Fast512Params p,
                                                                    const BatchArgs b,
                                                                    float* __restrict__ out,
                                                                    double* __restrict__ energy_out) {
@@ -121,7 +127,6 @@ __global__ __launch_bounds__(kWaves * 64, 3) void fbank512_kernel(const Fast512P
   const float2* __restrict__ t_tw16 = t_win + 256;
   const float2* __restrict__ t_tw512 = t_tw16 + 256;
   const int* __restrict__ t_first = reinterpret_cast<const int*>(tab + p.off_first);
-  const int* __restrict__ t_count = reinterpret_cast<const int*>(tab + p.off_count);
   const float* __restrict__ t_w = tab + p.off_w;
   const float* __restrict__ t_dct = tab + p.off_dct;
   const float* __restrict__ t_lifter = tab + p.off_lifter;
@@ -188,15 +193,17 @@ __global__ __launch_bounds__(kWaves * 64, 3) void fbank512_kernel(const Fast512P
         const float xo = static_cast<float>(raw[j] >> 16);
         const float2 w = t_win[l + 16 * j];  // zero outside the window
         const float ae = xe + neg_mean, ao = xo + neg_mean, ap = xp + neg_mean;
-        if (p.need_raw && in) e_raw += ae * ae + ao * ao;
+        if (ENERGY == 1 && in) e_raw += ae * ae + ao * ao;
         const float ye = (ae - p.preemph * ap) * w.x;
         const float yo = (ao - p.preemph * ae) * w.y;
         z[j] = make_float2(ye, yo);
-        if (p.need_post) e_post += ye * ye + yo * yo;
+        if (ENERGY == 2) e_post += ye * ye + yo * yo;
       } else {
         z[j] = make_float2(0.0f, 0.0f);
       }
     }
+    float e_lin = 0.0f;
+    if (ENERGY != 0) e_lin = row_sum16(ENERGY == 1 ? e_raw : e_post);
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- B: pass 1 (FFT over j), inter-pass twiddle, transpose -------------------------------------
@@ -220,11 +227,11 @@ __global__ __launch_bounds__(kWaves * 64, 3) void fbank512_kernel(const Fast512P
     for (int r = 0; r < 8; ++r) tile[r * 16 + l] = z[r + 8];
     wave_lds_sync();
     float pk[8], pm[8];  // 4 P[k], 4 P[256-k] for k = l + 16 k1
-    const int pbase = l > 0 ? 7 * 16 + (16 - l) : 8 * 16;
+    const float2* __restrict__ partner = tile + (16 - l);  // Z[256 - k]: row 7-k1, column 16-l
 #pragma unroll
     for (int k1 = 0; k1 < 8; ++k1) {
       const float2 zk = z[k1];
-      const float2 zp = tile[pbase - 16 * k1];
+      const float2 zp = partner[16 * (7 - k1)];
       const float2 w = t_tw512[l + 16 * k1];
       const float c_re = zk.x + zp.x, c_im = zk.y - zp.y;
       const float d_re = zk.y + zp.y, d_im = zp.x - zk.x;
@@ -246,18 +253,18 @@ __global__ __launch_bounds__(kWaves * 64, 3) void fbank512_kernel(const Fast512P
     const float p128 = 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y);
     wave_lds_sync();
     // ---- E: power tile ------------------------------------------------------------------------------
+    float* __restrict__ pmirror = ptile + (144 - l);
 #pragma unroll
     for (int k1 = 0; k1 < 8; ++k1) {
       ptile[l + 16 * k1] = pk[k1];
-      ptile[256 - l - 16 * k1] = pm[k1];
+      pmirror[16 * (7 - k1)] = pm[k1];  // index 256 - l - 16 k1
     }
     if (l == 0) ptile[128] = p128;
     wave_lds_sync();
 
     // ---- log-energy column ---------------------------------------------------------------------------
     float log_energy = 0.0f;
-    if (p.need_raw || p.need_post) {
-      const float e_lin = row_sum16(p.need_raw ? e_raw : e_post);
+    if (ENERGY != 0) {
       if (KIND == SNF_KIND_PLP) {
         if (valid && l == 0) energy_out[g] = log(fmax(static_cast<double>(e_lin), DBL_EPSILON));
       } else {
@@ -439,15 +446,22 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
   const int64_t max_blocks = 256 * 2 * 8;  // resident workgroups x grid-stride depth
   if (blocks > max_blocks) blocks = max_blocks;
   const dim3 grid(static_cast<unsigned>(blocks)), block(kWaves * 64);
-#define SNF_LAUNCH(NJ_, KIND_)                                                                      \
+#define SNF_LAUNCH3(NJ_, KIND_, EN_)                                                                \
   do {                                                                                              \
     if (lds > 64 * 1024)                                                                            \
-      SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fbank512_kernel<NJ_, KIND_>), \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize,                 \
-                                        static_cast<int>(lds)));                                    \
-    hipLaunchKernelGGL((fbank512_kernel<NJ_, KIND_>), grid, block, lds, stream, q, b, out,           \
+      SNF_HIP_CHECK(hipFuncSetAttribute(                                                            \
+          reinterpret_cast<const void*>(fbank512_kernel<NJ_, KIND_, EN_>),                          \
+          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                      \
+    hipLaunchKernelGGL((fbank512_kernel<NJ_, KIND_, EN_>), grid, block, lds, stream, q, b, out,      \
                        energy_out);                                                                 \
   } while (0)
+#define SNF_LAUNCH(NJ_, KIND_)                                                                      \
+  do {                                                                                              \
+    if (energy == 0) SNF_LAUNCH3(NJ_, KIND_, 0);                                                    \
+    else if (energy == 1) SNF_LAUNCH3(NJ_, KIND_, 1);                                               \
+    else SNF_LAUNCH3(NJ_, KIND_, 2);                                                                \
+  } while (0)
+  const int energy = p.need_raw ? 1 : (p.need_post ? 2 : 0);
   if (nj == 13) {
     if (p.kind == SNF_KIND_FBANK) SNF_LAUNCH(13, SNF_KIND_FBANK);
     else if (p.kind == SNF_KIND_MFCC) SNF_LAUNCH(13, SNF_KIND_MFCC);
@@ -457,6 +471,7 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
     else if (p.kind == SNF_KIND_MFCC) SNF_LAUNCH(16, SNF_KIND_MFCC);
     else SNF_LAUNCH(16, SNF_KIND_PLP);
   }
+#undef SNF_LAUNCH3
 #undef SNF_LAUNCH
   SNF_HIP_CHECK(hipGetLastError());
   return SNF_OK;
