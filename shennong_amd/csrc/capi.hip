@@ -82,7 +82,8 @@ struct snf_plan {
 
   // scratch (host-pointer entry points and intermediates)
   DevBuf s_wave, s_out, s_in, s_soff, s_foff, s_uwarp, s_mel, s_energy;
-  DevBuf s_down, s_stats, s_bp, s_doff, s_dp1, s_fp1, s_states;
+  DevBuf s_down, s_stats, s_bp, s_doff, s_dp1, s_fp1, s_states, s_setidx;
+  bool setidx_valid = false;
 
   // last uploaded offsets tables (re-validated / re-uploaded only when they change)
   std::vector<int64_t> h_soff, h_foff;
@@ -659,6 +660,7 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     if ((rc = plan->s_foff.upload(foff, s))) return rc;
     plan->h_soff.swap(soff);
     plan->h_foff.swap(foff);
+    plan->setidx_valid = false;
   }
   if (any_warp && (rc = plan->s_uwarp.upload(warp_ids, s))) return rc;
   BatchArgs b{};
@@ -675,6 +677,16 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     if ((rc = plan->s_energy.ensure(sizeof(double) * static_cast<size_t>(total_frames)))) return rc;
   }
   const bool use_fast = plan->fast512 && !any_warp;
+  if (use_fast && !plan->setidx_valid) {
+    // frame-set -> utterance index: built once per offsets table, reused by every later call
+    const int64_t n_sets = (total_frames + 3) / 4;
+    if ((rc = plan->s_setidx.ensure(sizeof(int32_t) * static_cast<size_t>(n_sets)))) return rc;
+    if ((rc = launch_build_set_index(plan->s_foff.as<int64_t>(), n_utts, total_frames,
+                                     plan->s_setidx.as<int32_t>(), s)))
+      return rc;
+    plan->setidx_valid = true;
+  }
+  b.set_utt = plan->s_setidx.as<int32_t>();
   if (own_stream) begin_timing(plan);
   if (plan->kind == SNF_KIND_PLP) {
     const int nb = plan->o.mel.num_bins;
