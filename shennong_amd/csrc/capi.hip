@@ -263,10 +263,13 @@ int build_mel_plan(snf_plan* plan) {
       make_dct_matrix(o.num_ceps, o.mel.num_bins, &dct_h);
       if (o.cepstral_lifter != 0.0f) make_lifter(o.cepstral_lifter, o.num_ceps, &lifter_h);
     }
-    if ((rc = fast512_build(p, window, plan->banks[0], dct_h, lifter_h, &blob, &plan->fp))) return rc;
-    if ((rc = plan->d_fast_tables.upload(blob, plan->stream))) return rc;
-    plan->fp.tables = plan->d_fast_tables.as<float>();
-    plan->fast512 = true;
+    rc = fast512_build(p, window, plan->banks[0], dct_h, lifter_h, &blob, &plan->fp);
+    if (rc < 0) return rc;
+    if (rc == 0) {  // rc > 0: shape not covered by the fast kernel, keep the generic one
+      if ((rc = plan->d_fast_tables.upload(blob, plan->stream))) return rc;
+      plan->fp.tables = plan->d_fast_tables.as<float>();
+      plan->fast512 = true;
+    }
   }
   return SNF_OK;
 }

@@ -147,6 +147,7 @@ int launch_deltas(const DeltaParams& p, const float* in, int in_cols, const int6
 
 // ---- register-resident 512-point fast path (kernels_fbank512.hip) ----------------------------------
 constexpr int kFast512MaxRounds = 4;
+constexpr int kFast512MaxGroups = 16;  // 4-tap groups per mel round (bins up to 61 FFT bins wide)
 struct Fast512Params {
   int win_len, win_shift, remove_dc;
   float preemph;
@@ -160,7 +161,7 @@ struct Fast512Params {
   //   float2 win[256] | float2 tw16[256] | float2 tw512[128] | int first[rounds*16] |
   //   int count[rounds*16] | float w[...] | float dct_t[num_bins*16] | float lifter[16]
   const float* tables;
-  int off_first, off_count, off_w, off_dct, off_lifter;  // float offsets into the blob
+  int off_first, off_w, off_dct, off_lifter;  // float offsets into the blob
 };
 
 bool fast512_eligible(const MelParams& mp, bool any_warp);
