@@ -81,26 +81,51 @@ __device__ __forceinline__ void read_strided_rev(const void* base, float2 (&dst)
     read_strided_rev<N, STRIDE_BYTES, I + 1>(base, dst);
   }
 }
+// acc += sum over `ngroups` (a multiple of 2) groups of 4 taps of w * x; weights [group][16 lanes]
+// float4 at `wbase`, data contiguous at `pbase`.  Up to four groups (8 x ds_read_b128) are in flight
+// per wait.  (Counted lgkmcnt waits are not usable here: the compiler's scalar loads share the
+// counter and return out of order.)
+__device__ __forceinline__ void fma4(const float4& w, const float4& x, float& acc) {
+  acc += w.x * x.x;
+  acc += w.y * x.y;
+  acc += w.z * x.z;
+  acc += w.w * x.w;
+}
 template <int G, int I = 0>
 __device__ __forceinline__ void mel_groups(const void* wbase, const void* pbase, int ngroups,
                                            float& acc) {
   if constexpr (I < G) {
-    if (I < ngroups) {  // wave-uniform
-      const float4 w = lds_read_b128<I * 256>(wbase);  // [group][16 lanes] float4
-      const float4 x = lds_read_b128<I * 16>(pbase);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      acc += w.x * x.x;
-      acc += w.y * x.y;
-      acc += w.z * x.z;
-      acc += w.w * x.w;
-      mel_groups<G, I + 1>(wbase, pbase, ngroups, acc);
+    if (I + 4 <= ngroups) {  // wave-uniform
+      float4 w[4], x[4];
+      w[0] = lds_read_b128<(I + 0) * 256>(wbase);
+      x[0] = lds_read_b128<(I + 0) * 16>(pbase);
+      w[1] = lds_read_b128<(I + 1) * 256>(wbase);
+      x[1] = lds_read_b128<(I + 1) * 16>(pbase);
+      w[2] = lds_read_b128<(I + 2) * 256>(wbase);
+      x[2] = lds_read_b128<(I + 2) * 16>(pbase);
+      w[3] = lds_read_b128<(I + 3) * 256>(wbase);
+      x[3] = lds_read_b128<(I + 3) * 16>(pbase);
+      lds_wait();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fma4(w[i], x[i], acc);
+      mel_groups<G, I + 4>(wbase, pbase, ngroups, acc);
+    } else if (I + 2 <= ngroups) {
+      float4 w[2], x[2];
+      w[0] = lds_read_b128<(I + 0) * 256>(wbase);
+      x[0] = lds_read_b128<(I + 0) * 16>(pbase);
+      w[1] = lds_read_b128<(I + 1) * 256>(wbase);
+      x[1] = lds_read_b128<(I + 1) * 16>(pbase);
+      lds_wait();
+      fma4(w[0], x[0], acc);
+      fma4(w[1], x[1], acc);
     }
   }
 }
 
 constexpr int kMaxGroups = kFast512MaxGroups;  // 4-tap groups per mel round
 
-constexpr int kWaves = 8;                 // wavefronts per workgroup (2 workgroups per CU)
+constexpr int kWaves = 16;                // wavefronts per workgroup: one 1024-thread workgroup per CU,
+                                          // so the LDS tables are staged once per CU
 constexpr int kTileRow = 17;               // complex per transposed row (16 + 1 pad: conflict-free)
 constexpr int kFrameTileBytes = 16 * kTileRow * 8;  // wave-private LDS per frame (2176 B)
 constexpr int kMaxRounds = kFast512MaxRounds;  // mel bins <= 64
@@ -378,7 +403,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512_kernel(const Fast512P
         if (r < p.rounds && l + 16 * r < p.num_bins) ptile[l + 16 * r] = logmel[r];
       wave_lds_sync();
       float v = 0.0f;
-      mel_groups<16>(t_dct + 4 * l, ptile, (p.num_bins + 3) >> 2, v);  // num_bins <= 64
+      mel_groups<16>(t_dct + 4 * l, ptile, ((p.num_bins + 7) >> 3) << 1, v);  // num_bins <= 64
       v *= t_lifter[l];
       if (l == 0 && p.use_energy) v = log_energy;
       int oc = l;
@@ -483,8 +508,8 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
       std::memcpy(&as_float, &start[r * 16 + l], 4);
       blob->push_back(as_float);
     }
-    p.mel_maxcount[r] = groups;  // number of 4-tap groups of this round
     if (groups > kMaxGroups) return 1;  // a bin is too wide for the unrolled tap loop: not eligible
+    p.mel_maxcount[r] = (groups + 1) & ~1;  // 4-tap groups of this round (even: read in batches)
   }
   while (blob->size() % 4) blob->push_back(0.0f);  // 16-byte alignment of the float4 weights
   p.off_w = static_cast<int>(blob->size());
@@ -508,7 +533,7 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
   p.off_dct = static_cast<int>(blob->size());
   if (mp.kind == SNF_KIND_MFCC) {
     // [group of 4 bins][lane = cepstrum][4]
-    for (int g = 0; g < (mp.num_bins + 3) / 4; ++g)
+    for (int g = 0; g < ((mp.num_bins + 7) / 8) * 2; ++g)
       for (int c = 0; c < 16; ++c)
         for (int i = 0; i < 4; ++i) {
           const int m = 4 * g + i;
@@ -531,11 +556,11 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
   q.out_cols = out_cols;
   const int tab_bytes = (p.table_floats * 4 + 255) & ~255;
   const size_t lds = static_cast<size_t>(tab_bytes) + kWaves * 4 * kFrameTileBytes;
-  if (lds > 80 * 1024) return set_error(SNF_E_RUNTIME, "fast512: tables do not fit in LDS");
+  if (lds > 160 * 1024) return set_error(SNF_E_RUNTIME, "fast512: tables do not fit in LDS");
   const int nj = (p.win_len + 31) / 32;
   const int64_t n_sets = (b.total_frames + 3) / 4;
   int64_t blocks = (n_sets + kWaves - 1) / kWaves;
-  const int64_t max_blocks = 256 * 2 * 8;  // resident workgroups x grid-stride depth
+  const int64_t max_blocks = 256 * 4;  // one resident workgroup per CU x grid-stride depth
   if (blocks > max_blocks) blocks = max_blocks;
   const dim3 grid(static_cast<unsigned>(blocks)), block(kWaves * 64);
 #define SNF_LAUNCH3(NJ_, KIND_, EN_)                                                                \
