@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
+#include <pthread.h>
 
 #include "../include/shennong_amd.h"
 
@@ -711,6 +712,41 @@ ORC_API int orc_compute(const snf_options* o, const int16_t* wave16, int64_t n, 
   free(wave); free(wfn); free(win); free(mel); free(ac); free(lpc); free(tmp); free(cep);
   melbanks_free(&mb); free(dct); free(lift); free(eql); free(idft);
   return 0;
+}
+
+/* Batch driver for the CPU baseline: one utterance per task over `nthreads` POSIX threads, the
+ * reference's own threading model (joblib threads over utterances, processor/base.py:104-107). */
+typedef struct {
+  const snf_options* o; const int16_t* wave; const int64_t* soff; const int64_t* foff;
+  int64_t n_utts; int ndims; float* out; int tid, nthreads; int rc;
+} batch_job_t;
+static void* batch_worker(void* arg) {
+  batch_job_t* j = (batch_job_t*)arg;
+  for (int64_t u = j->tid; u < j->n_utts; u += j->nthreads) {
+    int rc = orc_compute(j->o, j->wave + j->soff[u], j->soff[u + 1] - j->soff[u], 1.0f,
+                         j->out + j->foff[u] * j->ndims);
+    if (rc) j->rc = rc;
+  }
+  return NULL;
+}
+ORC_API int orc_compute_batch(const snf_options* o, const int16_t* wave, const int64_t* soff,
+                              const int64_t* foff, int64_t n_utts, float* out, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)nthreads);
+  batch_job_t* jobs = (batch_job_t*)malloc(sizeof(batch_job_t) * (size_t)nthreads);
+  int ndims = orc_ndims(o), rc = 0;
+  for (int t = 0; t < nthreads; t++) {
+    batch_job_t j = {o, wave, soff, foff, n_utts, ndims, out, t, nthreads, 0};
+    jobs[t] = j;
+    if (nthreads == 1) batch_worker(&jobs[t]);
+    else pthread_create(&th[t], NULL, batch_worker, &jobs[t]);
+  }
+  for (int t = 0; t < nthreads; t++) {
+    if (nthreads > 1) pthread_join(th[t], NULL);
+    if (jobs[t].rc) rc = jobs[t].rc;
+  }
+  free(th); free(jobs);
+  return rc;
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -57,6 +57,8 @@ def lib():
     L.orc_rasta.argtypes = [pf, i64, i32, pf, i32]
     L.orc_ndims.argtypes = [OP]
     L.orc_compute.argtypes = [OP, C.POINTER(C.c_int16), i64, f32, pf]
+    L.orc_compute_batch.argtypes = [
+        OP, C.POINTER(C.c_int16), C.POINTER(i64), C.POINTER(i64), i64, pf, i32]
     L.orc_delta_scales.argtypes = [i32, i32, pf]
     L.orc_deltas.argtypes = [i32, i32, pf, i64, i32, pf]
     L.orc_pitch_num_frames.argtypes = [PO, i64]
@@ -173,6 +175,22 @@ def compute(opts, wave, vtln_warp=1.0):
         wave.shape[0], vtln_warp, _fp(out)))
     if nframes == 0:
         return np.zeros((0, 0), dtype=np.float32)
+    return out
+
+
+def compute_batch(opts, waves, nthreads=1):
+    """[n_utts, nsamples] int16 -> concatenated float32 [total_frames, ndims], one utterance per
+    task over `nthreads` POSIX threads (CPU baseline driver)"""
+    waves = np.ascontiguousarray(waves, dtype=np.int16)
+    n, ns = waves.shape
+    nf = num_frames(opts.frame, ns)
+    soff = np.arange(n + 1, dtype=np.int64) * ns
+    foff = np.arange(n + 1, dtype=np.int64) * nf
+    out = np.zeros((n * nf, ndims(opts)), dtype=np.float32)
+    _check(lib().orc_compute_batch(
+        C.byref(opts), waves.ctypes.data_as(C.POINTER(C.c_int16)),
+        soff.ctypes.data_as(C.POINTER(C.c_int64)),
+        foff.ctypes.data_as(C.POINTER(C.c_int64)), n, _fp(out), int(nthreads)))
     return out
 
 
