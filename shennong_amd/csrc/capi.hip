@@ -263,7 +263,9 @@ int build_mel_plan(snf_plan* plan) {
       make_dct_matrix(o.num_ceps, o.mel.num_bins, &dct_h);
       if (o.cepstral_lifter != 0.0f) make_lifter(o.cepstral_lifter, o.num_ceps, &lifter_h);
     }
-    rc = fast512_build(p, window, plan->banks[0], dct_h, lifter_h, &blob, &plan->fp);
+    const MelBanksHost no_banks;
+    rc = fast512_build(p, window, plan->banks.empty() ? no_banks : plan->banks[0], dct_h, lifter_h,
+                       &blob, &plan->fp);
     if (rc < 0) return rc;
     if (rc == 0) {  // rc > 0: shape not covered by the fast kernel, keep the generic one
       if ((rc = plan->d_fast_tables.upload(blob, plan->stream))) return rc;

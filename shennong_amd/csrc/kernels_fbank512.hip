@@ -371,6 +371,18 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512_kernel(const Fast512P
 
     // ---- F: sparse mel filterbank, log, epilogue ------------------------------------------------------
     float* __restrict__ row = out + g * static_cast<int64_t>(p.out_cols);
+    if (KIND == SNF_KIND_SPECTROGRAM) {
+      // log power spectrum, 257 bins: lane l stores bins l + 16 i (64-byte segments), bin 0 = energy
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float v = fast_log(fmaxf(0.25f * ptile[l + 16 * i], FLT_EPSILON));
+          if (i == 0 && l == 0) v = log_energy;
+          row[l + 16 * i] = v;
+        }
+        if (l == 0) row[256] = fast_log(fmaxf(0.25f * ptile[256], FLT_EPSILON));
+      }
+    }
     const int mel_col = (KIND == SNF_KIND_FBANK && p.use_energy && !p.htk_compat) ? 1 : 0;
     float logmel[kMaxRounds];
 #pragma unroll
@@ -445,7 +457,9 @@ bool fast512_eligible(const MelParams& mp, bool any_warp) {
   if (mp.win_len & 1) return false;
   const int nj = (mp.win_len + 31) / 32;  // only the last j may be partially outside the window
   if (nj != 13 && nj != 16) return false;
-  if (mp.kind != SNF_KIND_FBANK && mp.kind != SNF_KIND_MFCC && mp.kind != SNF_KIND_PLP) return false;
+  if (mp.kind != SNF_KIND_FBANK && mp.kind != SNF_KIND_MFCC && mp.kind != SNF_KIND_PLP &&
+      mp.kind != SNF_KIND_SPECTROGRAM)
+    return false;
   if (mp.kind == SNF_KIND_FBANK && !mp.use_power) return false;
   if (mp.num_bins > 16 * kMaxRounds) return false;
   if (mp.kind == SNF_KIND_MFCC && mp.num_ceps > 16) return false;
@@ -582,10 +596,12 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
   if (nj == 13) {
     if (p.kind == SNF_KIND_FBANK) SNF_LAUNCH(13, SNF_KIND_FBANK);
     else if (p.kind == SNF_KIND_MFCC) SNF_LAUNCH(13, SNF_KIND_MFCC);
+    else if (p.kind == SNF_KIND_SPECTROGRAM) SNF_LAUNCH(13, SNF_KIND_SPECTROGRAM);
     else SNF_LAUNCH(13, SNF_KIND_PLP);
   } else {
     if (p.kind == SNF_KIND_FBANK) SNF_LAUNCH(16, SNF_KIND_FBANK);
     else if (p.kind == SNF_KIND_MFCC) SNF_LAUNCH(16, SNF_KIND_MFCC);
+    else if (p.kind == SNF_KIND_SPECTROGRAM) SNF_LAUNCH(16, SNF_KIND_SPECTROGRAM);
     else SNF_LAUNCH(16, SNF_KIND_PLP);
   }
 #undef SNF_LAUNCH3

@@ -207,10 +207,80 @@ __global__ void delta_kernel(const DeltaParams p, const float* __restrict__ in, 
   }
 }
 
+// Tiled variant: a workgroup stages kDeltaRows + 2*halo input rows in LDS once (each HBM row is read
+// ~1.1x instead of 9x through the caches) and writes its output rows fully coalesced.  The edge clamp
+// is per utterance; a clamped neighbour is never farther than the unclamped one, so it is in the tile.
+constexpr int kDeltaRows = 64;
+
+__global__ __launch_bounds__(256) void delta_tiled_kernel(
+    const DeltaParams p, const float* __restrict__ in, const int D, const int halo,
+    const int64_t* __restrict__ frame_offsets, const int64_t n_utts, const int64_t total_frames,
+    float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* row_lo = reinterpret_cast<int*>(smem);   // [kDeltaRows] first row of the utterance (tile-relative)
+  int* row_hi = row_lo + kDeltaRows;            // [kDeltaRows] last row of the utterance (tile-relative)
+  float* scales = reinterpret_cast<float*>(row_hi + kDeltaRows);  // [n_scales]
+  float* tile = scales + ((p.n_scales + 3) & ~3);                 // [(kDeltaRows + 2 halo), D]
+  const int64_t g0 = static_cast<int64_t>(blockIdx.x) * kDeltaRows;
+  const int64_t t0 = g0 - halo;
+  const int tile_rows = kDeltaRows + 2 * halo;
+  const int64_t first = t0 * D, limit = total_frames * D;
+  for (int i = threadIdx.x; i < tile_rows * D; i += blockDim.x) {
+    const int64_t a = first + i;
+    tile[i] = (a >= 0 && a < limit) ? in[a] : 0.0f;
+  }
+  for (int i = threadIdx.x; i < p.n_scales; i += blockDim.x) scales[i] = p.scales[i];
+  if (threadIdx.x < kDeltaRows) {
+    const int64_t g = g0 + threadIdx.x;
+    if (g < total_frames) {
+      const int64_t u = find_utt(frame_offsets, n_utts, g);
+      const int64_t lo = frame_offsets[u] - t0, hi = frame_offsets[u + 1] - 1 - t0;
+      row_lo[threadIdx.x] = lo < 0 ? 0 : static_cast<int>(lo);  // rows outside the tile are never
+      row_hi[threadIdx.x] = hi > tile_rows - 1 ? tile_rows - 1 : static_cast<int>(hi);  // reached
+    }
+  }
+  __syncthreads();
+  const int OD = D * (p.order + 1);
+  const int rows_here = static_cast<int>(total_frames - g0 < kDeltaRows ? total_frames - g0 : kDeltaRows);
+  // element e = (row r, column c); advanced without divisions
+  int r = threadIdx.x / D, c = threadIdx.x - r * D;
+  const int dr = blockDim.x / D, dc = blockDim.x - dr * D;
+  float* __restrict__ obase = out + g0 * OD;
+  for (; r < rows_here; r += dr, c += dc) {
+    if (c >= D) { c -= D; ++r; if (r >= rows_here) break; }
+    const int lo = row_lo[r], hi = row_hi[r], centre = r + halo;
+    const float* __restrict__ sc = scales;
+    float* __restrict__ orow = obase + static_cast<int64_t>(r) * OD + c;
+    for (int i = 0; i <= p.order; ++i) {
+      const int max_off = i * p.window;
+      float acc = 0.0f;
+      for (int j = -max_off; j <= max_off; ++j) {
+        int t = centre + j;
+        t = t < lo ? lo : (t > hi ? hi : t);
+        const float s = sc[j + max_off];
+        if (s != 0.0f) acc += s * tile[t * D + c];
+      }
+      orow[i * D] = acc;
+      sc += 2 * max_off + 1;
+    }
+  }
+}
+
 int launch_deltas(const DeltaParams& p, const float* in, int in_cols, const int64_t* frame_offsets,
                   int64_t n_utts, int64_t total_frames, float* out, hipStream_t stream) {
   const int64_t total = total_frames * in_cols;
   if (total <= 0) return SNF_OK;
+  const int halo = p.order * p.window;
+  const size_t lds = 2 * sizeof(int) * kDeltaRows + sizeof(float) * ((p.n_scales + 3) & ~3) +
+                     sizeof(float) * static_cast<size_t>(kDeltaRows + 2 * halo) * in_cols;
+  if (lds <= 48 * 1024 && in_cols <= 256) {
+    hipLaunchKernelGGL(delta_tiled_kernel,
+                       dim3(static_cast<unsigned>((total_frames + kDeltaRows - 1) / kDeltaRows)),
+                       dim3(256), lds, stream, p, in, in_cols, halo, frame_offsets, n_utts,
+                       total_frames, out);
+    SNF_HIP_CHECK(hipGetLastError());
+    return SNF_OK;
+  }
   const int threads = 256;
   hipLaunchKernelGGL(delta_kernel, dim3(static_cast<unsigned>((total + threads - 1) / threads)),
                      dim3(threads), 0, stream, p, in, in_cols, frame_offsets, n_utts, total_frames,
