@@ -110,6 +110,10 @@ struct TrackShared {
   float* fwd;      // [num_states]
   float* nxt;      // [num_states]
   float* red;      // [16]
+  float* part_e2;  // [chunks][num_lags] partial sums of the lag correlation
+  float* part_ip;  // [chunks][num_lags]
+  float* rep_cost; // [16] Viterbi: best cost of the representative states 0, 32, 64, ...
+  int* rep_bp;     // [16] and their backpointers
 };
 
 __device__ __forceinline__ float block_min(float v, float* red) {
@@ -155,18 +159,48 @@ __device__ void forward_pass(const PitchDevTables& t, const float* __restrict__ 
                              float new_ballast, int16_t* __restrict__ bp, const TrackShared& sh) {
   const int S = t.num_states, L = t.num_lags, W = t.win_size;
   for (int s = threadIdx.x; s < S; s += blockDim.x) sh.fwd[s] = 0.0f;
+  // per-state constants of the lag resampler stay in registers across the frame loop when every
+  // thread owns at most one state
+  constexpr int kRegTaps = 12;
+  const bool reg_taps = S <= static_cast<int>(blockDim.x) && t.ar_max_taps <= kRegTaps;
+  float wreg[kRegTaps];
+  int my_first = 0, my_n = 0;
+  float my_lag = 0.0f;
+  if (reg_taps && static_cast<int>(threadIdx.x) < S) {
+    my_first = t.ar_first[threadIdx.x];
+    my_n = t.ar_n[threadIdx.x];
+    my_lag = t.lags[threadIdx.x];
+#pragma unroll
+    for (int j = 0; j < kRegTaps; ++j)
+      wreg[j] = j < my_n ? t.ar_w[threadIdx.x * t.ar_max_taps + j] : 0.0f;
+  }
   for (int64_t frame = 0; frame < T; ++frame) {
     const double ms = frame < T1 ? ms1 : ms2;
     const float ballast = static_cast<float>(pow(ms * W, 2.0) * static_cast<double>(t.nccf_ballast));
     const float e1 = load_frame(t, x, nd, frame, sh.win);
-    // batched-lag correlation: one thread per integer lag
-    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+    // batched-lag correlation: (lag, sample chunk) pairs over the whole workgroup, then one thread per
+    // lag adds the chunk partials in a fixed order (deterministic)
+    const int chunks = blockDim.x / L > 0 ? blockDim.x / L : 1;
+    const int chunk_len = (W + chunks - 1) / chunks;
+    for (int idx = threadIdx.x; idx < L * chunks; idx += blockDim.x) {
+      const int l = idx % L, c = idx / L;
+      const int i0 = c * chunk_len, i1 = i0 + chunk_len < W ? i0 + chunk_len : W;
       const float* __restrict__ a = sh.win;
-      const float* __restrict__ c = sh.win + t.first_lag + l;
+      const float* __restrict__ cw = sh.win + t.first_lag + l;
       float e2 = 0.0f, ip = 0.0f;
-      for (int i = 0; i < W; ++i) {
-        e2 += c[i] * c[i];
-        ip += a[i] * c[i];
+      for (int i = i0; i < i1; ++i) {
+        e2 += cw[i] * cw[i];
+        ip += a[i] * cw[i];
+      }
+      sh.part_e2[c * L + l] = e2;
+      sh.part_ip[c * L + l] = ip;
+    }
+    __syncthreads();
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+      float e2 = 0.0f, ip = 0.0f;
+      for (int c = 0; c < chunks; ++c) {
+        e2 += sh.part_e2[c * L + l];
+        ip += sh.part_ip[c * L + l];
       }
       const float norm = e1 * e2;
       const float den = static_cast<float>(sqrt(static_cast<double>(norm + ballast)));
@@ -184,25 +218,82 @@ __device__ void forward_pass(const PitchDevTables& t, const float* __restrict__ 
           static_cast<float>(pow(static_cast<double>(old_ms) * W, 2.0) * static_cast<double>(t.nccf_ballast));
       scale = powf((old_ballast + avg_norm_prod) / (new_ballast + avg_norm_prod), 0.5f);
     }
+    // ---- Viterbi step.  cost(i, j) = (j - i)^2 * factor + fwd[j]; its argmin is monotone in i (Kaldi's
+    // search relies on the same property), so: (1) exact argmin for the representative states
+    // 0, 32, 64, ... (32 lanes per representative, strided scan + lane reduction, lowest index wins
+    // ties); (2) every other state scans only between the backpointers of its two neighbouring
+    // representatives.  No FMA contraction: costs must round like Kaldi's.
+    const bool mono = S <= 512 && blockDim.x >= 512;
+    if (mono) {
+      const int rep = threadIdx.x >> 5, lane32 = threadIdx.x & 31;
+      const int i_rep = rep << 5;
+      float best = FLT_MAX;
+      int best_j = 0;
+      if (i_rep < S) {
+        const float fi = static_cast<float>(i_rep);
+        for (int j = lane32; j < S; j += 32) {
+          const float d = static_cast<float>(j) - fi;
+          const float c = __fadd_rn(__fmul_rn(d * d, t.inter_frame_factor), sh.fwd[j]);
+          if (c < best) { best = c; best_j = j; }
+        }
+      }
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) {
+        const float oc = __shfl_xor(best, off, 32);
+        const int oj = __shfl_xor(best_j, off, 32);
+        if (oc < best || (oc == best && oj < best_j)) { best = oc; best_j = oj; }
+      }
+      if (lane32 == 0 && i_rep < S) { sh.rep_cost[rep] = best; sh.rep_bp[rep] = best_j; }
+      __syncthreads();
+    }
     // sinc-resample the NCCF to the log-spaced lags, local cost, Viterbi step
     for (int s = threadIdx.x; s < S; s += blockDim.x) {
-      const float* __restrict__ wt = t.ar_w + s * t.ar_max_taps;
-      const float* __restrict__ src = sh.nccf + t.ar_first[s];
-      const int n = t.ar_n[s];
-      float v = 0.0f;
-      for (int j = 0; j < n; ++j) v += src[j] * wt[j];
+      float v = 0.0f, lag_s;
+      if (reg_taps) {
+        const float* __restrict__ src = sh.nccf + my_first;
+#pragma unroll
+        for (int j = 0; j < kRegTaps; ++j)
+          if (j < my_n) v += src[j] * wreg[j];
+        lag_s = my_lag;
+      } else {
+        const float* __restrict__ wt = t.ar_w + s * t.ar_max_taps;
+        const float* __restrict__ src = sh.nccf + t.ar_first[s];
+        const int n = t.ar_n[s];
+        for (int j = 0; j < n; ++j) v += src[j] * wt[j];
+        lag_s = t.lags[s];
+      }
       if (rescale) v *= scale;
       float local = 1.0f - v;
-      local += t.soft_min_f0 * t.lags[s] * v;
-      // exact argmin_j (j-s)^2 * factor + fwd[j]; lowest index wins ties (what Kaldi's bounded
-      // two-sweep search converges to).  No FMA contraction: costs must round like Kaldi's.
+      local += t.soft_min_f0 * lag_s * v;
       const float fs = static_cast<float>(s);
-      float best = __fadd_rn(__fmul_rn(fs * fs, t.inter_frame_factor), sh.fwd[0]);
-      int best_j = 0;
-      for (int j = 1; j < S; ++j) {
-        const float d = static_cast<float>(j) - fs;
-        const float c = __fadd_rn(__fmul_rn(d * d, t.inter_frame_factor), sh.fwd[j]);
-        if (c < best) { best = c; best_j = j; }
+      float best;
+      int best_j;
+      if (mono) {
+        const int k = s >> 5;
+        if ((s & 31) == 0) {
+          best = sh.rep_cost[k];
+          best_j = sh.rep_bp[k];
+        } else {
+          const int lo = sh.rep_bp[k];
+          const int hi = ((k + 1) << 5) < S ? sh.rep_bp[k + 1] : S - 1;
+          const float d0 = static_cast<float>(lo) - fs;
+          best = __fadd_rn(__fmul_rn(d0 * d0, t.inter_frame_factor), sh.fwd[lo]);
+          best_j = lo;
+          for (int j = lo + 1; j <= hi; ++j) {
+            const float d = static_cast<float>(j) - fs;
+            const float c = __fadd_rn(__fmul_rn(d * d, t.inter_frame_factor), sh.fwd[j]);
+            if (c < best) { best = c; best_j = j; }
+          }
+        }
+      } else {
+        // exact argmin over all states; lowest index wins ties
+        best = __fadd_rn(__fmul_rn(fs * fs, t.inter_frame_factor), sh.fwd[0]);
+        best_j = 0;
+        for (int j = 1; j < S; ++j) {
+          const float d = static_cast<float>(j) - fs;
+          const float c = __fadd_rn(__fmul_rn(d * d, t.inter_frame_factor), sh.fwd[j]);
+          if (c < best) { best = c; best_j = j; }
+        }
       }
       sh.nxt[s] = __fadd_rn(best, local);
       bp[frame * S + s] = static_cast<int16_t>(best_j);
@@ -237,6 +328,11 @@ __global__ __launch_bounds__(kTrackThreads) void pitch_track_kernel(
   sh.fwd = sh.norm + ((L + 3) & ~3);
   sh.nxt = sh.fwd + ((S + 3) & ~3);
   sh.red = sh.nxt + ((S + 3) & ~3);
+  const int chunks = kTrackThreads / L > 0 ? kTrackThreads / L : 1;
+  sh.part_e2 = sh.red + 16;
+  sh.part_ip = sh.part_e2 + chunks * L;
+  sh.rep_cost = sh.part_ip + chunks * L;
+  sh.rep_bp = reinterpret_cast<int*>(sh.rep_cost + 16);
   int16_t* __restrict__ bp = backptr + f0 * S;
 
   const double sq1 = stats[u * 4 + 0], s1 = stats[u * 4 + 1], sq2 = stats[u * 4 + 2],
@@ -333,8 +429,10 @@ int launch_pitch(const PitchDevTables& t, const PitchBatch& b, float* down, doub
   hipLaunchKernelGGL(pitch_stats_kernel, dim3(static_cast<unsigned>(b.n_utts)), dim3(256), 0, stream,
                      b, down, stats);
   SNF_HIP_CHECK(hipGetLastError());
+  const int chunks = kTrackThreads / t.num_lags > 0 ? kTrackThreads / t.num_lags : 1;
   const size_t lds = sizeof(float) * (((t.full_len + 3) & ~3) + 2 * ((t.num_lags + 3) & ~3) +
-                                      2 * ((t.num_states + 3) & ~3) + 16);
+                                      2 * ((t.num_states + 3) & ~3) + 16 + 2 * chunks * t.num_lags +
+                                      32);
   if (lds > 160 * 1024) return set_error(SNF_E_RUNTIME, "pitch state space does not fit in LDS");
   if (lds > 64 * 1024)
     SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pitch_track_kernel),
