@@ -683,15 +683,15 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
   }
   const bool use_fast = plan->fast512 && !any_warp;
   if (use_fast && !plan->setidx_valid) {
-    // frame-set -> utterance index: built once per offsets table, reused by every later call
-    const int64_t n_sets = (total_frames + 3) / 4;
-    if ((rc = plan->s_setidx.ensure(sizeof(int32_t) * static_cast<size_t>(n_sets)))) return rc;
-    if ((rc = launch_build_set_index(plan->s_foff.as<int64_t>(), n_utts, total_frames,
-                                     plan->s_setidx.as<int32_t>(), s)))
+    // frame -> first-sample index: built once per offsets table, reused by every later call
+    if ((rc = plan->s_setidx.ensure(sizeof(int64_t) * static_cast<size_t>(total_frames)))) return rc;
+    if ((rc = launch_build_frame_start(plan->s_foff.as<int64_t>(), plan->s_soff.as<int64_t>(), n_utts,
+                                       total_frames, plan->mp.win_shift,
+                                       plan->s_setidx.as<int64_t>(), s)))
       return rc;
     plan->setidx_valid = true;
   }
-  b.set_utt = plan->s_setidx.as<int32_t>();
+  b.frame_start = plan->s_setidx.as<int64_t>();
   if (own_stream) begin_timing(plan);
   if (plan->kind == SNF_KIND_PLP) {
     const int nb = plan->o.mel.num_bins;

@@ -232,57 +232,72 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512_kernel(const Fast512P
 
   const int64_t n_sets = (b.total_frames + 3) >> 2;
   const int64_t set_stride = static_cast<int64_t>(gridDim.x) * kWaves;
-  for (int64_t set = static_cast<int64_t>(blockIdx.x) * kWaves + wid; set < n_sets; set += set_stride) {
-    int64_t g = set * 4 + q;
-    const bool valid = g < b.total_frames;
-    if (!valid) g = b.total_frames - 1;
-    // the four frames of a set are consecutive rows: the utterance of the first one comes from the
-    // set index (built once per offsets table), then a short per-frame walk across boundaries
-    int64_t u = b.set_utt[set];  // utterance of the first frame of the set (prepass)
-    while (g >= b.frame_offsets[u + 1]) ++u;
-    const int f = static_cast<int>(g - b.frame_offsets[u]);
-    const int16_t* __restrict__ wp = b.wave + b.sample_offsets[u] + static_cast<int64_t>(f) * p.win_shift;
-
-    // ---- A: load, DC removal, pre-emphasis, window ------------------------------------------------
-    // A1: one dword (two int16 samples) per element; sum for the DC offset.  Only the last j can
-    // fall outside the window (NJ = ceil(win_len / 32)): every other load is base + constant.
-    typedef int __attribute__((aligned(2))) int_a2;
+  typedef int __attribute__((aligned(2))) int_a2;
+  const int64_t last_frame = b.total_frames - 1;
+  // Software pipeline over frame sets: the samples of set i+1 and the start offset of set i+2 are
+  // requested while set i is being transformed, so no global-memory latency sits on the critical
+  // path of a wave.  frame_start[g] (sample index of the first sample of global frame g) is built
+  // once per offsets table by build_frame_start_kernel.
+  int64_t set = static_cast<int64_t>(blockIdx.x) * kWaves + wid;
+  const bool in_last = 2 * (l + 16 * (NJ - 1)) < p.win_len;
+  int raw[NJ];
+  int64_t start_next = 0;
+  if (set < n_sets) {
+    const int64_t g = set * 4 + q;
+    const int16_t* __restrict__ wp = b.wave + b.frame_start[g < last_frame ? g : last_frame];
     const int16_t* __restrict__ wl = wp + 2 * l;
-    const bool in_last = 2 * (l + 16 * (NJ - 1)) < p.win_len;
-    const int16_t* __restrict__ wlast = in_last ? wl + 32 * (NJ - 1) : wp;
-    float2 win[NJ];
-    read_strided<NJ, 128>(t_win + l, win);  // in flight while the samples arrive
-    int raw[NJ];
 #pragma unroll
     for (int j = 0; j < NJ - 1; ++j) raw[j] = *reinterpret_cast<const int_a2*>(wl + 32 * j);
-    raw[NJ - 1] = *reinterpret_cast<const int_a2*>(wlast);
+    raw[NJ - 1] = *reinterpret_cast<const int_a2*>(in_last ? wl + 32 * (NJ - 1) : wp);
+    const int64_t gn = (set + set_stride) * 4 + q;
+    start_next = b.frame_start[gn < last_frame ? gn : last_frame];
+  }
+  for (; set < n_sets; set += set_stride) {
+    const int64_t g = set * 4 + q;
+    const bool valid = g <= last_frame;
+
+    // ---- A: DC removal, pre-emphasis, window ------------------------------------------------------
+    // A1: one dword (two int16 samples) per element, requested one iteration ago.  Only the last j
+    // can fall outside the window (NJ = ceil(win_len / 32)).
+    float2 win[NJ];
+    read_strided<NJ, 128>(t_win + l, win);
+    float xe[NJ], xo[NJ];
     float part = 0.0f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const float s2 = static_cast<float>(static_cast<short>(raw[j] & 0xffff)) +
-                       static_cast<float>(raw[j] >> 16);
+      xe[j] = static_cast<float>(static_cast<short>(raw[j] & 0xffff));
+      xo[j] = static_cast<float>(raw[j] >> 16);
+      const float s2 = xe[j] + xo[j];
       part += (j < NJ - 1 || in_last) ? s2 : 0.0f;
+    }
+    // prefetch: samples of the next set (its start offset arrived during the previous iteration),
+    // start offset of the set after it
+    if (set + set_stride < n_sets) {
+      const int16_t* __restrict__ wp = b.wave + start_next;
+      const int16_t* __restrict__ wl = wp + 2 * l;
+#pragma unroll
+      for (int j = 0; j < NJ - 1; ++j) raw[j] = *reinterpret_cast<const int_a2*>(wl + 32 * j);
+      raw[NJ - 1] = *reinterpret_cast<const int_a2*>(in_last ? wl + 32 * (NJ - 1) : wp);
+      const int64_t gn = (set + 2 * set_stride) * 4 + q;
+      start_next = b.frame_start[gn < last_frame ? gn : last_frame];
     }
     float neg_mean = 0.0f;
     if (p.remove_dc) neg_mean = -row_sum16(part) / static_cast<float>(p.win_len);
     lds_wait();
     // A2: the left neighbour x[2n-1] is the odd sample of element n-1 = lane l-1 (same j), or lane 15
-    // of j-1 for lane 0: one DPP row rotate per element instead of a second trip to memory
+    // of j-1 for lane 0: one DPP row rotate of the mean-removed value per element
     float2 z[16];
     float e_raw = 0.0f, e_post = 0.0f;
-    int rot_prev = raw[0] << 16;  // lane 0, j = 0: x[-1] := x[0] (Kaldi Preemphasize)
+    float rot_prev = xe[0] + neg_mean;  // lane 0, j = 0: x[-1] := x[0] (Kaldi Preemphasize)
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       if (j < NJ) {
         const bool in = j < NJ - 1 || in_last;
-        // row_ror:1 -> lane l receives lane (l - 1) mod 16 of its own frame
-        const int rot = __builtin_amdgcn_update_dpp(0, raw[j], 0x121, 0xf, 0xf, false);
-        const float xp = static_cast<float>((l == 0 ? rot_prev : rot) >> 16);
+        const float ae = xe[j] + neg_mean, ao = xo[j] + neg_mean;
+        const float rot = dpp_row_ror<0x121>(ao);  // lane l <- lane (l - 1) mod 16 of its frame
+        const float ap = l == 0 ? rot_prev : rot;
         rot_prev = rot;
-        const float xe = static_cast<float>(static_cast<short>(raw[j] & 0xffff));
-        const float xo = static_cast<float>(raw[j] >> 16);
         const float2 w = win[j];  // zero outside the window
-        const float ae = xe + neg_mean, ao = xo + neg_mean, ap = xp + neg_mean;
         if (ENERGY == 1 && in) e_raw += ae * ae + ao * ao;
         const float ye = (ae - p.preemph * ap) * w.x;
         const float yo = (ao - p.preemph * ae) * w.y;
@@ -430,19 +445,25 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512_kernel(const Fast512P
   }
 }
 
-// one thread per frame set: utterance that owns its first frame
-__global__ void build_set_index_kernel(const int64_t* __restrict__ frame_offsets, int64_t n_utts,
-                                       int64_t n_sets, int32_t* __restrict__ set_utt) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < n_sets) set_utt[i] = static_cast<int32_t>(find_utt(frame_offsets, n_utts, i * 4));
+// one thread per frame: sample index (into the concatenated wave) of the frame's first sample
+__global__ void build_frame_start_kernel(const int64_t* __restrict__ frame_offsets,
+                                         const int64_t* __restrict__ sample_offsets, int64_t n_utts,
+                                         int64_t total_frames, int win_shift,
+                                         int64_t* __restrict__ frame_start) {
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= total_frames) return;
+  const int64_t u = find_utt(frame_offsets, n_utts, g);
+  frame_start[g] = sample_offsets[u] + (g - frame_offsets[u]) * win_shift;
 }
 
-int launch_build_set_index(const int64_t* d_frame_offsets, int64_t n_utts, int64_t total_frames,
-                           int32_t* d_set_utt, hipStream_t stream) {
-  const int64_t n_sets = (total_frames + 3) / 4;
-  if (n_sets <= 0) return SNF_OK;
-  hipLaunchKernelGGL(build_set_index_kernel, dim3(static_cast<unsigned>((n_sets + 255) / 256)),
-                     dim3(256), 0, stream, d_frame_offsets, n_utts, n_sets, d_set_utt);
+int launch_build_frame_start(const int64_t* d_frame_offsets, const int64_t* d_sample_offsets,
+                             int64_t n_utts, int64_t total_frames, int win_shift,
+                             int64_t* d_frame_start, hipStream_t stream) {
+  if (total_frames <= 0) return SNF_OK;
+  hipLaunchKernelGGL(build_frame_start_kernel,
+                     dim3(static_cast<unsigned>((total_frames + 255) / 256)), dim3(256), 0, stream,
+                     d_frame_offsets, d_sample_offsets, n_utts, total_frames, win_shift,
+                     d_frame_start);
   SNF_HIP_CHECK(hipGetLastError());
   return SNF_OK;
 }

@@ -110,7 +110,7 @@ struct BatchArgs {
   const int64_t* sample_offsets;  // [n_utts+1]
   const int64_t* frame_offsets;   // [n_utts+1]
   const int32_t* utt_warp;        // [n_utts] index into the plan's warp tables, or nullptr
-  const int32_t* set_utt;         // [ceil(total_frames/4)] utterance of frame 4*i (fast path only)
+  const int64_t* frame_start;     // [total_frames] first sample of every frame (fast path only)
   int64_t n_utts;
   int64_t total_frames;
 };
@@ -168,8 +168,9 @@ bool fast512_eligible(const MelParams& mp, bool any_warp);
 int fast512_build(const MelParams& mp, const std::vector<float>& window, const MelBanksHost& mb,
                   const std::vector<float>& dct, const std::vector<float>& lifter,
                   std::vector<float>* blob, Fast512Params* out);
-int launch_build_set_index(const int64_t* d_frame_offsets, int64_t n_utts, int64_t total_frames,
-                           int32_t* d_set_utt, hipStream_t stream);
+int launch_build_frame_start(const int64_t* d_frame_offsets, const int64_t* d_sample_offsets,
+                             int64_t n_utts, int64_t total_frames, int win_shift,
+                             int64_t* d_frame_start, hipStream_t stream);
 int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int out_cols,
                     double* energy_out, hipStream_t stream);
 
