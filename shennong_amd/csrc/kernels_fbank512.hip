@@ -122,6 +122,26 @@ __device__ __forceinline__ void mel_groups(const void* wbase, const void* pbase,
   }
 }
 
+// counter-based N(0,1) pair for Kaldi's per-frame dither (statistical stand-in for RandGauss(), which
+// draws from C rand() and is not reproducible): murmur-style 32-bit finalisers + Box-Muller on the
+// hardware log2 / sqrt / sin / cos (v_sin_f32 and v_cos_f32 take revolutions)
+__device__ __forceinline__ unsigned fmix32(unsigned h) {
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ float2 gauss_pair(unsigned key_lo, unsigned key_hi, unsigned n) {
+  const unsigned h1 = fmix32(key_lo + n * 0x9E3779B1u);
+  const unsigned h2 = fmix32(key_hi ^ h1);
+  const float u1 = (static_cast<float>(h1 >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+  const float u2 = static_cast<float>(h2 >> 8) * (1.0f / 16777216.0f);           // [0, 1)
+  const float r = __builtin_amdgcn_sqrtf(-1.38629436111989f * __builtin_amdgcn_logf(u1));
+  return make_float2(r * __builtin_amdgcn_cosf(u2), r * __builtin_amdgcn_sinf(u2));
+}
+
 constexpr int kMaxGroups = kFast512MaxGroups;  // 4-tap groups per mel round
 
 constexpr int kWaves = 16;                // wavefronts per workgroup: one 1024-thread workgroup per CU,
@@ -203,7 +223,7 @@ __device__ __forceinline__ void fft16(float2 (&v)[16]) {
 }  // namespace
 
 // ENERGY: 0 = no log-energy column, 1 = raw (before pre-emphasis/window), 2 = after the window
-template <int NJ, int KIND, int ENERGY>
+template <int NJ, int KIND, int ENERGY, bool DITHER>
 __global__ __launch_bounds__(kWaves * 64, 4) void fbank512_kernel(const Fast512Params p,
                                                                    const BatchArgs b,
                                                                    float* __restrict__ out,
@@ -261,12 +281,23 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512_kernel(const Fast512P
     // can fall outside the window (NJ = ceil(win_len / 32)).
     float2 win[NJ];
     read_strided<NJ, 128>(t_win + l, win);
+    unsigned dkey_lo = 0, dkey_hi = 0;
+    if (DITHER) {
+      const unsigned long long k = (static_cast<unsigned long long>(g) + 1) * 0x9E3779B97F4A7C15ull ^ p.seed;
+      dkey_lo = fmix32(static_cast<unsigned>(k));
+      dkey_hi = fmix32(static_cast<unsigned>(k >> 32) ^ dkey_lo);
+    }
     float xe[NJ], xo[NJ];
     float part = 0.0f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       xe[j] = static_cast<float>(static_cast<short>(raw[j] & 0xffff));
       xo[j] = static_cast<float>(raw[j] >> 16);
+      if (DITHER) {  // Kaldi dithers before the DC removal
+        const float2 nz = gauss_pair(dkey_lo, dkey_hi, static_cast<unsigned>(l + 16 * j));
+        xe[j] += p.dither * nz.x;
+        xo[j] += p.dither * nz.y;
+      }
       const float s2 = xe[j] + xo[j];
       part += (j < NJ - 1 || in_last) ? s2 : 0.0f;
     }
@@ -474,7 +505,7 @@ int launch_build_frame_start(const int64_t* d_frame_offsets, const int64_t* d_sa
 bool fast512_eligible(const MelParams& mp, bool any_warp) {
   if (getenv("SNF_DISABLE_FAST512")) return false;
   if (any_warp) return false;
-  if (mp.padded != 512 || !mp.pow2 || !mp.snip_edges || mp.dither != 0.0f) return false;
+  if (mp.padded != 512 || !mp.pow2 || !mp.snip_edges) return false;
   if (mp.win_len & 1) return false;
   const int nj = (mp.win_len + 31) / 32;  // only the last j may be partially outside the window
   if (nj != 13 && nj != 16) return false;
@@ -497,6 +528,8 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
   p.win_shift = mp.win_shift;
   p.remove_dc = mp.remove_dc;
   p.preemph = mp.preemph;
+  p.dither = mp.dither;
+  p.seed = mp.seed;
   p.kind = mp.kind;
   p.use_energy = mp.use_energy;
   p.need_raw = mp.need_raw;
@@ -598,14 +631,19 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
   const int64_t max_blocks = 256 * 4;  // one resident workgroup per CU x grid-stride depth
   if (blocks > max_blocks) blocks = max_blocks;
   const dim3 grid(static_cast<unsigned>(blocks)), block(kWaves * 64);
-#define SNF_LAUNCH3(NJ_, KIND_, EN_)                                                                \
+#define SNF_LAUNCH4(NJ_, KIND_, EN_, DI_)                                                              \
   do {                                                                                              \
     if (lds > 64 * 1024)                                                                            \
       SNF_HIP_CHECK(hipFuncSetAttribute(                                                            \
-          reinterpret_cast<const void*>(fbank512_kernel<NJ_, KIND_, EN_>),                          \
+          reinterpret_cast<const void*>(fbank512_kernel<NJ_, KIND_, EN_, DI_>),                     \
           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                      \
-    hipLaunchKernelGGL((fbank512_kernel<NJ_, KIND_, EN_>), grid, block, lds, stream, q, b, out,      \
+    hipLaunchKernelGGL((fbank512_kernel<NJ_, KIND_, EN_, DI_>), grid, block, lds, stream, q, b, out, \
                        energy_out);                                                                 \
+  } while (0)
+#define SNF_LAUNCH3(NJ_, KIND_, EN_)                                                                \
+  do {                                                                                              \
+    if (p.dither != 0.0f) SNF_LAUNCH4(NJ_, KIND_, EN_, true);                                       \
+    else SNF_LAUNCH4(NJ_, KIND_, EN_, false);                                                       \
   } while (0)
 #define SNF_LAUNCH(NJ_, KIND_)                                                                      \
   do {                                                                                              \
@@ -625,6 +663,7 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
     else if (p.kind == SNF_KIND_SPECTROGRAM) SNF_LAUNCH(16, SNF_KIND_SPECTROGRAM);
     else SNF_LAUNCH(16, SNF_KIND_PLP);
   }
+#undef SNF_LAUNCH4
 #undef SNF_LAUNCH3
 #undef SNF_LAUNCH
   SNF_HIP_CHECK(hipGetLastError());

@@ -150,7 +150,8 @@ constexpr int kFast512MaxRounds = 4;
 constexpr int kFast512MaxGroups = 16;  // 4-tap groups per mel round (bins up to 61 FFT bins wide)
 struct Fast512Params {
   int win_len, win_shift, remove_dc;
-  float preemph;
+  float preemph, dither;
+  unsigned long long seed;
   int kind, out_cols, use_energy, need_raw, need_post, htk_compat, use_log, has_floor;
   float log_energy_floor;
   int num_bins, num_ceps, rounds;

@@ -210,3 +210,24 @@ def test_full_size_properties(gpu):
     f1 = proc.process(Audio(half, 16000)).data
     f2 = proc.process(Audio((half * 2).astype(np.int16), 16000)).data
     np.testing.assert_allclose(f2, 4 * f1, rtol=2e-5)
+
+
+@pytest.mark.parametrize('snip_edges', [True, False])  # fast 512-point kernel / generic kernel
+def test_dither_statistics(gpu, snip_edges):
+    """Dither cannot be bit-compared (Kaldi draws from C rand()); it must be N(0, dither^2) per
+    sample and per frame: on a silent signal the raw frame energy is (L-1) chi2-distributed."""
+    wave = np.zeros(48000, dtype=np.int16)
+    proc = MfccProcessor(dither=1.0, snip_edges=snip_edges)
+    a = proc.process(Audio(wave, 16000)).data
+    e = a[:, 0]  # log sum (x - mean)^2 over 400 samples of unit-variance noise
+    assert abs(e.mean() - np.log(399.0)) < 0.03, e.mean()
+    assert 0.04 < e.std() < 0.11, e.std()
+    # overlapping frames draw independent noise (Kaldi dithers every extracted window)
+    assert abs(np.corrcoef(e[:-1], e[1:])[0, 1]) < 0.25
+    # deterministic for a given seed
+    assert np.array_equal(a, proc.process(Audio(wave, 16000)).data)
+    # a loud signal is barely affected (reference test_parallel.py: is_close(atol=10))
+    loud = synth.utterances(3, 1, 16000)[0]
+    clean = MfccProcessor(dither=0, snip_edges=snip_edges).process(Audio(loud, 16000)).data
+    noisy = proc.process(Audio(loud, 16000)).data
+    assert np.abs(clean - noisy).max() < 0.05
