@@ -19,6 +19,12 @@
  *         (reference shennong/processor/energy.py:148-186)
  *   - Frames.nframes / window():      num_frames / FeatureWindowFunction
  *         (reference shennong/frames.py:137; shennong/window.py:107-114)
+ *   - VadPostProcessor.process:       kaldi.ivector.compute_vad_energy
+ *         (reference shennong/postprocessor/vad.py:182-185)
+ *   - CmvnPostProcessor.accumulate / process: kaldi.transform.cmvn.Cmvn.accumulate / apply
+ *         (reference shennong/postprocessor/cmvn.py:216-219, :277-278)
+ *   - SlidingWindowCmvnPostProcessor.process: kaldi.feat.functions.sliding_window_cmn
+ *         (reference shennong/postprocessor/cmvn.py:493-495)
  *
  * The ABI is batch-first: one call covers N utterances given as one concatenated int16 buffer
  * plus an offsets table (the reference's process_all / joblib loop, base.py:56-107, becomes a
@@ -60,6 +66,9 @@ extern "C" {
 #define SNF_KIND_PITCH_POST 5
 #define SNF_KIND_DELTA 6
 #define SNF_KIND_ENERGY 7
+#define SNF_KIND_VAD 8
+#define SNF_KIND_CMVN 9
+#define SNF_KIND_SLIDING_CMVN 10
 
 /* ---- window types (reference shennong/processor/base.py:215-221) --------------------------- */
 #define SNF_WINDOW_HAMMING 0
@@ -133,6 +142,22 @@ typedef struct snf_pitch_post_options {
   int32_t add_raw_log_pitch;           /* 0 */
 } snf_pitch_post_options;
 
+/* Kaldi VadEnergyOptions (reference shennong/postprocessor/vad.py:77-78). */
+typedef struct snf_vad_options {
+  float energy_threshold;     /* 5.0 */
+  float energy_mean_scale;    /* 0.5 */
+  int32_t frames_context;     /* 0 */
+  float proportion_threshold; /* 0.6 */
+} snf_vad_options;
+
+/* Kaldi SlidingWindowCmnOptions (reference shennong/postprocessor/cmvn.py:407-408). */
+typedef struct snf_sliding_cmvn_options {
+  int32_t center;             /* 1 */
+  int32_t cmn_window;         /* 600 */
+  int32_t min_window;         /* 100 */
+  int32_t normalize_variance; /* 0 */
+} snf_sliding_cmvn_options;
+
 /* One flat options record; `kind` selects which fields are read. */
 typedef struct snf_options {
   int32_t kind; /* SNF_KIND_* */
@@ -157,6 +182,8 @@ typedef struct snf_options {
   int32_t delta_window; /* 2 */
   snf_pitch_options pitch;
   snf_pitch_post_options pitch_post;
+  snf_vad_options vad;
+  snf_sliding_cmvn_options sliding_cmvn;
   uint64_t seed; /* RNG seed for dither / delta-pitch noise */
 } snf_options;
 
@@ -217,7 +244,8 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
                               const int64_t* frame_offsets, void* stream);
 
 /*
- * Features -> Features post-processors (kinds DELTA, PITCH_POST).
+ * Features -> Features post-processors (kinds DELTA, PITCH_POST, VAD, SLIDING_CMVN).
+ * VAD writes one column of 0.0 / 1.0 (the reference casts it to uint8).
  *   in   concatenated row-major float32 [frame_offsets[n_utts], in_cols]
  *   out  concatenated row-major float32 [frame_offsets[n_utts], snf_post_ndims(plan, in_cols)]
  */
@@ -227,6 +255,22 @@ int snf_post_run_batch(snf_plan* plan, const float* in, int32_t in_cols,
 int snf_post_run_batch_device(snf_plan* plan, const float* d_in, int32_t in_cols,
                               const int64_t* frame_offsets, int64_t n_utts, float* d_out,
                               void* stream);
+
+/*
+ * CMVN (plan kind SNF_KIND_CMVN).  Statistics are Kaldi's double [2, cols+1] blocks
+ * (row 0: sums and, last, the weighted frame count; row 1: sums of squares).
+ *   accumulate: stats[group[u]] += stats of utterance u (weights: per-frame, NULL = 1.0;
+ *               group: per-utterance speaker index, NULL = one group 0).  `stats` is
+ *               [n_groups, 2, cols+1] on the host and is accumulated INTO.
+ *   apply:      out = Kaldi ApplyCmvn / ApplyCmvnReverse of each utterance with stats[group[u]];
+ *               fails with SNF_E_INVALID when a used group has count < 1.
+ */
+int snf_cmvn_accumulate(snf_plan* plan, const float* in, int32_t cols, const int64_t* frame_offsets,
+                        int64_t n_utts, const float* weights, const int32_t* group,
+                        int32_t n_groups, double* stats);
+int snf_cmvn_apply(snf_plan* plan, const float* in, int32_t cols, const int64_t* frame_offsets,
+                   int64_t n_utts, const double* stats, const int32_t* group, int32_t n_groups,
+                   int32_t norm_vars, int32_t reverse, float* out);
 
 /* ---- device memory + timing (so hosts without torch can keep data resident in HBM) ---------- */
 int snf_malloc(void** dptr, uint64_t bytes);

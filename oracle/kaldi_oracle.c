@@ -1261,3 +1261,146 @@ ORC_API int orc_process_pitch(const snf_pitch_post_options* o, const float* in, 
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* VAD and CMVN                                                          */
+/* ------------------------------------------------------------------------------------------ */
+/* [KALDI-UPSTREAM ivector/voice-activity-detection.cc ComputeVadEnergy]; reference call site
+ * postprocessor/vad.py:182-185.  `feats` is [T, D] float32, column 0 is the log-energy. */
+ORC_API int orc_vad_energy(float energy_threshold, float energy_mean_scale, int frames_context,
+                           float proportion_threshold, const float* feats, int64_t T, int D,
+                           float* out) {
+  if (T == 0) return 0;
+  float thr = energy_threshold;
+  if (energy_mean_scale != 0.0f) {
+    double dsum = 0.0; /* VectorBase<float>::Sum() accumulates in double */
+    for (int64_t t = 0; t < T; t++) dsum += feats[t * D];
+    float sum = (float)dsum;
+    thr += energy_mean_scale * sum / (float)T;
+  }
+  for (int64_t t = 0; t < T; t++) {
+    int num = 0, den = 0;
+    for (int64_t t2 = t - frames_context; t2 <= t + frames_context; t2++) {
+      if (t2 >= 0 && t2 < T) {
+        den++;
+        if (feats[t2 * D] > thr) num++;
+      }
+    }
+    out[t] = ((float)num >= (float)den * proportion_threshold) ? 1.0f : 0.0f;
+  }
+  return 0;
+}
+
+/* [KALDI-UPSTREAM transform/cmvn.cc AccCmvnStats]; reference call site postprocessor/cmvn.py:216-219.
+ * stats is [2, D+1] double, accumulated into. */
+ORC_API int orc_cmvn_accumulate(const float* feats, int64_t T, int D, const float* weights,
+                                double* stats) {
+  double* mean = stats;
+  double* var = stats + (D + 1);
+  for (int64_t t = 0; t < T; t++) {
+    float w = weights ? weights[t] : 1.0f;
+    if (w == 0.0f) continue;
+    mean[D] += (double)w;
+    for (int d = 0; d < D; d++) {
+      float x = feats[t * D + d];
+      mean[d] += (double)(x * w);
+      var[d] += (double)(x * x * w);
+    }
+  }
+  return 0;
+}
+
+/* [KALDI-UPSTREAM transform/cmvn.cc ApplyCmvn / ApplyCmvnReverse]; reference call site
+ * postprocessor/cmvn.py:277-278.  In place on feats [T, D]. */
+ORC_API int orc_cmvn_apply(const double* stats, int D, int norm_vars, int reverse, float* feats,
+                           int64_t T) {
+  double count = stats[D];
+  if (count < 1.0) return orc_fail("Insufficient stats for cepstral mean and variance normalization");
+  for (int d = 0; d < D; d++) {
+    double mean = stats[d] / count, scale = 1.0, offset;
+    if (!reverse) {
+      if (!norm_vars) {
+        /* offset.AddVec(-1.0 / count, mean_stats): AddVec's alpha is a BaseFloat */
+        float alpha = (float)(-1.0 / count);
+        float off = (float)((double)alpha * stats[d]);
+        for (int64_t t = 0; t < T; t++) feats[t * D + d] += off;
+        continue;
+      }
+      double var = stats[(D + 1) + d] / count - mean * mean;
+      if (var < 1.0e-20) var = 1.0e-20;
+      scale = 1.0 / sqrt(var);
+      offset = -(mean * scale);
+    } else {
+      offset = mean;
+      if (norm_vars) {
+        double var = stats[(D + 1) + d] / count - mean * mean;
+        if (var < 1.0e-20) var = 1.0e-20;
+        scale = sqrt(var);
+      }
+    }
+    float fs = (float)scale, fo = (float)offset;
+    for (int64_t t = 0; t < T; t++) {
+      float x = feats[t * D + d];
+      if (norm_vars) x = x * fs;      /* MulColsVec */
+      feats[t * D + d] = x + fo;      /* AddVecToRows */
+    }
+  }
+  return 0;
+}
+
+/* [KALDI-UPSTREAM feat/feature-functions.cc SlidingWindowCmnInternal] (double arithmetic, incremental
+ * window sums); reference call site postprocessor/cmvn.py:493-495. */
+ORC_API int orc_sliding_cmn(int center, int cmn_window, int min_window, int normalize_variance,
+                            const float* in, int64_t T, int D, float* out) {
+  if (cmn_window <= 0 || min_window <= 0) return orc_fail("bad sliding window options");
+  double* cur_sum = (double*)calloc((size_t)D, sizeof(double));
+  double* cur_sumsq = (double*)calloc((size_t)D, sizeof(double));
+  int64_t last_start = -1, last_end = -1;
+  for (int64_t t = 0; t < T; t++) {
+    int64_t ws, we;
+    if (center) { ws = t - (cmn_window / 2); we = ws + cmn_window; }
+    else { ws = t - cmn_window; we = t + 1; }
+    if (ws < 0) { we -= ws; ws = 0; }
+    if (!center) {
+      if (we > t) we = (t + 1 > min_window) ? t + 1 : min_window;
+    }
+    if (we > T) { ws -= (we - T); we = T; if (ws < 0) ws = 0; }
+    if (last_start == -1) {
+      for (int d = 0; d < D; d++) {
+        double s = 0.0, q = 0.0;
+        for (int64_t r = ws; r < we; r++) { double x = in[r * D + d]; s += x; q += x * x; }
+        cur_sum[d] = s; cur_sumsq[d] = q;
+      }
+    } else {
+      if (ws > last_start)
+        for (int d = 0; d < D; d++) {
+          double x = in[last_start * D + d];
+          cur_sum[d] += -1.0 * x;
+          if (normalize_variance) cur_sumsq[d] += -1.0 * x * x;
+        }
+      if (we > last_end)
+        for (int d = 0; d < D; d++) {
+          double x = in[last_end * D + d];
+          cur_sum[d] += 1.0 * x;
+          if (normalize_variance) cur_sumsq[d] += 1.0 * x * x;
+        }
+    }
+    int64_t wf = we - ws;
+    last_start = ws; last_end = we;
+    for (int d = 0; d < D; d++) {
+      double o = (double)in[t * D + d] + (-1.0 / (double)wf) * cur_sum[d];
+      if (normalize_variance) {
+        if (wf == 1) o = 0.0;
+        else {
+          double v = cur_sumsq[d] * (1.0 / (double)wf);
+          v += (-1.0 / ((double)wf * (double)wf)) * cur_sum[d] * cur_sum[d];
+          if (v < 1.0e-10) v = 1.0e-10;
+          o *= pow(v, -0.5);
+        }
+      }
+      out[t * D + d] = (float)o;
+    }
+  }
+  free(cur_sum); free(cur_sumsq);
+  return 0;
+}

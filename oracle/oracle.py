@@ -67,6 +67,10 @@ def lib():
     L.orc_pitch_lags.argtypes = [PO, pf, C.POINTER(i32), C.POINTER(i32)]
     L.orc_linear_resample.argtypes = [i32, i32, f32, i32, pf, i64, pf, i32]
     L.orc_linear_resample.restype = i64
+    L.orc_vad_energy.argtypes = [f32, f32, i32, f32, pf, i64, i32, pf]
+    L.orc_cmvn_accumulate.argtypes = [pf, i64, i32, pf, C.POINTER(C.c_double)]
+    L.orc_cmvn_apply.argtypes = [C.POINTER(C.c_double), i32, i32, i32, pf, i64]
+    L.orc_sliding_cmn.argtypes = [i32, i32, i32, i32, pf, i64, i32, pf]
     L.orc_process_pitch_ndims.argtypes = [PPO]
     L.orc_process_pitch.argtypes = [PPO, pf, i64, pf]
     _LIB = L
@@ -261,4 +265,44 @@ def process_pitch(post_opts, raw):
     out = np.zeros((raw.shape[0], max(d, 1)), dtype=np.float32)
     _check(lib().orc_process_pitch(
         C.byref(post_opts), _fp(raw), raw.shape[0], _fp(out)))
+    return out
+
+
+def vad_energy(feats, energy_threshold=5.0, energy_mean_scale=0.5, frames_context=0,
+               proportion_threshold=0.6):
+    feats = np.ascontiguousarray(feats, dtype=np.float32)
+    out = np.zeros(feats.shape[0], dtype=np.float32)
+    _check(lib().orc_vad_energy(
+        energy_threshold, energy_mean_scale, frames_context, proportion_threshold,
+        _fp(feats), feats.shape[0], feats.shape[1], _fp(out)))
+    return out
+
+
+def cmvn_accumulate(feats, weights=None, stats=None):
+    feats = np.ascontiguousarray(feats, dtype=np.float32)
+    d = feats.shape[1]
+    if stats is None:
+        stats = np.zeros((2, d + 1), dtype=np.float64)
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float32)
+    _check(lib().orc_cmvn_accumulate(
+        _fp(feats), feats.shape[0], d, _fp(w) if w is not None else None,
+        stats.ctypes.data_as(C.POINTER(C.c_double))))
+    return stats
+
+
+def cmvn_apply(feats, stats, norm_vars=True, reverse=False):
+    out = np.array(feats, dtype=np.float32, order='C', copy=True)
+    stats = np.ascontiguousarray(stats, dtype=np.float64)
+    _check(lib().orc_cmvn_apply(
+        stats.ctypes.data_as(C.POINTER(C.c_double)), out.shape[1], int(norm_vars),
+        int(reverse), _fp(out), out.shape[0]))
+    return out
+
+
+def sliding_cmn(feats, center=True, cmn_window=600, min_window=100, normalize_variance=False):
+    feats = np.ascontiguousarray(feats, dtype=np.float32)
+    out = np.zeros_like(feats)
+    _check(lib().orc_sliding_cmn(
+        int(center), cmn_window, min_window, int(normalize_variance), _fp(feats),
+        feats.shape[0], feats.shape[1], _fp(out)))
     return out

@@ -21,6 +21,9 @@ KIND_PITCH = 4
 KIND_PITCH_POST = 5
 KIND_DELTA = 6
 KIND_ENERGY = 7
+KIND_VAD = 8
+KIND_CMVN = 9
+KIND_SLIDING_CMVN = 10
 
 WINDOW_TYPES = {
     'hamming': 0, 'hanning': 1, 'povey': 2, 'rectangular': 3, 'blackman': 4}
@@ -88,6 +91,22 @@ class PitchPostOptions(C.Structure):
         ('add_raw_log_pitch', C.c_int32)]
 
 
+class VadOptions(C.Structure):
+    _fields_ = [
+        ('energy_threshold', C.c_float),
+        ('energy_mean_scale', C.c_float),
+        ('frames_context', C.c_int32),
+        ('proportion_threshold', C.c_float)]
+
+
+class SlidingCmvnOptions(C.Structure):
+    _fields_ = [
+        ('center', C.c_int32),
+        ('cmn_window', C.c_int32),
+        ('min_window', C.c_int32),
+        ('normalize_variance', C.c_int32)]
+
+
 class Options(C.Structure):
     _fields_ = [
         ('kind', C.c_int32),
@@ -110,6 +129,8 @@ class Options(C.Structure):
         ('delta_window', C.c_int32),
         ('pitch', PitchOptions),
         ('pitch_post', PitchPostOptions),
+        ('vad', VadOptions),
+        ('sliding_cmvn', SlidingCmvnOptions),
         ('seed', C.c_uint64)]
 
 
@@ -172,6 +193,11 @@ def default_options(kind):
     opts.delta_window = 2
     opts.pitch = default_pitch_options()
     opts.pitch_post = default_pitch_post_options()
+    opts.vad = VadOptions(
+        energy_threshold=5.0, energy_mean_scale=0.5, frames_context=0,
+        proportion_threshold=0.6)
+    opts.sliding_cmvn = SlidingCmvnOptions(
+        center=1, cmn_window=600, min_window=100, normalize_variance=0)
     opts.seed = 0
     return opts
 

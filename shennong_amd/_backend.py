@@ -29,6 +29,7 @@ EXPORTS = [
     'snf_plan_create', 'snf_plan_destroy', 'snf_plan_ndims',
     'snf_plan_num_frames', 'snf_plan_run_batch', 'snf_plan_run_batch_device',
     'snf_post_ndims', 'snf_post_run_batch', 'snf_post_run_batch_device',
+    'snf_cmvn_accumulate', 'snf_cmvn_apply',
     'snf_malloc', 'snf_free', 'snf_memcpy_h2d', 'snf_memcpy_d2h', 'snf_memset',
     'snf_plan_last_kernel_ms', 'snf_plan_kernel_name']
 
@@ -79,6 +80,11 @@ def lib():
         L.snf_post_ndims.argtypes = [vp, i32]
         L.snf_post_run_batch.argtypes = [vp, pf, i32, pi64, i64, pf]
         L.snf_post_run_batch_device.argtypes = [vp, vp, i32, pi64, i64, vp, vp]
+        pi32, pf64 = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+        L.snf_cmvn_accumulate.argtypes = [
+            vp, pf, i32, pi64, i64, pf, pi32, i32, pf64]
+        L.snf_cmvn_apply.argtypes = [
+            vp, pf, i32, pi64, i64, pf64, pi32, i32, i32, i32, pf]
         L.snf_malloc.argtypes = [C.POINTER(vp), C.c_uint64]
         L.snf_free.argtypes = [vp]
         L.snf_memcpy_h2d.argtypes = [vp, vp, C.c_uint64]
@@ -258,6 +264,67 @@ class Plan:
         check(lib().snf_post_run_batch(
             self.handle, data.ctypes.data_as(C.POINTER(C.c_float)), cols,
             foff.ctypes.data_as(C.POINTER(C.c_int64)), n,
+            out.ctypes.data_as(C.POINTER(C.c_float))))
+        if n == 1:
+            return [out]
+        return [out[foff[u]:foff[u + 1]].copy() for u in range(n)]
+
+    # -- CMVN (plan kind CMVN): statistics on the GPU, per-speaker sums on the host --
+    @staticmethod
+    def _pack(mats):
+        n = len(mats)
+        cols = mats[0].shape[1]
+        nfr = np.fromiter((m.shape[0] for m in mats), np.int64, n)
+        foff = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(nfr, out=foff[1:])
+        if n == 1:
+            data = np.ascontiguousarray(mats[0], dtype=np.float32)
+        else:
+            data = np.ascontiguousarray(
+                np.concatenate(mats, axis=0), dtype=np.float32)
+        return data, cols, foff
+
+    def cmvn_accumulate(self, mats, stats, weights=None, groups=None):
+        """stats[groups[u]] += CMVN statistics of mats[u]; `stats` is float64
+        [n_groups, 2, cols + 1] (accumulated into, in place)"""
+        n = len(mats)
+        if n == 0:
+            return stats
+        data, cols, foff = self._pack(mats)
+        assert stats.dtype == np.float64 and stats.flags.c_contiguous
+        assert stats.shape[1:] == (2, cols + 1)
+        w = None
+        if weights is not None:
+            w = np.ascontiguousarray(np.concatenate(
+                [np.asarray(x, dtype=np.float32).ravel() for x in weights]))
+            if w.shape[0] != foff[-1]:
+                raise ValueError('one weight per frame is required')
+        g = None if groups is None else np.ascontiguousarray(groups, np.int32)
+        check(lib().snf_cmvn_accumulate(
+            self.handle, data.ctypes.data_as(C.POINTER(C.c_float)), cols,
+            foff.ctypes.data_as(C.POINTER(C.c_int64)), n,
+            w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None,
+            g.ctypes.data_as(C.POINTER(C.c_int32)) if g is not None else None,
+            stats.shape[0], stats.ctypes.data_as(C.POINTER(C.c_double))))
+        return stats
+
+    def cmvn_apply(self, mats, stats, groups=None, norm_vars=True,
+                   reverse=False):
+        """Kaldi ApplyCmvn / ApplyCmvnReverse of mats[u] with stats[groups[u]]"""
+        n = len(mats)
+        if n == 0:
+            return []
+        data, cols, foff = self._pack(mats)
+        stats = np.ascontiguousarray(stats, dtype=np.float64)
+        assert stats.shape[1:] == (2, cols + 1)
+        g = None if groups is None else np.ascontiguousarray(groups, np.int32)
+        out = np.empty_like(data)
+        check(lib().snf_cmvn_apply(
+            self.handle, data.ctypes.data_as(C.POINTER(C.c_float)), cols,
+            foff.ctypes.data_as(C.POINTER(C.c_int64)), n,
+            stats.ctypes.data_as(C.POINTER(C.c_double)),
+            g.ctypes.data_as(C.POINTER(C.c_int32)) if g is not None else None,
+            stats.shape[0], int(bool(norm_vars)), int(bool(reverse)),
             out.ctypes.data_as(C.POINTER(C.c_float))))
         if n == 1:
             return [out]

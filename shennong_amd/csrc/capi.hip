@@ -117,7 +117,12 @@ int ilog2(int v) {
 // ---- mel-family plan -----------------------------------------------------------------------------
 int build_mel_plan(snf_plan* plan) {
   const snf_options& o = plan->o;
-  const snf_frame_options& fo = o.frame;
+  snf_frame_options fo = o.frame;
+  if (plan->kind == SNF_KIND_ENERGY && o.raw_energy) {
+    // reference processor/energy.py:150-154: raw energy = no pre-emphasis, rectangular window
+    fo.preemph_coeff = 0.0f;
+    fo.window_type = SNF_WINDOW_RECTANGULAR;
+  }
   MelParams& p = plan->mp;
   p.win_len = window_size(fo);
   p.win_shift = window_shift(fo);
@@ -201,10 +206,19 @@ int build_mel_plan(snf_plan* plan) {
     case SNF_KIND_PLP:
       plan->ndims = o.num_ceps;
       break;
+    case SNF_KIND_ENERGY:
+      if (o.compression != SNF_COMPRESS_OFF && o.compression != SNF_COMPRESS_LOG &&
+          o.compression != SNF_COMPRESS_SQRT)
+        return set_error(SNF_E_INVALID, "compression must be in off, log, sqrt");
+      plan->ndims = 1;
+      p.need_raw = 0;
+      p.need_post = 0;
+      p.num_bins = 0;
+      break;
     default:
       return set_error(SNF_E_INVALID, "not a mel-family kind");
   }
-  if (plan->kind != SNF_KIND_SPECTROGRAM) {
+  if (plan->kind != SNF_KIND_SPECTROGRAM && plan->kind != SNF_KIND_ENERGY) {
     p.need_raw = (o.use_energy && o.raw_energy) ? 1 : 0;
     p.need_post = (o.use_energy && !o.raw_energy) ? 1 : 0;
     // Kaldi builds the warp-1.0 banks in the computer's constructor: option errors surface here
@@ -558,7 +572,28 @@ int snf_plan_create(const snf_options* opts, int device_id, snf_plan** out) {
     case SNF_KIND_FBANK:
     case SNF_KIND_MFCC:
     case SNF_KIND_PLP:
+    case SNF_KIND_ENERGY:
       rc = build_mel_plan(plan.get());
+      break;
+    case SNF_KIND_VAD: {
+      const snf_vad_options& v = opts->vad;
+      plan->ndims = 1;
+      rc = SNF_OK;
+      if (v.frames_context < 0)
+        rc = set_error(SNF_E_RUNTIME, "vad-frames-context must be >= 0");
+      else if (!(v.proportion_threshold > 0.0f && v.proportion_threshold < 1.0f))
+        rc = set_error(SNF_E_RUNTIME, "vad-proportion-threshold must be in (0, 1)");
+      break;
+    }
+    case SNF_KIND_SLIDING_CMVN: {
+      const snf_sliding_cmvn_options& c = opts->sliding_cmvn;
+      rc = SNF_OK;
+      if (c.cmn_window <= 0) rc = set_error(SNF_E_RUNTIME, "cmn_window must be positive");
+      else if (c.min_window <= 0) rc = set_error(SNF_E_RUNTIME, "min_window must be positive");
+      break;
+    }
+    case SNF_KIND_CMVN:
+      rc = SNF_OK;
       break;
     case SNF_KIND_DELTA:
       rc = build_delta_plan(plan.get());
@@ -607,6 +642,7 @@ int64_t snf_plan_num_frames(const snf_plan* plan, int64_t n) {
     case SNF_KIND_FBANK:
     case SNF_KIND_MFCC:
     case SNF_KIND_PLP:
+    case SNF_KIND_ENERGY:
       return num_frames(plan->o.frame, n);
     case SNF_KIND_PITCH:
       return pitch_frames_for(plan, n, nullptr, nullptr, nullptr);
@@ -650,7 +686,7 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     return SNF_OK;
   }
   if (plan->kind != SNF_KIND_SPECTROGRAM && plan->kind != SNF_KIND_FBANK &&
-      plan->kind != SNF_KIND_MFCC && plan->kind != SNF_KIND_PLP)
+      plan->kind != SNF_KIND_MFCC && plan->kind != SNF_KIND_PLP && plan->kind != SNF_KIND_ENERGY)
     return set_error(SNF_E_INVALID, "plan kind does not take audio input");
 
   std::vector<int32_t> warp_ids;
@@ -767,6 +803,8 @@ int32_t snf_post_ndims(const snf_plan* plan, int32_t in_cols) {
   if (!plan) return -1;
   if (plan->kind == SNF_KIND_DELTA) return in_cols * (plan->o.delta_order + 1);
   if (plan->kind == SNF_KIND_PITCH_POST) return plan->ndims;
+  if (plan->kind == SNF_KIND_VAD) return 1;
+  if (plan->kind == SNF_KIND_SLIDING_CMVN) return in_cols;
   return -1;
 }
 
@@ -804,6 +842,19 @@ int snf_post_run_batch_device(snf_plan* plan, const float* d_in, int32_t in_cols
                                 total_frames, d_out, s)))
       return rc;
     if (own_stream) mark_kernel(plan, "pitch_post_kernel");
+  } else if (plan->kind == SNF_KIND_VAD) {
+    if (in_cols <= 0) return set_error(SNF_E_INVALID, "in_cols must be positive");
+    if ((rc = plan->s_stats.ensure(sizeof(float) * static_cast<size_t>(n_utts)))) return rc;
+    if ((rc = launch_vad(plan->o.vad, d_in, in_cols, plan->s_foff.as<int64_t>(), n_utts,
+                         total_frames, plan->s_stats.as<float>(), d_out, s)))
+      return rc;
+    if (own_stream) mark_kernel(plan, "vad_kernel");
+  } else if (plan->kind == SNF_KIND_SLIDING_CMVN) {
+    if (in_cols <= 0) return set_error(SNF_E_INVALID, "in_cols must be positive");
+    if ((rc = launch_sliding_cmvn(plan->o.sliding_cmvn, d_in, in_cols, plan->s_foff.as<int64_t>(),
+                                  n_utts, d_out, s)))
+      return rc;
+    if (own_stream) mark_kernel(plan, "sliding_cmvn_kernel");
   } else {
     return set_error(SNF_E_INVALID, "plan kind is not a post-processor");
   }
@@ -835,6 +886,153 @@ int snf_post_run_batch(snf_plan* plan, const float* in, int32_t in_cols,
   if (rc) return rc;
   std::lock_guard<std::mutex> lock(plan->mu);
   SNF_HIP_CHECK(hipMemcpy(out, d_out, sizeof(float) * total_frames * out_cols, hipMemcpyDeviceToHost));
+  return SNF_OK;
+}
+
+namespace {
+int cmvn_check(const snf_plan* plan, int32_t cols, const int64_t* frame_offsets, int64_t n_utts,
+               const int32_t* group, int32_t n_groups) {
+  if (!plan) return set_error(SNF_E_INVALID, "null plan");
+  if (plan->kind != SNF_KIND_CMVN) return set_error(SNF_E_INVALID, "plan kind is not CMVN");
+  if (n_utts < 0) return set_error(SNF_E_INVALID, "n_utts < 0");
+  if (cols <= 0) return set_error(SNF_E_INVALID, "dimension must be a strictly positive integer");
+  if (n_groups <= 0) return set_error(SNF_E_INVALID, "n_groups must be positive");
+  if (n_utts > 0 && !frame_offsets) return set_error(SNF_E_INVALID, "null offsets table");
+  if (n_utts > 0 && frame_offsets[0] != 0) return set_error(SNF_E_INVALID, "offsets tables must start at 0");
+  for (int64_t u = 0; u < n_utts; ++u) {
+    if (frame_offsets[u + 1] < frame_offsets[u])
+      return set_error(SNF_E_INVALID, "offsets tables must be non-decreasing");
+    const int32_t g = group ? group[u] : 0;
+    if (g < 0 || g >= n_groups) return set_error(SNF_E_INVALID, "group index out of range");
+  }
+  return SNF_OK;
+}
+}  // namespace
+
+int snf_cmvn_accumulate(snf_plan* plan, const float* in, int32_t cols, const int64_t* frame_offsets,
+                        int64_t n_utts, const float* weights, const int32_t* group,
+                        int32_t n_groups, double* stats) {
+  int rc = cmvn_check(plan, cols, frame_offsets, n_utts, group, n_groups);
+  if (rc) return rc;
+  if (n_utts == 0) return SNF_OK;
+  if (!stats) return set_error(SNF_E_INVALID, "null stats");
+  std::lock_guard<std::mutex> lock(plan->mu);
+  if ((rc = guard_device(plan))) return rc;
+  const int64_t total_frames = frame_offsets[n_utts];
+  if (total_frames == 0) return SNF_OK;
+  if (!in) return set_error(SNF_E_INVALID, "null input");
+  hipStream_t s = plan->stream;
+  const size_t blk = 2 * static_cast<size_t>(cols + 1);
+  if ((rc = plan->s_in.ensure(sizeof(float) * static_cast<size_t>(total_frames) * cols))) return rc;
+  if ((rc = plan->s_stats.ensure(sizeof(double) * blk * static_cast<size_t>(n_utts)))) return rc;
+  SNF_HIP_CHECK(hipMemcpyAsync(plan->s_in.p, in, sizeof(float) * total_frames * cols,
+                               hipMemcpyHostToDevice, s));
+  const float* d_w = nullptr;
+  if (weights) {
+    if ((rc = plan->s_energy.ensure(sizeof(float) * static_cast<size_t>(total_frames)))) return rc;
+    SNF_HIP_CHECK(hipMemcpyAsync(plan->s_energy.p, weights, sizeof(float) * total_frames,
+                                 hipMemcpyHostToDevice, s));
+    d_w = plan->s_energy.as<float>();
+  }
+  std::vector<int64_t> foff(frame_offsets, frame_offsets + n_utts + 1);
+  if ((rc = plan->s_foff.upload(foff, s))) return rc;
+  begin_timing(plan);
+  if ((rc = launch_cmvn_stats(plan->s_in.as<float>(), cols, plan->s_foff.as<int64_t>(), d_w, n_utts,
+                              plan->s_stats.as<double>(), s)))
+    return rc;
+  mark_kernel(plan, "cmvn_stats_kernel");
+  std::vector<double> per_utt(blk * static_cast<size_t>(n_utts));
+  SNF_HIP_CHECK(hipMemcpyAsync(per_utt.data(), plan->s_stats.p, sizeof(double) * per_utt.size(),
+                               hipMemcpyDeviceToHost, s));
+  SNF_HIP_CHECK(hipStreamSynchronize(s));
+  // the per-speaker sum runs over a handful of [2, cols+1] blocks: host, in utterance order
+  for (int64_t u = 0; u < n_utts; ++u) {
+    double* dst = stats + blk * static_cast<size_t>(group ? group[u] : 0);
+    const double* src = per_utt.data() + blk * static_cast<size_t>(u);
+    for (size_t i = 0; i < blk; ++i) dst[i] += src[i];
+  }
+  return SNF_OK;
+}
+
+int snf_cmvn_apply(snf_plan* plan, const float* in, int32_t cols, const int64_t* frame_offsets,
+                   int64_t n_utts, const double* stats, const int32_t* group, int32_t n_groups,
+                   int32_t norm_vars, int32_t reverse, float* out) {
+  int rc = cmvn_check(plan, cols, frame_offsets, n_utts, group, n_groups);
+  if (rc) return rc;
+  if (n_utts == 0) return SNF_OK;
+  if (!stats) return set_error(SNF_E_INVALID, "null stats");
+  // [KALDI-UPSTREAM] transform/cmvn.cc ApplyCmvn / ApplyCmvnReverse: float (offset, scale) per column
+  const size_t blk = 2 * static_cast<size_t>(cols + 1);
+  std::vector<float> norm(static_cast<size_t>(n_groups) * 2 * cols, 0.0f);
+  std::vector<char> used(n_groups, 0);
+  for (int64_t u = 0; u < n_utts; ++u) used[group ? group[u] : 0] = 1;
+  for (int32_t g = 0; g < n_groups; ++g) {
+    if (!used[g]) continue;
+    const double* st = stats + blk * static_cast<size_t>(g);
+    const double count = st[cols];
+    if (count < 1.0)
+      return set_error(SNF_E_INVALID, "Insufficient stats for cepstral mean and variance "
+                                      "normalization: count = " + std::to_string(count));
+    float* off = norm.data() + static_cast<size_t>(g) * 2 * cols;
+    float* scl = off + cols;
+    for (int d = 0; d < cols; ++d) {
+      const double mean = st[d] / count;
+      double offset, scale;
+      if (!reverse) {
+        // without variance normalisation Kaldi adds offset.AddVec(-1.0 / count, mean_stats), whose
+        // alpha is a BaseFloat
+        offset = static_cast<double>(static_cast<float>(-1.0 / count)) * st[d];
+        scale = 1.0;
+        if (norm_vars) {
+          double var = st[(cols + 1) + d] / count - mean * mean;
+          const double floor = 1.0e-20;
+          if (var < floor) var = floor;
+          scale = 1.0 / std::sqrt(var);
+          if (scale != scale || 1.0 / scale == 0.0)
+            return set_error(SNF_E_RUNTIME, "NaN or infinity in cepstral mean/variance computation");
+          offset = -(mean * scale);
+        }
+      } else {
+        offset = mean;
+        scale = 1.0;
+        if (norm_vars) {
+          double var = st[(cols + 1) + d] / count - mean * mean;
+          const double floor = 1.0e-20;
+          if (var < floor) var = floor;
+          scale = std::sqrt(var);
+        }
+      }
+      off[d] = static_cast<float>(offset);
+      scl[d] = static_cast<float>(scale);
+    }
+  }
+  std::lock_guard<std::mutex> lock(plan->mu);
+  if ((rc = guard_device(plan))) return rc;
+  const int64_t total_frames = frame_offsets[n_utts];
+  if (total_frames == 0) return SNF_OK;
+  if (!in || !out) return set_error(SNF_E_INVALID, "null buffer");
+  hipStream_t s = plan->stream;
+  const size_t bytes = sizeof(float) * static_cast<size_t>(total_frames) * cols;
+  if ((rc = plan->s_in.ensure(bytes))) return rc;
+  if ((rc = plan->s_out.ensure(bytes))) return rc;
+  SNF_HIP_CHECK(hipMemcpyAsync(plan->s_in.p, in, bytes, hipMemcpyHostToDevice, s));
+  std::vector<int64_t> foff(frame_offsets, frame_offsets + n_utts + 1);
+  if ((rc = plan->s_foff.upload(foff, s))) return rc;
+  if ((rc = plan->s_mel.upload(norm, s))) return rc;
+  const int32_t* d_group = nullptr;
+  if (group) {
+    std::vector<int32_t> gv(group, group + n_utts);
+    if ((rc = plan->s_uwarp.upload(gv, s))) return rc;
+    d_group = plan->s_uwarp.as<int32_t>();
+  }
+  begin_timing(plan);
+  if ((rc = launch_cmvn_apply(plan->s_in.as<float>(), cols, plan->s_foff.as<int64_t>(), n_utts,
+                              total_frames, d_group, plan->s_mel.as<float>(), norm_vars ? 1 : 0,
+                              plan->s_out.as<float>(), s)))
+    return rc;
+  mark_kernel(plan, "cmvn_apply_kernel");
+  SNF_HIP_CHECK(hipMemcpyAsync(out, plan->s_out.p, bytes, hipMemcpyDeviceToHost, s));
+  SNF_HIP_CHECK(hipStreamSynchronize(s));
   return SNF_OK;
 }
 

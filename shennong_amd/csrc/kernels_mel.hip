@@ -137,6 +137,25 @@ __global__ __launch_bounds__(kWaves * 64) void mel_features_generic_kernel(
     }
     float post_energy = 0.0f;
     if (p.need_post) post_energy = wave_sum(e2_part);
+    if (p.kind == SNF_KIND_ENERGY) {
+      // EnergyProcessor (reference processor/energy.py:173-183): float64 sum of squares of the
+      // processed window, floored at the smallest double, then compressed
+      wave_lds_sync();
+      double de = 0.0;
+      for (int i = lane; i < L; i += 64) {
+        const double y = p.pow2 ? zsf[2 * bit_reverse(i >> 1, p.log2_half) + (i & 1)] : zsf[i];
+        de += y * y;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) de += __shfl_xor(de, off, 64);
+      de = fmax(de, DBL_MIN);
+      double v = de;
+      if (p.compression == SNF_COMPRESS_LOG) v = log(de);
+      else if (p.compression == SNF_COMPRESS_SQRT) v = sqrt(de);
+      if (lane == 0) out[g * static_cast<int64_t>(out_cols)] = static_cast<float>(v);
+      wave_lds_sync();
+      continue;
+    }
 
     if (p.pow2) {
       // ---- complex FFT of size M = N/2 on the packed frame (radix-2 DIT, data stays in LDS) -------

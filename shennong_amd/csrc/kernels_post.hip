@@ -366,4 +366,210 @@ int launch_pitch_post(const PitchPostParams& p, const float* in, const int64_t* 
   return SNF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// energy VAD, CMVN, sliding-window CMVN
+// ------------------------------------------------------------------------------------------------
+// VAD ([KALDI-UPSTREAM] ivector/voice-activity-detection.cc ComputeVadEnergy; reference
+// postprocessor/vad.py:182-185): per-utterance threshold from the mean of column 0, then the
+// proportion test over a +-context window, one thread per frame.
+__global__ void vad_threshold_kernel(const snf_vad_options o, const float* __restrict__ in,
+                                     const int D, const int64_t* __restrict__ frame_offsets,
+                                     float* __restrict__ thr) {
+  const int64_t u = blockIdx.x;
+  const int64_t f0 = frame_offsets[u], T = frame_offsets[u + 1] - f0;
+  double s = 0.0;
+  for (int64_t t = threadIdx.x; t < T; t += blockDim.x) s += in[(f0 + t) * D];
+  __shared__ double red[16];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (unsigned i = 0; i < (blockDim.x >> 6); ++i) tot += red[i];
+    float v = o.energy_threshold;
+    if (o.energy_mean_scale != 0.0f && T > 0)
+      v += o.energy_mean_scale * static_cast<float>(tot) / static_cast<float>(T);
+    thr[u] = v;
+  }
+}
+
+__global__ void vad_kernel(const snf_vad_options o, const float* __restrict__ in, const int D,
+                           const int64_t* __restrict__ frame_offsets, const int64_t n_utts,
+                           const int64_t total_frames, const float* __restrict__ thr,
+                           float* __restrict__ out) {
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= total_frames) return;
+  const int64_t u = find_utt(frame_offsets, n_utts, g);
+  const int64_t f0 = frame_offsets[u], f1 = frame_offsets[u + 1];
+  const float th = thr[u];
+  int num = 0, den = 0;
+  for (int64_t t = g - o.frames_context; t <= g + o.frames_context; ++t)
+    if (t >= f0 && t < f1) {
+      ++den;
+      if (in[t * D] > th) ++num;
+    }
+  out[g] = (static_cast<float>(num) >= static_cast<float>(den) * o.proportion_threshold) ? 1.0f : 0.0f;
+}
+
+int launch_vad(const snf_vad_options& o, const float* in, int in_cols, const int64_t* frame_offsets,
+               int64_t n_utts, int64_t total_frames, float* thr_scratch, float* out,
+               hipStream_t stream) {
+  if (total_frames <= 0) return SNF_OK;
+  hipLaunchKernelGGL(vad_threshold_kernel, dim3(static_cast<unsigned>(n_utts)), dim3(256), 0, stream,
+                     o, in, in_cols, frame_offsets, thr_scratch);
+  hipLaunchKernelGGL(vad_kernel, dim3(static_cast<unsigned>((total_frames + 255) / 256)), dim3(256),
+                     0, stream, o, in, in_cols, frame_offsets, n_utts, total_frames, thr_scratch, out);
+  SNF_HIP_CHECK(hipGetLastError());
+  return SNF_OK;
+}
+
+// CMVN statistics of every utterance ([KALDI-UPSTREAM] transform/cmvn.cc AccCmvnStats): one
+// workgroup per utterance, deterministic reduction; stats[u] = [2, D+1] doubles.
+__global__ __launch_bounds__(256) void cmvn_stats_kernel(const float* __restrict__ in, const int D,
+                                                         const int64_t* __restrict__ frame_offsets,
+                                                         const float* __restrict__ weights,
+                                                         double* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* part = reinterpret_cast<double*>(smem);  // [R][2 D + 1]
+  const int64_t u = blockIdx.x;
+  const int64_t f0 = frame_offsets[u], T = frame_offsets[u + 1] - f0;
+  const int W = 2 * D + 1;
+  const int R = blockDim.x / D > 0 ? blockDim.x / D : 1;  // rows processed in parallel
+  const int r = threadIdx.x / D, c = threadIdx.x - r * D;
+  if (r < R) {
+    double s = 0.0, q = 0.0, n = 0.0;
+    for (int64_t t = r; t < T; t += R) {
+      const float w = weights ? weights[f0 + t] : 1.0f;
+      if (w != 0.0f) {
+        const float x = in[(f0 + t) * D + c];
+        s += static_cast<double>(x * w);
+        q += static_cast<double>(x * x * w);
+        n += static_cast<double>(w);
+      }
+    }
+    part[r * W + c] = s;
+    part[r * W + D + c] = q;
+    if (c == 0) part[r * W + 2 * D] = n;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < W; e += blockDim.x) {
+    double tot = 0.0;
+    for (int k = 0; k < R; ++k) tot += part[k * W + e];
+    double* st = stats + u * 2 * (D + 1);
+    if (e < D) st[e] = tot;                       // row 0: sums
+    else if (e < 2 * D) st[(D + 1) + (e - D)] = tot;  // row 1: sums of squares
+    else { st[D] = tot; st[(D + 1) + D] = 0.0; }  // count; stats(1, D) unused
+  }
+}
+
+int launch_cmvn_stats(const float* in, int in_cols, const int64_t* frame_offsets,
+                      const float* weights, int64_t n_utts, double* stats, hipStream_t stream) {
+  if (n_utts <= 0) return SNF_OK;
+  if (in_cols > 256) return set_error(SNF_E_RUNTIME, "CMVN: more than 256 columns not supported");
+  const int R = 256 / in_cols > 0 ? 256 / in_cols : 1;
+  const size_t lds = sizeof(double) * R * (2 * in_cols + 1);
+  hipLaunchKernelGGL(cmvn_stats_kernel, dim3(static_cast<unsigned>(n_utts)), dim3(256), lds, stream,
+                     in, in_cols, frame_offsets, weights, stats);
+  SNF_HIP_CHECK(hipGetLastError());
+  return SNF_OK;
+}
+
+// out = in * scale + offset with two roundings (Kaldi MulColsVec then AddVecToRows);
+// norm[group][2][D] = {offset, scale} in float.
+__global__ void cmvn_apply_kernel(const float* __restrict__ in, const int D,
+                                  const int64_t* __restrict__ frame_offsets, const int64_t n_utts,
+                                  const int64_t total_frames, const int32_t* __restrict__ group,
+                                  const float* __restrict__ norm, const int scale_it,
+                                  float* __restrict__ out) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= total_frames * D) return;
+  const int64_t g = idx / D;
+  const int c = static_cast<int>(idx - g * D);
+  const int64_t u = find_utt(frame_offsets, n_utts, g);
+  const float* __restrict__ nm = norm + static_cast<int64_t>(group ? group[u] : 0) * 2 * D;
+  float x = in[idx];
+  if (scale_it) x = __fmul_rn(x, nm[D + c]);
+  out[idx] = __fadd_rn(x, nm[c]);
+}
+
+int launch_cmvn_apply(const float* in, int in_cols, const int64_t* frame_offsets, int64_t n_utts,
+                      int64_t total_frames, const int32_t* group, const float* norm, int scale_it,
+                      float* out, hipStream_t stream) {
+  const int64_t total = total_frames * in_cols;
+  if (total <= 0) return SNF_OK;
+  hipLaunchKernelGGL(cmvn_apply_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+                     stream, in, in_cols, frame_offsets, n_utts, total_frames, group, norm, scale_it,
+                     out);
+  SNF_HIP_CHECK(hipGetLastError());
+  return SNF_OK;
+}
+
+// Sliding-window CMN ([KALDI-UPSTREAM] feat/feature-functions.cc SlidingWindowCmnInternal): one thread
+// per (utterance, column) walks the frames with Kaldi's incremental double-precision window sums.
+__global__ void sliding_cmvn_kernel(const snf_sliding_cmvn_options o, const float* __restrict__ in,
+                                    const int D, const int64_t* __restrict__ frame_offsets,
+                                    const int64_t n_utts, float* __restrict__ out) {
+  const int64_t tid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (tid >= n_utts * D) return;
+  const int64_t u = tid / D;
+  const int d = static_cast<int>(tid - u * D);
+  const int64_t f0 = frame_offsets[u], T = frame_offsets[u + 1] - f0;
+  const float* __restrict__ x = in + f0 * D + d;
+  float* __restrict__ y = out + f0 * D + d;
+  double cur_sum = 0.0, cur_sumsq = 0.0;
+  int64_t last_start = -1, last_end = -1;
+  for (int64_t t = 0; t < T; ++t) {
+    int64_t ws, we;
+    if (o.center) { ws = t - (o.cmn_window / 2); we = ws + o.cmn_window; }
+    else { ws = t - o.cmn_window; we = t + 1; }
+    if (ws < 0) { we -= ws; ws = 0; }
+    if (!o.center && we > t) we = (t + 1 > o.min_window) ? t + 1 : o.min_window;
+    if (we > T) { ws -= (we - T); we = T; if (ws < 0) ws = 0; }
+    if (last_start == -1) {
+      for (int64_t r = ws; r < we; ++r) {
+        const double v = x[r * D];
+        cur_sum += v;
+        cur_sumsq += v * v;
+      }
+    } else {
+      if (ws > last_start) {
+        const double v = x[last_start * D];
+        cur_sum += -1.0 * v;
+        if (o.normalize_variance) cur_sumsq += -1.0 * v * v;
+      }
+      if (we > last_end) {
+        const double v = x[last_end * D];
+        cur_sum += 1.0 * v;
+        if (o.normalize_variance) cur_sumsq += 1.0 * v * v;
+      }
+    }
+    const int64_t wf = we - ws;
+    last_start = ws;
+    last_end = we;
+    double r = static_cast<double>(x[t * D]) + (-1.0 / static_cast<double>(wf)) * cur_sum;
+    if (o.normalize_variance) {
+      if (wf == 1) r = 0.0;
+      else {
+        double v = cur_sumsq * (1.0 / static_cast<double>(wf));
+        v += (-1.0 / (static_cast<double>(wf) * static_cast<double>(wf))) * cur_sum * cur_sum;
+        if (v < 1.0e-10) v = 1.0e-10;
+        r *= pow(v, -0.5);
+      }
+    }
+    y[t * D] = static_cast<float>(r);
+  }
+}
+
+int launch_sliding_cmvn(const snf_sliding_cmvn_options& o, const float* in, int in_cols,
+                        const int64_t* frame_offsets, int64_t n_utts, float* out,
+                        hipStream_t stream) {
+  const int64_t total = n_utts * in_cols;
+  if (total <= 0) return SNF_OK;
+  hipLaunchKernelGGL(sliding_cmvn_kernel, dim3(static_cast<unsigned>((total + 63) / 64)), dim3(64), 0,
+                     stream, o, in, in_cols, frame_offsets, n_utts, out);
+  SNF_HIP_CHECK(hipGetLastError());
+  return SNF_OK;
+}
+
 }  // namespace snf

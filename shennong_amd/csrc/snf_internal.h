@@ -202,6 +202,18 @@ struct PitchBatch {
 int launch_pitch(const PitchDevTables& t, const PitchBatch& b, float* down, double* stats,
                  int16_t* backptr, int32_t* states, float* out, hipStream_t stream);
 
+int launch_vad(const snf_vad_options& o, const float* in, int in_cols, const int64_t* frame_offsets,
+               int64_t n_utts, int64_t total_frames, float* thr_scratch, float* out,
+               hipStream_t stream);
+int launch_cmvn_stats(const float* in, int in_cols, const int64_t* frame_offsets,
+                      const float* weights, int64_t n_utts, double* stats, hipStream_t stream);
+int launch_cmvn_apply(const float* in, int in_cols, const int64_t* frame_offsets, int64_t n_utts,
+                      int64_t total_frames, const int32_t* group, const float* norm, int scale_it,
+                      float* out, hipStream_t stream);
+int launch_sliding_cmvn(const snf_sliding_cmvn_options& o, const float* in, int in_cols,
+                        const int64_t* frame_offsets, int64_t n_utts, float* out,
+                        hipStream_t stream);
+
 struct PitchPostParams {
   snf_pitch_post_options o;
   int ndims;

@@ -1,5 +1,9 @@
 """Features post-processors"""
 
+from shennong_amd.postprocessor.cmvn import (
+    CmvnPostProcessor, SlidingWindowCmvnPostProcessor, apply_cmvn)
 from shennong_amd.postprocessor.delta import DeltaPostProcessor
+from shennong_amd.postprocessor.vad import VadPostProcessor
 
-__all__ = ['DeltaPostProcessor']
+__all__ = ['CmvnPostProcessor', 'DeltaPostProcessor',
+           'SlidingWindowCmvnPostProcessor', 'VadPostProcessor', 'apply_cmvn']

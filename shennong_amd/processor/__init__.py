@@ -1,5 +1,6 @@
 """Features extraction processors (same names as reference shennong/processor/__init__.py)"""
 
+from shennong_amd.processor.energy import EnergyProcessor
 from shennong_amd.processor.filterbank import FilterbankProcessor
 from shennong_amd.processor.mfcc import MfccProcessor
 from shennong_amd.processor.plp import PlpProcessor
@@ -8,5 +9,5 @@ from shennong_amd.processor.pitch_kaldi import (
     KaldiPitchProcessor, KaldiPitchPostProcessor)
 
 __all__ = [
-    'FilterbankProcessor', 'MfccProcessor', 'PlpProcessor',
+    'EnergyProcessor', 'FilterbankProcessor', 'MfccProcessor', 'PlpProcessor',
     'SpectrogramProcessor', 'KaldiPitchProcessor', 'KaldiPitchPostProcessor']

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
-from shennong_amd import Audio, Features, Utterances, window
+from shennong_amd import Audio, Features, Utterances, _abi, window
 from shennong_amd.frames import Frames
 from shennong_amd.processor import (
     FilterbankProcessor, MfccProcessor, PlpProcessor, SpectrogramProcessor,
@@ -315,7 +315,7 @@ def test_features_concatenate_golden(golden):
 
 
 def test_features_validate_and_equality():
-    data = np.random.random((5, 3)).astype(np.float32)
+    data = (np.random.default_rng(0).random((5, 3)) + 0.5).astype(np.float32)
     times = np.vstack((np.arange(5) * 0.01, np.arange(5) * 0.01 + 0.025)).T
     f = Features(data, times, properties={'a': np.arange(3)})
     assert f.is_valid() and f.shape == (5, 3) and f.ndims == 3 and f.nframes == 5
@@ -336,3 +336,111 @@ def test_features_validate_and_equality():
     assert 'non-finite' in str(err.value)
     assert Features(np.zeros((0, 0), np.float32), np.zeros((0, 2))).is_valid()
     assert f.copy(subsample=2).shape == (3, 3)
+
+
+# ---- energy / VAD / CMVN host logic (reference test_energy.py, test_vad.py, test_cmvn.py) ----------
+def test_energy_params():
+    from shennong_amd.processor import EnergyProcessor
+    c = {'window_type': 'hanning', 'compression': 'sqrt', 'dither': 0}
+    p1 = EnergyProcessor(**c)
+    p2 = EnergyProcessor().set_params(**c)
+    assert p1.get_params() == p2.get_params()
+    assert p1.ndims == 1 and p1.name == 'energy'
+    assert len(p1.get_params()) == 12
+    with pytest.raises(ValueError) as err:
+        p1.compression = 'bad'
+    assert 'compression must be in ' in str(err.value)
+    # raw energy = rectangular window, no pre-emphasis, only inside the options record
+    o = p1._build_options()
+    assert o.kind == _abi.KIND_ENERGY and o.raw_energy == 1 and o.compression == 2
+    assert p1.window_type == 'hanning'
+
+
+def test_vad_params():
+    from shennong_amd.postprocessor import VadPostProcessor
+    p = VadPostProcessor()
+    with pytest.raises(ValueError) as err:
+        p.energy_mean_scale = -1
+    assert 'must be >= 0' in str(err.value)
+    with pytest.raises(ValueError) as err:
+        p.frames_context = -1
+    assert 'must be >= 0' in str(err.value)
+    with pytest.raises(ValueError) as err:
+        p.proportion_threshold = 0
+    assert 'must be in ]0, 1[' in str(err.value)
+    p = VadPostProcessor(energy_threshold=0, energy_mean_scale=0, frames_context=0,
+                         proportion_threshold=0.1)
+    assert p.get_params() == pytest.approx({
+        'energy_threshold': 0, 'energy_mean_scale': 0, 'frames_context': 0,
+        'proportion_threshold': 0.1})
+    assert p.ndims == 1 and p.name == 'vad'
+
+
+@pytest.mark.parametrize('dim', [-2, 0, 1, 3, 2.54, 'a'])
+def test_cmvn_dim(dim):
+    from shennong_amd.postprocessor import CmvnPostProcessor
+    if dim in (1, 3):
+        assert CmvnPostProcessor(dim).dim == dim
+    else:
+        with pytest.raises(ValueError) as err:
+            CmvnPostProcessor(dim)
+        assert 'dimension must be a strictly positive integer' in str(err.value)
+
+
+def test_cmvn_params_and_errors():
+    from shennong_amd import Features, FeaturesCollection
+    from shennong_amd.postprocessor import (
+        CmvnPostProcessor, SlidingWindowCmvnPostProcessor, apply_cmvn)
+    c = CmvnPostProcessor(dim=1, stats=None)
+    assert c.get_params()['dim'] == 1
+    assert c.get_params()['stats'].shape == (2, 2)
+    assert c.get_params()['stats'].dtype == np.float64
+    assert c.get_params()['stats'].sum() == 0.0
+    with pytest.raises(ValueError) as err:
+        c.set_params(dim=None)
+    assert 'cannot set attribute dim for CmvnPostProcessor' in str(err.value)
+    with pytest.raises(ValueError) as err:
+        c.set_params(stats=None)
+    assert 'cannot set attribute stats for CmvnPostProcessor' in str(err.value)
+    with pytest.raises(ValueError) as err:
+        CmvnPostProcessor(13, stats=1)
+    assert 'shape (2, 14), but is shaped as ()' in str(err.value)
+    with pytest.raises(ValueError) as err:
+        CmvnPostProcessor(13, stats=np.random.random((2, 13)))
+    assert 'shape (2, 14), but is shaped as (2, 13)' in str(err.value)
+    stats = np.random.random((2, 14))
+    assert stats == pytest.approx(CmvnPostProcessor(13, stats=stats.copy()).stats)
+
+    feats = Features(np.random.random((10, 13)).astype(np.float32), np.arange(10.0))
+    proc = CmvnPostProcessor(13)
+    with pytest.raises(ValueError) as err:
+        proc.process(feats)
+    assert 'insufficient accumulation of stats' in str(err.value)
+    with pytest.raises(ValueError) as err:
+        proc.accumulate(feats, weights=np.asarray([[1, 2], [3, 4]]))
+    assert 'weights must have a single dimension' in str(err.value)
+    with pytest.raises(ValueError) as err:
+        proc.accumulate(feats, weights=np.asarray([]))
+    assert 'there is 0 weights but 10 feature frames' in str(err.value)
+
+    coll = FeaturesCollection(a=feats, b=feats.copy())
+    with pytest.raises(ValueError) as err:
+        apply_cmvn(coll, weights={})
+    assert 'keys differ for ' in str(err.value)
+    for sd in ([-1], [13]):
+        with pytest.raises(ValueError) as err:
+            apply_cmvn(coll, skip_dims=sd)
+        assert 'out of bounds dimensions' in str(err.value)
+    coll['new'] = Features(np.random.random((2, 1)), np.asarray([0, 1]))
+    with pytest.raises(ValueError) as err:
+        apply_cmvn(coll)
+    assert 'must have consistent dimensions' in str(err.value)
+
+    s = SlidingWindowCmvnPostProcessor(normalize_variance=True, center=False)
+    assert s.get_params() == {'center': False, 'cmn_window': 600, 'min_window': 100,
+                              'max_warnings': 5, 'normalize_variance': True}
+    with pytest.raises(ValueError) as err:
+        s.ndims
+    assert 'dimension for sliding window CMVN processor depends on input' in str(err.value)
+    o = s._build_options()
+    assert (o.sliding_cmvn.center, o.sliding_cmvn.normalize_variance) == (0, 1)

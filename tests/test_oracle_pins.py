@@ -279,3 +279,99 @@ def test_pitch_tracks_a_tone():
     post.delta_pitch_noise_stddev = 0
     feats = orc.process_pitch(post, raw)
     assert feats.shape == (raw.shape[0], 3) and np.all(np.isfinite(feats))
+
+
+# ---- energy, VAD, CMVN -----------------------------------------------------------
+def _mfcc_oracle(wave, **kw):
+    o = _abi.default_options(_abi.KIND_MFCC)
+    o.frame.dither = 0.0
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return orc.compute(o, wave)
+
+
+def _energy_oracle(wave, raw_energy=True, compression='log'):
+    o = _abi.default_options(_abi.KIND_ENERGY)
+    o.frame.dither = 0.0
+    o.raw_energy = int(raw_energy)
+    o.compression = _abi.COMPRESSION[compression]
+    return orc.compute(o, wave)
+
+
+def test_vad_known_answer(wave):
+    """reference postprocessor/vad.py:55-56 doctest: 119 voiced frames out of 140 on test.wav"""
+    mfcc = _mfcc_oracle(wave)
+    vad = orc.vad_energy(mfcc)
+    assert vad.shape == (140,) and int(vad.sum()) == 119
+    assert set(np.unique(vad)) <= {0.0, 1.0}
+    # reference test/postprocessor/test_vad.py:54-62
+    assert np.all(orc.vad_energy(mfcc, energy_threshold=0) == 1)
+    assert not np.any(orc.vad_energy(mfcc, energy_threshold=1e10))
+
+
+@pytest.mark.parametrize('raw_energy', [True, False])
+def test_energy_is_first_cepstral_coefficient(wave, raw_energy):
+    """reference test/processor/test_energy.py:40-48 (np.allclose defaults) and
+    test/postprocessor/test_vad.py:70-77"""
+    mfcc = _mfcc_oracle(wave, raw_energy=int(raw_energy))
+    plp = orc.compute(_plp_opts(raw_energy), wave)
+    energy = _energy_oracle(wave, raw_energy)
+    assert energy.shape == (140, 1)
+    assert np.allclose(mfcc[:, 0], energy[:, 0])
+    assert np.allclose(plp[:, 0], energy[:, 0])
+    assert np.array_equal(orc.vad_energy(energy), orc.vad_energy(mfcc))
+
+
+def _plp_opts(raw_energy):
+    o = _abi.default_options(_abi.KIND_PLP)
+    o.frame.dither = 0.0
+    o.raw_energy = int(raw_energy)
+    return o
+
+
+def test_energy_compression(wave):
+    """reference processor/energy.py:30-33 doctest: log(off) == log"""
+    off = _energy_oracle(wave, compression='off')
+    np.testing.assert_allclose(np.log(off), _energy_oracle(wave), rtol=1e-6)
+    np.testing.assert_allclose(np.sqrt(off), _energy_oracle(wave, compression='sqrt'), rtol=1e-6)
+
+
+@pytest.mark.parametrize('norm_vars', [True, False])
+def test_cmvn_oracle(wave, norm_vars):
+    """reference test/postprocessor/test_cmvn.py:41-84 and the cmvn.py:38-43 doctest"""
+    mfcc = _mfcc_oracle(wave)
+    stats = orc.cmvn_accumulate(mfcc)
+    assert stats.shape == (2, 14) and stats[0, -1] == 140 and stats[1, -1] == 0
+    np.testing.assert_allclose(stats[0, :13], mfcc.astype(np.float64).sum(axis=0), rtol=1e-12)
+    np.testing.assert_allclose(stats[1, :13], (mfcc.astype(np.float64) ** 2).sum(axis=0), rtol=1e-7)
+    out = orc.cmvn_apply(mfcc, stats, norm_vars=norm_vars)
+    assert np.all(np.isclose(out.mean(axis=0), 0, atol=1e-6))
+    if norm_vars:
+        assert np.all(np.isclose(out.var(axis=0), 1, atol=1e-6))
+    else:
+        assert out.var(axis=0) == pytest.approx(mfcc.var(axis=0))
+    back = orc.cmvn_apply(out, stats, norm_vars=norm_vars, reverse=True)
+    assert back == pytest.approx(mfcc, abs=1e-5)
+    twice = orc.cmvn_accumulate(mfcc, stats=stats.copy())
+    assert twice == pytest.approx(stats * 2)
+    # weights (test_cmvn.py:101-122)
+    assert orc.cmvn_accumulate(mfcc, weights=np.zeros(140))[0, -1] == 0
+    assert orc.cmvn_accumulate(mfcc, weights=np.ones(140) * 0.5)[0, -1] == 70
+    w = np.zeros(140)
+    w[:2] = 0.1
+    assert orc.cmvn_accumulate(mfcc, weights=w)[0, -1] == pytest.approx(0.2)
+
+
+@pytest.mark.parametrize('norm_vars, center', [(s, v) for s in (True, False) for v in (True, False)])
+def test_sliding_cmvn_oracle(wave, norm_vars, center):
+    """reference test/postprocessor/test_cmvn.py:223-263"""
+    mfcc = _mfcc_oracle(wave)
+    ws = 40
+    out = orc.sliding_cmn(mfcc, center=center, cmn_window=ws, min_window=ws,
+                          normalize_variance=norm_vars)
+    frame = 70
+    a, b = (frame - ws // 2, frame + ws // 2) if center else (frame - ws, frame + 1)
+    want = mfcc[frame] - mfcc[a:b].mean(axis=0)
+    if norm_vars:
+        want = want / mfcc[a:b].std(axis=0)
+    assert np.all(np.isclose(out[frame], want, atol=1e-6))

@@ -231,3 +231,199 @@ def test_dither_statistics(gpu, snip_edges):
     clean = MfccProcessor(dither=0, snip_edges=snip_edges).process(Audio(loud, 16000)).data
     noisy = proc.process(Audio(loud, 16000)).data
     assert np.abs(clean - noisy).max() < 0.05
+
+
+# ---- energy, VAD, CMVN, sliding-window CMVN -----------------------------------
+from shennong_amd import Features, FeaturesCollection  # noqa: E402
+from shennong_amd.processor import EnergyProcessor  # noqa: E402
+from shennong_amd.postprocessor import (  # noqa: E402
+    CmvnPostProcessor, SlidingWindowCmvnPostProcessor, VadPostProcessor, apply_cmvn)
+
+
+@pytest.mark.parametrize('opts', [
+    dict(), dict(raw_energy=False), dict(compression='off'), dict(compression='sqrt'),
+    dict(raw_energy=False, window_type='hanning', preemph_coeff=0.5),
+    dict(snip_edges=False), dict(frame_shift=0.02, frame_length=0.05),
+    dict(round_to_power_of_two=False), dict(remove_dc_offset=False)])
+def test_energy(gpu, audio, wave, opts):
+    proc = EnergyProcessor(dither=0, **opts)
+    got = proc.process(audio)
+    want = _oracle(proc, wave)
+    assert got.shape == want.shape and got.shape[1] == 1
+    np.testing.assert_allclose(got.data, want, rtol=1e-6)
+    assert got.properties['energy']['raw_energy'] == opts.get('raw_energy', True)
+
+
+@pytest.mark.parametrize('raw_energy', [True, False])
+def test_energy_matches_c0(gpu, audio, raw_energy):
+    """reference test/processor/test_energy.py:40-48"""
+    p = {'raw_energy': raw_energy, 'dither': 0}
+    mfcc = MfccProcessor(**p).process(audio).data[:, 0]
+    plp = PlpProcessor(**p).process(audio).data[:, 0]
+    energy = EnergyProcessor(**p).process(audio).data[:, 0]
+    assert np.allclose(mfcc, energy) and np.allclose(plp, energy)
+
+
+def test_energy_shapes(gpu, audio):
+    """reference test/processor/test_energy.py:51-56"""
+    assert EnergyProcessor(frame_shift=0.01).process(audio).shape == (140, 1)
+    assert EnergyProcessor(frame_shift=0.02).process(audio).shape == (70, 1)
+    assert EnergyProcessor(frame_shift=0.02, frame_length=0.05).process(audio).shape == (69, 1)
+
+
+@pytest.mark.parametrize('opts', [
+    dict(), dict(frames_context=2), dict(frames_context=5, proportion_threshold=0.3),
+    dict(energy_mean_scale=0.0, energy_threshold=12.0), dict(energy_mean_scale=1.0, energy_threshold=0.5)])
+def test_vad(gpu, audio, opts):
+    mfcc = MfccProcessor(dither=0).process(audio)
+    got = VadPostProcessor(**opts).process(mfcc)
+    want = orc.vad_energy(mfcc.data, **opts)
+    assert got.shape == (140, 1) and got.dtype == np.uint8
+    assert np.array_equal(got.data[:, 0], want.astype(np.uint8))
+    assert np.array_equal(got.times, mfcc.times)
+
+
+def test_vad_reference_behaviour(gpu, audio):
+    """reference vad.py:55-56 doctest (119 of 140) and test/postprocessor/test_vad.py:43-77"""
+    mfcc = MfccProcessor(dither=0).process(audio)
+    p = VadPostProcessor()
+    vad = p.process(mfcc)
+    assert int(vad.data.sum()) == 119
+    p.energy_threshold = 0
+    assert np.all(p.process(mfcc).data)
+    p.energy_threshold = 1e10
+    assert not np.any(p.process(mfcc).data)
+    vad1 = VadPostProcessor().process(EnergyProcessor(dither=0).process(audio))
+    assert Features(vad1.data, vad1.times) == Features(vad.data, vad.times)
+
+
+def test_vad_batch(gpu, synth_waves):
+    proc = MfccProcessor(dither=0)
+    feats = proc._process_batch([Audio(w, 16000) for w in synth_waves])
+    outs = VadPostProcessor(frames_context=3)._process_batch(feats)
+    for f, o in zip(feats, outs):
+        want = orc.vad_energy(f.data, frames_context=3)
+        assert np.array_equal(o.data[:, 0], want.astype(np.uint8))
+
+
+@pytest.mark.parametrize('norm_vars', [True, False])
+def test_cmvn(gpu, audio, norm_vars):
+    """parity with the oracle + the reference's own checks (test/postprocessor/test_cmvn.py:41-84)"""
+    mfcc = MfccProcessor(dither=0).process(audio)
+    backup = mfcc.data.copy()
+    proc = CmvnPostProcessor(mfcc.ndims)
+    proc.accumulate(mfcc)
+    assert proc.count == mfcc.nframes
+    want_stats = orc.cmvn_accumulate(mfcc.data)
+    np.testing.assert_allclose(proc.stats, want_stats, rtol=1e-13)
+    cmvn1 = proc.process(mfcc, norm_vars=norm_vars)
+    # same statistics -> the apply step must be bit-exact
+    assert np.array_equal(cmvn1.data, orc.cmvn_apply(mfcc.data, proc.stats, norm_vars=norm_vars))
+    assert np.array_equal(backup, mfcc.data)
+    assert cmvn1.shape == mfcc.shape and cmvn1.dtype == mfcc.dtype
+    assert cmvn1.data.mean() == pytest.approx(0, abs=1e-6)
+    if norm_vars:
+        assert cmvn1.data.var(axis=0) == pytest.approx(np.ones(cmvn1.ndims))
+    else:
+        assert cmvn1.data.var(axis=0) == pytest.approx(mfcc.data.var(axis=0))
+    cmvn2 = proc.process(cmvn1, norm_vars=norm_vars, reverse=True)
+    assert np.array_equal(
+        cmvn2.data, orc.cmvn_apply(cmvn1.data, proc.stats, norm_vars=norm_vars, reverse=True))
+    assert cmvn2.data == pytest.approx(mfcc.data, abs=1e-5)
+    stats = proc.stats.copy()
+    proc.accumulate(mfcc)
+    assert proc.stats == pytest.approx(stats * 2)
+    assert 'cmvn' not in mfcc.properties and cmvn2.properties['cmvn']['stats'].shape == (2, 14)
+
+
+def test_cmvn_weights_and_skip_dims(gpu, audio):
+    """reference test/postprocessor/test_cmvn.py:101-161"""
+    mfcc = MfccProcessor(dither=0).process(audio)
+    rng = np.random.default_rng(0)
+    w = rng.random(mfcc.nframes)
+    w[::7] = 0.0
+    proc = CmvnPostProcessor(mfcc.ndims)
+    proc.accumulate(mfcc, weights=w)
+    np.testing.assert_allclose(proc.stats, orc.cmvn_accumulate(mfcc.data, weights=w), rtol=1e-12)
+    for weights, count in ((np.zeros(140), 0), (np.ones(140), 140), (np.ones(140) * 0.5, 70)):
+        p = CmvnPostProcessor(dim=mfcc.ndims)
+        p.accumulate(mfcc, weights=weights)
+        assert p.count == count
+    proc = CmvnPostProcessor(mfcc.ndims)
+    proc.accumulate(mfcc)
+    cmvn1 = proc.process(mfcc, skip_dims=None)
+    assert cmvn1 == proc.process(mfcc, skip_dims=[])
+    cmvn3 = proc.process(mfcc, skip_dims=[0, 1, 2])
+    assert np.array_equal(cmvn3.data[:, :3], mfcc.data[:, :3])
+    assert np.array_equal(cmvn3.data[:, 3:], cmvn1.data[:, 3:])
+    assert proc.process(mfcc, skip_dims=[1, 2, 0]) == cmvn3
+    assert np.array_equal(proc.process(mfcc, skip_dims=list(range(13))).data, mfcc.data)
+    for d in ([-1], [-1, 2, 3], [100], [100, -1, 5]):
+        with pytest.raises(ValueError):
+            proc.process(mfcc, skip_dims=d)
+
+
+@pytest.mark.parametrize('by_collection', [True, False])
+def test_apply_cmvn(gpu, synth_waves, by_collection):
+    """reference test/postprocessor/test_cmvn.py:164-220; one stats launch + one apply launch"""
+    proc = MfccProcessor(dither=0)
+    feats = proc._process_batch([Audio(w, 16000) for w in synth_waves])
+    coll = FeaturesCollection({str(i): f for i, f in enumerate(feats)})
+    cmvns = apply_cmvn(coll, by_collection=by_collection)
+    assert list(cmvns.keys()) == list(coll.keys())
+    if by_collection:
+        stats = np.zeros((2, 14))
+        for f in feats:
+            orc.cmvn_accumulate(f.data, stats=stats)
+        allc = np.concatenate([f.data for f in cmvns.values()], axis=0)
+        assert allc.mean(axis=0) == pytest.approx(0, abs=1e-5)
+        assert allc.var(axis=0) == pytest.approx(1, abs=1e-5)
+    for k, f in coll.items():
+        st = stats if by_collection else orc.cmvn_accumulate(f.data)
+        np.testing.assert_allclose(cmvns[k].properties['cmvn']['stats'], st, rtol=1e-12)
+        want = orc.cmvn_apply(f.data, cmvns[k].properties['cmvn']['stats'])
+        assert np.array_equal(cmvns[k].data, want)
+        if not by_collection:
+            assert cmvns[k].data.mean(axis=0) == pytest.approx(0, abs=1e-5)
+            assert cmvns[k].data.var(axis=0) == pytest.approx(1, abs=1e-5)
+    weights = {k: None for k in coll.keys()}
+    assert apply_cmvn(coll, by_collection=by_collection, weights=weights) == cmvns
+    skipped = apply_cmvn(coll, skip_dims=[0, 1], by_collection=False)
+    for k, f in skipped.items():
+        assert np.array_equal(f.data[:, :2], coll[k].data[:, :2])
+        assert f.data[:, 2:].mean(axis=0) == pytest.approx(0, abs=1e-5)
+
+
+@pytest.mark.parametrize('norm_vars, center', [(s, v) for s in (True, False) for v in (True, False)])
+@pytest.mark.parametrize('window', [(40, 40), (600, 100), (30, 10), (7, 50)])
+def test_sliding_cmvn(gpu, audio, norm_vars, center, window):
+    """bit-exact against the oracle (same double-precision incremental sums) + the reference's own
+    frame-70 check (test/postprocessor/test_cmvn.py:223-263)"""
+    mfcc = MfccProcessor(dither=0).process(audio)
+    backup = mfcc.data.copy()
+    proc = SlidingWindowCmvnPostProcessor(
+        normalize_variance=norm_vars, center=center, cmn_window=window[0], min_window=window[1])
+    got = proc.process(mfcc)
+    want = orc.sliding_cmn(mfcc.data, center=center, cmn_window=window[0], min_window=window[1],
+                           normalize_variance=norm_vars)
+    assert got.shape == mfcc.shape and got.dtype == mfcc.dtype
+    np.testing.assert_allclose(got.data, want, rtol=1e-6, atol=1e-6)
+    assert np.array_equal(got.times, mfcc.times) and np.array_equal(backup, mfcc.data)
+    if window == (40, 40):
+        frame = 70
+        a, b = (frame - 20, frame + 20) if center else (frame - 40, frame + 1)
+        ref = mfcc.data[frame] - mfcc.data[a:b].mean(axis=0)
+        if norm_vars:
+            ref = ref / mfcc.data[a:b].std(axis=0)
+        assert np.all(np.isclose(got.data[frame], ref, atol=1e-6))
+
+
+def test_sliding_cmvn_batch(gpu, synth_waves):
+    proc = MfccProcessor(dither=0)
+    feats = proc._process_batch([Audio(w, 16000) for w in synth_waves])
+    feats.append(Features(feats[0].data[:1].copy(), feats[0].times[:1].copy()))
+    post = SlidingWindowCmvnPostProcessor(cmn_window=50, min_window=20, normalize_variance=True)
+    outs = post._process_batch(feats)
+    for f, o in zip(feats, outs):
+        want = orc.sliding_cmn(f.data, cmn_window=50, min_window=20, normalize_variance=True)
+        np.testing.assert_allclose(o.data, want, rtol=1e-6, atol=1e-6)
