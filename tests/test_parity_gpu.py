@@ -376,16 +376,18 @@ def test_apply_cmvn(gpu, synth_waves, by_collection):
         for f in feats:
             orc.cmvn_accumulate(f.data, stats=stats)
         allc = np.concatenate([f.data for f in cmvns.values()], axis=0)
-        assert allc.mean(axis=0) == pytest.approx(0, abs=1e-5)
-        assert allc.var(axis=0) == pytest.approx(1, abs=1e-5)
+        # (the synthetic C0 has |mean| / std ~ 400: Kaldi's float32 x*x and offset lose ~1e-3 there,
+        # identically in the oracle - the bit-exact comparison below covers that column)
+        assert allc[:, 1:].mean(axis=0) == pytest.approx(0, abs=1e-5)
+        assert allc[:, 1:].var(axis=0) == pytest.approx(1, abs=1e-5)
     for k, f in coll.items():
         st = stats if by_collection else orc.cmvn_accumulate(f.data)
         np.testing.assert_allclose(cmvns[k].properties['cmvn']['stats'], st, rtol=1e-12)
         want = orc.cmvn_apply(f.data, cmvns[k].properties['cmvn']['stats'])
         assert np.array_equal(cmvns[k].data, want)
         if not by_collection:
-            assert cmvns[k].data.mean(axis=0) == pytest.approx(0, abs=1e-5)
-            assert cmvns[k].data.var(axis=0) == pytest.approx(1, abs=1e-5)
+            assert cmvns[k].data[:, 1:].mean(axis=0) == pytest.approx(0, abs=1e-5)
+            assert cmvns[k].data[:, 1:].var(axis=0) == pytest.approx(1, abs=1e-5)
     weights = {k: None for k in coll.keys()}
     assert apply_cmvn(coll, by_collection=by_collection, weights=weights) == cmvns
     skipped = apply_cmvn(coll, skip_dims=[0, 1], by_collection=False)
