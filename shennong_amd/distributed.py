@@ -6,6 +6,10 @@ The reference's only parallelism is a joblib thread pool over utterances sharing
   * ``gather_features``   - the one exchange step: variable-length gather of the float32 Features blocks
                             to a root rank as point-to-point sends (``gatherv``): every peer uses its own
                             direct xGMI link to the root instead of a ring.
+  * ``allreduce_cmvn_stats`` / ``apply_cmvn_sharded`` - per-speaker CMVN (reference
+    shennong/pipeline.py:580-603 accumulates every utterance of a speaker before applying): the only
+    real reduction on the path.  The [n_speakers, 2, dim+1] float64 blocks are all-gathered and summed
+    in rank order, so the result does not depend on the collective's internal reduction order.
 ``torch.distributed`` (backend "nccl" = RCCL on ROCm, "gloo" on CPU) is plumbing only.
 """
 
@@ -97,3 +101,87 @@ def process_all_sharded(processor, utterances, dst=0, group=None, **kwargs):
             data, processor.times(data.shape[0]),
             properties=processor.get_properties(**extra), validate=False)
     return out
+
+
+def _default_device(group):
+    import torch
+    import torch.distributed as dist
+    return torch.device('cuda', torch.cuda.current_device()) \
+        if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+
+
+def allreduce_cmvn_stats(stats, group=None, device=None):
+    """Sums float64 CMVN statistics blocks [n_speakers, 2, dim + 1] over the ranks.
+
+    One all-gather of the (tiny) blocks, then a rank-ordered host sum: deterministic and identical
+    on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    stats = np.ascontiguousarray(stats, dtype=np.float64)
+    if world == 1:
+        return stats.copy()
+    if device is None:
+        device = _default_device(group)
+    send = torch.from_numpy(stats.reshape(-1)).to(device)
+    recv = torch.empty(world * send.numel(), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    parts = recv.cpu().numpy().reshape((world,) + stats.shape)
+    total = np.zeros_like(stats)
+    for r in range(world):
+        total += parts[r]
+    return total
+
+
+def apply_cmvn_sharded(local_feats, utt2speak=None, norm_vars=True, weights=None,
+                       skip_dims=None, group=None, _plan=None):
+    """Per-speaker CMVN when the utterances of a speaker are spread over the ranks.
+
+    `local_feats` is THIS rank's FeaturesCollection (as ``process_all`` over its shard returns);
+    `utt2speak` maps utterance name -> speaker (None: one normalisation over the whole distributed
+    collection, the reference's ``apply_cmvn(by_collection=True)``).  Every rank gets its own shard
+    normalised with the statistics of the complete speakers: local statistics launch ->
+    ``allreduce_cmvn_stats`` -> local apply launch.  Returns ``(FeaturesCollection, stats dict)``."""
+    import torch.distributed as dist
+    from shennong_amd import _abi, _backend
+    from shennong_amd.features import Features, FeaturesCollection
+    from shennong_amd.postprocessor.cmvn import CmvnPostProcessor, _fake_stats_for_dims
+    world = dist.get_world_size(group)
+    keys = list(local_feats.keys())
+    speak = [None if utt2speak is None else utt2speak[k] for k in keys]
+    meta = [None] * world
+    dist.all_gather_object(
+        meta, (sorted(set(speak), key=str), sorted(set(local_feats[k].ndims for k in keys))),
+        group=group)
+    speakers = sorted(set(s for m in meta for s in m[0]), key=str)
+    dims = sorted(set(d for m in meta for d in m[1]))
+    if len(dims) != 1:
+        raise ValueError(
+            'features in the collection must have consistent dimensions '
+            'but dimensions are: {}'.format(dims))
+    dim = dims[0]
+    index = {s: i for i, s in enumerate(speakers)}
+    groups = np.asarray([index[s] for s in speak], dtype=np.int32)
+    plan = _plan or _backend.get_plan(_abi.default_options(_abi.KIND_CMVN))
+    mats = [np.asarray(local_feats[k].data, dtype=np.float32) for k in keys]
+    stats = np.zeros((len(speakers), 2, dim + 1), dtype=np.float64)
+    if mats:
+        plan.cmvn_accumulate(
+            mats, stats, groups=groups,
+            weights=None if weights is None else [weights[k] for k in keys])
+    stats = allreduce_cmvn_stats(stats, group=group)
+    for s, i in index.items():
+        if stats[i, 0, -1] < 1.0:
+            raise ValueError(
+                'insufficient accumulation of stats for CMVN, '
+                'must be >= 1.0 but is {}'.format(stats[i, 0, -1]))
+    applied = stats
+    if skip_dims:
+        applied = np.stack([_fake_stats_for_dims(st, skip_dims) for st in stats])
+    datas = plan.cmvn_apply(mats, applied, groups=groups, norm_vars=norm_vars) if mats else []
+    out = FeaturesCollection()
+    for u, k in enumerate(keys):
+        proc = CmvnPostProcessor(dim, stats=stats[groups[u]])
+        out[k] = Features(datas[u], local_feats[k].times,
+                          properties=proc.get_properties(local_feats[k]))
+    return out, {s: stats[i] for s, i in index.items()}

@@ -1,5 +1,7 @@
 """Features post-processors"""
 
+import shennong_amd.processor  # noqa: F401 (import order: the processors define the base classes)
+
 from shennong_amd.postprocessor.cmvn import (
     CmvnPostProcessor, SlidingWindowCmvnPostProcessor, apply_cmvn)
 from shennong_amd.postprocessor.delta import DeltaPostProcessor

@@ -61,3 +61,80 @@ def test_gather_features_gloo(tmp_path):
         port = s.getsockname()[1]
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert [open(tmp_path / f'ok{r}').read() for r in range(2)] == ['1', '1']
+
+
+class _OraclePlan:
+    """Stand-in for the HIP CMVN plan so that the collective logic can run on CPU ranks (test
+    infrastructure: same call surface as shennong_amd._backend.Plan.cmvn_*)"""
+    def cmvn_accumulate(self, mats, stats, weights=None, groups=None):
+        from oracle import oracle as orc
+        for u, m in enumerate(mats):
+            g = 0 if groups is None else int(groups[u])
+            orc.cmvn_accumulate(m, weights=None if weights is None else weights[u], stats=stats[g])
+        return stats
+
+    def cmvn_apply(self, mats, stats, groups=None, norm_vars=True, reverse=False):
+        from oracle import oracle as orc
+        return [orc.cmvn_apply(m, stats[0 if groups is None else int(groups[u])],
+                               norm_vars=norm_vars, reverse=reverse) for u, m in enumerate(mats)]
+
+
+def _cmvn_case():
+    from shennong_amd import Features, FeaturesCollection
+    rng = np.random.default_rng(11)
+    nframes = rng.integers(3, 60, size=9)
+    coll = FeaturesCollection()
+    for i, n in enumerate(nframes):
+        data = (rng.standard_normal((int(n), 4)) * (1 + i % 3) + i).astype(np.float32)
+        coll[f'utt{i}'] = Features(data, np.arange(int(n), dtype=np.float64))
+    utt2speak = {f'utt{i}': f'spk{i % 3}' for i in range(9)}
+    return coll, utt2speak, nframes
+
+
+def _cmvn_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    from oracle import oracle as orc
+    from shennong_amd import FeaturesCollection
+    from shennong_amd.distributed import (
+        allreduce_cmvn_stats, apply_cmvn_sharded, shard_utterances)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    coll, utt2speak, nframes = _cmvn_case()
+    shards = shard_utterances(nframes, world)
+    local = FeaturesCollection({f'utt{i}': coll[f'utt{i}'] for i in shards[rank]})
+    ok = True
+    # the collective alone: rank-ordered sum of float64 blocks
+    mine = np.full((3, 2, 5), float(rank + 1)) * np.arange(30).reshape(3, 2, 5)
+    tot = allreduce_cmvn_stats(mine)
+    ok = ok and np.array_equal(tot, 3.0 * np.arange(30).reshape(3, 2, 5))
+    for mapping in (utt2speak, None):
+        got, stats = apply_cmvn_sharded(local, mapping, _plan=_OraclePlan())
+        ok = ok and list(got.keys()) == list(local.keys())
+        for k in local.keys():
+            spk = None if mapping is None else mapping[k]
+            members = [u for u in coll.keys() if mapping is None or mapping[u] == spk]
+            want_stats = np.zeros((2, 5))
+            for u in members:
+                orc.cmvn_accumulate(coll[u].data, stats=want_stats)
+            ok = ok and np.allclose(stats[spk], want_stats, rtol=1e-13, atol=0)
+            ok = ok and np.array_equal(got[k].data, orc.cmvn_apply(coll[k].data, stats[spk]))
+            ok = ok and got[k].properties['cmvn']['stats'].shape == (2, 5)
+    # a rank without any utterance still takes part in the reduction
+    got, stats = apply_cmvn_sharded(local if rank == 0 else FeaturesCollection(), None,
+                                    _plan=_OraclePlan())
+    ok = ok and len(got) == (len(local) if rank == 0 else 0)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmpdir, f'ok{rank}'), 'w').write('1' if ok else '0')
+
+
+@pytest.mark.timeout(120)
+def test_cmvn_sharded_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_cmvn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert [open(tmp_path / f'ok{r}').read() for r in range(2)] == ['1', '1']
