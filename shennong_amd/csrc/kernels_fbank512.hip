@@ -144,8 +144,8 @@ __device__ __forceinline__ float2 gauss_pair(unsigned key_lo, unsigned key_hi, u
 
 constexpr int kMaxGroups = kFast512MaxGroups;  // 4-tap groups per mel round
 
-constexpr int kWaves = 16;                // wavefronts per workgroup: one 1024-thread workgroup per CU,
-                                          // so the LDS tables are staged once per CU
+constexpr int kMaxWaves = 16;             // wavefronts per workgroup: 8 when two workgroups fit the LDS
+                                          // of a CU (measured 5 % faster), else one of 16
 constexpr int kTileRow = 17;               // complex per transposed row (16 + 1 pad: conflict-free)
 constexpr int kFrameTileBytes = 16 * kTileRow * 8;  // wave-private LDS per frame (2176 B)
 constexpr int kMaxRounds = kFast512MaxRounds;  // mel bins <= 64
@@ -224,7 +224,7 @@ __device__ __forceinline__ void fft16(float2 (&v)[16]) {
 
 // ENERGY: 0 = no log-energy column, 1 = raw (before pre-emphasis/window), 2 = after the window
 template <int NJ, int KIND, int ENERGY, bool DITHER>
-__global__ __launch_bounds__(kWaves * 64, 4) void fbank512_kernel(const Fast512Params p,
+__global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast512Params p,
                                                                    const BatchArgs b,
                                                                    float* __restrict__ out,
                                                                    double* __restrict__ energy_out) {
@@ -251,14 +251,15 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512_kernel(const Fast512P
   float* ptile = reinterpret_cast<float*>(wave_base) + (q & 1) * 16;
 
   const int64_t n_sets = (b.total_frames + 3) >> 2;
-  const int64_t set_stride = static_cast<int64_t>(gridDim.x) * kWaves;
+  const int n_waves = blockDim.x >> 6;
+  const int64_t set_stride = static_cast<int64_t>(gridDim.x) * n_waves;
   typedef int __attribute__((aligned(2))) int_a2;
   const int64_t last_frame = b.total_frames - 1;
   // Software pipeline over frame sets: the samples of set i+1 and the start offset of set i+2 are
   // requested while set i is being transformed, so no global-memory latency sits on the critical
   // path of a wave.  frame_start[g] (sample index of the first sample of global frame g) is built
   // once per offsets table by build_frame_start_kernel.
-  int64_t set = static_cast<int64_t>(blockIdx.x) * kWaves + wid;
+  int64_t set = static_cast<int64_t>(blockIdx.x) * n_waves + wid;
   const bool in_last = 2 * (l + 16 * (NJ - 1)) < p.win_len;
   int raw[NJ];
   int64_t start_next = 0;
@@ -623,14 +624,19 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
   Fast512Params q = p;
   q.out_cols = out_cols;
   const int tab_bytes = (p.table_floats * 4 + 255) & ~255;
-  const size_t lds = static_cast<size_t>(tab_bytes) + kWaves * 4 * kFrameTileBytes;
+  int n_waves = 8;
+  size_t lds = static_cast<size_t>(tab_bytes) + n_waves * 4 * kFrameTileBytes;
+  if (2 * (lds + 512) > 160 * 1024) {  // two 8-wave workgroups do not fit: one of 16 waves
+    n_waves = kMaxWaves;
+    lds = static_cast<size_t>(tab_bytes) + n_waves * 4 * kFrameTileBytes;
+  }
   if (lds > 160 * 1024) return set_error(SNF_E_RUNTIME, "fast512: tables do not fit in LDS");
   const int nj = (p.win_len + 31) / 32;
   const int64_t n_sets = (b.total_frames + 3) / 4;
-  int64_t blocks = (n_sets + kWaves - 1) / kWaves;
-  const int64_t max_blocks = 256 * 4;  // one resident workgroup per CU x grid-stride depth
+  int64_t blocks = (n_sets + n_waves - 1) / n_waves;
+  const int64_t max_blocks = 256 * 4 * (kMaxWaves / n_waves);  // resident workgroups x grid-stride depth 4
   if (blocks > max_blocks) blocks = max_blocks;
-  const dim3 grid(static_cast<unsigned>(blocks)), block(kWaves * 64);
+  const dim3 grid(static_cast<unsigned>(blocks)), block(n_waves * 64);
 #define SNF_LAUNCH4(NJ_, KIND_, EN_, DI_)                                                              \
   do {                                                                                              \
     if (lds > 64 * 1024)                                                                            \
