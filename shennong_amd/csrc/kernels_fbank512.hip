@@ -73,6 +73,14 @@ __device__ __forceinline__ void read_strided(const void* base, float2 (&dst)[N])
     read_strided<N, STRIDE_BYTES, I + 1>(base, dst);
   }
 }
+// N float4 (= 2 N complex) contiguous from `base`: plain 16-byte LDS loads (the compiler emits
+// ds_read_b128 - there is no slower merged form for 128-bit reads - and places the waits itself)
+template <int N>
+__device__ __forceinline__ void read_quads(const void* base, float4 (&dst)[N]) {
+  const float4* __restrict__ q = reinterpret_cast<const float4*>(base);
+#pragma unroll
+  for (int i = 0; i < N; ++i) dst[i] = q[i];
+}
 // dst[i] = element at offset (N - 1 - i) * STRIDE_BYTES
 template <int N, int STRIDE_BYTES, int I = 0>
 __device__ __forceinline__ void read_strided_rev(const void* base, float2 (&dst)[N]) {
@@ -233,9 +241,12 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
   // ---- stage the tables into LDS (the only workgroup-wide barrier of the kernel) -------------------
   for (int i = threadIdx.x; i < p.table_floats; i += blockDim.x) tab[i] = p.tables[i];
   __syncthreads();
+  // lane-major tables (row = one lane's values, padded so that the 16 lanes of a frame hit 64
+  // distinct banks with ds_read_b128): window pairs [16][16 + 2], inter-pass twiddles [16][16 + 2],
+  // unpack twiddles [16][8 + 2] complex
   const float2* __restrict__ t_win = reinterpret_cast<const float2*>(tab);
-  const float2* __restrict__ t_tw16 = t_win + 256;
-  const float2* __restrict__ t_tw512 = t_tw16 + 256;
+  const float2* __restrict__ t_tw16 = t_win + 16 * 18;
+  const float2* __restrict__ t_tw512 = t_tw16 + 16 * 18;
   const int* __restrict__ t_first = reinterpret_cast<const int*>(tab + p.off_first);
   const float* __restrict__ t_w = tab + p.off_w;
   const float* __restrict__ t_dct = tab + p.off_dct;
@@ -280,8 +291,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     // ---- A: DC removal, pre-emphasis, window ------------------------------------------------------
     // A1: one dword (two int16 samples) per element, requested one iteration ago.  Only the last j
     // can fall outside the window (NJ = ceil(win_len / 32)).
-    float2 win[NJ];
-    read_strided<NJ, 128>(t_win + l, win);
+    float4 win4[(NJ + 1) / 2];
+    read_quads<(NJ + 1) / 2>(t_win + l * 18, win4);
     unsigned dkey_lo = 0, dkey_hi = 0;
     if (DITHER) {
       const unsigned long long k = (static_cast<unsigned long long>(g) + 1) * 0x9E3779B97F4A7C15ull ^ p.seed;
@@ -329,7 +340,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
         const float rot = dpp_row_ror<0x121>(ao);  // lane l <- lane (l - 1) mod 16 of its frame
         const float ap = l == 0 ? rot_prev : rot;
         rot_prev = rot;
-        const float2 w = win[j];  // zero outside the window
+        const float2 w = (j & 1) ? make_float2(win4[j >> 1].z, win4[j >> 1].w)
+                                 : make_float2(win4[j >> 1].x, win4[j >> 1].y);  // zero outside the window
         if (ENERGY == 1 && in) e_raw += ae * ae + ao * ao;
         const float ye = (ae - p.preemph * ap) * w.x;
         const float yo = (ao - p.preemph * ae) * w.y;
@@ -344,12 +356,14 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- B: pass 1 (FFT over j), inter-pass twiddle, transpose -------------------------------------
-    float2 tw[16];
-    read_strided<16, 128>(t_tw16 + l, tw);  // W256^(l k2), lands while the butterflies run
+    float4 tw4[8];
+    read_quads<8>(t_tw16 + l * 18, tw4);  // W256^(l k2), lands while the butterflies run
     fft16(z);
     lds_wait();
 #pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2) z[k2] = cmul(z[k2], tw[k2]);
+    for (int k2 = 1; k2 < 16; ++k2)
+      z[k2] = cmul(z[k2], (k2 & 1) ? make_float2(tw4[k2 >> 1].z, tw4[k2 >> 1].w)
+                                   : make_float2(tw4[k2 >> 1].x, tw4[k2 >> 1].y));
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) tile[k2 * kTileRow + l] = z[k2];
     wave_lds_sync();
@@ -366,16 +380,18 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     for (int r = 0; r < 8; ++r) tile[r * 16 + l] = z[r + 8];
     wave_lds_sync();
     const float2* __restrict__ partner = tile + (16 - l);  // Z[256 - k]: row 7-k1, column 16-l
-    float2 zpart[8], w512[8];
+    float2 zpart[8];
+    float4 w512q[4];
     read_strided_rev<8, 128>(partner, zpart);   // zpart[k1] = Z[256 - l - 16 k1]
-    read_strided<8, 128>(t_tw512 + l, w512);    // W512^(l + 16 k1)
+    read_quads<4>(t_tw512 + l * 10, w512q);     // W512^(l + 16 k1)
     lds_wait();
     float pk[8], pm[8];  // 4 P[k], 4 P[256-k] for k = l + 16 k1
 #pragma unroll
     for (int k1 = 0; k1 < 8; ++k1) {
       const float2 zk = z[k1];
       const float2 zp = zpart[k1];
-      const float2 w = w512[k1];
+      const float2 w = (k1 & 1) ? make_float2(w512q[k1 >> 1].z, w512q[k1 >> 1].w)
+                                : make_float2(w512q[k1 >> 1].x, w512q[k1 >> 1].y);
       const float c_re = zk.x + zp.x, c_im = zk.y - zp.y;
       const float d_re = zk.y + zp.y, d_im = zp.x - zk.x;
       const float t_re = d_re * w.x - d_im * w.y, t_im = d_re * w.y + d_im * w.x;
@@ -543,24 +559,27 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
   p.num_ceps = mp.num_ceps;
   p.rounds = (mp.num_bins + 15) / 16;
   blob->clear();
-  // window pairs
-  for (int n = 0; n < 256; ++n) {
-    blob->push_back(2 * n < mp.win_len ? window[2 * n] : 0.0f);
-    blob->push_back(2 * n + 1 < mp.win_len ? window[2 * n + 1] : 0.0f);
-  }
-  // inter-pass twiddles T[k2][n1] = exp(-2 pi i n1 k2 / 256)
-  for (int k2 = 0; k2 < 16; ++k2)
-    for (int n1 = 0; n1 < 16; ++n1) {
-      const double a = -kTwoPi * (n1 * k2) / 256.0;
+  // window pairs, lane-major: row l = elements l + 16 j (j < 16), 2 complex of padding
+  for (int l = 0; l < 16; ++l)
+    for (int j = 0; j < 18; ++j) {
+      const int n = l + 16 * j;
+      blob->push_back(j < 16 && 2 * n < mp.win_len ? window[2 * n] : 0.0f);
+      blob->push_back(j < 16 && 2 * n + 1 < mp.win_len ? window[2 * n + 1] : 0.0f);
+    }
+  // inter-pass twiddles, lane-major: row n1 = exp(-2 pi i n1 k2 / 256), k2 < 16
+  for (int n1 = 0; n1 < 16; ++n1)
+    for (int k2 = 0; k2 < 18; ++k2) {
+      const double a = -kTwoPi * (n1 * (k2 < 16 ? k2 : 0)) / 256.0;
       blob->push_back(static_cast<float>(std::cos(a)));
       blob->push_back(static_cast<float>(std::sin(a)));
     }
-  // unpack twiddles exp(-2 pi i k / 512), k < 128
-  for (int k = 0; k < 128; ++k) {
-    const double a = -kTwoPi * k / 512.0;
-    blob->push_back(static_cast<float>(std::cos(a)));
-    blob->push_back(static_cast<float>(std::sin(a)));
-  }
+  // unpack twiddles, lane-major: row l = exp(-2 pi i (l + 16 k1) / 512), k1 < 8
+  for (int l = 0; l < 16; ++l)
+    for (int k1 = 0; k1 < 10; ++k1) {
+      const double a = -kTwoPi * (l + 16 * (k1 < 8 ? k1 : 0)) / 512.0;
+      blob->push_back(static_cast<float>(std::cos(a)));
+      blob->push_back(static_cast<float>(std::sin(a)));
+    }
   // mel: lane l of round r owns bin l + 16 r; its taps are read in aligned groups of 4
   p.off_first = static_cast<int>(blob->size());
   std::vector<int> start(p.rounds * 16, 0);
