@@ -489,6 +489,8 @@ int run_pitch_device(snf_plan* plan, const int16_t* d_wave, const int64_t* sampl
   if ((rc = plan->s_stats.ensure(sizeof(double) * 4 * static_cast<size_t>(n_utts)))) return rc;
   if ((rc = plan->s_bp.ensure(sizeof(int16_t) * static_cast<size_t>(total_frames) * plan->pd.num_states))) return rc;
   if ((rc = plan->s_states.ensure(sizeof(int32_t) * static_cast<size_t>(total_frames)))) return rc;
+  if ((rc = plan->s_mel.ensure(sizeof(float) * static_cast<size_t>(total_frames) * plan->pd.num_lags)))
+    return rc;
   SNF_HIP_CHECK(hipStreamSynchronize(s));  // host vectors above go out of scope after launch setup
   PitchBatch b{};
   b.wave = d_wave;
@@ -501,7 +503,8 @@ int run_pitch_device(snf_plan* plan, const int16_t* d_wave, const int64_t* sampl
   b.total_frames = total_frames;
   b.total_down = total_down;
   return launch_pitch(plan->pd, b, plan->s_down.as<float>(), plan->s_stats.as<double>(),
-                      plan->s_bp.as<int16_t>(), plan->s_states.as<int32_t>(), d_out, s);
+                      plan->s_bp.as<int16_t>(), plan->s_states.as<int32_t>(), plan->s_mel.as<float>(),
+                      d_out, s);
 }
 
 }  // namespace

@@ -16,6 +16,8 @@
 // parallel axis (10 000+ per launch).
 #include <float.h>
 
+#include <cstdlib>
+
 #include "snf_internal.h"
 
 namespace snf {
@@ -415,8 +417,431 @@ __global__ __launch_bounds__(kTrackThreads) void pitch_track_kernel(
   }
 }
 
+
+// ---- 3b. wave-per-utterance tracker ---------------------------------------------------------------
+// The Viterbi recursion is sequential over the frames of one utterance but utterances are
+// independent, and one frame is only ~30 kflop: a 512-thread workgroup per utterance spends its time
+// in workgroup barriers (11 per frame).  Here ONE wavefront owns an utterance (no workgroup barrier in
+// the frame loop, 16 utterances in flight per CU); the arithmetic of every frame is the same as in
+// pitch_track_kernel above (same summation trees for the frame mean / energy, same Viterbi costs and
+// tie-breaks), only the lag correlation adds its four 25-sample partials in a quad tree.
+namespace {
+
+constexpr int kWaveTrackWaves = 8;   // utterances (= wavefronts) per workgroup
+constexpr int kWaveMaxTaps = 12;
+
+struct WaveShared {
+  float* win;    // [full_len]
+  float* nccf;   // [num_lags]
+  float* norm;   // [num_lags]
+  float* fwd;    // [num_states]
+  float* nxt;    // [num_states]
+  int* bpw;      // [num_states]   backpointers of the current frame
+};
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Cross-lane steps on the VALU (DPP + v_readlane); __shfl_xor lowers to ds_bpermute_b32, an LDS round
+// trip per step.  quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E; row_ror:4 = 0x124, row_ror:8 = 0x128
+// (rotations reach the other three quads of a 16-lane row).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf,
+                                                               0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float lane_f(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// sum over the wave: DPP all-reduce inside the 16-lane rows, then the four row values (read with
+// v_readlane) are combined uniformly, so every lane gets the same bits
+__device__ __forceinline__ float wave_sum_v(float v) {
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x124>(v);
+  v += dpp_f<0x128>(v);
+  return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+  v = fminf(v, dpp_f<0xB1>(v));
+  v = fminf(v, dpp_f<0x4E>(v));
+  v = fminf(v, dpp_f<0x124>(v));
+  v = fminf(v, dpp_f<0x128>(v));
+  return fminf(fminf(lane_f(v, 0), lane_f(v, 16)), fminf(lane_f(v, 32), lane_f(v, 48)));
+}
+// (cost, index) argmin step: lower cost wins, lower index on ties
+__device__ __forceinline__ void argmin_take(float& c, int& j, float oc, int oj) {
+  if (oc < c || (oc == c && oj < j)) { c = oc; j = oj; }
+}
+__device__ __forceinline__ void quad_argmin(float& c, int& j) {
+  argmin_take(c, j, dpp_f<0xB1>(c), dpp_i<0xB1>(j));
+  argmin_take(c, j, dpp_f<0x4E>(c), dpp_i<0x4E>(j));
+}
+__device__ __forceinline__ void wave_argmin(float& c, int& j) {
+  quad_argmin(c, j);
+  argmin_take(c, j, dpp_f<0x124>(c), dpp_i<0x124>(j));
+  argmin_take(c, j, dpp_f<0x128>(c), dpp_i<0x128>(j));
+  float bc = lane_f(c, 0);
+  int bj = __builtin_amdgcn_readlane(j, 0);
+  argmin_take(bc, bj, lane_f(c, 16), __builtin_amdgcn_readlane(j, 16));
+  argmin_take(bc, bj, lane_f(c, 32), __builtin_amdgcn_readlane(j, 32));
+  argmin_take(bc, bj, lane_f(c, 48), __builtin_amdgcn_readlane(j, 48));
+  c = bc;
+  j = bj;
+}
+
+// cost of reaching state i from state j: must round exactly like Kaldi's
+// (j - i)^2 * inter_frame_factor + prev_forward_cost[j] (no FMA contraction)
+__device__ __forceinline__ float trans_cost(int j, float fi, float factor, float fwd_j) {
+  const float d = static_cast<float>(j) - fi;
+  return __fadd_rn(__fmul_rn(d * d, factor), fwd_j);
+}
+
+// exact argmin over j in [lo, hi] (lowest index wins ties), 4 candidates in flight per step
+__device__ __forceinline__ void scan_range(const float* __restrict__ fwd, int lo, int hi, float fi,
+                                           float factor, float& best, int& best_j) {
+  best = trans_cost(lo, fi, factor, fwd[lo]);
+  best_j = lo;
+  for (int j = lo + 1; j <= hi; j += 4) {
+    const int j1 = j + 1 <= hi ? j + 1 : hi, j2 = j + 2 <= hi ? j + 2 : hi, j3 = j + 3 <= hi ? j + 3 : hi;
+    const float f0 = fwd[j], f1 = fwd[j1], f2 = fwd[j2], f3 = fwd[j3];
+    const float c0 = trans_cost(j, fi, factor, f0), c1 = trans_cost(j1, fi, factor, f1);
+    const float c2 = trans_cost(j2, fi, factor, f2), c3 = trans_cost(j3, fi, factor, f3);
+    // (clamped duplicates of `hi` can never win: strict comparison against an equal cost)
+    if (c0 < best) { best = c0; best_j = j; }
+    if (c1 < best) { best = c1; best_j = j1; }
+    if (c2 < best) { best = c2; best_j = j2; }
+    if (c3 < best) { best = c3; best_j = j3; }
+  }
+}
+
+constexpr int kLagGroup = 5;  // lags per work item of the correlation
+constexpr int kCorrChunks = 4;  // window quarters per lag group (the 4 lanes of a quad)
+constexpr int kLongRange = 24;  // candidate ranges at least this long are scanned by the whole wave
+
+__device__ void forward_pass_wave(const PitchDevTables& t, const float* __restrict__ x, int64_t nd,
+                                  int64_t T, int64_t T1, double ms1, double ms2, bool rescale,
+                                  float new_ballast, int16_t* __restrict__ bp,
+                                  float* __restrict__ pov_nccf, const WaveShared& sh,
+                                  const float* __restrict__ taps, const int* __restrict__ st_first,
+                                  const float* __restrict__ st_lag, const int lane) {
+  const int S = t.num_states, L = t.num_lags, W = t.win_size;
+  for (int s = lane; s < S; s += 64) sh.fwd[s] = 0.0f;
+  for (int i = lane; i < 8; i += 64) sh.win[t.full_len + i] = 0.0f;  // read-ahead padding
+  for (int i = lane; i < kWaveMaxTaps; i += 64) sh.nccf[L + i] = 0.0f;  // (taps are zero-padded)
+  const float ballast1 = static_cast<float>(pow(ms1 * W, 2.0) * static_cast<double>(t.nccf_ballast));
+  const float ballast2 = static_cast<float>(pow(ms2 * W, 2.0) * static_cast<double>(t.nccf_ballast));
+  const int chunk_len = (W + kCorrChunks - 1) / kCorrChunks;
+  const int groups = (L + kLagGroup - 1) / kLagGroup;
+  const int passes = (groups * kCorrChunks + 63) >> 6;
+  const float factor = t.inter_frame_factor;
+  for (int64_t frame = 0; frame < T; ++frame) {
+    const double ms = frame < T1 ? ms1 : ms2;
+    const float ballast = frame < T1 ? ballast1 : ballast2;
+    // ---- frame window, mean removal, e1 ----------------------------------------------------------
+    int64_t start;
+    if (t.snip_edges) start = frame * t.win_shift;
+    else start = static_cast<int64_t>((static_cast<double>(frame) + 0.5) * t.win_shift) - t.full_len / 2;
+    wave_sync();
+    for (int i = lane; i < t.full_len; i += 64) {
+      const int64_t k = start + i;
+      sh.win[i] = (k >= 0 && k < nd) ? x[k] : 0.0f;
+    }
+    wave_sync();
+    float sm = 0.0f;
+    for (int i = lane; i < W; i += 64) sm += sh.win[i];
+    const float neg_mean = -wave_sum_v(sm) / static_cast<float>(W);
+    wave_sync();
+    for (int i = lane; i < t.full_len; i += 64) sh.win[i] += neg_mean;
+    wave_sync();
+    float e = 0.0f;
+    for (int i = lane; i < W; i += 64) e += sh.win[i] * sh.win[i];
+    const float e1 = wave_sum_v(e);
+    // ---- lag correlation.  Work item = (group of 5 consecutive lags, quarter of the window); the
+    // 5 x 5 (lag, sample) blocks reuse 9 window values from registers.  The four quarters of a group
+    // sit in the four lanes of a quad and are added as (q0 + q1) + (q2 + q3). ----------------------
+    for (int pass = 0; pass < passes; ++pass) {
+      const int item = (pass << 6) + lane;
+      const int g = item >> 2, c = item & 3;
+      const int l0 = g * kLagGroup;
+      float e2[kLagGroup], ip[kLagGroup];
+#pragma unroll
+      for (int d = 0; d < kLagGroup; ++d) e2[d] = ip[d] = 0.0f;
+      if (g < groups) {
+        const int i0 = c * chunk_len, i1 = i0 + chunk_len < W ? i0 + chunk_len : W;
+        const float* __restrict__ a = sh.win;
+        const float* __restrict__ cw = sh.win + t.first_lag + l0;
+        int i = i0;
+        for (; i + kLagGroup <= i1; i += kLagGroup) {
+          float av[kLagGroup], cv[2 * kLagGroup - 1], sq[2 * kLagGroup - 1];
+#pragma unroll
+          for (int u = 0; u < kLagGroup; ++u) av[u] = a[i + u];
+#pragma unroll
+          for (int u = 0; u < 2 * kLagGroup - 1; ++u) cv[u] = cw[i + u];
+#pragma unroll
+          for (int u = 0; u < 2 * kLagGroup - 1; ++u) sq[u] = cv[u] * cv[u];
+#pragma unroll
+          for (int u = 0; u < kLagGroup; ++u)
+#pragma unroll
+            for (int d = 0; d < kLagGroup; ++d) {
+              e2[d] += sq[u + d];
+              ip[d] += av[u] * cv[u + d];
+            }
+        }
+        for (; i < i1; ++i) {  // window quarters that are not a multiple of 5 samples
+          const float ai = a[i];
+#pragma unroll
+          for (int d = 0; d < kLagGroup; ++d) {
+            const float vc = cw[i + d];
+            e2[d] += vc * vc;
+            ip[d] += ai * vc;
+          }
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < kLagGroup; ++d) {
+        e2[d] += dpp_f<0xB1>(e2[d]);
+        ip[d] += dpp_f<0xB1>(ip[d]);
+        e2[d] += dpp_f<0x4E>(e2[d]);
+        ip[d] += dpp_f<0x4E>(ip[d]);
+      }
+      // every lane of the quad holds the totals: lane c finishes lag l0 + c (lane 0 also l0 + 4)
+#pragma unroll
+      for (int d = 0; d < kLagGroup; ++d) {
+        const int l = l0 + d;
+        if (g < groups && l < L && (d & 3) == c) {
+          const float norm = e1 * e2[d];
+          const float den = static_cast<float>(sqrt(static_cast<double>(norm + ballast)));
+          sh.nccf[l] = den != 0.0f ? ip[d] / den : 0.0f;
+          sh.norm[l] = norm;
+          if (!rescale) {
+            // the POV feature uses the NCCF without ballast; only the lags around the state chosen by
+            // the traceback will be read back
+            const float den0 = static_cast<float>(sqrt(static_cast<double>(norm + 0.0f)));
+            pov_nccf[frame * L + l] = den0 != 0.0f ? ip[d] / den0 : 0.0f;
+          }
+        }
+      }
+    }
+    wave_sync();
+    float scale = 1.0f;
+    if (rescale) {
+      float sum = 0.0f;
+      for (int l = 0; l < L; ++l) sum += sh.norm[l];
+      const float avg_norm_prod = sum / static_cast<float>(L);
+      const float old_ms = static_cast<float>(ms);
+      const float old_ballast =
+          static_cast<float>(pow(static_cast<double>(old_ms) * W, 2.0) * static_cast<double>(t.nccf_ballast));
+      scale = powf((old_ballast + avg_norm_prod) / (new_ballast + avg_norm_prod), 0.5f);
+    }
+    // ---- local cost of every state (NCCF resampled at its lag) -> nxt ------------------------------
+#pragma unroll 2
+    for (int s = lane; s < S; s += 64) {
+      float v = 0.0f;
+      const float* __restrict__ src = sh.nccf + st_first[s];
+      const float4* __restrict__ wt = reinterpret_cast<const float4*>(taps + s * kWaveMaxTaps);
+#pragma unroll
+      for (int j = 0; j < kWaveMaxTaps / 4; ++j) {  // weights beyond the state's taps are zero
+        const float4 wq = wt[j];
+        v += src[4 * j] * wq.x;
+        v += src[4 * j + 1] * wq.y;
+        v += src[4 * j + 2] * wq.z;
+        v += src[4 * j + 3] * wq.w;
+      }
+      if (rescale) v *= scale;
+      float local = 1.0f - v;
+      local += t.soft_min_f0 * st_lag[s] * v;
+      sh.nxt[s] = local;
+    }
+    // ---- Viterbi step.  cost(i, j) = (j - i)^2 * factor + fwd[j]; its argmin is monotone in i
+    // (Kaldi's own search relies on it).  Level 1: exact argmin of the states 0, 32, 64, ... (4 lanes
+    // per state, strided scan, lowest index wins ties).  Then the strides 16, 8, 4, 2, 1: every new
+    // state scans only between the backpointers of its two already known neighbours. -----------------
+    {
+      const int rep = lane >> 2, sub = lane & 3;
+      const int i_rep = rep << 5;
+      float best = FLT_MAX;
+      int best_j = 0x7fffffff;
+      if (i_rep < S) {
+        const float fi = static_cast<float>(i_rep);
+        for (int j = sub; j < S; j += 32) {
+          int jj[8];
+          float ff[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) jj[u] = j + 4 * u < S ? j + 4 * u : j;  // duplicates never win
+#pragma unroll
+          for (int u = 0; u < 8; ++u) ff[u] = sh.fwd[jj[u]];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const float c = trans_cost(jj[u], fi, factor, ff[u]);
+            if (c < best) { best = c; best_j = jj[u]; }
+          }
+        }
+      }
+      quad_argmin(best, best_j);
+      wave_sync();  // local costs (nxt) written above are read below
+      if (sub == 0 && i_rep < S) {
+        sh.bpw[i_rep] = best_j;
+        sh.nxt[i_rep] = __fadd_rn(best, sh.nxt[i_rep]);
+      }
+    }
+    for (int h = 16; h >= 1; h >>= 1) {
+      wave_sync();
+      const int count = (S - h + 2 * h - 1) / (2 * h);  // states h, 3h, 5h, ... < S
+      for (int m0 = 0; m0 < count; m0 += 64) {
+        const int m = m0 + lane;
+        const bool active = m < count;
+        const int i = h + 2 * h * (active ? m : 0);
+        const int lo = sh.bpw[i - h];
+        const int hi = i + h < S ? sh.bpw[i + h] : S - 1;
+        const bool is_long = active && hi - lo >= kLongRange;
+        float best = FLT_MAX;
+        int best_j = lo;
+        if (active && !is_long) scan_range(sh.fwd, lo, hi, static_cast<float>(i), factor, best, best_j);
+        // a jump of the backpointer function makes ONE state of every level scan a long range: those
+        // are searched by the whole wave (64 candidates per step + an argmin reduction) instead
+        unsigned long long pending = __ballot(is_long);
+        while (pending) {
+          const int src_lane = __ffsll(static_cast<long long>(pending)) - 1;
+          pending &= pending - 1;
+          const int li = __builtin_amdgcn_readlane(i, src_lane),
+                    llo = __builtin_amdgcn_readlane(lo, src_lane),
+                    lhi = __builtin_amdgcn_readlane(hi, src_lane);
+          const float fi = static_cast<float>(li);
+          float cb = FLT_MAX;
+          int cj = 0x7fffffff;
+          for (int j = llo + lane; j <= lhi; j += 64) {
+            const float c = trans_cost(j, fi, factor, sh.fwd[j]);
+            if (c < cb) { cb = c; cj = j; }
+          }
+          wave_argmin(cb, cj);
+          if (lane == src_lane) { best = cb; best_j = cj; }
+        }
+        if (active) {
+          sh.bpw[i] = best_j;
+          sh.nxt[i] = __fadd_rn(best, sh.nxt[i]);
+        }
+      }
+    }
+    wave_sync();
+    float lane_min = FLT_MAX;
+    for (int s = lane; s < S; s += 64) {
+      lane_min = fminf(lane_min, sh.nxt[s]);
+      bp[frame * S + s] = static_cast<int16_t>(sh.bpw[s]);
+    }
+    const float m = wave_min_f(lane_min);
+    for (int s = lane; s < S; s += 64) sh.fwd[s] = sh.nxt[s] + (-m);
+    wave_sync();
+  }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kWaveTrackWaves * 64, 4) void pitch_track_wave_kernel(
+    const PitchDevTables t, const PitchBatch b, const float* __restrict__ down,
+    const double* __restrict__ stats, int16_t* __restrict__ backptr, int32_t* __restrict__ states,
+    float* __restrict__ pov_all, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int S = t.num_states, L = t.num_lags, W = t.win_size;
+  // resampler taps of every state, shared by the wavefronts of the workgroup
+  float* taps = reinterpret_cast<float*>(smem);
+  const int S4 = (S + 3) & ~3;
+  int* st_first = reinterpret_cast<int*>(taps + ((S * kWaveMaxTaps + 3) & ~3));
+  float* st_lag = reinterpret_cast<float*>(st_first + S4);
+  for (int i = threadIdx.x; i < S * kWaveMaxTaps; i += blockDim.x) {
+    const int s = i / kWaveMaxTaps, j = i - s * kWaveMaxTaps;
+    taps[i] = (j < t.ar_max_taps && j < t.ar_n[s]) ? t.ar_w[s * t.ar_max_taps + j] : 0.0f;
+  }
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    st_first[s] = t.ar_first[s];
+    st_lag[s] = t.lags[s];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t u = static_cast<int64_t>(blockIdx.x) * kWaveTrackWaves + wid;
+  if (u >= b.n_utts) return;
+  const int64_t f0 = b.frame_offsets[u], T = b.frame_offsets[u + 1] - f0;
+  if (T <= 0) return;
+  const int64_t T1 = b.frames_phase1[u];
+  const int64_t d0 = b.down_offsets[u], nd = b.down_offsets[u + 1] - d0, nd1 = b.down_phase1[u];
+  const float* __restrict__ x = down + d0;
+  const int per_wave = ((t.full_len + 8 + 3) & ~3) + ((L + kWaveMaxTaps + 3) & ~3) + ((L + 3) & ~3) +
+                       3 * ((S + 3) & ~3);
+  WaveShared sh;
+  sh.win = st_lag + S4 + wid * per_wave;
+  sh.nccf = sh.win + ((t.full_len + 8 + 3) & ~3);
+  sh.norm = sh.nccf + ((L + kWaveMaxTaps + 3) & ~3);
+  sh.fwd = sh.norm + ((L + 3) & ~3);
+  sh.nxt = sh.fwd + ((S + 3) & ~3);
+  sh.bpw = reinterpret_cast<int*>(sh.nxt + ((S + 3) & ~3));
+  int16_t* __restrict__ bp = backptr + f0 * S;
+  float* __restrict__ pov_nccf = pov_all + f0 * L;
+
+  const double sq1 = stats[u * 4 + 0], s1 = stats[u * 4 + 1], sq2 = stats[u * 4 + 2],
+               s2 = stats[u * 4 + 3];
+  const double n1 = static_cast<double>(nd1), n2 = static_cast<double>(nd);
+  const double ms1 = nd1 > 0 ? sq1 / n1 - pow(s1 / n1, 2.0) : 0.0;
+  const double ms2 = sq2 / n2 - pow(s2 / n2, 2.0);
+
+  forward_pass_wave(t, x, nd, T, T1, ms1, ms2, false, 0.0f, bp, pov_nccf, sh, taps, st_first, st_lag, lane);
+
+  if (T < t.recompute_frame && T1 > 0) {
+    const double mean = s2 / n2;
+    const float ms_final = static_cast<float>(sq2 / n2 - mean * mean);
+    const float a = static_cast<float>(ms1);
+    const bool approx_equal = (a == ms_final) || (fabsf(a - ms_final) <= 0.01f * (fabsf(a) + fabsf(ms_final)));
+    if (!approx_equal) {
+      const float new_ballast =
+          static_cast<float>(pow(static_cast<double>(ms_final) * W, 2.0) * static_cast<double>(t.nccf_ballast));
+      wave_sync();
+      forward_pass_wave(t, x, nd, T, T1, ms1, ms2, true, new_ballast, bp, pov_nccf, sh, taps, st_first,
+                        st_lag, lane);
+    }
+  }
+
+  // traceback: best final state (lowest index wins ties), then the chain of backpointers
+  wave_sync();
+  __threadfence_block();
+  {
+    float bv = FLT_MAX;
+    int best = 0x7fffffff;
+    for (int s = lane; s < S; s += 64) {
+      const float c = sh.fwd[s];
+      if (c < bv) { bv = c; best = s; }
+    }
+    wave_argmin(bv, best);
+    if (lane == 0) {
+      for (int64_t frame = T - 1; frame >= 0; --frame) {
+        states[f0 + frame] = best;
+        best = bp[frame * S + best];
+      }
+    }
+  }
+  wave_sync();
+  __threadfence_block();
+
+  // output rows: (POV NCCF resampled at the chosen lag, 1 / lag)
+  for (int64_t frame = lane; frame < T; frame += 64) {
+    const int s = states[f0 + frame];
+    const float* __restrict__ wt = t.ar_w + s * t.ar_max_taps;
+    const float* __restrict__ src = pov_nccf + frame * L + t.ar_first[s];
+    const int n = t.ar_n[s];
+    float pov = 0.0f;
+    for (int j = 0; j < n; ++j) pov += src[j] * wt[j];
+    out[(f0 + frame) * 2 + 0] = pov;
+    out[(f0 + frame) * 2 + 1] = 1.0f / t.lags[s];
+  }
+}
+
 int launch_pitch(const PitchDevTables& t, const PitchBatch& b, float* down, double* stats,
-                 int16_t* backptr, int32_t* states, float* out, hipStream_t stream) {
+                 int16_t* backptr, int32_t* states, float* pov_nccf, float* out, hipStream_t stream) {
   if (b.total_frames <= 0) return SNF_OK;
   if (t.num_states > 32767) return set_error(SNF_E_RUNTIME, "too many pitch states (delta_pitch too small)");
   if (b.total_down > 0) {
@@ -429,6 +854,26 @@ int launch_pitch(const PitchDevTables& t, const PitchBatch& b, float* down, doub
   hipLaunchKernelGGL(pitch_stats_kernel, dim3(static_cast<unsigned>(b.n_utts)), dim3(256), 0, stream,
                      b, down, stats);
   SNF_HIP_CHECK(hipGetLastError());
+  const bool wave_path = t.num_states <= 512 && t.ar_max_taps <= kWaveMaxTaps &&
+                         !getenv("SNF_PITCH_BLOCK_KERNEL");
+  if (wave_path) {
+    const int per_wave = ((t.full_len + 8 + 3) & ~3) + ((t.num_lags + kWaveMaxTaps + 3) & ~3) +
+                         ((t.num_lags + 3) & ~3) + 3 * ((t.num_states + 3) & ~3);
+    const size_t lds_w = sizeof(float) * (((t.num_states * kWaveMaxTaps + 3) & ~3) +
+                                          2 * ((t.num_states + 3) & ~3) +
+                                          static_cast<size_t>(kWaveTrackWaves) * per_wave);
+    if (lds_w <= 80 * 1024) {
+      if (lds_w > 64 * 1024)
+        SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pitch_track_wave_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          static_cast<int>(lds_w)));
+      const unsigned blocks = static_cast<unsigned>((b.n_utts + kWaveTrackWaves - 1) / kWaveTrackWaves);
+      hipLaunchKernelGGL(pitch_track_wave_kernel, dim3(blocks), dim3(kWaveTrackWaves * 64), lds_w, stream,
+                         t, b, down, stats, backptr, states, pov_nccf, out);
+      SNF_HIP_CHECK(hipGetLastError());
+      return SNF_OK;
+    }
+  }
   const int chunks = kTrackThreads / t.num_lags > 0 ? kTrackThreads / t.num_lags : 1;
   const size_t lds = sizeof(float) * (((t.full_len + 3) & ~3) + 2 * ((t.num_lags + 3) & ~3) +
                                       2 * ((t.num_states + 3) & ~3) + 16 + 2 * chunks * t.num_lags +

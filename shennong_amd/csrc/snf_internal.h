@@ -198,9 +198,10 @@ struct PitchBatch {
   int64_t n_utts, total_frames, total_down;
 };
 // resample -> signal statistics -> fused NCCF + Viterbi per utterance -> traceback + POV output.
-// `backptr` is [total_frames, num_states] int16, `states` [total_frames] int32 scratch.
+// `backptr` is [total_frames, num_states] int16, `states` [total_frames] int32, `pov_nccf`
+// [total_frames, num_lags] float scratch.
 int launch_pitch(const PitchDevTables& t, const PitchBatch& b, float* down, double* stats,
-                 int16_t* backptr, int32_t* states, float* out, hipStream_t stream);
+                 int16_t* backptr, int32_t* states, float* pov_nccf, float* out, hipStream_t stream);
 
 int launch_vad(const snf_vad_options& o, const float* in, int in_cols, const int64_t* frame_offsets,
                int64_t n_utts, int64_t total_frames, float* thr_scratch, float* out,
