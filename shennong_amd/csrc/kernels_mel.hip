@@ -31,10 +31,23 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// sum over the 64 lanes, same bits in every lane.  __shfl_xor lowers to ds_bpermute_b32 (an LDS round
+// trip per step); DPP keeps the reduction on the VALU: quad_perm [1,0,3,2] / [2,3,0,1], row_ror:4 / :8
+// inside the 16-lane rows, then the four row sums are read with v_readlane and added uniformly.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf,
+                                                               0xf, false));
+}
+__device__ __forceinline__ float lane_f(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x124>(v);
+  v += dpp_f<0x128>(v);
+  return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
 }
 
 // largest u with offsets[u] <= g (offsets[n] > g): the utterance that owns global row g
