@@ -6,6 +6,7 @@ nsamples / dtype``, ``astype`` (int16 <-> float scaling by 2**15, audio.py:469-5
 resampling and sox scanning, which are file-format plumbing and out of scope here).
 """
 
+import collections
 import warnings
 
 import numpy as np
@@ -69,6 +70,25 @@ class Audio:
         except Exception as err:  # noqa
             raise ValueError(f'{filename}: cannot read file: {err}') from None
         return cls(data, sample_rate, validate=False)
+
+    _metadata = collections.namedtuple(
+        '_metadata', 'nchannels sample_rate nsamples duration')
+
+    @classmethod
+    def scan(cls, filename):
+        """Returns (nchannels, sample_rate, nsamples, duration) without decoding the samples
+        (reference audio.py:179-240 asks sox; wav headers are read with scipy here).  An
+        in-memory :class:`Audio` is accepted too (benchmark / tests)."""
+        if isinstance(filename, Audio):
+            return cls._metadata(filename.nchannels, filename.sample_rate,
+                                 filename.nsamples, filename.duration)
+        try:
+            sample_rate, data = scipy.io.wavfile.read(filename, mmap=True)
+        except Exception as err:  # noqa
+            raise ValueError(f'{filename}: cannot read file: {err}') from None
+        nchannels = 1 if data.ndim == 1 else data.shape[1]
+        return cls._metadata(nchannels, sample_rate, data.shape[0],
+                             data.shape[0] / sample_rate)
 
     @staticmethod
     def _is_valid_dtype(dtype):

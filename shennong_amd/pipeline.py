@@ -1,0 +1,451 @@
+"""High-level features extraction pipeline
+
+Same entry points, configuration dictionary, checks and result layout as the reference's
+``shennong/pipeline.py`` (``get_default_config``:97-210, ``extract_features``:213-280, the two-pass
+ordering of ``_extract_features``:525-567 and ``_extract_pass_one/_two``:570-643, the processor
+wiring of ``pipeline_manager.py``:247-313), but every stage runs as ONE batched launch over all the
+utterances instead of a per-utterance thread pool:
+
+    features (+ VTLN warps) -> [energy -> VAD -> CMVN statistics per speaker / utterance]
+    -> [pitch -> pitch post-processing] -> CMVN apply -> delta -> pitch concatenation (tolerance 2)
+
+Not provided by this backend (out of scope): VTLN *training* (`with_vtln`, the 'vtln'
+configuration entry; precomputed `warps` are supported), CREPE pitch, bottleneck features.
+"""
+
+import os
+
+import numpy as np
+import yaml
+
+from shennong_amd import _abi, _backend
+from shennong_amd.features import Features, FeaturesCollection
+from shennong_amd.logger import get_logger
+from shennong_amd.postprocessor.cmvn import (
+    CmvnPostProcessor, _fake_stats_for_dims)  # noqa: F401
+from shennong_amd.utils import get_njobs
+
+
+_PROCESSORS = {
+    'energy': ('processor', 'EnergyProcessor'),
+    'filterbank': ('processor', 'FilterbankProcessor'),
+    'mfcc': ('processor', 'MfccProcessor'),
+    'kaldi_pitch': ('processor', 'KaldiPitchProcessor'),
+    'kaldi_pitch_post': ('processor', 'KaldiPitchPostProcessor'),
+    'plp': ('processor', 'PlpProcessor'),
+    'spectrogram': ('processor', 'SpectrogramProcessor'),
+    'cmvn': ('postprocessor', 'CmvnPostProcessor'),
+    'delta': ('postprocessor', 'DeltaPostProcessor'),
+    'sliding_window_cmvn': ('postprocessor', 'SlidingWindowCmvnPostProcessor'),
+    'vad': ('postprocessor', 'VadPostProcessor')}
+
+
+def valid_features():
+    """The main features the pipeline can extract (post-processing excluded)"""
+    return ['spectrogram', 'filterbank', 'mfcc', 'plp']
+
+
+def _processor_class(name):
+    try:
+        module, cls = _PROCESSORS[name]
+    except KeyError:
+        raise ValueError('invalid processor "{}"'.format(name)) from None
+    import importlib
+    return getattr(importlib.import_module(f'shennong_amd.{module}'), cls)
+
+
+def _processor_params(name):
+    return _processor_class(name)().get_params()
+
+
+def get_default_config(features, to_yaml=False, yaml_commented=True,
+                       with_pitch=False, with_cmvn=False, with_delta=False,
+                       with_vtln=False):
+    """Returns the default configuration for the specified pipeline
+
+    Same dictionary layout as the reference (one entry per processor, parameters with their default
+    values, `sample_rate` and `htk_compat` filtered out of the features entry, frame parameters
+    filtered out of the pitch entry).
+
+    Raises
+    ------
+    ValueError
+        If `features` is not in :func:`valid_features`, or if `with_pitch` / `with_vtln` ask for
+        something this backend does not provide ('crepe', VTLN training).
+    """
+    if features not in valid_features():
+        raise ValueError('invalid features "{}", must be in {}'.format(
+            features, ', '.join(valid_features())))
+    if with_pitch not in (False, 'kaldi', 'crepe'):
+        raise ValueError(
+            f'with_pitch argument must be False, "kaldi" or "crepe" '
+            f'but is "{with_pitch}"')
+    if with_pitch == 'crepe':
+        raise ValueError('crepe pitch is not available in this backend')
+    if with_vtln not in (False, 'simple', 'full'):
+        raise ValueError(
+            f'with_vtln argument must be False, "simple" or "full" '
+            f'but is "{with_vtln}"')
+    if with_vtln:
+        raise ValueError(
+            'VTLN training is not available in this backend '
+            '(precomputed warps can be given to extract_features)')
+
+    config = {}
+    config[features] = {
+        k: v for k, v in _processor_params(features).items()
+        if k not in ('sample_rate', 'htk_compat')}
+
+    if with_pitch:
+        config['pitch'] = {'processor': with_pitch}
+        for key, value in _processor_params('kaldi_pitch').items():
+            if key not in ('frame_length', 'frame_shift', 'sample_rate'):
+                config['pitch'][key] = value
+        config['pitch']['postprocessing'] = _processor_params('kaldi_pitch_post')
+
+    if with_cmvn:
+        config['cmvn'] = {'by_speaker': True, 'with_vad': True}
+        config['cmvn']['vad'] = _processor_params('vad')
+
+    if with_delta:
+        config['delta'] = _processor_params('delta')
+
+    if to_yaml:
+        return _get_config_to_yaml(config, comments=yaml_commented)
+    return config
+
+
+def _get_config_to_yaml(config, comments=True):
+    """Dict -> YAML string; with `comments` the parameters docstrings are interleaved as in the
+    reference (pipeline.py:315-416)"""
+    import re
+    import textwrap
+
+    class _Dumper(yaml.SafeDumper):
+        pass
+    _Dumper.add_representer(
+        dict, lambda self, data: self.represent_dict(data.items()))
+    _Dumper.add_representer(
+        np.float32, lambda self, data: self.represent_float(float(data)))
+    _Dumper.add_representer(
+        np.float64, lambda self, data: self.represent_float(float(data)))
+    text = yaml.dump(config, Dumper=_Dumper).strip()
+    if not comments:
+        return text + '\n'
+
+    def docstring(processor, param, default):
+        doc = getattr(_processor_class(processor), param).__doc__ or ''
+        doc = re.sub(r'\n\n', '. ', doc)
+        doc = re.sub(r'\n', ' ', doc)
+        doc = re.sub(r'`', '', doc)
+        doc = re.sub(':func:', '', doc)
+        doc += '. Default is {}.'.format(default)
+        doc = re.sub(r'\.+', '.', doc)
+        doc = re.sub(r' +', ' ', doc)
+        doc = re.sub(r'\. \.', '.', doc)
+        return doc.strip()
+
+    out, processors, prev_offset = [], [], 0
+    for line in text.split('\n'):
+        head = line.split(': ')[0]
+        offset = len(head) - len(head.strip())
+        for _ in range((prev_offset - offset) // 2):
+            processors.pop()
+        if line.endswith(':'):
+            processor = line[:-1].strip()
+            if processor == 'postprocessing':
+                processor = f'{processors[-1]}_post'
+            processors.append(processor)
+            if processor == 'vad':
+                out.append("  # The vad options are not used if 'with_vad' is false")
+            out.append(line)
+        else:
+            param = line.split(': ')[0].strip()
+            default = line.split(': ')[1].strip()
+            processor = processors[-1]
+            if processor == 'cmvn' and param == 'by_speaker':
+                doc = ('If false, do normalization by utterance, '
+                       'if true do normalization by speaker.')
+            elif processor == 'cmvn' and param == 'with_vad':
+                doc = ('If true do normalization only on frames where '
+                       'voice activity has been detected, if false do not '
+                       'consider voice activity for normalization.')
+            elif processor == 'pitch' and param == 'processor':
+                doc = 'Computing pitch using kaldi'
+            elif 'pitch' in processor:
+                doc = docstring('kaldi_' + processor, param, default)
+            else:
+                doc = docstring(processor, param, default)
+            out += [' ' * offset + '# ' + w
+                    for w in textwrap.wrap(doc, width=68 - offset)]
+            out.append(line)
+        prev_offset = offset
+    return '\n'.join(out) + '\n'
+
+
+def _init_config(config, log=get_logger('pipeline', 'warning')):
+    """Loads (dict, YAML string or YAML file) and validates a configuration; same checks and
+    messages as reference pipeline.py:419-493"""
+    try:
+        if os.path.isfile(config):
+            log.debug('loading configuration from %s', config)
+            config = open(config, 'r').read()
+    except TypeError:
+        pass
+    if isinstance(config, str):
+        try:
+            config = yaml.load(config, Loader=yaml.FullLoader)
+        except yaml.YAMLError as err:
+            raise ValueError(f'error in configuration: {err}') from None
+
+    known = valid_features() + ['cmvn', 'delta', 'pitch', 'vtln', 'bottleneck']
+    unknown_keys = [k for k in config.keys() if k not in known]
+    if unknown_keys:
+        raise ValueError(
+            'invalid keys in configuration: {}'.format(', '.join(unknown_keys)))
+    if 'bottleneck' in config:
+        raise ValueError('bottleneck features are not available in this backend')
+
+    features = [k for k in config.keys() if k in valid_features()]
+    if not features:
+        raise ValueError(
+            'the configuration does not define any features extraction '
+            '(must have one and only one entry of {})'
+            .format(', '.join(valid_features())))
+    if len(features) > 1:
+        raise ValueError(
+            'more than one features extraction processors are defined, '
+            '(must have one and only one entry of {}): {}'
+            .format(', '.join(valid_features()), ', '.join(features)))
+
+    if 'vtln' in config:
+        if features[0] == 'spectrogram':
+            raise ValueError(f'{features[0]} features do not support VTLN')
+        raise ValueError(
+            'VTLN training is not available in this backend '
+            '(give precomputed warps to extract_features instead)')
+
+    if 'cmvn' in config:
+        if 'by_speaker' not in config['cmvn']:
+            log.warning(
+                'by_speaker option not specified for cmvn, '
+                'assuming it is false and doing cmvn by utterance')
+            config['cmvn']['by_speaker'] = False
+        if 'with_vad' not in config['cmvn']:
+            config['cmvn']['with_vad'] = True
+
+    if 'pitch' in config:
+        if config['pitch'].get('processor', 'kaldi') != 'kaldi':
+            raise ValueError('only the kaldi pitch processor is available in this backend')
+        if 'postprocessing' not in config['pitch']:
+            config['pitch']['postprocessing'] = {}
+
+    msg = []
+    if 'pitch' in config:
+        msg.append('kaldi pitch')
+    if 'delta' in config:
+        msg.append('delta')
+    if 'cmvn' in config:
+        msg.append('cmvn by {}{}'.format(
+            'speaker' if config['cmvn']['by_speaker'] else 'utterance',
+            ' with vad' if config['cmvn']['with_vad'] else ''))
+    log.info(
+        'pipeline configured for %s features extraction%s',
+        features[0], ' with {}'.format(', '.join(msg)) if msg else '')
+    return config
+
+
+def _init_warps(warps, config, utterances, log):
+    """Per-utterance float warps from warps given by utterance or by speaker
+    (reference pipeline.py:496-522)"""
+    features = [k for k in config.keys() if k in valid_features()][0]
+    if features == 'spectrogram':
+        raise ValueError(f'{features} features do not support VTLN')
+    if 'vtln' in config:  # pragma: nocover (rejected by _init_config)
+        raise ValueError(
+            'warps are given but "vtln" processor already defined '
+            'in the configuration')
+    if warps.keys() == utterances.by_name().keys():
+        log.info('VTLN warps are defined by utterance')
+    elif not utterances.has_speakers() or \
+            warps.keys() != utterances.by_speaker().keys():
+        raise ValueError(
+            'warps do not match utterances, either by speaker or by utterance')
+    else:
+        log.info('VTLN warps are defined by speaker')
+        warps = {utt.name: warps[utt.speaker] for utt in utterances}
+    return {name: float(warp) for name, warp in warps.items()}
+
+
+def extract_features(configuration, utterances, warps=None, njobs=1,
+                     log=get_logger('pipeline', 'warning')):
+    """Speech features extraction pipeline
+
+    Parameters
+    ----------
+    configuration : dict or str
+        The pipeline configuration: a dictionary, a path to a YAML file or a YAML string
+        (see :func:`get_default_config`).
+    utterances : :class:`~shennong_amd.utterances.Utterances`
+        The utterances to extract the features on.
+    warps : dict, optional
+        Precomputed VTLN warps (str: float) indexed by utterance name or by speaker.
+    njobs : int, optional
+        Validated like the reference; the work itself is batched on the GPU.
+
+    Returns
+    -------
+    features : FeaturesCollection, one :class:`Features` per utterance, keyed by name
+
+    Raises
+    ------
+    ValueError
+        If the configuration, the utterances or the warps are invalid.
+    """
+    get_njobs(njobs, log=log)
+    config = _init_config(configuration, log=log)
+    log.info('detected format for utterances index is: %s',
+             utterances.format(type=str))
+    if warps:
+        warps = _init_warps(warps, config, utterances, log)
+    return _extract_features(config, utterances, warps, log)
+
+
+def _extract_features(config, utterances, warps, log, tolerance=2):
+    features_name = [k for k in config.keys() if k in valid_features()][0]
+    with_cmvn = 'cmvn' in config
+    if with_cmvn and config['cmvn']['by_speaker'] and not utterances.has_speakers():
+        raise ValueError(
+            'cmvn normalization by speaker requested '
+            'but no speaker information provided')
+
+    utts = list(utterances)
+    metadata = {}
+    for utt in utts:
+        key = id(utt.audio_file) if not isinstance(utt.audio_file, str) else utt.audio_file
+        if key not in metadata:
+            from shennong_amd.audio import Audio
+            metadata[key] = Audio.scan(utt.audio_file)
+    meta_of = [metadata[id(u.audio_file) if not isinstance(u.audio_file, str) else u.audio_file]
+               for u in utts]
+    speakers = ('' if not utterances.has_speakers() else ' from {} speakers'.format(
+        len(set(u.speaker for u in utts))))
+    import datetime
+    log.info('get %s utterances%s in %s audio files, total duration: %s',
+             len(utts), speakers, len(metadata),
+             datetime.timedelta(seconds=utterances.duration()))
+    if not all(m.nchannels == 1 for m in meta_of):
+        raise ValueError('all audio files are not mono')
+    samplerates = sorted(set(m.sample_rate for m in meta_of))
+    if len(samplerates) > 1:
+        log.warning(
+            'several sample rates found in audio files: %s, features '
+            'extraction pipeline will work but this may not be a good '
+            'idea to work on heterogeneous data',
+            ', '.join(str(s) + 'Hz' for s in samplerates))
+
+    # ---- pass one: features, (energy -> VAD), pitch; one batched launch per stage and sample rate ----
+    n = len(utts)
+    audios = [u.load_audio() for u in utts]
+    feats = [None] * n
+    weights = [None] * n
+    pitch = [None] * n
+    frame_length = frame_shift = None
+    for rate in samplerates:
+        idx = [i for i in range(n) if meta_of[i].sample_rate == rate]
+        group = [audios[i] for i in idx]
+        proc = _processor_class(features_name)(**config[features_name])
+        proc.sample_rate = rate
+        if frame_length is None:
+            frame_length, frame_shift = proc.frame_length, proc.frame_shift
+        log.debug('extract %s on %d utterances at %d Hz', features_name, len(idx), rate)
+        if warps:
+            out = proc._process_batch(group, vtln_warp=[warps[utts[i].name] for i in idx])
+        else:
+            out = proc._process_batch(group)
+        for i, f in zip(idx, out):
+            feats[i] = f
+
+        if with_cmvn and config['cmvn']['with_vad']:
+            energy = _processor_class('energy')()
+            energy.frame_length = frame_length
+            energy.frame_shift = frame_shift
+            energy.sample_rate = rate
+            vad = _processor_class('vad')(**config['cmvn']['vad'])
+            decisions = vad._process_batch(energy._process_batch(group))
+            for i, v in zip(idx, decisions):
+                weights[i] = v.data.reshape((v.shape[0], ))
+
+        if 'pitch' in config:
+            params = {k: v for k, v in config['pitch'].items()
+                      if k not in ('processor', 'postprocessing')}
+            params['sample_rate'] = rate
+            params['frame_shift'] = frame_shift
+            params['frame_length'] = frame_length
+            raw = _processor_class('kaldi_pitch')(**params)._process_batch(group)
+            post = _processor_class('kaldi_pitch_post')(
+                **config['pitch']['postprocessing'])._process_batch(raw)
+            for i, p in zip(idx, post):
+                pitch[i] = p
+
+    for i, utt in enumerate(utts):
+        props = feats[i].properties
+        if utt.speaker:
+            props['speaker'] = utt.speaker
+        props['audio'] = {
+            'file': (os.path.abspath(utt.audio_file)
+                     if isinstance(utt.audio_file, str) else None),
+            'sample_rate': meta_of[i].sample_rate}
+        if utt.tstart is not None:
+            props['audio']['tstart'] = utt.tstart
+            props['audio']['tstop'] = utt.tstop
+        props['audio']['duration'] = utt.duration
+
+    # ---- CMVN: statistics of every utterance in one launch, summed per speaker (or kept per
+    # utterance) in utterance order; one apply launch ------------------------------------------------
+    if with_cmvn:
+        dims = set(f.ndims for f in feats)
+        if len(dims) != 1:  # pragma: nocover (one processor, one dimension)
+            raise ValueError('features have inconsistent dimensions')
+        dim = dims.pop()
+        if config['cmvn']['by_speaker']:
+            names = list(dict.fromkeys(u.speaker for u in utts))
+            groups = np.asarray([names.index(u.speaker) for u in utts], dtype=np.int32)
+        else:
+            names = [u.name for u in utts]
+            groups = np.arange(n, dtype=np.int32)
+        for i, f in enumerate(feats):
+            if weights[i] is not None and weights[i].shape[0] != f.nframes:
+                raise ValueError(
+                    'there is {} weights but {} feature frames, must be equal'
+                    .format(weights[i].shape[0], f.nframes))
+        plan = _backend.get_plan(_abi.default_options(_abi.KIND_CMVN))
+        mats = [np.asarray(f.data, dtype=np.float32) for f in feats]
+        stats = np.zeros((len(names), 2, dim + 1), dtype=np.float64)
+        use_weights = config['cmvn']['with_vad']
+        plan.cmvn_accumulate(
+            mats, stats, groups=groups,
+            weights=[w.astype(np.float32) for w in weights] if use_weights else None)
+        for g in range(len(names)):
+            if stats[g, 0, -1] < 1.0:
+                raise ValueError(
+                    'insufficient accumulation of stats for CMVN, '
+                    'must be >= 1.0 but is {}'.format(stats[g, 0, -1]))
+        datas = plan.cmvn_apply(mats, stats, groups=groups, norm_vars=True)
+        for i, f in enumerate(feats):
+            cmvn = CmvnPostProcessor(dim, stats=stats[groups[i]])
+            feats[i] = Features(datas[i], f.times, properties=cmvn.get_properties(f))
+
+    # ---- delta: one launch; pitch concatenation on the host ------------------------------------------
+    if 'delta' in config:
+        feats = _processor_class('delta')(**config['delta'])._process_batch(feats)
+
+    out = FeaturesCollection()
+    for i, utt in enumerate(utts):
+        f = feats[i]
+        if pitch[i] is not None:
+            # the number of frames can differ by a few because of the downsampling in the pitch
+            # tracker (same tolerance as Kaldi's paste-feats)
+            f = f.concatenate(pitch[i], tolerance=tolerance, log=log)
+        out[utt.name] = f
+    return out

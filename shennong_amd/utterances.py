@@ -1,12 +1,21 @@
-"""Minimal utterances index: ``<id> <audio> [<speaker>] [<tstart> <tstop>]``
+"""Utterances index: ``<id> <audio> [<speaker>] [<tstart> <tstop>]``
 
-Enough of reference shennong/utterances.py:37-260 to drive ``process_all``; `audio` may be a wav
-path or an in-memory :class:`Audio` (the benchmark feeds arrays directly).
+Mirror of reference shennong/utterances.py:37-346 (formats, validation, duration bookkeeping,
+grouping by speaker); `audio` may be a wav path or an in-memory :class:`Audio` (the benchmark feeds
+arrays directly).  File-based load/save of the index and `fit_to_duration` are not needed by the
+feature-extraction path and are not provided.
 """
 
 import collections
+import warnings
 
 from shennong_amd.audio import Audio
+
+VALID_FORMATS = {
+    1: '<utterance-id> <audio-file>',
+    2: '<utterance-id> <audio-file> <speaker-id>',
+    3: '<utterance-id> <audio-file> <tstart> <tstop>',
+    4: '<utterance-id> <audio-file> <speaker-id> <tstart> <tstop>'}
 
 
 class Utterance:
@@ -19,15 +28,47 @@ class Utterance:
         if len(args) == 3:
             self._speaker = args[2]
         elif len(args) == 4:
-            self._tstart, self._tstop = float(args[2]), float(args[3])
+            self._tstart, self._tstop = args[2], args[3]
         elif len(args) == 5:
             self._speaker = args[2]
-            self._tstart, self._tstop = float(args[3]), float(args[4])
+            self._tstart, self._tstop = args[3], args[4]
+
+        if self._tstart is not None:
+            try:
+                self._tstart = float(self._tstart)
+            except ValueError:
+                raise ValueError(
+                    f'cannot cast tstart as float: {self._tstart}') from None
+        if self._tstop is not None:
+            try:
+                self._tstop = float(self._tstop)
+            except ValueError:
+                raise ValueError(
+                    f'cannot cast tstop as float: {self._tstop}') from None
+        if (self._tstart is None) != (self._tstop is None):
+            raise ValueError('both tstart and tstop must be defined or None')
         if self._tstart is not None and (
                 self._tstart < 0 or self._tstart >= self._tstop):
             raise ValueError(
                 'we must have 0 <= tstart < tstop, but '
                 f'(tstart, tstop)=({self._tstart}, {self._tstop})')
+
+        # utterance duration; scanning raises if the file is not found nor valid
+        self._duration = Audio.scan(self._audio).duration
+        if self._tstart is not None:
+            if self._tstop > self._duration:
+                warnings.warn(
+                    f'{self._audio}: file duration is {self._duration} but '
+                    f'asking interval ({self._tstart}, {self._tstop}), '
+                    f'will be truncated')
+                self._tstop = self._duration
+            self._duration = self._tstop - self._tstart
+
+    def __eq__(self, other):
+        return str(self) == str(other)
+
+    def __hash__(self):
+        return hash(str(self))
 
     name = property(lambda self: self._name)
     audio_file = property(lambda self: self._audio)
@@ -35,6 +76,17 @@ class Utterance:
     tstart = property(lambda self: self._tstart)
     tstop = property(lambda self: self._tstop)
     format = property(lambda self: self._format)
+    duration = property(lambda self: self._duration)
+
+    def __str__(self):
+        if self._format == 1:
+            return f'{self.name} {self.audio_file}'
+        if self._format == 2:
+            return f'{self.name} {self.audio_file} {self.speaker}'
+        if self._format == 3:
+            return f'{self.name} {self.audio_file} {self.tstart} {self.tstop}'
+        return (f'{self.name} {self.audio_file} {self.speaker} '
+                f'{self.tstart} {self.tstop}')
 
     def load_audio(self):
         data = (self._audio if isinstance(self._audio, Audio)
@@ -64,6 +116,7 @@ class Utterances:
         if duplicates:
             raise ValueError(
                 f'duplicates found in utterances: {", ".join(duplicates)}')
+        self._format = parsed[0].format
         self._utterances = {u.name: u for u in parsed}
 
     def __len__(self):
@@ -75,5 +128,29 @@ class Utterances:
     def __getitem__(self, name):
         return self._utterances[name]
 
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+    def format(self, type=int):
+        """The utterances format: its code (`type` int) or its description (`type` str)"""
+        return VALID_FORMATS[self._format] if type is str else self._format
+
+    def has_speakers(self):
+        """True if there is speaker information"""
+        return self.format(type=int) in (2, 4)
+
+    def by_speaker(self):
+        """Dictionary speaker -> list of :class:`Utterance`"""
+        if not self.has_speakers():
+            raise ValueError('utterances have no speaker information')
+        by_speaker = collections.defaultdict(list)
+        for utt in self:
+            by_speaker[utt.speaker].append(utt)
+        return by_speaker
+
     def by_name(self):
-        return dict(self._utterances)
+        return self._utterances
+
+    def duration(self):
+        """Total duration of the utterances in seconds"""
+        return sum(utt.duration for utt in self)

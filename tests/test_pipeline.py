@@ -1,0 +1,316 @@
+"""Pipeline orchestration: the reference's test/test_pipeline.py re-expressed
+against shennong_amd.pipeline.  Configuration handling runs on CPU; extraction needs the GPU."""
+
+import os
+
+import numpy as np
+import pytest
+import yaml
+
+from conftest import GOLDEN
+from shennong_amd import Audio, Utterances, pipeline
+from shennong_amd.logger import get_logger
+
+WAV = os.path.join(GOLDEN, 'test.wav')
+WAV_8K = os.path.join(GOLDEN, 'test.8k.wav')
+
+
+@pytest.fixture(scope='module')
+def utterances():
+    return Utterances([('utt1', WAV, 'speaker1'), ('utt2', WAV, 'speaker2')])
+
+
+def equal_dict(d1, d2):
+    assert 'htk_compat' not in d1.keys()
+    assert 'sample_rate' not in d1.keys()
+    if not d1.keys() == d2.keys():
+        return False
+    for k, v in d1.items():
+        if isinstance(v, str):
+            if not v == d2[k]:
+                return False
+        elif isinstance(v, dict):
+            if not equal_dict(v, d2[k]):
+                return False
+        else:
+            if v != pytest.approx(d2[k]):
+                return False
+    return True
+
+
+@pytest.mark.parametrize('features, with_pitch', [
+    (f, p) for f in ('mfcc', 'plp', 'filterbank', 'spectrogram') for p in (False, 'kaldi')])
+def test_config_good(features, with_pitch):
+    """reference test_pipeline.py:48-70"""
+    c1 = pipeline.get_default_config(features, to_yaml=False, with_pitch=with_pitch,
+                                     with_cmvn=True, with_delta=True)
+    c2 = pipeline.get_default_config(features, to_yaml=True, yaml_commented=False,
+                                     with_pitch=with_pitch, with_cmvn=True, with_delta=True)
+    c3 = pipeline.get_default_config(features, to_yaml=True, yaml_commented=True,
+                                     with_pitch=with_pitch, with_cmvn=True, with_delta=True)
+    assert features in c1.keys()
+    assert '#' not in c2
+    assert '#' in c3
+    assert equal_dict(c1, yaml.load(c2, Loader=yaml.FullLoader))
+    assert equal_dict(c1, yaml.load(c3, Loader=yaml.FullLoader))
+
+
+def test_config_keys():
+    """reference pipeline.py:18-30 doctest"""
+    config = pipeline.get_default_config('mfcc', with_pitch='kaldi', with_cmvn=True, with_delta=True)
+    assert list(config.keys()) == ['mfcc', 'pitch', 'cmvn', 'delta']
+    assert list(pipeline.get_default_config('mfcc', with_pitch='kaldi').keys()) == ['mfcc', 'pitch']
+    assert config['cmvn'] == {'by_speaker': True, 'with_vad': True, 'vad': {
+        'energy_threshold': 5.0, 'energy_mean_scale': 0.5, 'frames_context': 0,
+        'proportion_threshold': pytest.approx(0.6)}}
+    assert config['delta'] == {'order': 2, 'window': 2}
+    assert config['pitch']['processor'] == 'kaldi'
+    assert 'frame_shift' not in config['pitch'] and 'sample_rate' not in config['pitch']
+    assert len(config['pitch']['postprocessing']) == 13
+    assert 'sample_rate' not in config['mfcc'] and 'htk_compat' not in config['mfcc']
+    assert pipeline.valid_features() == ['spectrogram', 'filterbank', 'mfcc', 'plp']
+
+
+@pytest.mark.parametrize('kind', ['dict', 'file', 'str'])
+def test_config_format(capsys, tmpdir, kind):
+    """reference test_pipeline.py:73-98"""
+    config = pipeline.get_default_config(
+        'mfcc', with_pitch='kaldi', with_cmvn=True, with_delta=True, to_yaml=kind != 'dict')
+    if kind == 'file':
+        tempfile = str(tmpdir.join('foo'))
+        open(tempfile, 'w').write(config)
+        config = tempfile
+    if kind == 'str':
+        with pytest.raises(ValueError) as err:
+            pipeline._init_config('a:\nb\n')
+        assert 'error in configuration' in str(err.value)
+    parsed = pipeline._init_config(config, log=get_logger('pipeline', level='info'))
+    output = capsys.readouterr().err
+    for word in ('mfcc', 'pitch', 'cmvn', 'delta'):
+        assert word in output
+        assert word in parsed
+
+
+def test_config_bad(utterances):
+    """reference test_pipeline.py:101-160 (the backend-specific refusals are documented in
+    shennong_amd/pipeline.py)"""
+    with pytest.raises(ValueError) as err:
+        pipeline.get_default_config('bad')
+    assert 'invalid features "bad"' in str(err.value)
+
+    config = pipeline.get_default_config('mfcc')
+    del config['mfcc']
+    with pytest.raises(ValueError) as err:
+        pipeline.extract_features(config, utterances)
+    assert 'the configuration does not define any features' in str(err.value)
+
+    config = pipeline.get_default_config('mfcc')
+    config['plp'] = config['mfcc']
+    with pytest.raises(ValueError) as err:
+        pipeline.extract_features(config, utterances)
+    assert 'more than one features extraction processor' in str(err.value)
+
+    config = pipeline.get_default_config('mfcc')
+    config['invalid'] = config['mfcc']
+    with pytest.raises(ValueError) as err:
+        pipeline.extract_features(config, utterances)
+    assert 'invalid keys in configuration' in str(err.value)
+
+    with pytest.raises(ValueError) as err:
+        pipeline.get_default_config('mfcc', with_vtln=True)
+    assert 'must be False, "simple" or "full" but is "True"' in str(err.value)
+    with pytest.raises(ValueError) as err:
+        pipeline.get_default_config('mfcc', with_pitch='bad')
+    assert 'with_pitch argument must be' in str(err.value)
+    for kwargs in (dict(with_vtln='simple'), dict(with_vtln='full'), dict(with_pitch='crepe')):
+        with pytest.raises(ValueError) as err:
+            pipeline.get_default_config('mfcc', **kwargs)
+        assert 'not available in this backend' in str(err.value)
+    with pytest.raises(ValueError):
+        pipeline.get_default_config('bottleneck')
+
+    config = pipeline.get_default_config('mfcc', with_cmvn=True)
+    del config['cmvn']['with_vad']
+    parsed = pipeline._init_config(config)
+    assert parsed['cmvn']['with_vad']
+    config = pipeline.get_default_config('mfcc', with_cmvn=True)
+    del config['cmvn']['by_speaker']
+    assert not pipeline._init_config(config)['cmvn']['by_speaker']
+    config = pipeline.get_default_config('mfcc', with_pitch='kaldi')
+    del config['pitch']['postprocessing']
+    assert pipeline._init_config(config)['pitch']['postprocessing'] == {}
+
+    config = pipeline.get_default_config('spectrogram')
+    config['vtln'] = {}
+    with pytest.raises(ValueError) as err:
+        pipeline.extract_features(config, utterances)
+    assert 'do not support VTLN' in str(err.value)
+
+    config = pipeline.get_default_config('mfcc', with_cmvn=True)
+    with pytest.raises(ValueError) as err:
+        pipeline.extract_features(config, Utterances([('toto', WAV)]))
+    assert 'no speaker information provided' in str(err.value)
+
+
+def test_init_warps(utterances, capsys):
+    """reference test_pipeline.py:163-205"""
+    log = get_logger('test', 'info')
+    with pytest.raises(ValueError) as err:
+        pipeline._init_warps({}, pipeline.get_default_config('spectrogram'), utterances, log)
+    assert 'features do not support VTLN' in str(err.value)
+    for warps in ({}, {'a': 0}, {'utt1': 0}):
+        with pytest.raises(ValueError) as err:
+            pipeline._init_warps(warps, pipeline.get_default_config('mfcc'), utterances, log)
+        assert 'warps do not match utterances' in str(err.value)
+    capsys.readouterr()
+    w = pipeline._init_warps({'utt1': 1.0, 'utt2': 0.0}, pipeline.get_default_config('mfcc'),
+                             utterances, log)
+    assert 'warps are defined by utterance' in capsys.readouterr().err
+    assert w == {'utt1': 1.0, 'utt2': 0.0}
+    w = pipeline._init_warps({'speaker1': 1.0, 'speaker2': 0.0},
+                             pipeline.get_default_config('mfcc'), utterances, log)
+    assert 'warps are defined by speaker' in capsys.readouterr().err
+    assert w == {'utt1': 1.0, 'utt2': 0.0}
+    with pytest.raises(ValueError) as err:
+        pipeline._init_warps({'speaker1': 'a', 'speaker2': 0.0},
+                             pipeline.get_default_config('mfcc'), utterances, log)
+    assert 'could not convert string to float' in str(err.value)
+
+
+def test_utterances_index():
+    """reference utterances.py semantics used by the pipeline"""
+    utts = Utterances([('u1', WAV, 's1', 0, 1), ('u2', WAV, 's2', 1, 1.2)])
+    assert utts.has_speakers() and utts.format() == 4
+    assert utts.format(type=str) == '<utterance-id> <audio-file> <speaker-id> <tstart> <tstop>'
+    assert sorted(utts.by_speaker().keys()) == ['s1', 's2']
+    assert utts.duration() == pytest.approx(1.2)
+    with pytest.warns(UserWarning):
+        u3 = Utterances([('u3', WAV_8K, 1, 3)])
+    assert u3['u3'].duration < 0.5 and not u3.has_speakers()
+    with pytest.raises(ValueError) as err:
+        Utterances([('1', WAV, 1, 0)])
+    assert 'we must have 0 <= tstart < tstop' in str(err.value)
+    with pytest.raises(ValueError):
+        Utterances([('u1', WAV), ('u1', WAV)])
+    meta = Audio.scan(WAV)
+    assert (meta.nchannels, meta.sample_rate, meta.nsamples) == (1, 16000, 22713)
+
+
+# ---- extraction (GPU) ----------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('features', pipeline.valid_features())
+def test_extract_features(gpu, utterances, features):
+    """reference test_pipeline.py:279-315"""
+    config = pipeline.get_default_config(features, with_delta=True)
+    feat1 = pipeline.extract_features(config, utterances)['utt1']
+    assert feat1.is_valid() and feat1.shape[0] == 140 and feat1.dtype == np.float32
+
+    config = pipeline.get_default_config(features, with_delta=True, with_pitch='kaldi')
+    feat2 = pipeline.extract_features(config, utterances)['utt1']
+    assert feat2.is_valid() and feat2.shape == (140, feat1.shape[1] + 3)
+
+    config = pipeline.get_default_config(features, with_delta=True)
+    feat3 = pipeline.extract_features(config, Utterances([('utt1', WAV, 0, 1)]))['utt1']
+    assert feat3.is_valid() and feat3.shape == (98, feat1.shape[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('by_speaker, with_vad',
+                         [(s, v) for s in (True, False) for v in (True, False)])
+def test_pipeline_cmvn(gpu, by_speaker, with_vad):
+    """reference test_pipeline.py:318-329 + equality with the step-by-step processors and the
+    oracle's VAD / CMVN arithmetic"""
+    from oracle import oracle as orc
+    from shennong_amd.processor import EnergyProcessor, MfccProcessor
+    from shennong_amd.postprocessor import VadPostProcessor
+    utts = Utterances([('utt1', WAV, 'spk1', 0, 1), ('utt2', WAV, 'spk1', 0.5, 1.4),
+                       ('utt3', WAV, 'spk2', 0, 1.4)])
+    config = pipeline.get_default_config('mfcc', with_cmvn=True)
+    config['mfcc']['dither'] = 0
+    config['cmvn']['by_speaker'] = by_speaker
+    config['cmvn']['with_vad'] = with_vad
+    feats = pipeline.extract_features(config, utts)
+    assert list(feats.keys()) == ['utt1', 'utt2', 'utt3']
+    mfcc = {u.name: MfccProcessor(dither=0).process(u.load_audio()) for u in utts}
+    vads = {}
+    for u in utts:
+        w = None
+        if with_vad:
+            w = VadPostProcessor().process(EnergyProcessor().process(u.load_audio())).data[:, 0]
+            # (the energy used for the VAD is dithered like in the reference: compare loosely)
+            assert w.shape[0] == mfcc[u.name].nframes
+        vads[u.name] = w
+    groups = {'utt1': 'a', 'utt2': 'a', 'utt3': 'b'} if by_speaker else {k: k for k in mfcc}
+    for name, f in feats.items():
+        assert f.is_valid() and f.shape == mfcc[name].shape and f.dtype == np.float32
+        assert f.properties['pipeline'] == [
+            {'name': 'mfcc', 'columns': [0, 12]}, {'name': 'cmvn', 'columns': [0, 12]}]
+        assert f.properties['speaker'] == utts[name].speaker
+        assert f.properties['audio']['file'] == WAV
+        stats = f.properties['cmvn']['stats']
+        if not with_vad:
+            want = np.zeros((2, 14))
+            for other in mfcc:
+                if groups[other] == groups[name]:
+                    orc.cmvn_accumulate(mfcc[other].data, stats=want)
+            np.testing.assert_allclose(stats, want, rtol=1e-12)
+        assert np.array_equal(f.data, orc.cmvn_apply(mfcc[name].data, stats))
+
+
+@pytest.mark.gpu
+def test_pipeline_full(gpu, tmp_path, capsys):
+    """reference test_pipeline.py:355-410: different sampling rates, speakers and segments; the
+    result must equal the chain of the individual processors"""
+    import scipy.io.wavfile
+    from shennong_amd.processor import (
+        KaldiPitchPostProcessor, KaldiPitchProcessor, MfccProcessor)
+    from shennong_amd.postprocessor import CmvnPostProcessor, DeltaPostProcessor
+    audio = Audio.load(WAV)
+    wav_f32 = str(tmp_path / 'test.float32.wav')
+    scipy.io.wavfile.write(wav_f32, 16000, (audio.data / 2 ** 15).astype(np.float32))
+    with pytest.warns(UserWarning):
+        index = Utterances([('u1', WAV, 's1', 0, 1), ('u2', wav_f32, 's2', 1, 1.2),
+                            ('u3', WAV_8K, 's1', 1, 3)])
+    config = pipeline.get_default_config('mfcc', with_cmvn=True, with_delta=True, with_pitch='kaldi')
+    config['cmvn']['with_vad'] = False
+    config['mfcc']['dither'] = 0
+    config['pitch']['postprocessing']['delta_pitch_noise_stddev'] = 0
+    feats = pipeline.extract_features(config, index, njobs=2, log=get_logger('test', 'info'))
+    messages = capsys.readouterr().err
+    assert 'INFO - test - get 3 utterances from 2 speakers in 3 audio files' in messages
+    assert 'WARNING - test - several sample rates found in audio files' in messages
+    p1, p2, p3 = (feats[u].properties for u in ('u1', 'u2', 'u3'))
+    assert p1['audio']['file'] == WAV and p1['audio']['duration'] == 1.0
+    assert p2['audio']['duration'] == pytest.approx(0.2)
+    assert p3['audio']['duration'] < 0.5
+    assert p1['mfcc'] == p2['mfcc'] and p1['mfcc']['sample_rate'] != p3['mfcc']['sample_rate']
+    assert p1.keys() == {'audio', 'mfcc', 'cmvn', 'pitch', 'delta', 'speaker', 'pipeline'}
+    assert p1.keys() == p2.keys() == p3.keys()
+    assert p1['pipeline'] == p2['pipeline'] == p3['pipeline']
+    assert feats['u1'].shape == (98, 42) and feats['u2'].shape == (18, 42)
+    assert all(f.dtype == np.float32 and f.is_valid() for f in feats.values())
+
+    # the same thing, one processor at a time
+    mfcc, pitch = {}, {}
+    for u in index:
+        a = u.load_audio()
+        mfcc[u.name] = MfccProcessor(sample_rate=a.sample_rate, dither=0).process(a)
+        raw = KaldiPitchProcessor(sample_rate=a.sample_rate).process(a)
+        pitch[u.name] = KaldiPitchPostProcessor(delta_pitch_noise_stddev=0).process(raw)
+    cmvn = {'s1': CmvnPostProcessor(13), 's2': CmvnPostProcessor(13)}
+    for u in index:
+        cmvn[u.speaker].accumulate(mfcc[u.name])
+    for u in index:
+        want = DeltaPostProcessor().process(cmvn[u.speaker].process(mfcc[u.name]))
+        want = want.concatenate(pitch[u.name], tolerance=2)
+        assert np.array_equal(feats[u.name].data, want.data)
+        assert np.array_equal(feats[u.name].times, want.times)
+
+
+@pytest.mark.gpu
+def test_pipeline_warps(gpu, utterances):
+    """reference test_pipeline.py:346-352"""
+    config = pipeline.get_default_config('mfcc')
+    feats = pipeline.extract_features(config, utterances, warps={'speaker1': 1.2, 'speaker2': 0.85})
+    assert feats['utt1'].properties['mfcc']['vtln_warp'] == 1.2
+    assert feats['utt2'].properties['mfcc']['vtln_warp'] == 0.85
