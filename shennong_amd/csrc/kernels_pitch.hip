@@ -524,7 +524,7 @@ __device__ __forceinline__ void scan_range(const float* __restrict__ fwd, int lo
 
 constexpr int kLagGroup = 5;  // lags per work item of the correlation
 constexpr int kCorrChunks = 4;  // window quarters per lag group (the 4 lanes of a quad)
-constexpr int kLongRange = 24;  // candidate ranges at least this long are scanned by the whole wave
+constexpr int kLongRange = 8;  // candidate ranges at least this long are scanned by a 16-lane row
 
 __device__ void forward_pass_wave(const PitchDevTables& t, const float* __restrict__ x, int64_t nd,
                                   int64_t T, int64_t T1, double ms1, double ms2, bool rescale,
@@ -705,24 +705,45 @@ __device__ void forward_pass_wave(const PitchDevTables& t, const float* __restri
         float best = FLT_MAX;
         int best_j = lo;
         if (active && !is_long) scan_range(sh.fwd, lo, hi, static_cast<float>(i), factor, best, best_j);
-        // a jump of the backpointer function makes ONE state of every level scan a long range: those
-        // are searched by the whole wave (64 candidates per step + an argmin reduction) instead
+        // a jump of the backpointer function makes one state of every level scan a long range: those
+        // are searched four at a time, one per 16-lane row (16 candidates per step + a row argmin)
         unsigned long long pending = __ballot(is_long);
         while (pending) {
-          const int src_lane = __ffsll(static_cast<long long>(pending)) - 1;
-          pending &= pending - 1;
-          const int li = __builtin_amdgcn_readlane(i, src_lane),
-                    llo = __builtin_amdgcn_readlane(lo, src_lane),
-                    lhi = __builtin_amdgcn_readlane(hi, src_lane);
-          const float fi = static_cast<float>(li);
+          int src[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            src[r] = pending ? __ffsll(static_cast<long long>(pending)) - 1 : -1;
+            if (pending) pending &= pending - 1;
+          }
+          const int row = lane >> 4, sub = lane & 15;
+          int ri = 0, rlo = 0, rhi = -1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (src[r] >= 0) {
+              const int a = __builtin_amdgcn_readlane(i, src[r]);
+              const int b = __builtin_amdgcn_readlane(lo, src[r]);
+              const int c = __builtin_amdgcn_readlane(hi, src[r]);
+              if (row == r) { ri = a; rlo = b; rhi = c; }
+            }
+          }
+          const float fi = static_cast<float>(ri);
           float cb = FLT_MAX;
           int cj = 0x7fffffff;
-          for (int j = llo + lane; j <= lhi; j += 64) {
+          for (int j = rlo + sub; j <= rhi; j += 16) {
             const float c = trans_cost(j, fi, factor, sh.fwd[j]);
             if (c < cb) { cb = c; cj = j; }
           }
-          wave_argmin(cb, cj);
-          if (lane == src_lane) { best = cb; best_j = cj; }
+          quad_argmin(cb, cj);
+          argmin_take(cb, cj, dpp_f<0x124>(cb), dpp_i<0x124>(cj));
+          argmin_take(cb, cj, dpp_f<0x128>(cb), dpp_i<0x128>(cj));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (src[r] >= 0) {
+              const float c = lane_f(cb, 16 * r);
+              const int jn = __builtin_amdgcn_readlane(cj, 16 * r);
+              if (lane == src[r]) { best = c; best_j = jn; }
+            }
+          }
         }
         if (active) {
           sh.bpw[i] = best_j;
