@@ -25,6 +25,7 @@
 // reference at shennong/processor/base.py:429-431.
 #include <float.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -247,7 +248,10 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
   const float2* __restrict__ t_win = reinterpret_cast<const float2*>(tab);
   const float2* __restrict__ t_tw16 = t_win + 16 * 18;
   const float2* __restrict__ t_tw512 = t_tw16 + 16 * 18;
+  // per mel slot (round, lane): first tap (multiple of 4), output bin (-1: none), split flag
   const int* __restrict__ t_first = reinterpret_cast<const int*>(tab + p.off_first);
+  const int* __restrict__ t_bin = t_first + 16 * kMaxRounds;
+  const int* __restrict__ t_pair = t_bin + 16 * kMaxRounds;
   const float* __restrict__ t_w = tab + p.off_w;
   const float* __restrict__ t_dct = tab + p.off_dct;
   const float* __restrict__ t_lifter = tab + p.off_lifter;
@@ -448,21 +452,29 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     }
     const int mel_col = (KIND == SNF_KIND_FBANK && p.use_energy && !p.htk_compat) ? 1 : 0;
     float logmel[kMaxRounds];
+    int mbin[kMaxRounds];
 #pragma unroll
     for (int r = 0; r < kMaxRounds; ++r) {
+      mbin[r] = -1;
       if (r < p.rounds) {
-        const int m = l + 16 * r;
         const int start = t_first[r * 16 + l];  // first tap rounded down to a multiple of 4
-        // taps outside [first, first + count) carry zero weights and read finite filler in the tile
+        const int m = t_bin[r * 16 + l];        // mel bin stored by this slot, or -1
+        const int pair = t_pair[r * 16 + l];    // this slot and its quad neighbour share a wide bin
+        // taps outside the slot's range carry zero weights and read finite filler in the tile
         float acc = 0.0f;
         mel_groups<kMaxGroups>(t_w + p.mel_woff[r] + 4 * l, ptile + start, p.mel_maxcount[r], acc);
+        // wide bins are split over two neighbouring lanes of the same round (the idle slots of the
+        // last round would otherwise dictate the group count of the whole round)
+        const float other = dpp_row_ror<0xB1>(acc);  // quad_perm [1,0,3,2]: lane l ^ 1
+        if (pair) acc += other;
         if (KIND == SNF_KIND_FBANK) {
           const float v = p.use_log ? fast_log(fmaxf(acc, FLT_EPSILON)) : acc;
-          if (valid && m < p.num_bins) row[mel_col + m] = v;
+          if (valid && m >= 0) row[mel_col + m] = v;
         } else if (KIND == SNF_KIND_MFCC) {
           logmel[r] = fast_log(fmaxf(acc, FLT_EPSILON));
+          mbin[r] = m;
         } else {
-          if (valid && m < p.num_bins) row[m] = acc;
+          if (valid && m >= 0) row[m] = acc;
         }
       }
     }
@@ -475,7 +487,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
       wave_lds_sync();
 #pragma unroll
       for (int r = 0; r < kMaxRounds; ++r)
-        if (r < p.rounds && l + 16 * r < p.num_bins) ptile[l + 16 * r] = logmel[r];
+        if (r < p.rounds && mbin[r] >= 0) ptile[mbin[r]] = logmel[r];
       wave_lds_sync();
       float v = 0.0f;
       mel_groups<16>(t_dct + 4 * l, ptile, ((p.num_bins + 7) >> 3) << 1, v);  // num_bins <= 64
@@ -580,23 +592,91 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
       blob->push_back(static_cast<float>(std::cos(a)));
       blob->push_back(static_cast<float>(std::sin(a)));
     }
-  // mel: lane l of round r owns bin l + 16 r; its taps are read in aligned groups of 4
+  // mel: every (round, lane) slot sums one run of 4-tap groups.  A bin is one slot, or - for the
+  // widest bins, as many as there are idle slots - two slots in neighbouring lanes of one round whose
+  // partial sums are added through DPP.  Slots are sorted by size so that the rounds are as short as
+  // possible (a round costs the group count of its longest slot).
+  struct Piece { int bin, start, groups, units; };  // units = 2: pair (two consecutive pieces)
+  std::vector<Piece> singles, pairs;  // pairs hold the first half; the second half follows it
+  {
+    std::vector<int> order(mb.num_bins), groups_of(mb.num_bins), start_of(mb.num_bins);
+    for (int m = 0; m < mb.num_bins; ++m) {
+      order[m] = m;
+      start_of[m] = mb.first[m] & ~3;
+      groups_of[m] = (mb.first[m] + mb.size[m] - start_of[m] + 3) / 4;
+    }
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int x, int y) { return groups_of[x] > groups_of[y]; });
+    int spare = 16 * p.rounds - mb.num_bins;
+    std::vector<char> split(mb.num_bins, 0);
+    for (int m : order)
+      if (spare > 0 && groups_of[m] >= 2) { split[m] = 1; --spare; }
+    for (int m = 0; m < mb.num_bins; ++m) {
+      if (split[m]) {
+        const int ga = (groups_of[m] + 1) / 2;
+        pairs.push_back({m, start_of[m], ga, 2});
+        pairs.push_back({-1, start_of[m] + 4 * ga, groups_of[m] - ga, 0});
+      } else {
+        singles.push_back({m, start_of[m], groups_of[m], 1});
+      }
+    }
+  }
+  // units sorted by decreasing size; pairs (2 slots, even lane first) are placed before the singles
+  // of the same round
+  std::vector<std::vector<Piece>> round_slots(p.rounds);
+  {
+    std::vector<std::pair<int, int>> units;  // (groups, index) index < 0: pair -(idx+1), else single
+    for (size_t i = 0; i < pairs.size(); i += 2) units.push_back({pairs[i].groups, -static_cast<int>(i) - 1});
+    for (size_t i = 0; i < singles.size(); ++i) units.push_back({singles[i].groups, static_cast<int>(i)});
+    std::stable_sort(units.begin(), units.end(),
+                     [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first > y.first; });
+    std::vector<char> used(units.size(), 0);
+    for (int r = 0; r < p.rounds; ++r) {
+      std::vector<Piece> pr, sg;
+      int free_slots = 16;
+      for (size_t u = 0; u < units.size() && free_slots > 0; ++u) {
+        if (used[u]) continue;
+        if (units[u].second < 0) {
+          if (free_slots < 2) continue;
+          const size_t i = static_cast<size_t>(-units[u].second - 1);
+          pr.push_back(pairs[i]);
+          pr.push_back(pairs[i + 1]);
+          free_slots -= 2;
+        } else {
+          sg.push_back(singles[units[u].second]);
+          free_slots -= 1;
+        }
+        used[u] = 1;
+      }
+      round_slots[r] = pr;
+      round_slots[r].insert(round_slots[r].end(), sg.begin(), sg.end());
+    }
+    for (char u : used)
+      if (!u) return 1;  // (cannot happen: 16 * rounds slots >= pieces)
+  }
   p.off_first = static_cast<int>(blob->size());
-  std::vector<int> start(p.rounds * 16, 0);
+  auto push_int = [&](int v) {
+    float as_float;
+    std::memcpy(&as_float, &v, 4);
+    blob->push_back(as_float);
+  };
+  for (int table = 0; table < 3; ++table)  // first tap, output bin, pair flag: [kMaxRounds][16] each
+    for (int r = 0; r < kMaxRounds; ++r)
+      for (int l = 0; l < 16; ++l) {
+        int v = table == 1 ? -1 : 0;
+        if (r < p.rounds && l < static_cast<int>(round_slots[r].size())) {
+          const Piece& pc = round_slots[r][l];
+          const bool second = pc.units == 0;
+          if (table == 0) v = pc.start;
+          else if (table == 1) v = pc.bin;
+          else v = (pc.units == 2 || second) ? 1 : 0;
+        }
+        push_int(v);
+      }
   for (int r = 0; r < p.rounds; ++r) {
     int groups = 0;
-    for (int l = 0; l < 16; ++l) {
-      const int m = l + 16 * r;
-      if (m < mb.num_bins) {
-        start[r * 16 + l] = mb.first[m] & ~3;
-        const int g = (mb.first[m] + mb.size[m] - start[r * 16 + l] + 3) / 4;
-        if (g > groups) groups = g;
-      }
-      float as_float;
-      std::memcpy(&as_float, &start[r * 16 + l], 4);
-      blob->push_back(as_float);
-    }
-    if (groups > kMaxGroups) return 1;  // a bin is too wide for the unrolled tap loop: not eligible
+    for (const Piece& pc : round_slots[r]) groups = pc.groups > groups ? pc.groups : groups;
+    if (groups > kMaxGroups) return 1;  // a slot is too long for the unrolled tap loop: not eligible
     p.mel_maxcount[r] = (groups + 1) & ~1;  // 4-tap groups of this round (even: read in batches)
   }
   while (blob->size() % 4) blob->push_back(0.0f);  // 16-byte alignment of the float4 weights
@@ -607,11 +687,13 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
     for (int g = 0; g < p.mel_maxcount[r]; ++g)
       for (int l = 0; l < 16; ++l)
         for (int i = 0; i < 4; ++i) {
-          const int m = l + 16 * r;
           float w = 0.0f;
-          if (m < mb.num_bins) {
-            const int k = start[r * 16 + l] + 4 * g + i;  // FFT bin of this tap
-            if (k >= mb.first[m] && k < mb.first[m] + mb.size[m])
+          if (l < static_cast<int>(round_slots[r].size())) {
+            const Piece& pc = round_slots[r][l];
+            // the second half of a split bin takes its bin from the slot before it
+            const int m = pc.units == 0 ? round_slots[r][l - 1].bin : pc.bin;
+            const int k = pc.start + 4 * g + i;  // FFT bin of this tap
+            if (g < pc.groups && k >= mb.first[m] && k < mb.first[m] + mb.size[m])
               w = 0.25f * mb.w[mb.offset[m] + k - mb.first[m]];  // exact power-of-two scaling
           }
           blob->push_back(w);
