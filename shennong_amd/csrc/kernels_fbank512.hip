@@ -275,7 +275,13 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
   // path of a wave.  frame_start[g] (sample index of the first sample of global frame g) is built
   // once per offsets table by build_frame_start_kernel.
   int64_t set = static_cast<int64_t>(blockIdx.x) * n_waves + wid;
+  // NJ = 13 is the exact shape of the 25 ms / 16 kHz window (only element j = 12 can fall outside the
+  // window); NJ = 16 covers every other window length that pads to 512 samples with a per-element test
   const bool in_last = 2 * (l + 16 * (NJ - 1)) < p.win_len;
+  auto in_window = [&](int j) -> bool {
+    if (NJ == 13) return j < NJ - 1 || in_last;
+    return 2 * (l + 16 * j) < p.win_len;
+  };
   int raw[NJ];
   int64_t start_next = 0;
   if (set < n_sets) {
@@ -283,8 +289,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     const int16_t* __restrict__ wp = b.wave + b.frame_start[g < last_frame ? g : last_frame];
     const int16_t* __restrict__ wl = wp + 2 * l;
 #pragma unroll
-    for (int j = 0; j < NJ - 1; ++j) raw[j] = *reinterpret_cast<const int_a2*>(wl + 32 * j);
-    raw[NJ - 1] = *reinterpret_cast<const int_a2*>(in_last ? wl + 32 * (NJ - 1) : wp);
+    for (int j = 0; j < NJ; ++j)
+      raw[j] = *reinterpret_cast<const int_a2*>((NJ == 13 && j < NJ - 1) || in_window(j) ? wl + 32 * j : wp);
     const int64_t gn = (set + set_stride) * 4 + q;
     start_next = b.frame_start[gn < last_frame ? gn : last_frame];
   }
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
         xo[j] += p.dither * nz.y;
       }
       const float s2 = xe[j] + xo[j];
-      part += (j < NJ - 1 || in_last) ? s2 : 0.0f;
+      part += in_window(j) ? s2 : 0.0f;
     }
     // prefetch: samples of the next set (its start offset arrived during the previous iteration),
     // start offset of the set after it
@@ -323,8 +329,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
       const int16_t* __restrict__ wp = b.wave + start_next;
       const int16_t* __restrict__ wl = wp + 2 * l;
 #pragma unroll
-      for (int j = 0; j < NJ - 1; ++j) raw[j] = *reinterpret_cast<const int_a2*>(wl + 32 * j);
-      raw[NJ - 1] = *reinterpret_cast<const int_a2*>(in_last ? wl + 32 * (NJ - 1) : wp);
+      for (int j = 0; j < NJ; ++j)
+        raw[j] = *reinterpret_cast<const int_a2*>((NJ == 13 && j < NJ - 1) || in_window(j) ? wl + 32 * j : wp);
       const int64_t gn = (set + 2 * set_stride) * 4 + q;
       start_next = b.frame_start[gn < last_frame ? gn : last_frame];
     }
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       if (j < NJ) {
-        const bool in = j < NJ - 1 || in_last;
+        const bool in = in_window(j);
         const float ae = xe[j] + neg_mean, ao = xo[j] + neg_mean;
         const float rot = dpp_row_ror<0x121>(ao);  // lane l <- lane (l - 1) mod 16 of its frame
         const float ap = l == 0 ? rot_prev : rot;
@@ -536,8 +542,7 @@ bool fast512_eligible(const MelParams& mp, bool any_warp) {
   if (any_warp) return false;
   if (mp.padded != 512 || !mp.pow2 || !mp.snip_edges) return false;
   if (mp.win_len & 1) return false;
-  const int nj = (mp.win_len + 31) / 32;  // only the last j may be partially outside the window
-  if (nj != 13 && nj != 16) return false;
+  if (mp.win_len <= 256) return false;  // (pads to 512 samples, see above: 257..512)
   if (mp.kind != SNF_KIND_FBANK && mp.kind != SNF_KIND_MFCC && mp.kind != SNF_KIND_PLP &&
       mp.kind != SNF_KIND_SPECTROGRAM)
     return false;
@@ -732,7 +737,7 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
     lds = static_cast<size_t>(tab_bytes) + n_waves * 4 * kFrameTileBytes;
   }
   if (lds > 160 * 1024) return set_error(SNF_E_RUNTIME, "fast512: tables do not fit in LDS");
-  const int nj = (p.win_len + 31) / 32;
+  const int nj = (p.win_len + 31) / 32 == 13 ? 13 : 16;
   const int64_t n_sets = (b.total_frames + 3) / 4;
   int64_t blocks = (n_sets + n_waves - 1) / n_waves;
   const int64_t max_blocks = 256 * 4 * (kMaxWaves / n_waves);  // resident workgroups x grid-stride depth 4

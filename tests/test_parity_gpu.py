@@ -10,7 +10,7 @@ import pytest
 
 from conftest import assert_close
 from oracle import oracle as orc
-from shennong_amd import Audio, _abi, synth
+from shennong_amd import Audio, _abi, _backend, synth
 from shennong_amd.processor import (
     FilterbankProcessor, MfccProcessor, PlpProcessor, SpectrogramProcessor,
     KaldiPitchProcessor, KaldiPitchPostProcessor)
@@ -429,3 +429,18 @@ def test_sliding_cmvn_batch(gpu, synth_waves):
     for f, o in zip(feats, outs):
         want = orc.sliding_cmn(f.data, cmn_window=50, min_window=20, normalize_variance=True)
         np.testing.assert_allclose(o.data, want, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('frame_length', [0.0165, 0.02, 0.03, 0.032])
+@pytest.mark.parametrize('cls', [FilterbankProcessor, MfccProcessor])
+def test_fast_kernel_window_lengths(gpu, audio, wave, cls, frame_length):
+    """every even window length that pads to 512 samples runs on the register-resident kernel
+    (generic per-element window test instead of the 25 ms special case)"""
+    proc = cls(dither=0, frame_length=frame_length)
+    got = proc.process(audio)
+    want = _oracle(proc, wave)
+    assert got.shape == want.shape
+    assert_close(got.data, want, what=f'{cls.__name__} {frame_length}')
+    plan = _backend.get_plan(proc._build_options())
+    plan.run([np.asarray(wave, np.int16)])
+    assert plan.kernel_name(1) == 'fbank512_kernel'
