@@ -82,7 +82,7 @@ struct snf_plan {
 
   // scratch (host-pointer entry points and intermediates)
   DevBuf s_wave, s_out, s_in, s_soff, s_foff, s_uwarp, s_mel, s_energy;
-  DevBuf s_down, s_stats, s_bp, s_doff, s_dp1, s_fp1, s_states, s_setidx;
+  DevBuf s_down, s_stats, s_bp, s_doff, s_dp1, s_fp1, s_states, s_setidx, s_edge;
   bool setidx_valid = false;
 
   // last uploaded offsets tables (re-validated / re-uploaded only when they change)
@@ -720,17 +720,27 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     if ((rc = plan->s_mel.ensure(sizeof(float) * static_cast<size_t>(total_frames) * nb))) return rc;
     if ((rc = plan->s_energy.ensure(sizeof(double) * static_cast<size_t>(total_frames)))) return rc;
   }
-  const bool use_fast = plan->fast512 && !any_warp;
+  bool use_fast = plan->fast512 && !any_warp;
+  if (use_fast && !plan->mp.snip_edges) {
+    // the clamped bulk loads of the centred frames need every utterance to hold one full window
+    for (int64_t u = 0; u < n_utts && use_fast; ++u) {
+      const int64_t n = sample_offsets[u + 1] - sample_offsets[u];
+      if (n > 0 && n < plan->mp.win_len) use_fast = false;
+    }
+  }
   if (use_fast && !plan->setidx_valid) {
-    // frame -> first-sample index: built once per offsets table, reused by every later call
+    // frame -> first-sample index (+ edge marks): built once per offsets table, reused by later calls
     if ((rc = plan->s_setidx.ensure(sizeof(int64_t) * static_cast<size_t>(total_frames)))) return rc;
+    if ((rc = plan->s_edge.ensure(sizeof(int32_t) * static_cast<size_t>(total_frames)))) return rc;
     if ((rc = launch_build_frame_start(plan->s_foff.as<int64_t>(), plan->s_soff.as<int64_t>(), n_utts,
-                                       total_frames, plan->mp.win_shift,
-                                       plan->s_setidx.as<int64_t>(), s)))
+                                       total_frames, plan->mp.win_shift, plan->mp.win_len,
+                                       plan->mp.snip_edges, plan->s_setidx.as<int64_t>(),
+                                       plan->s_edge.as<int32_t>(), s)))
       return rc;
     plan->setidx_valid = true;
   }
   b.frame_start = plan->s_setidx.as<int64_t>();
+  b.frame_edge = plan->s_edge.as<int32_t>();
   if (own_stream) begin_timing(plan);
   if (plan->kind == SNF_KIND_PLP) {
     const int nb = plan->o.mel.num_bins;

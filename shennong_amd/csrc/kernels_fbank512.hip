@@ -232,7 +232,7 @@ __device__ __forceinline__ void fft16(float2 (&v)[16]) {
 }  // namespace
 
 // ENERGY: 0 = no log-energy column, 1 = raw (before pre-emphasis/window), 2 = after the window
-template <int NJ, int KIND, int ENERGY, bool DITHER>
+template <int NJ, int KIND, int ENERGY, bool DITHER, bool SNIP>
 __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast512Params p,
                                                                    const BatchArgs b,
                                                                    float* __restrict__ out,
@@ -284,6 +284,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
   };
   int raw[NJ];
   int64_t start_next = 0;
+  int edge_next = 0;  // snip_edges = false: 0 for an interior frame, utterance + 1 for a frame that
+                      // reaches outside its utterance (reloaded with Kaldi's reflection)
   if (set < n_sets) {
     const int64_t g = set * 4 + q;
     const int16_t* __restrict__ wp = b.wave + b.frame_start[g < last_frame ? g : last_frame];
@@ -293,10 +295,12 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
       raw[j] = *reinterpret_cast<const int_a2*>((NJ == 13 && j < NJ - 1) || in_window(j) ? wl + 32 * j : wp);
     const int64_t gn = (set + set_stride) * 4 + q;
     start_next = b.frame_start[gn < last_frame ? gn : last_frame];
+    if (!SNIP) edge_next = b.frame_edge[g < last_frame ? g : last_frame];
   }
   for (; set < n_sets; set += set_stride) {
     const int64_t g = set * 4 + q;
     const bool valid = g <= last_frame;
+    const int edge_cur = edge_next;
 
     // ---- A: DC removal, pre-emphasis, window ------------------------------------------------------
     // A1: one dword (two int16 samples) per element, requested one iteration ago.  Only the last j
@@ -315,6 +319,28 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     for (int j = 0; j < NJ; ++j) {
       xe[j] = static_cast<float>(static_cast<short>(raw[j] & 0xffff));
       xo[j] = static_cast<float>(raw[j] >> 16);
+    }
+    if (!SNIP && edge_cur != 0 && valid) {
+      // [KALDI-UPSTREAM] ExtractWindow, snip_edges = false: samples outside the utterance are
+      // reflected (-k - 1 below the start, 2 n - 1 - k beyond the end).  Only the first and last
+      // frames of an utterance take this path; their prefetched samples came from a clamped window.
+      const int64_t u = edge_cur - 1;
+      const int64_t s0 = b.sample_offsets[u], n = b.sample_offsets[u + 1] - s0;
+      const int64_t rel = (g - b.frame_offsets[u]) * p.win_shift + p.win_shift / 2 - p.win_len / 2;
+      const int16_t* __restrict__ w0 = b.wave + s0;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (in_window(j)) {
+          int64_t k0 = rel + 2 * (l + 16 * j), k1 = k0 + 1;
+          while (k0 < 0 || k0 >= n) k0 = k0 < 0 ? -k0 - 1 : 2 * n - 1 - k0;
+          while (k1 < 0 || k1 >= n) k1 = k1 < 0 ? -k1 - 1 : 2 * n - 1 - k1;
+          xe[j] = static_cast<float>(w0[k0]);
+          xo[j] = static_cast<float>(w0[k1]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
       if (DITHER) {  // Kaldi dithers before the DC removal
         const float2 nz = gauss_pair(dkey_lo, dkey_hi, static_cast<unsigned>(l + 16 * j));
         xe[j] += p.dither * nz.x;
@@ -333,6 +359,10 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
         raw[j] = *reinterpret_cast<const int_a2*>((NJ == 13 && j < NJ - 1) || in_window(j) ? wl + 32 * j : wp);
       const int64_t gn = (set + 2 * set_stride) * 4 + q;
       start_next = b.frame_start[gn < last_frame ? gn : last_frame];
+      if (!SNIP) {
+        const int64_t g1 = (set + set_stride) * 4 + q;
+        edge_next = b.frame_edge[g1 < last_frame ? g1 : last_frame];
+      }
     }
     float neg_mean = 0.0f;
     if (p.remove_dc) neg_mean = -row_sum16(part) / static_cast<float>(p.win_len);
@@ -511,25 +541,41 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
   }
 }
 
-// one thread per frame: sample index (into the concatenated wave) of the frame's first sample
+// one thread per frame: sample index (into the concatenated wave) of the frame's first sample.
+// snip_edges = false: frames are centred (start = f shift + shift / 2 - len / 2, [KALDI-UPSTREAM]
+// FirstSampleOfFrame) and may reach outside the utterance; their start is clamped into the utterance
+// for the bulk loads and frame_edge marks them for the reflecting reload.
 __global__ void build_frame_start_kernel(const int64_t* __restrict__ frame_offsets,
                                          const int64_t* __restrict__ sample_offsets, int64_t n_utts,
-                                         int64_t total_frames, int win_shift,
-                                         int64_t* __restrict__ frame_start) {
+                                         int64_t total_frames, int win_shift, int win_len,
+                                         int snip_edges, int64_t* __restrict__ frame_start,
+                                         int32_t* __restrict__ frame_edge) {
   const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (g >= total_frames) return;
   const int64_t u = find_utt(frame_offsets, n_utts, g);
-  frame_start[g] = sample_offsets[u] + (g - frame_offsets[u]) * win_shift;
+  const int64_t s0 = sample_offsets[u], n = sample_offsets[u + 1] - s0;
+  const int64_t f = g - frame_offsets[u];
+  if (snip_edges) {
+    frame_start[g] = s0 + f * win_shift;
+    return;
+  }
+  const int64_t rel = f * win_shift + win_shift / 2 - win_len / 2;
+  const bool edge = rel < 0 || rel + win_len > n;
+  int64_t safe = rel < 0 ? 0 : rel;
+  if (safe + win_len > n) safe = n - win_len;  // n >= win_len is checked by the host
+  frame_start[g] = s0 + safe;
+  frame_edge[g] = edge ? static_cast<int32_t>(u + 1) : 0;
 }
 
 int launch_build_frame_start(const int64_t* d_frame_offsets, const int64_t* d_sample_offsets,
-                             int64_t n_utts, int64_t total_frames, int win_shift,
-                             int64_t* d_frame_start, hipStream_t stream) {
+                             int64_t n_utts, int64_t total_frames, int win_shift, int win_len,
+                             int snip_edges, int64_t* d_frame_start, int32_t* d_frame_edge,
+                             hipStream_t stream) {
   if (total_frames <= 0) return SNF_OK;
   hipLaunchKernelGGL(build_frame_start_kernel,
                      dim3(static_cast<unsigned>((total_frames + 255) / 256)), dim3(256), 0, stream,
-                     d_frame_offsets, d_sample_offsets, n_utts, total_frames, win_shift,
-                     d_frame_start);
+                     d_frame_offsets, d_sample_offsets, n_utts, total_frames, win_shift, win_len,
+                     snip_edges, d_frame_start, d_frame_edge);
   SNF_HIP_CHECK(hipGetLastError());
   return SNF_OK;
 }
@@ -540,7 +586,7 @@ int launch_build_frame_start(const int64_t* d_frame_offsets, const int64_t* d_sa
 bool fast512_eligible(const MelParams& mp, bool any_warp) {
   if (getenv("SNF_DISABLE_FAST512")) return false;
   if (any_warp) return false;
-  if (mp.padded != 512 || !mp.pow2 || !mp.snip_edges) return false;
+  if (mp.padded != 512 || !mp.pow2) return false;
   if (mp.win_len & 1) return false;
   if (mp.win_len <= 256) return false;  // (pads to 512 samples, see above: 257..512)
   if (mp.kind != SNF_KIND_FBANK && mp.kind != SNF_KIND_MFCC && mp.kind != SNF_KIND_PLP &&
@@ -561,6 +607,7 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
   p.win_len = mp.win_len;
   p.win_shift = mp.win_shift;
   p.remove_dc = mp.remove_dc;
+  p.snip_edges = mp.snip_edges;
   p.preemph = mp.preemph;
   p.dither = mp.dither;
   p.seed = mp.seed;
@@ -743,14 +790,19 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
   const int64_t max_blocks = 256 * 4 * (kMaxWaves / n_waves);  // resident workgroups x grid-stride depth 4
   if (blocks > max_blocks) blocks = max_blocks;
   const dim3 grid(static_cast<unsigned>(blocks)), block(n_waves * 64);
-#define SNF_LAUNCH4(NJ_, KIND_, EN_, DI_)                                                              \
+#define SNF_LAUNCH5(NJ_, KIND_, EN_, DI_, SN_)                                                       \
   do {                                                                                              \
     if (lds > 64 * 1024)                                                                            \
       SNF_HIP_CHECK(hipFuncSetAttribute(                                                            \
-          reinterpret_cast<const void*>(fbank512_kernel<NJ_, KIND_, EN_, DI_>),                     \
+          reinterpret_cast<const void*>(fbank512_kernel<NJ_, KIND_, EN_, DI_, SN_>),                \
           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                      \
-    hipLaunchKernelGGL((fbank512_kernel<NJ_, KIND_, EN_, DI_>), grid, block, lds, stream, q, b, out, \
-                       energy_out);                                                                 \
+    hipLaunchKernelGGL((fbank512_kernel<NJ_, KIND_, EN_, DI_, SN_>), grid, block, lds, stream, q, b, \
+                       out, energy_out);                                                            \
+  } while (0)
+#define SNF_LAUNCH4(NJ_, KIND_, EN_, DI_)                                                           \
+  do {                                                                                              \
+    if (p.snip_edges) SNF_LAUNCH5(NJ_, KIND_, EN_, DI_, true);                                      \
+    else SNF_LAUNCH5(NJ_, KIND_, EN_, DI_, false);                                                  \
   } while (0)
 #define SNF_LAUNCH3(NJ_, KIND_, EN_)                                                                \
   do {                                                                                              \
@@ -775,6 +827,7 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
     else if (p.kind == SNF_KIND_SPECTROGRAM) SNF_LAUNCH(16, SNF_KIND_SPECTROGRAM);
     else SNF_LAUNCH(16, SNF_KIND_PLP);
   }
+#undef SNF_LAUNCH5
 #undef SNF_LAUNCH4
 #undef SNF_LAUNCH3
 #undef SNF_LAUNCH

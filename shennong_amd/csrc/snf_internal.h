@@ -111,6 +111,7 @@ struct BatchArgs {
   const int64_t* frame_offsets;   // [n_utts+1]
   const int32_t* utt_warp;        // [n_utts] index into the plan's warp tables, or nullptr
   const int64_t* frame_start;     // [total_frames] first sample of every frame (fast path only)
+  const int32_t* frame_edge;      // [total_frames] snip_edges = false: utterance + 1 of edge frames
   int64_t n_utts;
   int64_t total_frames;
 };
@@ -149,7 +150,7 @@ int launch_deltas(const DeltaParams& p, const float* in, int in_cols, const int6
 constexpr int kFast512MaxRounds = 4;
 constexpr int kFast512MaxGroups = 16;  // 4-tap groups per mel round (bins up to 61 FFT bins wide)
 struct Fast512Params {
-  int win_len, win_shift, remove_dc;
+  int win_len, win_shift, remove_dc, snip_edges;
   float preemph, dither;
   unsigned long long seed;
   int kind, out_cols, use_energy, need_raw, need_post, htk_compat, use_log, has_floor;
@@ -170,8 +171,9 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
                   const std::vector<float>& dct, const std::vector<float>& lifter,
                   std::vector<float>* blob, Fast512Params* out);
 int launch_build_frame_start(const int64_t* d_frame_offsets, const int64_t* d_sample_offsets,
-                             int64_t n_utts, int64_t total_frames, int win_shift,
-                             int64_t* d_frame_start, hipStream_t stream);
+                             int64_t n_utts, int64_t total_frames, int win_shift, int win_len,
+                             int snip_edges, int64_t* d_frame_start, int32_t* d_frame_edge,
+                             hipStream_t stream);
 int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int out_cols,
                     double* energy_out, hipStream_t stream);
 

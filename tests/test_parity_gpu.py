@@ -444,3 +444,25 @@ def test_fast_kernel_window_lengths(gpu, audio, wave, cls, frame_length):
     plan = _backend.get_plan(proc._build_options())
     plan.run([np.asarray(wave, np.int16)])
     assert plan.kernel_name(1) == 'fbank512_kernel'
+
+
+@pytest.mark.parametrize('cls', [FilterbankProcessor, MfccProcessor, PlpProcessor,
+                                 SpectrogramProcessor])
+def test_fast_kernel_centred_frames(gpu, synth_waves, cls):
+    """snip_edges = False on the register-resident kernel: the first / last frames of every
+    utterance are reloaded with Kaldi's reflection, interior frames take the bulk path"""
+    proc = cls(dither=0, snip_edges=False)
+    waves = list(synth_waves)
+    feats = proc._process_batch([Audio(w, 16000) for w in waves])
+    plan = _backend.get_plan(proc._build_options())
+    assert plan.kernel_name(1) == 'fbank512_kernel'
+    for w, f in zip(waves, feats):
+        want = _oracle(proc, w)
+        assert f.shape == want.shape
+        assert_close(f.data, want, rtol=2e-4, what=cls.__name__)
+    # an utterance shorter than one window cannot take the clamped bulk loads: generic kernel
+    short = [waves[0], np.asarray(waves[1][:300])]
+    feats = proc._process_batch([Audio(w, 16000) for w in short])
+    assert plan.kernel_name(1) == 'mel_features_generic_kernel'
+    for w, f in zip(short, feats):
+        assert_close(f.data, _oracle(proc, w), rtol=2e-4, what='short')
