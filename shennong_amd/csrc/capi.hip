@@ -69,6 +69,12 @@ struct snf_plan {
   bool fast512 = false;
   Fast512Params fp{};
   DevBuf d_fast_tables;
+  // ... and its per-warp-factor tables (VTLN): one blob per warp id, `fp_warp.table_stride` apart
+  std::vector<float> h_window, h_dct, h_lifter;
+  Fast512Params fp_warp{};
+  DevBuf d_fast_warp_tables, s_blk_utt, s_blk_set0;
+  size_t fast_warps_built = 0;   // number of warp ids covered by d_fast_warp_tables
+  bool fast_warps_ok = true;     // false: some warp's banks do not fit the fast kernel
 
   // delta
   DeltaParams dp{};
@@ -285,6 +291,9 @@ int build_mel_plan(snf_plan* plan) {
       if ((rc = plan->d_fast_tables.upload(blob, plan->stream))) return rc;
       plan->fp.tables = plan->d_fast_tables.as<float>();
       plan->fast512 = true;
+      plan->h_window = window;
+      plan->h_dct = dct_h;
+      plan->h_lifter = lifter_h;
     }
   }
   return SNF_OK;
@@ -326,6 +335,38 @@ int sync_warp_tables(snf_plan* plan) {
   // the uploads read from host vectors that die at scope exit
   SNF_HIP_CHECK(hipStreamSynchronize(plan->stream));
   plan->warps_dirty = false;
+  return SNF_OK;
+}
+
+// fast-kernel tables of every warp factor seen so far (rebuilt when a new one appeared)
+int sync_fast_warp_tables(snf_plan* plan) {
+  if (!plan->fast512 || !plan->fast_warps_ok) return SNF_OK;
+  if (plan->fast_warps_built == plan->banks.size()) return SNF_OK;
+  std::vector<std::vector<float>> blobs(plan->banks.size());
+  size_t stride = 0;
+  Fast512Params fp0{};
+  for (size_t w = 0; w < plan->banks.size(); ++w) {
+    Fast512Params fp{};
+    const int rc = fast512_build(plan->mp, plan->h_window, plan->banks[w], plan->h_dct, plan->h_lifter,
+                                 &blobs[w], &fp);
+    if (rc < 0) return rc;
+    if (rc > 0) {  // this warp's banks need more taps per slot than the kernel unrolls
+      plan->fast_warps_ok = false;
+      return SNF_OK;
+    }
+    if (w == 0) fp0 = fp;
+    stride = std::max(stride, blobs[w].size());
+  }
+  stride = (stride + 3) & ~static_cast<size_t>(3);
+  std::vector<float> all(stride * blobs.size(), 0.0f);
+  for (size_t w = 0; w < blobs.size(); ++w)
+    std::copy(blobs[w].begin(), blobs[w].end(), all.begin() + w * stride);
+  int rc;
+  if ((rc = plan->d_fast_warp_tables.upload(all, plan->stream))) return rc;
+  plan->fp_warp = fp0;
+  plan->fp_warp.tables = plan->d_fast_warp_tables.as<float>();
+  plan->fp_warp.table_stride = static_cast<int>(stride);
+  plan->fast_warps_built = plan->banks.size();
   return SNF_OK;
 }
 
@@ -720,7 +761,11 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     if ((rc = plan->s_mel.ensure(sizeof(float) * static_cast<size_t>(total_frames) * nb))) return rc;
     if ((rc = plan->s_energy.ensure(sizeof(double) * static_cast<size_t>(total_frames)))) return rc;
   }
-  bool use_fast = plan->fast512 && !any_warp;
+  bool use_fast = plan->fast512;
+  if (use_fast && any_warp) {
+    if ((rc = sync_fast_warp_tables(plan))) return rc;
+    use_fast = plan->fast_warps_ok;
+  }
   if (use_fast && !plan->mp.snip_edges) {
     // the clamped bulk loads of the centred frames need every utterance to hold one full window
     for (int64_t u = 0; u < n_utts && use_fast; ++u) {
@@ -728,7 +773,23 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
       if (n > 0 && n < plan->mp.win_len) use_fast = false;
     }
   }
-  if (use_fast && !plan->setidx_valid) {
+  if (use_fast && any_warp) {
+    // workgroup -> (utterance, first frame set) list: every workgroup stages the tables of one warp
+    constexpr int kSetsPerBlock = 64;  // (kernels_fbank512.hip)
+    std::vector<int32_t> blk_utt, blk_set0;
+    for (int64_t u = 0; u < n_utts; ++u) {
+      const int64_t sets = (frame_offsets[u + 1] - frame_offsets[u] + 3) / 4;
+      for (int64_t s0 = 0; s0 < sets; s0 += kSetsPerBlock) {
+        blk_utt.push_back(static_cast<int32_t>(u));
+        blk_set0.push_back(static_cast<int32_t>(s0));
+      }
+    }
+    if ((rc = plan->s_blk_utt.upload(blk_utt, s))) return rc;
+    if ((rc = plan->s_blk_set0.upload(blk_set0, s))) return rc;
+    b.blk_utt = plan->s_blk_utt.as<int32_t>();
+    b.blk_set0 = plan->s_blk_set0.as<int32_t>();
+    b.n_blocks = static_cast<int64_t>(blk_utt.size());
+  } else if (use_fast && !plan->setidx_valid) {
     // frame -> first-sample index (+ edge marks): built once per offsets table, reused by later calls
     if ((rc = plan->s_setidx.ensure(sizeof(int64_t) * static_cast<size_t>(total_frames)))) return rc;
     if ((rc = plan->s_edge.ensure(sizeof(int32_t) * static_cast<size_t>(total_frames)))) return rc;
@@ -745,7 +806,7 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
   if (plan->kind == SNF_KIND_PLP) {
     const int nb = plan->o.mel.num_bins;
     if (use_fast) {
-      if ((rc = launch_fbank512(plan->fp, b, plan->s_mel.as<float>(), nb,
+      if ((rc = launch_fbank512(any_warp ? plan->fp_warp : plan->fp, b, plan->s_mel.as<float>(), nb,
                                 plan->s_energy.as<double>(), s)))
         return rc;
       if (own_stream) mark_kernel(plan, "fbank512_kernel");
@@ -765,7 +826,8 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     if (own_stream) mark_kernel(plan, "plp_tail_kernel");
   } else {
     if (use_fast) {
-      if ((rc = launch_fbank512(plan->fp, b, d_out, plan->ndims, nullptr, s))) return rc;
+      if ((rc = launch_fbank512(any_warp ? plan->fp_warp : plan->fp, b, d_out, plan->ndims, nullptr, s)))
+        return rc;
       if (own_stream) mark_kernel(plan, "fbank512_kernel");
     } else {
       if ((rc = launch_mel_features(plan->mp, b, d_out, plan->ndims, nullptr, s))) return rc;

@@ -158,6 +158,8 @@ constexpr int kMaxWaves = 16;             // wavefronts per workgroup: 8 when tw
 constexpr int kTileRow = 17;               // complex per transposed row (16 + 1 pad: conflict-free)
 constexpr int kFrameTileBytes = 16 * kTileRow * 8;  // wave-private LDS per frame (2176 B)
 constexpr int kMaxRounds = kFast512MaxRounds;  // mel bins <= 64
+constexpr int kFastHeaderFloats = 16;          // table header: the mel layout of this warp factor
+constexpr int kSetsPerBlock = 64;              // PERUTT: frame sets (of 4 frames) per workgroup
 
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -232,49 +234,107 @@ __device__ __forceinline__ void fft16(float2 (&v)[16]) {
 }  // namespace
 
 // ENERGY: 0 = no log-energy column, 1 = raw (before pre-emphasis/window), 2 = after the window
-template <int NJ, int KIND, int ENERGY, bool DITHER, bool SNIP>
+template <int NJ, int KIND, int ENERGY, bool DITHER, bool SNIP, bool PERUTT>
 __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast512Params p,
                                                                    const BatchArgs b,
                                                                    float* __restrict__ out,
                                                                    double* __restrict__ energy_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tab = reinterpret_cast<float*>(smem);
+  // PERUTT (utterances with VTLN warps): a workgroup works on a run of frame sets of ONE utterance
+  // and stages the tables of that utterance's warp factor; its mel layout comes from the table header
+  // instead of the kernel arguments.
+  int64_t pu_u = 0, pu_f0 = 0, pu_T = 0, pu_s0 = 0, pu_n = 0;
+  int pu_set0 = 0;
+  const float* __restrict__ gtab = p.tables;
+  int h_rounds = p.rounds, h_off_first = p.off_first, h_off_w = p.off_w, h_off_dct = p.off_dct,
+      h_off_lifter = p.off_lifter, h_table_floats = p.table_floats;
+  int h_maxcount[kMaxRounds], h_woff[kMaxRounds];
+#pragma unroll
+  for (int r = 0; r < kMaxRounds; ++r) {
+    h_maxcount[r] = p.mel_maxcount[r];
+    h_woff[r] = p.mel_woff[r];
+  }
+  if (PERUTT) {
+    pu_u = b.blk_utt[blockIdx.x];
+    pu_set0 = b.blk_set0[blockIdx.x];
+    pu_f0 = b.frame_offsets[pu_u];
+    pu_T = b.frame_offsets[pu_u + 1] - pu_f0;
+    pu_s0 = b.sample_offsets[pu_u];
+    pu_n = b.sample_offsets[pu_u + 1] - pu_s0;
+    gtab = p.tables + static_cast<int64_t>(b.utt_warp ? b.utt_warp[pu_u] : 0) * p.table_stride;
+    const int* __restrict__ hdr = reinterpret_cast<const int*>(gtab);
+    h_rounds = hdr[0];
+#pragma unroll
+    for (int r = 0; r < kMaxRounds; ++r) {
+      h_maxcount[r] = hdr[1 + r];
+      h_woff[r] = hdr[5 + r];
+    }
+    h_off_first = hdr[9];
+    h_off_w = hdr[10];
+    h_off_dct = hdr[11];
+    h_off_lifter = hdr[12];
+    h_table_floats = hdr[13];
+  }
   // ---- stage the tables into LDS (the only workgroup-wide barrier of the kernel) -------------------
-  for (int i = threadIdx.x; i < p.table_floats; i += blockDim.x) tab[i] = p.tables[i];
+  for (int i = threadIdx.x; i < h_table_floats; i += blockDim.x) tab[i] = gtab[i];
   __syncthreads();
   // lane-major tables (row = one lane's values, padded so that the 16 lanes of a frame hit 64
   // distinct banks with ds_read_b128): window pairs [16][16 + 2], inter-pass twiddles [16][16 + 2],
   // unpack twiddles [16][8 + 2] complex
-  const float2* __restrict__ t_win = reinterpret_cast<const float2*>(tab);
+  const float2* __restrict__ t_win = reinterpret_cast<const float2*>(tab + kFastHeaderFloats);
   const float2* __restrict__ t_tw16 = t_win + 16 * 18;
   const float2* __restrict__ t_tw512 = t_tw16 + 16 * 18;
   // per mel slot (round, lane): first tap (multiple of 4), output bin (-1: none), split flag
-  const int* __restrict__ t_first = reinterpret_cast<const int*>(tab + p.off_first);
+  const int* __restrict__ t_first = reinterpret_cast<const int*>(tab + h_off_first);
   const int* __restrict__ t_bin = t_first + 16 * kMaxRounds;
   const int* __restrict__ t_pair = t_bin + 16 * kMaxRounds;
-  const float* __restrict__ t_w = tab + p.off_w;
-  const float* __restrict__ t_dct = tab + p.off_dct;
-  const float* __restrict__ t_lifter = tab + p.off_lifter;
+  const float* __restrict__ t_w = tab + h_off_w;
+  const float* __restrict__ t_dct = tab + h_off_dct;
+  const float* __restrict__ t_lifter = tab + h_off_lifter;
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l = lane & 15, q = lane >> 4;
-  const int tab_bytes = (p.table_floats * 4 + 255) & ~255;
+  const int tab_bytes = ((PERUTT ? p.table_stride : p.table_floats) * 4 + 255) & ~255;
   char* wave_base = smem + tab_bytes + (wid * 4 + q) * kFrameTileBytes;
   float2* tile = reinterpret_cast<float2*>(wave_base);          // 16 rows x 17 complex
   // power tile aliases the frame tile: 257 floats, skewed by 16 banks for odd frames so that the
   // two frames of a 32-lane LDS group do not hit the same banks systematically
   float* ptile = reinterpret_cast<float*>(wave_base) + (q & 1) * 16;
 
-  const int64_t n_sets = (b.total_frames + 3) >> 2;
   const int n_waves = blockDim.x >> 6;
-  const int64_t set_stride = static_cast<int64_t>(gridDim.x) * n_waves;
+  // flat mode: sets of 4 consecutive global frames, grid-stride.  PERUTT: sets of 4 consecutive frames
+  // of the workgroup's utterance, kSetsPerBlock of them per workgroup.
+  int64_t n_sets = (b.total_frames + 3) >> 2;
+  int64_t set_stride = static_cast<int64_t>(gridDim.x) * n_waves;
+  if (PERUTT) {
+    const int64_t utt_sets = (pu_T + 3) >> 2;
+    n_sets = pu_set0 + kSetsPerBlock < utt_sets ? pu_set0 + kSetsPerBlock : utt_sets;
+    set_stride = n_waves;
+  }
   typedef int __attribute__((aligned(2))) int_a2;
-  const int64_t last_frame = b.total_frames - 1;
+  const int64_t last_frame = PERUTT ? pu_T - 1 : b.total_frames - 1;  // (local index when PERUTT)
+  // first sample / edge mark of (local) frame index gi, clamped to the last frame
+  auto start_of = [&](int64_t gi) -> int64_t {
+    const int64_t gc = gi < last_frame ? gi : last_frame;
+    if (!PERUTT) return b.frame_start[gc];
+    if (SNIP) return pu_s0 + gc * p.win_shift;
+    int64_t rel = gc * p.win_shift + p.win_shift / 2 - p.win_len / 2;
+    if (rel < 0) rel = 0;
+    if (rel + p.win_len > pu_n) rel = pu_n - p.win_len;
+    return pu_s0 + rel;
+  };
+  auto edge_of = [&](int64_t gi) -> int {
+    const int64_t gc = gi < last_frame ? gi : last_frame;
+    if (!PERUTT) return b.frame_edge[gc];
+    const int64_t rel = gc * p.win_shift + p.win_shift / 2 - p.win_len / 2;
+    return (rel < 0 || rel + p.win_len > pu_n) ? static_cast<int>(pu_u + 1) : 0;
+  };
   // Software pipeline over frame sets: the samples of set i+1 and the start offset of set i+2 are
   // requested while set i is being transformed, so no global-memory latency sits on the critical
   // path of a wave.  frame_start[g] (sample index of the first sample of global frame g) is built
   // once per offsets table by build_frame_start_kernel.
-  int64_t set = static_cast<int64_t>(blockIdx.x) * n_waves + wid;
+  int64_t set = PERUTT ? pu_set0 + wid : static_cast<int64_t>(blockIdx.x) * n_waves + wid;
   // NJ = 13 is the exact shape of the 25 ms / 16 kHz window (only element j = 12 can fall outside the
   // window); NJ = 16 covers every other window length that pads to 512 samples with a per-element test
   const bool in_last = 2 * (l + 16 * (NJ - 1)) < p.win_len;
@@ -288,18 +348,19 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
                       // reaches outside its utterance (reloaded with Kaldi's reflection)
   if (set < n_sets) {
     const int64_t g = set * 4 + q;
-    const int16_t* __restrict__ wp = b.wave + b.frame_start[g < last_frame ? g : last_frame];
+    const int16_t* __restrict__ wp = b.wave + start_of(g);
     const int16_t* __restrict__ wl = wp + 2 * l;
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
       raw[j] = *reinterpret_cast<const int_a2*>((NJ == 13 && j < NJ - 1) || in_window(j) ? wl + 32 * j : wp);
     const int64_t gn = (set + set_stride) * 4 + q;
-    start_next = b.frame_start[gn < last_frame ? gn : last_frame];
-    if (!SNIP) edge_next = b.frame_edge[g < last_frame ? g : last_frame];
+    start_next = start_of(gn);
+    if (!SNIP) edge_next = edge_of(g);
   }
   for (; set < n_sets; set += set_stride) {
-    const int64_t g = set * 4 + q;
-    const bool valid = g <= last_frame;
+    const int64_t gl = set * 4 + q;               // frame index (inside the utterance when PERUTT)
+    const bool valid = gl <= last_frame;
+    const int64_t g = PERUTT ? pu_f0 + gl : gl;   // global output row
     const int edge_cur = edge_next;
 
     // ---- A: DC removal, pre-emphasis, window ------------------------------------------------------
@@ -358,11 +419,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
       for (int j = 0; j < NJ; ++j)
         raw[j] = *reinterpret_cast<const int_a2*>((NJ == 13 && j < NJ - 1) || in_window(j) ? wl + 32 * j : wp);
       const int64_t gn = (set + 2 * set_stride) * 4 + q;
-      start_next = b.frame_start[gn < last_frame ? gn : last_frame];
-      if (!SNIP) {
-        const int64_t g1 = (set + set_stride) * 4 + q;
-        edge_next = b.frame_edge[g1 < last_frame ? g1 : last_frame];
-      }
+      start_next = start_of(gn);
+      if (!SNIP) edge_next = edge_of((set + set_stride) * 4 + q);
     }
     float neg_mean = 0.0f;
     if (p.remove_dc) neg_mean = -row_sum16(part) / static_cast<float>(p.win_len);
@@ -492,13 +550,13 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
 #pragma unroll
     for (int r = 0; r < kMaxRounds; ++r) {
       mbin[r] = -1;
-      if (r < p.rounds) {
+      if (r < h_rounds) {
         const int start = t_first[r * 16 + l];  // first tap rounded down to a multiple of 4
         const int m = t_bin[r * 16 + l];        // mel bin stored by this slot, or -1
         const int pair = t_pair[r * 16 + l];    // this slot and its quad neighbour share a wide bin
         // taps outside the slot's range carry zero weights and read finite filler in the tile
         float acc = 0.0f;
-        mel_groups<kMaxGroups>(t_w + p.mel_woff[r] + 4 * l, ptile + start, p.mel_maxcount[r], acc);
+        mel_groups<kMaxGroups>(t_w + h_woff[r] + 4 * l, ptile + start, h_maxcount[r], acc);
         // wide bins are split over two neighbouring lanes of the same round (the idle slots of the
         // last round would otherwise dictate the group count of the whole round)
         const float other = dpp_row_ror<0xB1>(acc);  // quad_perm [1,0,3,2]: lane l ^ 1
@@ -523,7 +581,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
       wave_lds_sync();
 #pragma unroll
       for (int r = 0; r < kMaxRounds; ++r)
-        if (r < p.rounds && mbin[r] >= 0) ptile[mbin[r]] = logmel[r];
+        if (r < h_rounds && mbin[r] >= 0) ptile[mbin[r]] = logmel[r];
       wave_lds_sync();
       float v = 0.0f;
       mel_groups<16>(t_dct + 4 * l, ptile, ((p.num_bins + 7) >> 3) << 1, v);  // num_bins <= 64
@@ -623,6 +681,7 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
   p.num_ceps = mp.num_ceps;
   p.rounds = (mp.num_bins + 15) / 16;
   blob->clear();
+  blob->resize(kFastHeaderFloats, 0.0f);  // header, filled in at the end
   // window pairs, lane-major: row l = elements l + 16 j (j < 16), 2 complex of padding
   for (int l = 0; l < 16; ++l)
     for (int j = 0; j < 18; ++j) {
@@ -767,6 +826,20 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
   for (int c = 0; c < 16; ++c)
     blob->push_back(c < static_cast<int>(lifter.size()) ? lifter[c] : 1.0f);
   p.table_floats = static_cast<int>(blob->size());
+  {  // header: what the PERUTT kernel needs to know about THIS warp factor's tables
+    int hdr[kFastHeaderFloats] = {};
+    hdr[0] = p.rounds;
+    for (int r = 0; r < kMaxRounds; ++r) {
+      hdr[1 + r] = p.mel_maxcount[r];
+      hdr[5 + r] = p.mel_woff[r];
+    }
+    hdr[9] = p.off_first;
+    hdr[10] = p.off_w;
+    hdr[11] = p.off_dct;
+    hdr[12] = p.off_lifter;
+    hdr[13] = p.table_floats;
+    std::memcpy(blob->data(), hdr, sizeof(hdr));
+  }
   *out = p;
   return SNF_OK;
 }
@@ -776,7 +849,8 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
   if (b.total_frames <= 0) return SNF_OK;
   Fast512Params q = p;
   q.out_cols = out_cols;
-  const int tab_bytes = (p.table_floats * 4 + 255) & ~255;
+  const int tab_bytes = ((b.blk_utt ? p.table_stride : p.table_floats) * 4 + 255) & ~255;
+  const bool per_utt = b.blk_utt != nullptr;
   int n_waves = 8;
   size_t lds = static_cast<size_t>(tab_bytes) + n_waves * 4 * kFrameTileBytes;
   if (2 * (lds + 512) > 160 * 1024) {  // two 8-wave workgroups do not fit: one of 16 waves
@@ -787,17 +861,24 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
   const int nj = (p.win_len + 31) / 32 == 13 ? 13 : 16;
   const int64_t n_sets = (b.total_frames + 3) / 4;
   int64_t blocks = (n_sets + n_waves - 1) / n_waves;
+  if (per_utt) blocks = b.n_blocks;
   const int64_t max_blocks = 256 * 4 * (kMaxWaves / n_waves);  // resident workgroups x grid-stride depth 4
-  if (blocks > max_blocks) blocks = max_blocks;
+  if (!per_utt && blocks > max_blocks) blocks = max_blocks;
   const dim3 grid(static_cast<unsigned>(blocks)), block(n_waves * 64);
-#define SNF_LAUNCH5(NJ_, KIND_, EN_, DI_, SN_)                                                       \
+#define SNF_LAUNCH6(NJ_, KIND_, EN_, DI_, SN_, PU_)                                                  \
   do {                                                                                              \
     if (lds > 64 * 1024)                                                                            \
       SNF_HIP_CHECK(hipFuncSetAttribute(                                                            \
-          reinterpret_cast<const void*>(fbank512_kernel<NJ_, KIND_, EN_, DI_, SN_>),                \
+          reinterpret_cast<const void*>(fbank512_kernel<NJ_, KIND_, EN_, DI_, SN_, PU_>),           \
           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                      \
-    hipLaunchKernelGGL((fbank512_kernel<NJ_, KIND_, EN_, DI_, SN_>), grid, block, lds, stream, q, b, \
-                       out, energy_out);                                                            \
+    hipLaunchKernelGGL((fbank512_kernel<NJ_, KIND_, EN_, DI_, SN_, PU_>), grid, block, lds, stream, \
+                       q, b, out, energy_out);                                                      \
+  } while (0)
+#define SNF_LAUNCH5(NJ_, KIND_, EN_, DI_, SN_)                                                       \
+  do {                                                                                              \
+    if (per_utt && KIND_ != SNF_KIND_SPECTROGRAM)                                                   \
+      SNF_LAUNCH6(NJ_, KIND_, EN_, DI_, SN_, (KIND_ != SNF_KIND_SPECTROGRAM));                      \
+    else SNF_LAUNCH6(NJ_, KIND_, EN_, DI_, SN_, false);                                             \
   } while (0)
 #define SNF_LAUNCH4(NJ_, KIND_, EN_, DI_)                                                           \
   do {                                                                                              \
@@ -827,6 +908,7 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
     else if (p.kind == SNF_KIND_SPECTROGRAM) SNF_LAUNCH(16, SNF_KIND_SPECTROGRAM);
     else SNF_LAUNCH(16, SNF_KIND_PLP);
   }
+#undef SNF_LAUNCH6
 #undef SNF_LAUNCH5
 #undef SNF_LAUNCH4
 #undef SNF_LAUNCH3

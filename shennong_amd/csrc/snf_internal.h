@@ -112,6 +112,9 @@ struct BatchArgs {
   const int32_t* utt_warp;        // [n_utts] index into the plan's warp tables, or nullptr
   const int64_t* frame_start;     // [total_frames] first sample of every frame (fast path only)
   const int32_t* frame_edge;      // [total_frames] snip_edges = false: utterance + 1 of edge frames
+  const int32_t* blk_utt;         // [n_blocks] fast path with VTLN warps: utterance of every workgroup
+  const int32_t* blk_set0;        // [n_blocks] ... and its first frame set inside that utterance
+  int64_t n_blocks;
   int64_t n_utts;
   int64_t total_frames;
 };
@@ -158,7 +161,8 @@ struct Fast512Params {
   int num_bins, num_ceps, rounds;
   int mel_maxcount[kFast512MaxRounds];
   int mel_woff[kFast512MaxRounds];
-  int table_floats;          // total floats of the packed table blob below
+  int table_floats;          // total floats of the packed table blob below (warp 1.0)
+  int table_stride;          // floats between the blobs of consecutive warp factors (VTLN)
   // one packed blob, copied to LDS at kernel start:
   //   float2 win[256] | float2 tw16[256] | float2 tw512[128] | int first[rounds*16] |
   //   int count[rounds*16] | float w[...] | float dct_t[num_bins*16] | float lifter[16]

@@ -466,3 +466,22 @@ def test_fast_kernel_centred_frames(gpu, synth_waves, cls):
     assert plan.kernel_name(1) == 'mel_features_generic_kernel'
     for w, f in zip(short, feats):
         assert_close(f.data, _oracle(proc, w), rtol=2e-4, what='short')
+
+
+@pytest.mark.parametrize('snip_edges', [True, False])
+@pytest.mark.parametrize('cls', [FilterbankProcessor, MfccProcessor, PlpProcessor])
+def test_fast_kernel_vtln(gpu, synth_waves, cls, snip_edges):
+    """utterances with VTLN warps stay on the register-resident kernel: a workgroup works on one
+    utterance and stages the mel tables of that utterance's warp factor"""
+    proc = cls(dither=0, snip_edges=snip_edges)
+    waves = list(synth_waves) + [np.zeros(100, np.int16)] if snip_edges else list(synth_waves)
+    warps = [[1.0, 0.85, 1.2, 1.07][i % 4] for i in range(len(waves))]
+    feats = proc._process_batch([Audio(w, 16000) for w in waves], vtln_warp=warps)
+    plan = _backend.get_plan(proc._build_options())
+    assert plan.kernel_name(1) == 'fbank512_kernel'
+    for w, wf, f in zip(waves, warps, feats):
+        want = _oracle(proc, w, wf)
+        assert f.shape == want.shape
+        if want.size:
+            assert_close(f.data, want, rtol=2e-4, what=f'{cls.__name__} warp {wf}')
+        assert f.properties[proc.name]['vtln_warp'] == wf
