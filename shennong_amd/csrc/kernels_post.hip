@@ -7,6 +7,8 @@
 // (plus an edge-clamped halo that stays in L2) and each output row written once.
 #include <float.h>
 
+#include <cstdlib>
+
 #include "snf_internal.h"
 
 namespace snf {
@@ -166,12 +168,130 @@ __global__ void plp_tail_kernel(const PlpParams p, const BatchArgs b,
   }
 }
 
+// Same arithmetic, same order, for the usual small shapes (num_bins <= 32, lpc_order <= 16): every
+// array has a compile-time bound and stays in registers (the generic kernel above indexes its arrays
+// at run time, i.e. from scratch memory), and the 64 mel rows of a workgroup are staged through LDS
+// with coalesced loads.
+template <int NBMAX, int ORDMAX>
+__global__ __launch_bounds__(64) void plp_tail_small_kernel(const PlpParams p, const BatchArgs b,
+                                                            const float* __restrict__ mel,
+                                                            const double* __restrict__ energy,
+                                                            float* __restrict__ out) {
+  __shared__ float rows[64 * NBMAX];
+  const int nb = p.num_bins, order = p.lpc_order, nc = p.num_ceps;
+  const int64_t g0 = static_cast<int64_t>(blockIdx.x) * 64;
+  const int64_t limit = b.total_frames * nb;
+  for (int i = threadIdx.x; i < 64 * nb; i += 64) {
+    const int64_t a = g0 * nb + i;
+    rows[i] = a < limit ? mel[a] : 1.0f;
+  }
+  __syncthreads();
+  const int64_t g = g0 + threadIdx.x;
+  if (g >= b.total_frames) return;
+  int warp_id = 0;
+  if (b.utt_warp) warp_id = b.utt_warp[find_utt(b.frame_offsets, b.n_utts, g)];
+  const float* __restrict__ eql = p.eql + warp_id * nb;
+  float m[NBMAX + 2];
+#pragma unroll
+  for (int i = 0; i < NBMAX; ++i) {
+    m[i + 1] = 0.0f;
+    if (i < nb) {
+      const float v = rows[threadIdx.x * nb + i] * eql[i];
+      m[i + 1] = powf(v, p.compress_factor);
+    }
+  }
+  m[0] = m[1];
+  {
+    float last = m[1];
+#pragma unroll
+    for (int i = 1; i <= NBMAX; ++i) if (i == nb) last = m[i];
+#pragma unroll
+    for (int i = 1; i <= NBMAX + 1; ++i) if (i == nb + 1) m[i] = last;
+  }
+  float ac[ORDMAX + 1], lpc[ORDMAX], tmp[ORDMAX], cep[ORDMAX];
+#pragma unroll
+  for (int i = 0; i <= ORDMAX; ++i) {
+    ac[i] = 0.0f;
+    if (i <= order) {
+      const float* __restrict__ basis = p.idft + i * (nb + 2);
+      float s = 0.0f;
+#pragma unroll
+      for (int j = 0; j < NBMAX + 2; ++j)
+        if (j < nb + 2) s += basis[j] * m[j];
+      ac[i] = s;
+    }
+  }
+  float E = ac[0];
+#pragma unroll
+  for (int i = 0; i < ORDMAX; ++i) lpc[i] = tmp[i] = cep[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < ORDMAX; ++i) {
+    if (i < order) {
+      float ki = ac[i + 1];
+#pragma unroll
+      for (int j = 0; j < ORDMAX; ++j)
+        if (j < i) ki += lpc[j] * ac[i - j];
+      ki = ki / E;
+      float c = 1 - ki * ki;
+      if (c < 1.0e-5f) c = 1.0e-5f;
+      E *= c;
+      tmp[i] = -ki;
+#pragma unroll
+      for (int j = 0; j < ORDMAX; ++j)
+        if (j < i) tmp[j] = lpc[j] - ki * lpc[i - j - 1];
+#pragma unroll
+      for (int j = 0; j < ORDMAX; ++j)
+        if (j <= i) lpc[j] = tmp[j];
+    }
+  }
+  const float res_f = static_cast<float>(-log(1.0 / static_cast<double>(E)));
+  const double res = fmax(static_cast<double>(res_f), DBL_EPSILON);
+#pragma unroll
+  for (int i = 0; i < ORDMAX; ++i) {
+    if (i < order) {
+      double sum = 0.0;
+#pragma unroll
+      for (int j = 0; j < ORDMAX; ++j)
+        if (j < i)
+          sum += static_cast<double>(i - j) * static_cast<double>(lpc[j]) *
+                 static_cast<double>(cep[i - j - 1]);
+      cep[i] = static_cast<float>(-static_cast<double>(lpc[i]) - sum / static_cast<double>(i + 1));
+    }
+  }
+  float* __restrict__ row = out + g * nc;
+#pragma unroll
+  for (int c = 0; c <= ORDMAX; ++c) {
+    if (c < nc) {
+      float v = static_cast<float>(res);
+#pragma unroll
+      for (int k = 1; k <= ORDMAX; ++k) if (k == c) v = cep[k - 1];
+      if (p.lifter) v *= p.lifter[c];
+      if (p.cepstral_scale != 1.0f) v *= p.cepstral_scale;
+      if (c == 0 && p.use_energy) {
+        double le = energy[g];
+        if (p.has_floor && le < p.log_energy_floor) le = p.log_energy_floor;
+        v = static_cast<float>(le);
+      }
+      int oc = c;
+      if (p.htk_compat) oc = c == 0 ? nc - 1 : c - 1;
+      row[oc] = v;
+    }
+  }
+}
+
 int launch_plp_tail(const PlpParams& p, const BatchArgs& b, const float* mel, const double* energy,
                     float* out, hipStream_t stream) {
   if (b.total_frames <= 0) return SNF_OK;
   if (p.num_bins > kMaxBins || p.lpc_order > kMaxLpc)
     return set_error(SNF_E_RUNTIME, "PLP: num_bins > 126 or lpc_order > 63 not supported");
   const int threads = 64;
+  if (p.num_bins <= 32 && p.lpc_order <= 16 && !getenv("SNF_PLP_GENERIC_TAIL")) {
+    hipLaunchKernelGGL((plp_tail_small_kernel<32, 16>),
+                       dim3(static_cast<unsigned>((b.total_frames + threads - 1) / threads)),
+                       dim3(threads), 0, stream, p, b, mel, energy, out);
+    SNF_HIP_CHECK(hipGetLastError());
+    return SNF_OK;
+  }
   hipLaunchKernelGGL(plp_tail_kernel,
                      dim3(static_cast<unsigned>((b.total_frames + threads - 1) / threads)),
                      dim3(threads), 0, stream, p, b, mel, energy, out);
