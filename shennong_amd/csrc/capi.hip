@@ -518,6 +518,8 @@ int run_pitch_device(snf_plan* plan, const int16_t* d_wave, const int64_t* sampl
     fp1[u] = t1;
   }
   const int64_t total_down = doff[n_utts];
+  int64_t max_down = 0;
+  for (int64_t u = 0; u < n_utts; ++u) max_down = std::max(max_down, doff[u + 1] - doff[u]);
   int rc;
   std::vector<int64_t> soff(sample_offsets, sample_offsets + n_utts + 1);
   std::vector<int64_t> foff(frame_offsets, frame_offsets + n_utts + 1);
@@ -543,6 +545,7 @@ int run_pitch_device(snf_plan* plan, const int16_t* d_wave, const int64_t* sampl
   b.n_utts = n_utts;
   b.total_frames = total_frames;
   b.total_down = total_down;
+  b.max_down = max_down;
   return launch_pitch(plan->pd, b, plan->s_down.as<float>(), plan->s_stats.as<double>(),
                       plan->s_bp.as<int16_t>(), plan->s_states.as<int32_t>(), plan->s_mel.as<float>(),
                       d_out, s);

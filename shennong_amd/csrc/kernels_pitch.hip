@@ -52,10 +52,11 @@ constexpr int kTrackThreads = 512;
 // ---- 1. LinearResample ---------------------------------------------------------------------------
 __global__ void pitch_resample_kernel(const PitchDevTables t, const PitchBatch b,
                                       float* __restrict__ down) {
-  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (idx >= b.total_down) return;
-  const int64_t u = find_utt(b.down_offsets, b.n_utts, idx);
-  const int64_t k = idx - b.down_offsets[u];
+  // blockIdx.y = utterance (no per-thread search), blockIdx.x = 256-sample chunk of its output
+  const int64_t u = blockIdx.y;
+  const int64_t d0 = b.down_offsets[u], nd = b.down_offsets[u + 1] - d0;
+  const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (k >= nd) return;
   const int64_t s0 = b.sample_offsets[u], n = b.sample_offsets[u + 1] - s0;
   const int16_t* __restrict__ w = b.wave + s0;
   const int64_t unit = k / t.rs_out_unit;
@@ -68,7 +69,7 @@ __global__ void pitch_resample_kernel(const PitchDevTables t, const PitchBatch b
     const int64_t j = first_in + i;
     if (j >= 0 && j < n) s += wt[i] * static_cast<float>(w[j]);
   }
-  down[idx] = s;
+  down[d0 + k] = s;
 }
 
 // ---- 2. signal statistics for the NCCF ballast -----------------------------------------------------
@@ -867,10 +868,18 @@ int launch_pitch(const PitchDevTables& t, const PitchBatch& b, float* down, doub
   if (t.num_states > 32767) return set_error(SNF_E_RUNTIME, "too many pitch states (delta_pitch too small)");
   if (b.total_down > 0) {
     const int threads = 256;
-    hipLaunchKernelGGL(pitch_resample_kernel,
-                       dim3(static_cast<unsigned>((b.total_down + threads - 1) / threads)),
-                       dim3(threads), 0, stream, t, b, down);
-    SNF_HIP_CHECK(hipGetLastError());
+    // grid.y is limited to 65535: utterances are launched in slices
+    for (int64_t u0 = 0; u0 < b.n_utts; u0 += 65535) {
+      PitchBatch bs = b;
+      bs.sample_offsets = b.sample_offsets + u0;
+      bs.down_offsets = b.down_offsets + u0;
+      const int64_t nu = b.n_utts - u0 < 65535 ? b.n_utts - u0 : 65535;
+      hipLaunchKernelGGL(pitch_resample_kernel,
+                         dim3(static_cast<unsigned>((b.max_down + threads - 1) / threads),
+                              static_cast<unsigned>(nu)),
+                         dim3(threads), 0, stream, t, bs, down);
+      SNF_HIP_CHECK(hipGetLastError());
+    }
   }
   hipLaunchKernelGGL(pitch_stats_kernel, dim3(static_cast<unsigned>(b.n_utts)), dim3(256), 0, stream,
                      b, down, stats);

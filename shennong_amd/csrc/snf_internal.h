@@ -202,6 +202,7 @@ struct PitchBatch {
   const int64_t* down_phase1;     // [n_utts] samples available before the flush
   const int64_t* frames_phase1;   // [n_utts] frames processed before the flush
   int64_t n_utts, total_frames, total_down;
+  int64_t max_down;               // longest downsampled utterance
 };
 // resample -> signal statistics -> fused NCCF + Viterbi per utterance -> traceback + POV output.
 // `backptr` is [total_frames, num_states] int16, `states` [total_frames] int32, `pov_nccf`
