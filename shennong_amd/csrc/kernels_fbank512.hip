@@ -1,5 +1,6 @@
-// Register-resident fused filterbank / MFCC kernel for the headline configuration
-// (padded frame = 512 samples: 25 ms @ 16 kHz, snip_edges, no VTLN warp) on gfx950.
+// Register-resident fused spectrogram / filterbank / MFCC / PLP-mel kernel for every configuration
+// whose frames pad to 512 samples (16-32 ms windows at 16 kHz; the 25 ms headline shape has its own
+// instantiation), both snip_edges modes, dither, per-utterance VTLN warps, on gfx950.
 //
 // Mapping (wave64 = 4 frames x 16 lanes; lane l of a frame, complex packing z[n] = x[2n] + i x[2n+1]):
 //   A  load: lane l reads samples of z[l + 16 j], j < NJ straight from HBM/L2 (int16 pairs, one dword
@@ -11,9 +12,9 @@
 //   D  real-FFT unpack + power: bins k and 256-k are paired; the partner Z[256-k] comes through LDS
 //      (half a tile), twiddles W512^k from an LDS table.  Scaled by 4 (the 1/2 factors of the unpack
 //      are folded into the mel weights as an exact power of two).
-//   E  power spectrum to a wave-private LDS tile; F: sparse mel filterbank (each lane owns bins
-//      l, l+16, l+32..), log, coalesced 64-byte row segments to HBM.  MFCC adds the 13x23 DCT-II and
-//      lifter from LDS tables.
+//   E  power spectrum to a wave-private LDS tile; F: sparse mel filterbank (one (round, lane) slot per
+//      bin, the widest bins split over two neighbouring lanes), log, row segments to HBM.  MFCC adds
+//      the 13x23 DCT-II and lifter from LDS tables.
 // Nothing but the int16 samples and the float32 features ever touches HBM; no workgroup barrier.
 //
 // The dense contractions (mel x frame, DCT-II) are NOT mapped to MFMA here: the mel matrix is 95 %

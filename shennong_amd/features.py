@@ -5,6 +5,7 @@ Mirrors reference shennong/features.py:62-437 (data [nframes, ndims], times [nfr
 per-frame Python loop in ``validate`` (features.py:342) is replaced by a vectorised check.
 """
 
+import collections
 import copy
 
 import numpy as np
@@ -197,8 +198,26 @@ class Features:
 
 
 class FeaturesCollection(dict):
-    """A dict of Features indexed by utterance name (return type of process_all;
-    reference shennong/features_collection.py:81 minus the on-disk serializers)"""
+    """A dict of Features indexed by utterance name (mirror of reference
+    shennong/features_collection.py:80-280)"""
+    @classmethod
+    def load(cls, filename, serializer=None, log=None):
+        """Loads a FeaturesCollection from a `filename`; the serializer is guessed from the file
+        extension when not specified (see shennong_amd.serializers)"""
+        from shennong_amd.logger import get_logger
+        from shennong_amd.serializers import get_serializer
+        log = log or get_logger('serializer', 'warning')
+        return get_serializer(cls, filename, log, serializer).load()
+
+    def save(self, filename, serializer=None, with_properties=True, log=None, **kwargs):
+        """Saves a FeaturesCollection to a `filename` (`compress` for numpy / matlab, `scp` for
+        kaldi); raises IOError if the file already exists"""
+        from shennong_amd.logger import get_logger
+        from shennong_amd.serializers import get_serializer
+        log = log or get_logger('serializer', 'warning')
+        get_serializer(self.__class__, filename, log, serializer).save(
+            self, with_properties=with_properties, **kwargs)
+
     def is_valid(self):
         return all(f.is_valid() for f in self.values())
 
@@ -207,3 +226,34 @@ class FeaturesCollection(dict):
             return False
         return all(
             self[k].is_close(other[k], rtol=rtol, atol=atol) for k in self)
+
+    def partition(self, index):
+        """Returns a partition of the collection as a dict of FeaturesCollection (e.g. one per
+        speaker); `index` maps every item of the collection to its sub-collection"""
+        undefined_utts = set(self.keys()).difference(index.keys())
+        if undefined_utts:
+            raise ValueError(
+                'following items are not defined in the partition index: {}'
+                .format(', '.join(sorted(undefined_utts))))
+        reverse_index = collections.defaultdict(list)
+        for key, value in index.items():
+            reverse_index[value].append(key)
+        return {k: FeaturesCollection({item: self[item] for item in items})
+                for k, items in reverse_index.items()}
+
+    def trim(self, vad):
+        """Returns a new FeaturesCollection where each features has been trimmed with the
+        corresponding boolean VAD array"""
+        if vad.keys() != self.keys():
+            raise ValueError('Vad keys are different from this keys.')
+        for key in vad.keys():
+            if vad[key].dtype != np.dtype('bool'):
+                raise ValueError('Vad arrays must be arrays of bool.')
+            if vad[key].shape[0] != self[key].nframes:
+                raise ValueError(
+                    'Vad arrays length must be equal to the number of frames.')
+        return FeaturesCollection({
+            k: Features(
+                self[k].data[vad[k]],
+                self[k].times[vad[k]],
+                properties=self[k].properties) for k in self.keys()})

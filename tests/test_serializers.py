@@ -1,0 +1,227 @@
+"""Serializers: the reference's test/test_serializers.py re-expressed against
+shennong_amd.serializers.  Host-only: the features are built from a fixed random matrix shaped like
+the MFCCs of test.wav, no device call."""
+
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from shennong_amd import Features, FeaturesCollection
+from shennong_amd import serializers
+from shennong_amd.logger import get_logger
+from shennong_amd.processor import MfccProcessor
+
+log = get_logger('test', 'info')
+
+SERIALIZERS = [
+    serializers.NumpySerializer, serializers.MatlabSerializer, serializers.PickleSerializer,
+    serializers.KaldiSerializer, serializers.CsvSerializer]
+
+
+@pytest.fixture(scope='module')
+def mfcc():
+    proc = MfccProcessor()
+    data = np.random.default_rng(0).standard_normal((140, 13)).astype(np.float32)
+    return Features(data, proc.times(140), properties=proc.get_properties(vtln_warp=1.0))
+
+
+@pytest.fixture()
+def mfcc_col(mfcc):
+    return FeaturesCollection(mfcc=mfcc)
+
+
+def _name(serializer):
+    return 'feats.ark' if serializer is serializers.KaldiSerializer else 'feats'
+
+
+@pytest.mark.parametrize('name', serializers.supported_serializers().keys())
+def test_get_serializer_byname(name):
+    filename = 'foo.file'
+    if name == 'kaldi':
+        with pytest.raises(ValueError) as err:
+            serializers.get_serializer(FeaturesCollection, 'foo.file', log, name)
+        assert 'the file extension must be ".ark", it is ".file"' in str(err.value)
+        filename = 'foo.ark'
+    h = serializers.get_serializer(FeaturesCollection, filename, log, name)
+    assert not os.path.isfile(filename)
+    assert isinstance(h, serializers.supported_serializers()[name])
+
+
+@pytest.mark.parametrize('ext', serializers.supported_extensions().keys())
+def test_get_serializer_byext(ext):
+    h = serializers.get_serializer(FeaturesCollection, 'foo' + ext, log, None)
+    assert isinstance(h, serializers.supported_extensions()[ext])
+
+
+def test_get_serializer_bad():
+    with pytest.raises(ValueError) as err:
+        serializers.get_serializer(int, 'foo', log, None)
+    assert 'must be shennong.features.FeaturesCollection' in str(err.value)
+    with pytest.raises(ValueError) as err:
+        serializers.get_serializer(FeaturesCollection, 'foo.spam', log, None)
+    assert 'invalid extension .spam' in str(err.value)
+    with pytest.raises(ValueError) as err:
+        serializers.get_serializer(FeaturesCollection, 'foo.spam', log, 'spam')
+    assert 'invalid serializer spam' in str(err.value)
+    with pytest.raises(ValueError) as err:   # h5features needs a binding this backend does not ship
+        serializers.get_serializer(FeaturesCollection, 'foo.h5f', log, None)
+    assert 'invalid extension .h5f' in str(err.value)
+
+
+def test_load_save_errors(tmpdir, mfcc, mfcc_col):
+    h = serializers.get_serializer(FeaturesCollection, 'foo.npz', log, None)
+    with pytest.raises(IOError) as err:
+        h.load()
+    assert 'file not found' in str(err.value)
+    f = str(tmpdir.join('foo.npz'))
+    open(f, 'w').write('something')
+    h = serializers.get_serializer(FeaturesCollection, f, log, None)
+    with pytest.raises(IOError) as err:
+        h.save(mfcc_col)
+    assert 'file already exists' in str(err.value)
+    h = serializers.get_serializer(FeaturesCollection, str(tmpdir.join('bar.npz')), log, None)
+    with pytest.raises(ValueError) as err:
+        h.save(mfcc)
+    assert 'features must be FeaturesCollection but are Features' in str(err.value)
+    feats = FeaturesCollection(mfcc=Features(data=mfcc.data, times=0, validate=False))
+    with pytest.raises(ValueError) as err:
+        h.save(feats)
+    assert 'features are not valid' in str(err.value)
+
+
+@pytest.mark.parametrize('serializer', SERIALIZERS)
+def test_simple(mfcc_col, serializer, tmpdir):
+    tmpfile = str(tmpdir.join(_name(serializer)))
+    serializer(mfcc_col.__class__, tmpfile, log).save(mfcc_col)
+    assert os.path.exists(tmpfile)
+    mfcc_col2 = serializer(mfcc_col.__class__, tmpfile, log).load()
+    assert mfcc_col2 == mfcc_col
+    assert mfcc_col2['mfcc'].dtype == np.float32
+    assert mfcc_col2['mfcc'].properties['pipeline'] == [{'name': 'mfcc', 'columns': [0, 12]}]
+
+
+@pytest.mark.parametrize('serializer', SERIALIZERS)
+def test_times_1d(serializer, tmpdir):
+    tmpfile = str(tmpdir.join(_name(serializer)))
+    times = MfccProcessor().times(10)[:, 1]
+    assert times.shape == (10,)
+    col = FeaturesCollection(mfcc=Features(np.random.random((10, 5)), times))
+    serializer(col.__class__, tmpfile, log).save(col)
+    assert serializer(col.__class__, tmpfile, log).load() == col
+
+
+@pytest.mark.parametrize('serializer', SERIALIZERS)
+def test_utf8(mfcc, serializer, tmpdir):
+    props = dict(mfcc.properties)
+    props['comments'] = '使用人口について正確な統計はないが、日本国'
+    feats = FeaturesCollection()
+    feats['æðÐ'] = Features(mfcc.data, mfcc.times, props)
+    h = serializer(feats.__class__, str(tmpdir.join(_name(serializer))), log)
+    h.save(feats)
+    assert h.load() == feats
+
+
+@pytest.mark.parametrize('serializer', SERIALIZERS)
+def test_heterogeneous(mfcc, serializer, tmpdir):
+    col = FeaturesCollection(mfcc32=mfcc, mfcc64=mfcc.copy(dtype=np.float64))
+    h = serializer(col.__class__, str(tmpdir.join(_name(serializer))), log)
+    h.save(col)
+    col2 = h.load()
+    assert col2 == col
+    assert col2['mfcc64'].dtype == np.float64 and col2['mfcc32'].dtype == np.float32
+
+
+@pytest.mark.parametrize('scp', [True, False])
+def test_kaldiserializer(mfcc_col, tmpdir, scp):
+    mfcc_col.save(str(tmpdir.join('foo.ark')), scp=scp)
+    for f in ('foo.ark', 'foo.times.ark', 'foo.properties.json'):
+        assert os.path.isfile(str(tmpdir.join(f)))
+    if scp:
+        lines = open(str(tmpdir.join('foo.scp'))).read().split('\n')
+        assert lines[0].startswith('mfcc ') and ':' in lines[0]
+        key, where = lines[0].split(' ')
+        ark, offset = where.rsplit(':', 1)
+        blob = open(ark, 'rb').read()
+        assert blob[int(offset):int(offset) + 5] == b'\0BDM '   # the scp points at the binary marker
+        assert os.path.isfile(str(tmpdir.join('foo.times.scp')))
+    assert FeaturesCollection.load(str(tmpdir.join('foo.ark'))) == mfcc_col
+
+
+def test_kaldiserializer_baditems(tmpdir, mfcc_col):
+    col2 = FeaturesCollection(one=mfcc_col['mfcc'], two=mfcc_col['mfcc'])
+    mfcc_col.save(str(tmpdir.join('one.ark')))
+    col2.save(str(tmpdir.join('two.ark')))
+    os.remove(str(tmpdir.join('two.times.ark')))
+    shutil.copyfile(str(tmpdir.join('one.times.ark')), str(tmpdir.join('two.times.ark')))
+    with pytest.raises(ValueError) as err:
+        FeaturesCollection.load(str(tmpdir.join('two.ark')))
+    assert 'items differ in data and times' in str(err.value)
+    os.remove(str(tmpdir.join('one.properties.json')))
+    shutil.copyfile(str(tmpdir.join('two.properties.json')), str(tmpdir.join('one.properties.json')))
+    with pytest.raises(ValueError) as err:
+        FeaturesCollection.load(str(tmpdir.join('one.ark')))
+    assert 'items differ in data and properties' in str(err.value)
+
+
+@pytest.mark.parametrize('missing', ['foo.ark', 'foo.times.ark', 'foo.properties.json'])
+def test_kaldiserializer_badfile(tmpdir, mfcc_col, missing):
+    filename = str(tmpdir.join('foo.ark'))
+    mfcc_col.save(filename)
+    os.remove(str(tmpdir.join(missing)))
+    with pytest.raises(IOError) as err:
+        FeaturesCollection.load(filename)
+    assert 'file not found: {}'.format(str(tmpdir.join(missing))) in str(err.value)
+
+
+def test_csvserializer_bad(tmpdir, mfcc_col):
+    np.savetxt(str(tmpdir.join('foo.csv')), mfcc_col['mfcc'].data)
+    with pytest.raises(ValueError) as err:
+        FeaturesCollection.load(str(tmpdir), serializer='csv')
+    assert 'failed to parse header' in str(err.value)
+    np.savetxt(str(tmpdir.join('foo.csv')), mfcc_col['mfcc'].data, header='data_dtype',
+               comments='# ')
+    with pytest.raises(ValueError) as err:
+        FeaturesCollection.load(str(tmpdir), serializer='csv')
+    assert 'failed to parse header' in str(err.value)
+    with pytest.raises(OSError) as err:
+        FeaturesCollection.load(str(tmpdir.join('notexistingfolder')))
+    assert 'directory not found' in str(err.value)
+    with pytest.raises(IOError) as err:
+        mfcc_col.save(str(tmpdir))
+    assert 'already exists: ' in str(err.value)
+
+
+@pytest.mark.parametrize('serializer, with_props', [
+    (s, p) for s in serializers.supported_serializers() for p in (True, False)])
+def test_no_properties(tmpdir, mfcc_col, serializer, with_props):
+    filename = str(tmpdir.join('feats.ark' if serializer == 'kaldi' else 'feats'))
+    mfcc_col.save(filename, serializer=serializer, with_properties=with_props)
+    mfcc_col2 = FeaturesCollection.load(filename, serializer=serializer)
+    if with_props:
+        assert mfcc_col == mfcc_col2
+    else:
+        assert mfcc_col != mfcc_col2
+        for name in mfcc_col:
+            assert mfcc_col2[name].properties == {}
+            assert np.all(mfcc_col[name].data == mfcc_col2[name].data)
+            assert np.all(mfcc_col[name].times == mfcc_col2[name].times)
+
+
+def test_partition_and_trim(mfcc):
+    """reference features_collection.py partition / trim"""
+    col = FeaturesCollection(a=mfcc, b=mfcc.copy(), c=mfcc.copy())
+    parts = col.partition({'a': 's1', 'b': 's2', 'c': 's1'})
+    assert sorted(parts) == ['s1', 's2'] and sorted(parts['s1']) == ['a', 'c']
+    with pytest.raises(ValueError) as err:
+        col.partition({'a': 's1'})
+    assert 'not defined in the partition index' in str(err.value)
+    vad = {k: np.arange(140) % 2 == 0 for k in col}
+    trimmed = col.trim(vad)
+    assert all(t.shape == (70, 13) for t in trimmed.values())
+    assert np.array_equal(trimmed['a'].data, mfcc.data[::2])
+    with pytest.raises(ValueError):
+        col.trim({'a': vad['a']})
+    with pytest.raises(ValueError):
+        col.trim({k: v.astype(int) for k, v in vad.items()})
