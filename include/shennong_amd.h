@@ -271,6 +271,26 @@ int snf_cmvn_accumulate(snf_plan* plan, const float* in, int32_t cols, const int
 int snf_cmvn_apply(snf_plan* plan, const float* in, int32_t cols, const int64_t* frame_offsets,
                    int64_t n_utts, const double* stats, const int32_t* group, int32_t n_groups,
                    int32_t norm_vars, int32_t reverse, float* out);
+/* the same with the feature blocks (and the optional per-frame weights) resident in HBM; offsets,
+ * group ids and statistics stay on the host */
+int snf_cmvn_accumulate_device(snf_plan* plan, const float* d_in, int32_t cols,
+                               const int64_t* frame_offsets, int64_t n_utts, const float* d_weights,
+                               const int32_t* group, int32_t n_groups, double* stats);
+int snf_cmvn_apply_device(snf_plan* plan, const float* d_in, int32_t cols,
+                          const int64_t* frame_offsets, int64_t n_utts, const double* stats,
+                          const int32_t* group, int32_t n_groups, int32_t norm_vars, int32_t reverse,
+                          float* d_out);
+
+/*
+ * Column-wise concatenation of two device-resident feature blocks, utterance by utterance (reference
+ * shennong/features.py:386-437 `Features.concatenate`, used by pipeline.py:636-641 to append the pitch
+ * columns): out[u] = [a[u][:rows], b[u][:rows]] with rows = offsets_out[u+1] - offsets_out[u] (the
+ * caller trims the longer side within its tolerance).  All offsets tables are host arrays [n_utts+1].
+ */
+int snf_concat_columns_device(int device_id, const float* d_a, int32_t cols_a,
+                              const int64_t* offsets_a, const float* d_b, int32_t cols_b,
+                              const int64_t* offsets_b, int64_t n_utts, float* d_out,
+                              const int64_t* offsets_out);
 
 /* ---- device memory + timing (so hosts without torch can keep data resident in HBM) ---------- */
 int snf_malloc(void** dptr, uint64_t bytes);

@@ -29,7 +29,8 @@ EXPORTS = [
     'snf_plan_create', 'snf_plan_destroy', 'snf_plan_ndims',
     'snf_plan_num_frames', 'snf_plan_run_batch', 'snf_plan_run_batch_device',
     'snf_post_ndims', 'snf_post_run_batch', 'snf_post_run_batch_device',
-    'snf_cmvn_accumulate', 'snf_cmvn_apply',
+    'snf_cmvn_accumulate', 'snf_cmvn_apply', 'snf_cmvn_accumulate_device',
+    'snf_cmvn_apply_device', 'snf_concat_columns_device',
     'snf_malloc', 'snf_free', 'snf_memcpy_h2d', 'snf_memcpy_d2h', 'snf_memset',
     'snf_plan_last_kernel_ms', 'snf_plan_kernel_name']
 
@@ -85,6 +86,12 @@ def lib():
             vp, pf, i32, pi64, i64, pf, pi32, i32, pf64]
         L.snf_cmvn_apply.argtypes = [
             vp, pf, i32, pi64, i64, pf64, pi32, i32, i32, i32, pf]
+        L.snf_cmvn_accumulate_device.argtypes = [
+            vp, vp, i32, pi64, i64, vp, pi32, i32, pf64]
+        L.snf_cmvn_apply_device.argtypes = [
+            vp, vp, i32, pi64, i64, pf64, pi32, i32, i32, i32, vp]
+        L.snf_concat_columns_device.argtypes = [
+            i32, vp, i32, pi64, vp, i32, pi64, i64, vp, pi64]
         L.snf_malloc.argtypes = [C.POINTER(vp), C.c_uint64]
         L.snf_free.argtypes = [vp]
         L.snf_memcpy_h2d.argtypes = [vp, vp, C.c_uint64]
@@ -330,6 +337,28 @@ class Plan:
             return [out]
         return [out[foff[u]:foff[u + 1]].copy() for u in range(n)]
 
+    def cmvn_accumulate_device(self, d_in, cols, foff, stats, d_weights=None, groups=None):
+        """device-resident `cmvn_accumulate` (d_in / d_weights are device pointers)"""
+        n = foff.shape[0] - 1
+        g = None if groups is None else np.ascontiguousarray(groups, np.int32)
+        check(lib().snf_cmvn_accumulate_device(
+            self.handle, C.c_void_p(d_in), cols, foff.ctypes.data_as(C.POINTER(C.c_int64)), n,
+            C.c_void_p(d_weights) if d_weights else None,
+            g.ctypes.data_as(C.POINTER(C.c_int32)) if g is not None else None,
+            stats.shape[0], stats.ctypes.data_as(C.POINTER(C.c_double))))
+        return stats
+
+    def cmvn_apply_device(self, d_in, cols, foff, stats, d_out, groups=None, norm_vars=True,
+                          reverse=False):
+        n = foff.shape[0] - 1
+        stats = np.ascontiguousarray(stats, dtype=np.float64)
+        g = None if groups is None else np.ascontiguousarray(groups, np.int32)
+        check(lib().snf_cmvn_apply_device(
+            self.handle, C.c_void_p(d_in), cols, foff.ctypes.data_as(C.POINTER(C.c_int64)), n,
+            stats.ctypes.data_as(C.POINTER(C.c_double)),
+            g.ctypes.data_as(C.POINTER(C.c_int32)) if g is not None else None,
+            stats.shape[0], int(bool(norm_vars)), int(bool(reverse)), C.c_void_p(d_out)))
+
     # -- device-resident variants (benchmark / pipelines that keep data in HBM) --
     def run_device(self, d_wave, soff, foff, d_out, vtln_warps=None, stream=None):
         n = soff.shape[0] - 1
@@ -350,6 +379,16 @@ class Plan:
             self.handle, C.c_void_p(d_in), in_cols,
             foff.ctypes.data_as(C.POINTER(C.c_int64)), n, C.c_void_p(d_out),
             C.c_void_p(stream) if stream else None))
+
+
+def concat_columns_device(d_a, cols_a, off_a, d_b, cols_b, off_b, d_out, off_out, device=None):
+    """out[u] = [a[u][:rows], b[u][:rows]] on the device (see include/shennong_amd.h)"""
+    n = off_a.shape[0] - 1
+    p64 = C.POINTER(C.c_int64)
+    check(lib().snf_concat_columns_device(
+        _DEVICE if device is None else int(device), C.c_void_p(d_a), cols_a,
+        off_a.ctypes.data_as(p64), C.c_void_p(d_b), cols_b, off_b.ctypes.data_as(p64), n,
+        C.c_void_p(d_out), off_out.ctypes.data_as(p64)))
 
 
 def get_plan(opts, device=None):

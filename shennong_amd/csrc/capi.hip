@@ -987,9 +987,9 @@ int cmvn_check(const snf_plan* plan, int32_t cols, const int64_t* frame_offsets,
 }
 }  // namespace
 
-int snf_cmvn_accumulate(snf_plan* plan, const float* in, int32_t cols, const int64_t* frame_offsets,
-                        int64_t n_utts, const float* weights, const int32_t* group,
-                        int32_t n_groups, double* stats) {
+int snf_cmvn_accumulate_device(snf_plan* plan, const float* d_in, int32_t cols,
+                               const int64_t* frame_offsets, int64_t n_utts, const float* d_weights,
+                               const int32_t* group, int32_t n_groups, double* stats) {
   int rc = cmvn_check(plan, cols, frame_offsets, n_utts, group, n_groups);
   if (rc) return rc;
   if (n_utts == 0) return SNF_OK;
@@ -998,24 +998,14 @@ int snf_cmvn_accumulate(snf_plan* plan, const float* in, int32_t cols, const int
   if ((rc = guard_device(plan))) return rc;
   const int64_t total_frames = frame_offsets[n_utts];
   if (total_frames == 0) return SNF_OK;
-  if (!in) return set_error(SNF_E_INVALID, "null input");
+  if (!d_in) return set_error(SNF_E_INVALID, "null input");
   hipStream_t s = plan->stream;
   const size_t blk = 2 * static_cast<size_t>(cols + 1);
-  if ((rc = plan->s_in.ensure(sizeof(float) * static_cast<size_t>(total_frames) * cols))) return rc;
   if ((rc = plan->s_stats.ensure(sizeof(double) * blk * static_cast<size_t>(n_utts)))) return rc;
-  SNF_HIP_CHECK(hipMemcpyAsync(plan->s_in.p, in, sizeof(float) * total_frames * cols,
-                               hipMemcpyHostToDevice, s));
-  const float* d_w = nullptr;
-  if (weights) {
-    if ((rc = plan->s_energy.ensure(sizeof(float) * static_cast<size_t>(total_frames)))) return rc;
-    SNF_HIP_CHECK(hipMemcpyAsync(plan->s_energy.p, weights, sizeof(float) * total_frames,
-                                 hipMemcpyHostToDevice, s));
-    d_w = plan->s_energy.as<float>();
-  }
   std::vector<int64_t> foff(frame_offsets, frame_offsets + n_utts + 1);
   if ((rc = plan->s_foff.upload(foff, s))) return rc;
   begin_timing(plan);
-  if ((rc = launch_cmvn_stats(plan->s_in.as<float>(), cols, plan->s_foff.as<int64_t>(), d_w, n_utts,
+  if ((rc = launch_cmvn_stats(d_in, cols, plan->s_foff.as<int64_t>(), d_weights, n_utts,
                               plan->s_stats.as<double>(), s)))
     return rc;
   mark_kernel(plan, "cmvn_stats_kernel");
@@ -1032,9 +1022,37 @@ int snf_cmvn_accumulate(snf_plan* plan, const float* in, int32_t cols, const int
   return SNF_OK;
 }
 
-int snf_cmvn_apply(snf_plan* plan, const float* in, int32_t cols, const int64_t* frame_offsets,
-                   int64_t n_utts, const double* stats, const int32_t* group, int32_t n_groups,
-                   int32_t norm_vars, int32_t reverse, float* out) {
+int snf_cmvn_accumulate(snf_plan* plan, const float* in, int32_t cols, const int64_t* frame_offsets,
+                        int64_t n_utts, const float* weights, const int32_t* group,
+                        int32_t n_groups, double* stats) {
+  int rc = cmvn_check(plan, cols, frame_offsets, n_utts, group, n_groups);
+  if (rc) return rc;
+  if (n_utts == 0) return SNF_OK;
+  const int64_t total_frames = frame_offsets[n_utts];
+  if (total_frames == 0) return SNF_OK;
+  if (!in) return set_error(SNF_E_INVALID, "null input");
+  const float *d_in, *d_w = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(plan->mu);
+    if ((rc = guard_device(plan))) return rc;
+    if ((rc = plan->s_in.ensure(sizeof(float) * static_cast<size_t>(total_frames) * cols))) return rc;
+    SNF_HIP_CHECK(hipMemcpy(plan->s_in.p, in, sizeof(float) * total_frames * cols,
+                            hipMemcpyHostToDevice));
+    d_in = plan->s_in.as<float>();
+    if (weights) {
+      if ((rc = plan->s_energy.ensure(sizeof(float) * static_cast<size_t>(total_frames)))) return rc;
+      SNF_HIP_CHECK(hipMemcpy(plan->s_energy.p, weights, sizeof(float) * total_frames,
+                              hipMemcpyHostToDevice));
+      d_w = plan->s_energy.as<float>();
+    }
+  }
+  return snf_cmvn_accumulate_device(plan, d_in, cols, frame_offsets, n_utts, d_w, group, n_groups, stats);
+}
+
+int snf_cmvn_apply_device(snf_plan* plan, const float* d_in, int32_t cols,
+                          const int64_t* frame_offsets, int64_t n_utts, const double* stats,
+                          const int32_t* group, int32_t n_groups, int32_t norm_vars, int32_t reverse,
+                          float* d_out) {
   int rc = cmvn_check(plan, cols, frame_offsets, n_utts, group, n_groups);
   if (rc) return rc;
   if (n_utts == 0) return SNF_OK;
@@ -1088,12 +1106,8 @@ int snf_cmvn_apply(snf_plan* plan, const float* in, int32_t cols, const int64_t*
   if ((rc = guard_device(plan))) return rc;
   const int64_t total_frames = frame_offsets[n_utts];
   if (total_frames == 0) return SNF_OK;
-  if (!in || !out) return set_error(SNF_E_INVALID, "null buffer");
+  if (!d_in || !d_out) return set_error(SNF_E_INVALID, "null buffer");
   hipStream_t s = plan->stream;
-  const size_t bytes = sizeof(float) * static_cast<size_t>(total_frames) * cols;
-  if ((rc = plan->s_in.ensure(bytes))) return rc;
-  if ((rc = plan->s_out.ensure(bytes))) return rc;
-  SNF_HIP_CHECK(hipMemcpyAsync(plan->s_in.p, in, bytes, hipMemcpyHostToDevice, s));
   std::vector<int64_t> foff(frame_offsets, frame_offsets + n_utts + 1);
   if ((rc = plan->s_foff.upload(foff, s))) return rc;
   if ((rc = plan->s_mel.upload(norm, s))) return rc;
@@ -1104,14 +1118,76 @@ int snf_cmvn_apply(snf_plan* plan, const float* in, int32_t cols, const int64_t*
     d_group = plan->s_uwarp.as<int32_t>();
   }
   begin_timing(plan);
-  if ((rc = launch_cmvn_apply(plan->s_in.as<float>(), cols, plan->s_foff.as<int64_t>(), n_utts,
-                              total_frames, d_group, plan->s_mel.as<float>(), norm_vars ? 1 : 0,
-                              plan->s_out.as<float>(), s)))
+  if ((rc = launch_cmvn_apply(d_in, cols, plan->s_foff.as<int64_t>(), n_utts, total_frames, d_group,
+                              plan->s_mel.as<float>(), norm_vars ? 1 : 0, d_out, s)))
     return rc;
   mark_kernel(plan, "cmvn_apply_kernel");
-  SNF_HIP_CHECK(hipMemcpyAsync(out, plan->s_out.p, bytes, hipMemcpyDeviceToHost, s));
   SNF_HIP_CHECK(hipStreamSynchronize(s));
   return SNF_OK;
+}
+
+int snf_cmvn_apply(snf_plan* plan, const float* in, int32_t cols, const int64_t* frame_offsets,
+                   int64_t n_utts, const double* stats, const int32_t* group, int32_t n_groups,
+                   int32_t norm_vars, int32_t reverse, float* out) {
+  int rc = cmvn_check(plan, cols, frame_offsets, n_utts, group, n_groups);
+  if (rc) return rc;
+  if (n_utts == 0) return SNF_OK;
+  const int64_t total_frames = frame_offsets[n_utts];
+  if (total_frames == 0) return SNF_OK;
+  if (!in || !out) return set_error(SNF_E_INVALID, "null buffer");
+  const size_t bytes = sizeof(float) * static_cast<size_t>(total_frames) * cols;
+  float *d_in, *d_out;
+  {
+    std::lock_guard<std::mutex> lock(plan->mu);
+    if ((rc = guard_device(plan))) return rc;
+    if ((rc = plan->s_in.ensure(bytes))) return rc;
+    if ((rc = plan->s_out.ensure(bytes))) return rc;
+    SNF_HIP_CHECK(hipMemcpy(plan->s_in.p, in, bytes, hipMemcpyHostToDevice));
+    d_in = plan->s_in.as<float>();
+    d_out = plan->s_out.as<float>();
+  }
+  rc = snf_cmvn_apply_device(plan, d_in, cols, frame_offsets, n_utts, stats, group, n_groups, norm_vars,
+                             reverse, d_out);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(plan->mu);
+  SNF_HIP_CHECK(hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost));
+  return SNF_OK;
+}
+
+int snf_concat_columns_device(int device_id, const float* d_a, int32_t cols_a,
+                              const int64_t* offsets_a, const float* d_b, int32_t cols_b,
+                              const int64_t* offsets_b, int64_t n_utts, float* d_out,
+                              const int64_t* offsets_out) {
+  if (n_utts < 0) return set_error(SNF_E_INVALID, "n_utts < 0");
+  if (n_utts == 0) return SNF_OK;
+  if (!offsets_a || !offsets_b || !offsets_out) return set_error(SNF_E_INVALID, "null offsets table");
+  if (cols_a <= 0 || cols_b <= 0) return set_error(SNF_E_INVALID, "bad column count");
+  for (int64_t u = 0; u < n_utts; ++u) {
+    const int64_t na = offsets_a[u + 1] - offsets_a[u], nb = offsets_b[u + 1] - offsets_b[u];
+    const int64_t no = offsets_out[u + 1] - offsets_out[u];
+    if (na < 0 || nb < 0 || no < 0 || no > na || no > nb)
+      return set_error(SNF_E_INVALID, "concatenation rows exceed an input for utterance " +
+                                          std::to_string(u));
+  }
+  const int64_t total = offsets_out[n_utts];
+  if (total == 0) return SNF_OK;
+  if (!d_a || !d_b || !d_out) return set_error(SNF_E_INVALID, "null buffer");
+  SNF_HIP_CHECK(hipSetDevice(device_id));
+  int64_t* d_off;
+  SNF_HIP_CHECK(hipMalloc(&d_off, sizeof(int64_t) * 3 * (n_utts + 1)));
+  int rc = SNF_OK;
+  if (hipMemcpy(d_off, offsets_a, sizeof(int64_t) * (n_utts + 1), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_off + (n_utts + 1), offsets_b, sizeof(int64_t) * (n_utts + 1),
+                hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_off + 2 * (n_utts + 1), offsets_out, sizeof(int64_t) * (n_utts + 1),
+                hipMemcpyHostToDevice) != hipSuccess)
+    rc = set_error(SNF_E_HIP, "offset upload failed");
+  if (!rc)
+    rc = launch_concat_columns(d_a, cols_a, d_off, d_b, cols_b, d_off + (n_utts + 1), n_utts, d_out,
+                               d_off + 2 * (n_utts + 1), total, nullptr);
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = set_error(SNF_E_HIP, "concat kernel failed");
+  (void)hipFree(d_off);
+  return rc;
 }
 
 int snf_malloc(void** dptr, uint64_t bytes) {

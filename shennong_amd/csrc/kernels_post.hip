@@ -583,10 +583,47 @@ __global__ __launch_bounds__(256) void cmvn_stats_kernel(const float* __restrict
   }
 }
 
+// more than 256 columns (spectrograms): every thread owns columns c, c + 256, ... over all the rows
+__global__ __launch_bounds__(256) void cmvn_stats_wide_kernel(const float* __restrict__ in, const int D,
+                                                              const int64_t* __restrict__ frame_offsets,
+                                                              const float* __restrict__ weights,
+                                                              double* __restrict__ stats) {
+  const int64_t u = blockIdx.x;
+  const int64_t f0 = frame_offsets[u], T = frame_offsets[u + 1] - f0;
+  double* st = stats + u * 2 * (D + 1);
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    double s = 0.0, q = 0.0;
+    for (int64_t t = 0; t < T; ++t) {
+      const float w = weights ? weights[f0 + t] : 1.0f;
+      if (w != 0.0f) {
+        const float x = in[(f0 + t) * D + c];
+        s += static_cast<double>(x * w);
+        q += static_cast<double>(x * x * w);
+      }
+    }
+    st[c] = s;
+    st[(D + 1) + c] = q;
+  }
+  if (threadIdx.x == 0) {
+    double n = 0.0;
+    for (int64_t t = 0; t < T; ++t) {
+      const float w = weights ? weights[f0 + t] : 1.0f;
+      if (w != 0.0f) n += static_cast<double>(w);
+    }
+    st[D] = n;
+    st[(D + 1) + D] = 0.0;
+  }
+}
+
 int launch_cmvn_stats(const float* in, int in_cols, const int64_t* frame_offsets,
                       const float* weights, int64_t n_utts, double* stats, hipStream_t stream) {
   if (n_utts <= 0) return SNF_OK;
-  if (in_cols > 256) return set_error(SNF_E_RUNTIME, "CMVN: more than 256 columns not supported");
+  if (in_cols > 256) {
+    hipLaunchKernelGGL(cmvn_stats_wide_kernel, dim3(static_cast<unsigned>(n_utts)), dim3(256), 0, stream,
+                       in, in_cols, frame_offsets, weights, stats);
+    SNF_HIP_CHECK(hipGetLastError());
+    return SNF_OK;
+  }
   const int R = 256 / in_cols > 0 ? 256 / in_cols : 1;
   const size_t lds = sizeof(double) * R * (2 * in_cols + 1);
   hipLaunchKernelGGL(cmvn_stats_kernel, dim3(static_cast<unsigned>(n_utts)), dim3(256), lds, stream,
@@ -688,6 +725,36 @@ int launch_sliding_cmvn(const snf_sliding_cmvn_options& o, const float* in, int 
   if (total <= 0) return SNF_OK;
   hipLaunchKernelGGL(sliding_cmvn_kernel, dim3(static_cast<unsigned>((total + 63) / 64)), dim3(64), 0,
                      stream, o, in, in_cols, frame_offsets, n_utts, out);
+  SNF_HIP_CHECK(hipGetLastError());
+  return SNF_OK;
+}
+
+// Column-wise concatenation of two feature blocks per utterance (reference Features.concatenate,
+// features.py:386-437: the longer side is trimmed to the shorter one within the caller's tolerance):
+// out[u][t] = [a[u][t], b[u][t]] for t < rows_out(u).  One thread per output element.
+__global__ void concat_columns_kernel(const float* __restrict__ a, const int ca,
+                                      const int64_t* __restrict__ off_a, const float* __restrict__ bm,
+                                      const int cb, const int64_t* __restrict__ off_b,
+                                      const int64_t n_utts, float* __restrict__ out,
+                                      const int64_t* __restrict__ off_o, const int64_t total_rows) {
+  const int co = ca + cb;
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= total_rows * co) return;
+  const int64_t g = idx / co;
+  const int c = static_cast<int>(idx - g * co);
+  const int64_t u = find_utt(off_o, n_utts, g);
+  const int64_t t = g - off_o[u];
+  out[idx] = c < ca ? a[(off_a[u] + t) * ca + c] : bm[(off_b[u] + t) * cb + (c - ca)];
+}
+
+int launch_concat_columns(const float* a, int cols_a, const int64_t* d_off_a, const float* b, int cols_b,
+                          const int64_t* d_off_b, int64_t n_utts, float* out, const int64_t* d_off_out,
+                          int64_t total_rows, hipStream_t stream) {
+  const int64_t total = total_rows * (cols_a + cols_b);
+  if (total <= 0) return SNF_OK;
+  hipLaunchKernelGGL(concat_columns_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256),
+                     0, stream, a, cols_a, d_off_a, b, cols_b, d_off_b, n_utts, out, d_off_out,
+                     total_rows);
   SNF_HIP_CHECK(hipGetLastError());
   return SNF_OK;
 }

@@ -154,11 +154,12 @@ class Features:
             raise ValueError(
                 'data contains non-finite numbers (nan of infinity)')
 
-    def concatenate(self, other, tolerance=0,
-                    log=get_logger('features', 'info')):
-        """Column-wise concatenation with `other` (reference features.py:350-437)"""
-        need_trim = False
-        diff = abs(self.nframes - other.nframes)
+    @staticmethod
+    def _concatenate_meta(nframes, ndims, times, properties, other_nframes, other_times,
+                          other_properties, tolerance, log):
+        """Frame count, times and properties of a column-wise concatenation (the data-independent
+        part of :func:`concatenate`, shared with the device-resident pipeline)"""
+        diff = abs(nframes - other_nframes)
         if diff:
             if not tolerance:
                 raise ValueError('features have a different number of frames')
@@ -166,23 +167,17 @@ class Features:
                 raise ValueError(
                     'features differs number of frames, and '
                     'greater than tolerance: |{} - {}| > {}'.format(
-                        self.nframes, other.nframes, tolerance))
+                        nframes, other_nframes, tolerance))
             log.warning(
                 'features differs in number of frames, but '
                 'within tolerance (|%s - %s| <= %s), trim the longest one',
-                self.nframes, other.nframes, tolerance)
-            need_trim = True
-        data1, data2 = self.data, other.data
-        times1, times2 = self.times, other.times
-        if need_trim:
-            if self.nframes > other.nframes:
-                data1, times1 = data1[:-diff], times1[:-diff]
-            else:
-                data2, times2 = data2[:-diff], times2[:-diff]
+                nframes, other_nframes, tolerance)
+        rows = min(nframes, other_nframes)
+        times1, times2 = times[:rows], other_times[:rows]
         if not np.allclose(times1, times2):
             raise ValueError('times are not equal')
-        properties = copy.deepcopy(self.properties)
-        other_properties = copy.deepcopy(other.properties)
+        properties = copy.deepcopy(properties)
+        other_properties = copy.deepcopy(other_properties)
         properties.update(
             {k: v for k, v in other_properties.items() if k != 'pipeline'})
         if 'pipeline' not in properties:
@@ -192,9 +187,18 @@ class Features:
                 properties['pipeline'].append(k)
                 columns = properties['pipeline'][-1]['columns']
                 properties['pipeline'][-1]['columns'] = [
-                    columns[0] + self.ndims, columns[1] + self.ndims]
+                    columns[0] + ndims, columns[1] + ndims]
+        return rows, times1, properties
+
+    def concatenate(self, other, tolerance=0,
+                    log=get_logger('features', 'info')):
+        """Column-wise concatenation with `other` (reference features.py:350-437)"""
+        rows, times, properties = self._concatenate_meta(
+            self.nframes, self.ndims, self.times, self.properties,
+            other.nframes, other.times, other.properties, tolerance, log)
         return Features(
-            np.hstack((data1, data2)), times1, properties=properties)
+            np.hstack((self.data[:rows], other.data[:rows])), times,
+            properties=properties)
 
 
 class FeaturesCollection(dict):

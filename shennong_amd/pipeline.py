@@ -311,7 +311,249 @@ def extract_features(configuration, utterances, warps=None, njobs=1,
     return _extract_features(config, utterances, warps, log)
 
 
+class _Meta:
+    """What the post-processors' `get_properties` need to know about features that live in HBM"""
+    def __init__(self, properties, ndims, nframes, times):
+        self.properties = properties
+        self.ndims = ndims
+        self.nframes = nframes
+        self.times = times
+
+
 def _extract_features(config, utterances, warps, log, tolerance=2):
+    """The whole pipeline with the intermediate features resident in HBM: the waveforms go up once,
+    every stage is one batched launch on device buffers (features, energy -> VAD, CMVN statistics and
+    apply, delta, pitch and its post-processing, column concatenation), the final matrices come down
+    once.  Stage order, arithmetic and properties are those of reference pipeline.py:525-643."""
+    features_name = [k for k in config.keys() if k in valid_features()][0]
+    with_cmvn = 'cmvn' in config
+    if with_cmvn and config['cmvn']['by_speaker'] and not utterances.has_speakers():
+        raise ValueError(
+            'cmvn normalization by speaker requested '
+            'but no speaker information provided')
+
+    from shennong_amd.audio import Audio
+    utts = list(utterances)
+    n = len(utts)
+    metadata = {}
+    for utt in utts:
+        key = utt.audio_file if isinstance(utt.audio_file, str) else id(utt.audio_file)
+        if key not in metadata:
+            metadata[key] = Audio.scan(utt.audio_file)
+    meta_of = [metadata[u.audio_file if isinstance(u.audio_file, str) else id(u.audio_file)]
+               for u in utts]
+    speakers = ('' if not utterances.has_speakers() else ' from {} speakers'.format(
+        len(set(u.speaker for u in utts))))
+    import datetime
+    log.info('get %s utterances%s in %s audio files, total duration: %s',
+             len(utts), speakers, len(metadata),
+             datetime.timedelta(seconds=utterances.duration()))
+    if not all(m.nchannels == 1 for m in meta_of):
+        raise ValueError('all audio files are not mono')
+    samplerates = sorted(set(m.sample_rate for m in meta_of))
+    if len(samplerates) > 1:
+        log.warning(
+            'several sample rates found in audio files: %s, features '
+            'extraction pipeline will work but this may not be a good '
+            'idea to work on heterogeneous data',
+            ', '.join(str(s) + 'Hz' for s in samplerates))
+
+    from shennong_amd.processor.base import check_signal
+    audios = [u.load_audio() for u in utts]
+    DB = _backend.DeviceBuffer
+    frame_length = frame_shift = None
+    groups_state = []   # per sample rate: buffers and tables of its utterances
+    meta = [None] * n   # _Meta of the main features
+    pmeta = [None] * n  # _Meta of the pitch features
+
+    def offsets(counts):
+        off = np.zeros(len(counts) + 1, dtype=np.int64)
+        np.cumsum(counts, out=off[1:])
+        return off
+
+    # ---- pass one: features, (energy -> VAD), pitch ---------------------------------------------------
+    for rate in samplerates:
+        idx = [i for i in range(n) if meta_of[i].sample_rate == rate]
+        proc = _processor_class(features_name)(**config[features_name])
+        proc.sample_rate = rate
+        if frame_length is None:
+            frame_length, frame_shift = proc.frame_length, proc.frame_shift
+        for i in idx:
+            check_signal(proc, audios[i])
+        waves = [audios[i].astype(np.int16).data for i in idx]
+        soff = offsets([w.shape[0] for w in waves])
+        wave = np.concatenate(waves) if len(waves) > 1 else np.ascontiguousarray(waves[0])
+        d_wave = DB(max(wave.nbytes, 16))
+        d_wave.upload(wave)
+        st = {'idx': idx, 'soff': soff, 'd_wave': d_wave}
+
+        opts = proc._build_options()
+        plan = _backend.get_plan(opts)
+        dim = plan.ndims
+        foff = offsets([plan.num_frames(w.shape[0]) for w in waves])
+        d_feat = DB(max(int(foff[-1]) * dim * 4, 16))
+        vt = wlist = None
+        if warps and features_name != 'spectrogram':
+            wlist = [warps[utts[i].name] for i in idx]
+            vt = np.asarray(wlist, dtype=np.float32)
+        log.debug('extract %s on %d utterances at %d Hz', features_name, len(idx), rate)
+        plan.run_device(d_wave.ptr, soff, foff, d_feat.ptr, vtln_warps=vt)
+        st.update(foff=foff, dim=dim, d_feat=d_feat)
+        for k, i in enumerate(idx):
+            t = int(foff[k + 1] - foff[k])
+            extra = {'vtln_warp': wlist[k] if wlist is not None else 1.0} \
+                if features_name != 'spectrogram' else {}
+            meta[i] = _Meta(proc.get_properties(**extra), dim, t, proc.times(t))
+
+        if with_cmvn and config['cmvn']['with_vad']:
+            energy = _processor_class('energy')()
+            energy.frame_length = frame_length
+            energy.frame_shift = frame_shift
+            energy.sample_rate = rate
+            eplan = _backend.get_plan(energy._build_options())
+            efoff = offsets([eplan.num_frames(w.shape[0]) for w in waves])
+            if not np.array_equal(efoff, foff):
+                raise ValueError('energy and features differ in number of frames')
+            d_energy = DB(max(int(foff[-1]) * 4, 16))
+            eplan.run_device(d_wave.ptr, soff, foff, d_energy.ptr)
+            vad = _processor_class('vad')(**config['cmvn']['vad'])
+            d_vad = DB(max(int(foff[-1]) * 4, 16))
+            _backend.get_plan(vad._build_options()).run_post_device(
+                d_energy.ptr, 1, foff, d_vad.ptr)
+            d_energy.free()
+            st['d_vad'] = d_vad
+
+        if 'pitch' in config:
+            params = {k: v for k, v in config['pitch'].items()
+                      if k not in ('processor', 'postprocessing')}
+            params['sample_rate'] = rate
+            params['frame_shift'] = frame_shift
+            params['frame_length'] = frame_length
+            pproc = _processor_class('kaldi_pitch')(**params)
+            post = _processor_class('kaldi_pitch_post')(**config['pitch']['postprocessing'])
+            pplan = _backend.get_plan(pproc._build_options())
+            pfoff = offsets([pplan.num_frames(w.shape[0]) for w in waves])
+            d_raw = DB(max(int(pfoff[-1]) * 2 * 4, 16))
+            pplan.run_device(d_wave.ptr, soff, pfoff, d_raw.ptr)
+            qplan = _backend.get_plan(post._build_options())
+            pdim = qplan.post_ndims(2)
+            d_pitch = DB(max(int(pfoff[-1]) * pdim * 4, 16))
+            qplan.run_post_device(d_raw.ptr, 2, pfoff, d_pitch.ptr)
+            d_raw.free()
+            st.update(pfoff=pfoff, pdim=pdim, d_pitch=d_pitch)
+            for k, i in enumerate(idx):
+                t = int(pfoff[k + 1] - pfoff[k])
+                raw_meta = _Meta(pproc.get_properties(), 2, t, pproc.times(t))
+                pmeta[i] = _Meta(post.get_properties(raw_meta), pdim, t, raw_meta.times)
+        d_wave.free()
+        groups_state.append(st)
+
+    for i, utt in enumerate(utts):
+        props = meta[i].properties
+        if utt.speaker:
+            props['speaker'] = utt.speaker
+        props['audio'] = {
+            'file': (os.path.abspath(utt.audio_file)
+                     if isinstance(utt.audio_file, str) else None),
+            'sample_rate': meta_of[i].sample_rate}
+        if utt.tstart is not None:
+            props['audio']['tstart'] = utt.tstart
+            props['audio']['tstop'] = utt.tstop
+        props['audio']['duration'] = utt.duration
+
+    # ---- CMVN: statistics of every utterance in one launch per sample rate, summed per speaker (or
+    # kept per utterance) on the host in utterance order; one apply launch per sample rate -----------
+    if with_cmvn:
+        dims = set(st['dim'] for st in groups_state)
+        if len(dims) != 1:  # pragma: nocover (one processor, one dimension)
+            raise ValueError('features have inconsistent dimensions')
+        dim = dims.pop()
+        if config['cmvn']['by_speaker']:
+            names = list(dict.fromkeys(u.speaker for u in utts))
+            group_of = np.asarray([names.index(u.speaker) for u in utts], dtype=np.int32)
+        else:
+            names = [u.name for u in utts]
+            group_of = np.arange(n, dtype=np.int32)
+        cplan = _backend.get_plan(_abi.default_options(_abi.KIND_CMVN))
+        per_utt = np.zeros((n, 2, dim + 1), dtype=np.float64)
+        for st in groups_state:
+            local = np.zeros((len(st['idx']), 2, dim + 1), dtype=np.float64)
+            cplan.cmvn_accumulate_device(
+                st['d_feat'].ptr, dim, st['foff'], local,
+                d_weights=st['d_vad'].ptr if 'd_vad' in st else None,
+                groups=np.arange(len(st['idx']), dtype=np.int32))
+            per_utt[st['idx']] = local
+            if 'd_vad' in st:
+                st['d_vad'].free()
+        stats = np.zeros((len(names), 2, dim + 1), dtype=np.float64)
+        for i in range(n):
+            stats[group_of[i]] += per_utt[i]
+        for g in range(len(names)):
+            if stats[g, 0, -1] < 1.0:
+                raise ValueError(
+                    'insufficient accumulation of stats for CMVN, '
+                    'must be >= 1.0 but is {}'.format(stats[g, 0, -1]))
+        for st in groups_state:
+            d_out = DB(max(int(st['foff'][-1]) * dim * 4, 16))
+            cplan.cmvn_apply_device(
+                st['d_feat'].ptr, dim, st['foff'], stats, d_out.ptr,
+                groups=group_of[st['idx']], norm_vars=True)
+            st['d_feat'].free()
+            st['d_feat'] = d_out
+        for i in range(n):
+            cmvn = CmvnPostProcessor(dim, stats=stats[group_of[i]])
+            meta[i] = _Meta(cmvn.get_properties(meta[i]), dim, meta[i].nframes, meta[i].times)
+
+    # ---- delta ----------------------------------------------------------------------------------------
+    if 'delta' in config:
+        delta = _processor_class('delta')(**config['delta'])
+        dplan = _backend.get_plan(delta._build_options())
+        for st in groups_state:
+            odim = dplan.post_ndims(st['dim'])
+            d_out = DB(max(int(st['foff'][-1]) * odim * 4, 16))
+            dplan.run_post_device(st['d_feat'].ptr, st['dim'], st['foff'], d_out.ptr)
+            st['d_feat'].free()
+            st['d_feat'], st['dim'] = d_out, odim
+            for i in st['idx']:
+                meta[i] = _Meta(delta.get_properties(meta[i]), odim, meta[i].nframes, meta[i].times)
+
+    # ---- pitch columns (the number of frames can differ by a few because of the downsampling in the
+    # pitch tracker: same tolerance as Kaldi's paste-feats), then the only device -> host copy -----------
+    out = FeaturesCollection()
+    results = [None] * n
+    for st in groups_state:
+        idx = st['idx']
+        if 'd_pitch' in st:
+            rows = []
+            for k, i in enumerate(idx):
+                r, times, props = Features._concatenate_meta(
+                    meta[i].nframes, meta[i].ndims, meta[i].times, meta[i].properties,
+                    pmeta[i].nframes, pmeta[i].times, pmeta[i].properties, tolerance, log)
+                rows.append(r)
+                meta[i] = _Meta(props, meta[i].ndims + pmeta[i].ndims, r, times)
+            ooff = offsets(rows)
+            odim = st['dim'] + st['pdim']
+            d_out = DB(max(int(ooff[-1]) * odim * 4, 16))
+            _backend.concat_columns_device(
+                st['d_feat'].ptr, st['dim'], st['foff'], st['d_pitch'].ptr, st['pdim'],
+                st['pfoff'], d_out.ptr, ooff)
+            st['d_feat'].free()
+            st['d_pitch'].free()
+            st['d_feat'], st['dim'], st['foff'] = d_out, odim, ooff
+        host = np.empty((int(st['foff'][-1]), st['dim']), dtype=np.float32)
+        if host.size:
+            st['d_feat'].download(host)
+        st['d_feat'].free()
+        for k, i in enumerate(idx):
+            results[i] = host[st['foff'][k]:st['foff'][k + 1]].copy()
+    for i, utt in enumerate(utts):
+        out[utt.name] = Features(results[i], meta[i].times, properties=meta[i].properties)
+    return out
+
+
+def _extract_features_by_stage(config, utterances, warps, log, tolerance=2):
+    """The same pipeline with every stage going through the host-pointer entry points of the
+    processors (kept as the step-by-step cross-check of the device-resident path)"""
     features_name = [k for k in config.keys() if k in valid_features()][0]
     with_cmvn = 'cmvn' in config
     if with_cmvn and config['cmvn']['by_speaker'] and not utterances.has_speakers():

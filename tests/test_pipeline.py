@@ -314,3 +314,34 @@ def test_pipeline_warps(gpu, utterances):
     feats = pipeline.extract_features(config, utterances, warps={'speaker1': 1.2, 'speaker2': 0.85})
     assert feats['utt1'].properties['mfcc']['vtln_warp'] == 1.2
     assert feats['utt2'].properties['mfcc']['vtln_warp'] == 0.85
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('features', ['mfcc', 'filterbank', 'plp', 'spectrogram'])
+def test_pipeline_resident_equals_by_stage(gpu, tmp_path, features):
+    """the device-resident pipeline (one upload, one download) returns exactly what the chain of
+    host-pointer processor calls returns: data, times and properties"""
+    # (spectrograms of 8 kHz and 16 kHz audio have different widths and cannot share CMVN statistics)
+    third = WAV if features == 'spectrogram' else WAV_8K
+    with pytest.warns(UserWarning):
+        index = Utterances([('u1', WAV, 's1', 0, 1), ('u2', WAV, 's2', 0.3, 1.4),
+                            ('u3', third, 's1', 1, 3), ('u4', WAV, 's2', 0.9, 1.3)])
+    config = pipeline.get_default_config(features, with_cmvn=True, with_delta=True,
+                                         with_pitch='kaldi')
+    config[features]['dither'] = 0
+    config['pitch']['postprocessing']['delta_pitch_noise_stddev'] = 0
+    log = get_logger('test', 'error')
+    for with_vad, by_speaker in ((False, True), (True, False)):
+        config['cmvn']['with_vad'] = with_vad
+        config['cmvn']['by_speaker'] = by_speaker
+        cfg = pipeline._init_config(config, log=log)
+        warps = None if features == 'spectrogram' else {'u1': 1.1, 'u2': 0.9, 'u3': 1.0, 'u4': 1.2}
+        a = pipeline._extract_features(cfg, index, warps, log)
+        b = pipeline._extract_features_by_stage(cfg, index, warps, log)
+        assert list(a.keys()) == list(b.keys())
+        for k in a:
+            if with_vad:
+                # (the VAD weights come from a dithered energy in both paths: compare the layout only)
+                assert a[k].shape == b[k].shape and a[k].properties.keys() == b[k].properties.keys()
+            else:
+                assert a[k] == b[k], k
