@@ -37,6 +37,15 @@ class BaseProcessor:
 
     @classmethod
     def _get_param_names(cls):
+        cached = cls.__dict__.get('_param_names_cache')
+        if cached is not None:
+            return cached
+        names = cls._inspect_param_names()
+        cls._param_names_cache = names
+        return names
+
+    @classmethod
+    def _inspect_param_names(cls):
         init = getattr(cls.__init__, 'deprecated_original', cls.__init__)
         if init is object.__init__:  # pragma: nocover
             return []

@@ -312,12 +312,24 @@ def extract_features(configuration, utterances, warps=None, njobs=1,
 
 
 class _Meta:
-    """What the post-processors' `get_properties` need to know about features that live in HBM"""
-    def __init__(self, properties, ndims, nframes, times):
+    """What the post-processors' `get_properties` need to know about features that live in HBM.
+    The properties of a stage are the same for every utterance that went through the same processors
+    with the same per-utterance arguments (warp factor, CMVN group): `key` names that history and
+    `cache` holds one properties dictionary per history, copied once per utterance at the end."""
+    def __init__(self, properties, ndims, nframes, times, key=None):
         self.properties = properties
         self.ndims = ndims
         self.nframes = nframes
         self.times = times
+        self.key = key
+
+    def derive(self, cache, tag, make_properties, ndims=None, nframes=None, times=None):
+        key = (self.key, tag)
+        if key not in cache:
+            cache[key] = make_properties(self)
+        return _Meta(cache[key], self.ndims if ndims is None else ndims,
+                     self.nframes if nframes is None else nframes,
+                     self.times if times is None else times, key)
 
 
 def _extract_features(config, utterances, warps, log, tolerance=2):
@@ -362,6 +374,7 @@ def _extract_features(config, utterances, warps, log, tolerance=2):
     audios = [u.load_audio() for u in utts]
     DB = _backend.DeviceBuffer
     frame_length = frame_shift = None
+    cache = {}          # properties per processing history (see _Meta)
     groups_state = []   # per sample rate: buffers and tables of its utterances
     meta = [None] * n   # _Meta of the main features
     pmeta = [None] * n  # _Meta of the pitch features
@@ -403,7 +416,10 @@ def _extract_features(config, utterances, warps, log, tolerance=2):
             t = int(foff[k + 1] - foff[k])
             extra = {'vtln_warp': wlist[k] if wlist is not None else 1.0} \
                 if features_name != 'spectrogram' else {}
-            meta[i] = _Meta(proc.get_properties(**extra), dim, t, proc.times(t))
+            key = (features_name, rate, extra.get('vtln_warp'))
+            if key not in cache:
+                cache[key] = proc.get_properties(**extra)
+            meta[i] = _Meta(cache[key], dim, t, proc.times(t), key)
 
         if with_cmvn and config['cmvn']['with_vad']:
             energy = _processor_class('energy')()
@@ -443,23 +459,13 @@ def _extract_features(config, utterances, warps, log, tolerance=2):
             st.update(pfoff=pfoff, pdim=pdim, d_pitch=d_pitch)
             for k, i in enumerate(idx):
                 t = int(pfoff[k + 1] - pfoff[k])
-                raw_meta = _Meta(pproc.get_properties(), 2, t, pproc.times(t))
-                pmeta[i] = _Meta(post.get_properties(raw_meta), pdim, t, raw_meta.times)
+                key = ('pitch', rate)
+                if key not in cache:
+                    cache[key] = pproc.get_properties()
+                raw_meta = _Meta(cache[key], 2, t, pproc.times(t), key)
+                pmeta[i] = raw_meta.derive(cache, 'post', post.get_properties, ndims=pdim)
         d_wave.free()
         groups_state.append(st)
-
-    for i, utt in enumerate(utts):
-        props = meta[i].properties
-        if utt.speaker:
-            props['speaker'] = utt.speaker
-        props['audio'] = {
-            'file': (os.path.abspath(utt.audio_file)
-                     if isinstance(utt.audio_file, str) else None),
-            'sample_rate': meta_of[i].sample_rate}
-        if utt.tstart is not None:
-            props['audio']['tstart'] = utt.tstart
-            props['audio']['tstop'] = utt.tstop
-        props['audio']['duration'] = utt.duration
 
     # ---- CMVN: statistics of every utterance in one launch per sample rate, summed per speaker (or
     # kept per utterance) on the host in utterance order; one apply launch per sample rate -----------
@@ -501,8 +507,10 @@ def _extract_features(config, utterances, warps, log, tolerance=2):
             st['d_feat'].free()
             st['d_feat'] = d_out
         for i in range(n):
-            cmvn = CmvnPostProcessor(dim, stats=stats[group_of[i]])
-            meta[i] = _Meta(cmvn.get_properties(meta[i]), dim, meta[i].nframes, meta[i].times)
+            g = int(group_of[i])
+            meta[i] = meta[i].derive(
+                cache, ('cmvn', g),
+                lambda m, g=g: CmvnPostProcessor(dim, stats=stats[g]).get_properties(m))
 
     # ---- delta ----------------------------------------------------------------------------------------
     if 'delta' in config:
@@ -515,7 +523,7 @@ def _extract_features(config, utterances, warps, log, tolerance=2):
             st['d_feat'].free()
             st['d_feat'], st['dim'] = d_out, odim
             for i in st['idx']:
-                meta[i] = _Meta(delta.get_properties(meta[i]), odim, meta[i].nframes, meta[i].times)
+                meta[i] = meta[i].derive(cache, 'delta', delta.get_properties, ndims=odim)
 
     # ---- pitch columns (the number of frames can differ by a few because of the downsampling in the
     # pitch tracker: same tolerance as Kaldi's paste-feats), then the only device -> host copy -----------
@@ -526,11 +534,16 @@ def _extract_features(config, utterances, warps, log, tolerance=2):
         if 'd_pitch' in st:
             rows = []
             for k, i in enumerate(idx):
-                r, times, props = Features._concatenate_meta(
-                    meta[i].nframes, meta[i].ndims, meta[i].times, meta[i].properties,
-                    pmeta[i].nframes, pmeta[i].times, pmeta[i].properties, tolerance, log)
+                r, times, _ = Features._concatenate_meta(
+                    meta[i].nframes, meta[i].ndims, meta[i].times, {},
+                    pmeta[i].nframes, pmeta[i].times, {}, tolerance, log)
                 rows.append(r)
-                meta[i] = _Meta(props, meta[i].ndims + pmeta[i].ndims, r, times)
+                meta[i] = meta[i].derive(
+                    cache, ('concat', pmeta[i].key),
+                    lambda m, o=pmeta[i]: Features._concatenate_meta(
+                        1, m.ndims, m.times[:1], m.properties, 1, m.times[:1], o.properties,
+                        tolerance, log)[2],
+                    ndims=meta[i].ndims + pmeta[i].ndims, nframes=r, times=times)
             ooff = offsets(rows)
             odim = st['dim'] + st['pdim']
             d_out = DB(max(int(ooff[-1]) * odim * 4, 16))
@@ -546,8 +559,20 @@ def _extract_features(config, utterances, warps, log, tolerance=2):
         st['d_feat'].free()
         for k, i in enumerate(idx):
             results[i] = host[st['foff'][k]:st['foff'][k + 1]].copy()
+    import copy
     for i, utt in enumerate(utts):
-        out[utt.name] = Features(results[i], meta[i].times, properties=meta[i].properties)
+        props = copy.deepcopy(meta[i].properties)
+        if utt.speaker:
+            props['speaker'] = utt.speaker
+        props['audio'] = {
+            'file': (os.path.abspath(utt.audio_file)
+                     if isinstance(utt.audio_file, str) else None),
+            'sample_rate': meta_of[i].sample_rate}
+        if utt.tstart is not None:
+            props['audio']['tstart'] = utt.tstart
+            props['audio']['tstop'] = utt.tstop
+        props['audio']['duration'] = utt.duration
+        out[utt.name] = Features(results[i], meta[i].times, properties=props)
     return out
 
 
