@@ -185,3 +185,72 @@ def apply_cmvn_sharded(local_feats, utt2speak=None, norm_vars=True, weights=None
         out[k] = Features(datas[u], local_feats[k].times,
                           properties=proc.get_properties(local_feats[k]))
     return out, {s: stats[i] for s, i in index.items()}
+
+
+def reduce_named_stats(names, stats, group=None):
+    """Sums ``stats[k]`` (float64 [len(names), 2, dim + 1]) of equally named entries over the ranks.
+
+    Ranks may know different name lists (each holds its own utterances): the union of the names is
+    agreed on with one small object all-gather, the blocks are summed with `allreduce_cmvn_stats`
+    (rank-ordered, deterministic).  Returns the blocks of THIS rank's `names`, in its order."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    gathered = [None] * world
+    dist.all_gather_object(
+        gathered, (list(names), int(stats.shape[-1]) if len(names) else None), group=group)
+    widths = sorted(set(w for _, w in gathered if w is not None))
+    if not widths:
+        return stats
+    if len(widths) != 1:
+        raise ValueError('features have inconsistent dimensions across ranks: {}'.format(widths))
+    union = sorted(set(n for ns, _ in gathered for n in ns), key=str)
+    index = {n: i for i, n in enumerate(union)}
+    full = np.zeros((len(union), 2, widths[0]), dtype=np.float64)
+    for k, name in enumerate(names):
+        full[index[name]] = stats[k]
+    full = allreduce_cmvn_stats(full, group=group)
+    return np.stack([full[index[name]] for name in names]) if len(names) else full[:0]
+
+
+def extract_features_sharded(configuration, utterances, warps=None, dst=0, group=None, log=None):
+    """``pipeline.extract_features`` over the ranks of one node: every rank passes the same
+    `utterances`, works on its length-balanced shard with the device-resident pipeline, and the CMVN
+    statistics of speakers whose utterances landed on several ranks are summed across the ranks before
+    they are applied (by-utterance CMVN needs no exchange).  Rank `dst` gets the complete
+    FeaturesCollection (point-to-point gather of the matrices, the properties travel as objects), the
+    others get None."""
+    import torch.distributed as dist
+    from shennong_amd import pipeline
+    from shennong_amd.features import Features, FeaturesCollection
+    from shennong_amd.logger import get_logger
+    from shennong_amd.utterances import Utterances
+    log = log or get_logger('pipeline', 'warning')
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    config = pipeline._init_config(configuration, log=log)
+    if warps:
+        warps = pipeline._init_warps(warps, config, utterances, log)
+    utts = list(utterances)
+    shards = shard_utterances([u.duration for u in utts], world)
+    mine = [utts[i] for i in shards[rank]]
+    by_speaker = 'cmvn' in config and config['cmvn']['by_speaker']
+    hook = (lambda names, stats: reduce_named_stats(names, stats, group=group)) if by_speaker else None
+    if mine:
+        local = pipeline._extract_features(
+            config, Utterances(mine), {u.name: warps[u.name] for u in mine} if warps else None, log,
+            stats_hook=hook)
+    else:
+        local = FeaturesCollection()
+        if hook is not None:  # still take part in the reduction
+            hook([], np.zeros((0, 2, 1), dtype=np.float64))
+    merged = gather_features({k: v.data for k, v in local.items()}, dst=dst, group=group)
+    meta = [None] * world
+    dist.all_gather_object(
+        meta, {k: (v.times, v.properties) for k, v in local.items()}, group=group)
+    if merged is None:
+        return None
+    out = FeaturesCollection()
+    everything = {k: v for m in meta for k, v in m.items()}
+    for u in utts:
+        times, properties = everything[u.name]
+        out[u.name] = Features(merged[u.name], times, properties=properties, validate=False)
+    return out

@@ -332,7 +332,7 @@ class _Meta:
                      self.times if times is None else times, key)
 
 
-def _extract_features(config, utterances, warps, log, tolerance=2):
+def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=None):
     """The whole pipeline with the intermediate features resident in HBM: the waveforms go up once,
     every stage is one batched launch on device buffers (features, energy -> VAD, CMVN statistics and
     apply, delta, pitch and its post-processing, column concatenation), the final matrices come down
@@ -494,6 +494,10 @@ def _extract_features(config, utterances, warps, log, tolerance=2):
         stats = np.zeros((len(names), 2, dim + 1), dtype=np.float64)
         for i in range(n):
             stats[group_of[i]] += per_utt[i]
+        if stats_hook is not None:
+            # several processes share the utterances of a speaker: their partial statistics are
+            # summed here (shennong_amd.distributed.extract_features_sharded)
+            stats = stats_hook(names, stats)
         for g in range(len(names)):
             if stats[g, 0, -1] < 1.0:
                 raise ValueError(

@@ -138,3 +138,39 @@ def test_cmvn_sharded_gloo(tmp_path):
         port = s.getsockname()[1]
     mp.spawn(_cmvn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert [open(tmp_path / f'ok{r}').read() for r in range(2)] == ['1', '1']
+
+
+def _named_stats_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    from shennong_amd.distributed import reduce_named_stats
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    rng = np.random.default_rng(5)
+    all_stats = {f's{k}': rng.random((2, 4)) for k in range(4)}
+    # rank 0 holds s0, s1, s2; rank 1 holds s2, s3 (each with its own partial sums)
+    names = [['s0', 's1', 's2'], ['s2', 's3']][rank]
+    mine = np.stack([all_stats[n] * (rank + 1) for n in names])
+    got = reduce_named_stats(names, mine)
+    weight = {'s0': 1, 's1': 1, 's2': 3, 's3': 2}
+    ok = got.shape == mine.shape and all(
+        np.allclose(got[k], all_stats[n] * weight[n], rtol=1e-15) for k, n in enumerate(names))
+    # a rank without any utterance still takes part
+    got = reduce_named_stats(names if rank == 0 else [], mine if rank == 0 else np.zeros((0, 2, 1)))
+    ok = ok and (np.array_equal(got, mine) if rank == 0 else got.shape[0] == 0)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmpdir, f'ok{rank}'), 'w').write('1' if ok else '0')
+
+
+@pytest.mark.timeout(120)
+def test_reduce_named_stats_gloo(tmp_path):
+    """the exchange step of the multi-rank pipeline (per-speaker CMVN statistics over ranks that know
+    different speaker lists)"""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_named_stats_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert [open(tmp_path / f'ok{r}').read() for r in range(2)] == ['1', '1']
