@@ -708,7 +708,8 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
   // widest bins, as many as there are idle slots - two slots in neighbouring lanes of one round whose
   // partial sums are added through DPP.  Slots are sorted by size so that the rounds are as short as
   // possible (a round costs the group count of its longest slot).
-  struct Piece { int bin, start, groups, units; };  // units = 2: pair (two consecutive pieces)
+  struct Piece { int bin, start, groups, units, lo; };  // units = 2: pair (two consecutive pieces);
+                                                        // lo: first tap the piece is responsible for
   std::vector<Piece> singles, pairs;  // pairs hold the first half; the second half follows it
   {
     std::vector<int> order(mb.num_bins), groups_of(mb.num_bins), start_of(mb.num_bins);
@@ -726,10 +727,10 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
     for (int m = 0; m < mb.num_bins; ++m) {
       if (split[m]) {
         const int ga = (groups_of[m] + 1) / 2;
-        pairs.push_back({m, start_of[m], ga, 2});
-        pairs.push_back({-1, start_of[m] + 4 * ga, groups_of[m] - ga, 0});
+        pairs.push_back({m, start_of[m], ga, 2, 0});
+        pairs.push_back({-1, start_of[m] + 4 * ga, groups_of[m] - ga, 0, start_of[m] + 4 * ga});
       } else {
-        singles.push_back({m, start_of[m], groups_of[m], 1});
+        singles.push_back({m, start_of[m], groups_of[m], 1, 0});
       }
     }
   }
@@ -766,6 +767,41 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
     for (char u : used)
       if (!u) return 1;  // (cannot happen: 16 * rounds slots >= pieces)
   }
+  // LDS bank conflicts of the 16-byte tap reads: two lanes of a frame collide on every group when
+  // their first taps differ by a multiple of 64 (same 16-byte slot modulo the 64 banks).  A slot that
+  // is shorter than its round may start up to (round length - own length) groups early (the extra
+  // leading taps carry zero weights), which moves its residue: choose the shifts greedily so that
+  // the 16 residues of a round are distinct; idle lanes get one of the free residues.
+  std::vector<std::vector<int>> idle_start(p.rounds, std::vector<int>(16, 0));
+  for (int r = 0; r < p.rounds; ++r) {
+    int round_groups = 0;
+    for (const Piece& pc : round_slots[r]) round_groups = pc.groups > round_groups ? pc.groups : round_groups;
+    round_groups = (round_groups + 1) & ~1;
+    bool taken[16] = {};
+    std::vector<int> order(round_slots[r].size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = static_cast<int>(i);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+      return round_slots[r][x].groups > round_slots[r][y].groups;  // least slack first
+    });
+    for (int i : order) {
+      Piece& pc = round_slots[r][i];
+      const int slack = round_groups - pc.groups;
+      int best = -1;
+      for (int k = 0; k <= slack && best < 0; ++k)
+        if (pc.start - 4 * k >= 0 && !taken[((pc.start - 4 * k) / 4) & 15]) best = k;
+      if (best > 0) {
+        pc.start -= 4 * best;
+        pc.groups += best;
+      }
+      taken[(pc.start / 4) & 15] = true;
+    }
+    for (int l = static_cast<int>(round_slots[r].size()); l < 16; ++l) {
+      int res = 0;
+      while (res < 15 && taken[res]) ++res;
+      taken[res] = true;
+      idle_start[r][l] = 4 * res;
+    }
+  }
   p.off_first = static_cast<int>(blob->size());
   auto push_int = [&](int v) {
     float as_float;
@@ -776,6 +812,7 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
     for (int r = 0; r < kMaxRounds; ++r)
       for (int l = 0; l < 16; ++l) {
         int v = table == 1 ? -1 : 0;
+        if (table == 0 && r < p.rounds) v = idle_start[r][l];
         if (r < p.rounds && l < static_cast<int>(round_slots[r].size())) {
           const Piece& pc = round_slots[r][l];
           const bool second = pc.units == 0;
@@ -805,7 +842,7 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
             // the second half of a split bin takes its bin from the slot before it
             const int m = pc.units == 0 ? round_slots[r][l - 1].bin : pc.bin;
             const int k = pc.start + 4 * g + i;  // FFT bin of this tap
-            if (g < pc.groups && k >= mb.first[m] && k < mb.first[m] + mb.size[m])
+            if (g < pc.groups && k >= pc.lo && k >= mb.first[m] && k < mb.first[m] + mb.size[m])
               w = 0.25f * mb.w[mb.offset[m] + k - mb.first[m]];  // exact power-of-two scaling
           }
           blob->push_back(w);
