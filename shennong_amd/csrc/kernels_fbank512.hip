@@ -299,9 +299,10 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
   const int tab_bytes = ((PERUTT ? p.table_stride : p.table_floats) * 4 + 255) & ~255;
   char* wave_base = smem + tab_bytes + (wid * 4 + q) * kFrameTileBytes;
   float2* tile = reinterpret_cast<float2*>(wave_base);          // 16 rows x 17 complex
-  // power tile aliases the frame tile: 257 floats, skewed by 16 banks for odd frames so that the
-  // two frames of a 32-lane LDS group do not hit the same banks systematically
-  float* ptile = reinterpret_cast<float*>(wave_base) + (q & 1) * 16;
+  // power tile aliases the frame tile: 257 floats.  The frame tiles are 544 floats apart (bank offset
+  // 0, 32, 0, 32): a skew of 16 q floats puts the 16-lane runs of the four frames of a 4-byte access on
+  // four disjoint bank windows
+  float* ptile = reinterpret_cast<float*>(wave_base) + q * 16;
 
   const int n_waves = blockDim.x >> 6;
   // flat mode: sets of 4 consecutive global frames, grid-stride.  PERUTT: sets of 4 consecutive frames
