@@ -174,6 +174,14 @@ __device__ __forceinline__ float dpp_row_ror(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL,
                                                                0xf, 0xf, false));
 }
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_ror_d(double v) {
+  const long long bits = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(bits), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(bits >> 32), CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, (static_cast<long long>(hi) << 32) |
+                                        static_cast<long long>(static_cast<unsigned>(lo)));
+}
 __device__ __forceinline__ float row_sum16(float v) {
   v += dpp_row_ror<0x128>(v);  // row_ror:8
   v += dpp_row_ror<0x124>(v);  // row_ror:4
@@ -451,6 +459,27 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
         z[j] = make_float2(0.0f, 0.0f);
       }
     }
+    if (KIND == SNF_KIND_ENERGY) {
+      // EnergyProcessor (reference processor/energy.py:173-183): float64 sum of squares of the
+      // processed float32 window, floored at the smallest double, then compressed; nothing else of
+      // the pipeline below is needed
+      double de = 0.0;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const double a = static_cast<double>(z[j].x), c = static_cast<double>(z[j].y);
+        de += a * a + c * c;
+      }
+      de += dpp_row_ror_d<0x128>(de);
+      de += dpp_row_ror_d<0x124>(de);
+      de += dpp_row_ror_d<0x122>(de);
+      de += dpp_row_ror_d<0x121>(de);
+      de = fmax(de, DBL_MIN);
+      double v = de;
+      if (p.compression == SNF_COMPRESS_LOG) v = log(de);
+      else if (p.compression == SNF_COMPRESS_SQRT) v = sqrt(de);
+      if (valid && l == 0) out[g * static_cast<int64_t>(p.out_cols)] = static_cast<float>(v);
+      continue;
+    }
     float e_lin = 0.0f;
     if (ENERGY != 0) e_lin = row_sum16(ENERGY == 1 ? e_raw : e_post);
     __builtin_amdgcn_sched_barrier(0);
@@ -650,7 +679,7 @@ bool fast512_eligible(const MelParams& mp, bool any_warp) {
   if (mp.win_len & 1) return false;
   if (mp.win_len <= 256) return false;  // (pads to 512 samples, see above: 257..512)
   if (mp.kind != SNF_KIND_FBANK && mp.kind != SNF_KIND_MFCC && mp.kind != SNF_KIND_PLP &&
-      mp.kind != SNF_KIND_SPECTROGRAM)
+      mp.kind != SNF_KIND_SPECTROGRAM && mp.kind != SNF_KIND_ENERGY)
     return false;
   if (mp.kind == SNF_KIND_FBANK && !mp.use_power) return false;
   if (mp.num_bins > 16 * kMaxRounds) return false;
@@ -672,6 +701,7 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
   p.dither = mp.dither;
   p.seed = mp.seed;
   p.kind = mp.kind;
+  p.compression = mp.compression;
   p.use_energy = mp.use_energy;
   p.need_raw = mp.need_raw;
   p.need_post = mp.need_post;
@@ -915,8 +945,9 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
   } while (0)
 #define SNF_LAUNCH5(NJ_, KIND_, EN_, DI_, SN_)                                                       \
   do {                                                                                              \
-    if (per_utt && KIND_ != SNF_KIND_SPECTROGRAM)                                                   \
-      SNF_LAUNCH6(NJ_, KIND_, EN_, DI_, SN_, (KIND_ != SNF_KIND_SPECTROGRAM));                      \
+    if (per_utt && KIND_ != SNF_KIND_SPECTROGRAM && KIND_ != SNF_KIND_ENERGY)                       \
+      SNF_LAUNCH6(NJ_, KIND_, EN_, DI_, SN_,                                                        \
+                  (KIND_ != SNF_KIND_SPECTROGRAM && KIND_ != SNF_KIND_ENERGY));                     \
     else SNF_LAUNCH6(NJ_, KIND_, EN_, DI_, SN_, false);                                             \
   } while (0)
 #define SNF_LAUNCH4(NJ_, KIND_, EN_, DI_)                                                           \
@@ -940,11 +971,13 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
     if (p.kind == SNF_KIND_FBANK) SNF_LAUNCH(13, SNF_KIND_FBANK);
     else if (p.kind == SNF_KIND_MFCC) SNF_LAUNCH(13, SNF_KIND_MFCC);
     else if (p.kind == SNF_KIND_SPECTROGRAM) SNF_LAUNCH(13, SNF_KIND_SPECTROGRAM);
+    else if (p.kind == SNF_KIND_ENERGY) SNF_LAUNCH3(13, SNF_KIND_ENERGY, 0);
     else SNF_LAUNCH(13, SNF_KIND_PLP);
   } else {
     if (p.kind == SNF_KIND_FBANK) SNF_LAUNCH(16, SNF_KIND_FBANK);
     else if (p.kind == SNF_KIND_MFCC) SNF_LAUNCH(16, SNF_KIND_MFCC);
     else if (p.kind == SNF_KIND_SPECTROGRAM) SNF_LAUNCH(16, SNF_KIND_SPECTROGRAM);
+    else if (p.kind == SNF_KIND_ENERGY) SNF_LAUNCH3(16, SNF_KIND_ENERGY, 0);
     else SNF_LAUNCH(16, SNF_KIND_PLP);
   }
 #undef SNF_LAUNCH6

@@ -158,7 +158,7 @@ struct Fast512Params {
   unsigned long long seed;
   int kind, out_cols, use_energy, need_raw, need_post, htk_compat, use_log, has_floor;
   float log_energy_floor;
-  int num_bins, num_ceps, rounds;
+  int num_bins, num_ceps, rounds, compression;
   int mel_maxcount[kFast512MaxRounds];
   int mel_woff[kFast512MaxRounds];
   int table_floats;          // total floats of the packed table blob below (warp 1.0)
