@@ -1,12 +1,13 @@
 """Utterances index: ``<id> <audio> [<speaker>] [<tstart> <tstop>]``
 
 Mirror of reference shennong/utterances.py:37-346 (formats, validation, duration bookkeeping,
-grouping by speaker); `audio` may be a wav path or an in-memory :class:`Audio` (the benchmark feeds
-arrays directly).  File-based load/save of the index and `fit_to_duration` are not needed by the
-feature-extraction path and are not provided.
+grouping by speaker, index files, `fit_to_duration`); `audio` may be a wav path or an in-memory
+:class:`Audio` (the benchmark feeds arrays directly).
 """
 
 import collections
+import os
+import random
 import warnings
 
 from shennong_amd.audio import Audio
@@ -117,6 +118,10 @@ class Utterances:
             raise ValueError(
                 f'duplicates found in utterances: {", ".join(duplicates)}')
         self._format = parsed[0].format
+        # sorted by audio file like the reference (its Audio.load cache); in-memory audio (this
+        # backend's extension) keeps the insertion order
+        if all(isinstance(u.audio_file, str) for u in parsed):
+            parsed = sorted(parsed, key=lambda u: (u.audio_file, u.name))
         self._utterances = {u.name: u for u in parsed}
 
     def __len__(self):
@@ -130,6 +135,55 @@ class Utterances:
 
     def __eq__(self, other):
         return list(self) == list(other)
+
+    @classmethod
+    def load(cls, filename):
+        """Utterances from an index file, one ``<id> <audio> [<speaker>] [<tstart> <tstop>]`` per
+        line, all lines in the same format"""
+        if not os.path.isfile(filename):
+            raise ValueError(f'{filename} not found')
+        with open(filename, 'r') as stream:
+            lines = (line.strip() for line in stream.readlines())
+        return cls([line.split(' ') for line in lines if line])
+
+    def save(self, filename):
+        """Writes the utterances index to `filename`"""
+        with open(filename, 'w') as stream:
+            stream.write('\n'.join(str(utt) for utt in self) + '\n')
+
+    def fit_to_duration(self, duration, truncate=False, shuffle=False):
+        """A subset of the utterances keeping `duration` seconds per speaker (reference
+        utterances.py:348-418); raises ValueError without speakers, for a non-positive duration, or
+        when a speaker has not enough audio and `truncate` is False (a warning when it is True)"""
+        if duration <= 0:
+            raise ValueError(
+                f'duration must be a positive number, it is {duration}')
+        segments = []
+        for speaker, utterances in self.by_speaker().items():
+            if shuffle:
+                random.shuffle(utterances)
+            remaining_duration = duration
+            for utt in utterances:
+                tstart = 0 if utt.tstart is None else utt.tstart
+                tstop = utt.duration - tstart if utt.tstop is None else utt.tstop
+                if utt.duration >= remaining_duration:
+                    segments.append(Utterance(
+                        utt.name, utt.audio_file, utt.speaker, tstart,
+                        tstart + remaining_duration))
+                    remaining_duration = 0
+                    break
+                segments.append(Utterance(
+                    utt.name, utt.audio_file, utt.speaker, tstart, tstop))
+                remaining_duration -= utt.duration
+            if remaining_duration > 0:
+                message = (
+                    f'speaker {speaker}: only {duration - remaining_duration}s'
+                    f' of audio available but {duration}s requested')
+                if truncate:
+                    warnings.warn(message)
+                else:
+                    raise ValueError(message)
+        return Utterances(segments)
 
     def format(self, type=int):
         """The utterances format: its code (`type` int) or its description (`type` str)"""

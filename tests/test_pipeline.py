@@ -345,3 +345,27 @@ def test_pipeline_resident_equals_by_stage(gpu, tmp_path, features):
                 assert a[k].shape == b[k].shape and a[k].properties.keys() == b[k].properties.keys()
             else:
                 assert a[k] == b[k], k
+
+
+def test_utterances_file_and_duration(tmp_path):
+    """reference test/test_utterances.py: index files, ordering, fit_to_duration"""
+    utts = Utterances([('b', WAV, 's1', 0, 1), ('a', WAV, 's1', 0.5, 1.4), ('c', WAV_8K, 's2', 0, 1)])
+    assert [u.name for u in utts] == ['c', 'a', 'b']   # sorted by (audio file, name)
+    index = str(tmp_path / 'index.txt')
+    utts.save(index)
+    assert Utterances.load(index) == utts
+    with pytest.raises(ValueError) as err:
+        Utterances.load(str(tmp_path / 'nothere'))
+    assert 'not found' in str(err.value)
+    sub = utts.fit_to_duration(0.8)
+    assert sub['a'].duration == pytest.approx(0.8) and sub['c'].duration == pytest.approx(0.8)
+    assert 'b' not in sub.by_name()
+    with pytest.raises(ValueError) as err:
+        utts.fit_to_duration(5)
+    assert 'of audio available but 5s requested' in str(err.value)
+    with pytest.warns(UserWarning):
+        assert len(utts.fit_to_duration(5, truncate=True)) == 3
+    with pytest.raises(ValueError):
+        utts.fit_to_duration(0)
+    with pytest.raises(ValueError):
+        Utterances([('x', WAV)]).fit_to_duration(1)
