@@ -88,7 +88,7 @@ struct snf_plan {
 
   // scratch (host-pointer entry points and intermediates)
   DevBuf s_wave, s_out, s_in, s_soff, s_foff, s_uwarp, s_mel, s_energy;
-  DevBuf s_down, s_stats, s_bp, s_doff, s_dp1, s_fp1, s_states, s_setidx, s_edge;
+  DevBuf s_down, s_stats, s_bp, s_doff, s_dp1, s_fp1, s_states, s_setidx, s_edge, s_futt;
   bool setidx_valid = false;
 
   // last uploaded offsets tables (re-validated / re-uploaded only when they change)
@@ -792,19 +792,22 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     b.blk_utt = plan->s_blk_utt.as<int32_t>();
     b.blk_set0 = plan->s_blk_set0.as<int32_t>();
     b.n_blocks = static_cast<int64_t>(blk_utt.size());
-  } else if (use_fast && !plan->setidx_valid) {
-    // frame -> first-sample index (+ edge marks): built once per offsets table, reused by later calls
+  } else if (!plan->setidx_valid) {
+    // frame -> first-sample index, edge marks and utterance index: built once per offsets table,
+    // reused by later calls (fast kernel: bulk loads; generic kernel: no per-frame binary search)
     if ((rc = plan->s_setidx.ensure(sizeof(int64_t) * static_cast<size_t>(total_frames)))) return rc;
     if ((rc = plan->s_edge.ensure(sizeof(int32_t) * static_cast<size_t>(total_frames)))) return rc;
+    if ((rc = plan->s_futt.ensure(sizeof(int32_t) * static_cast<size_t>(total_frames)))) return rc;
     if ((rc = launch_build_frame_start(plan->s_foff.as<int64_t>(), plan->s_soff.as<int64_t>(), n_utts,
                                        total_frames, plan->mp.win_shift, plan->mp.win_len,
                                        plan->mp.snip_edges, plan->s_setidx.as<int64_t>(),
-                                       plan->s_edge.as<int32_t>(), s)))
+                                       plan->s_edge.as<int32_t>(), plan->s_futt.as<int32_t>(), s)))
       return rc;
     plan->setidx_valid = true;
   }
   b.frame_start = plan->s_setidx.as<int64_t>();
   b.frame_edge = plan->s_edge.as<int32_t>();
+  b.frame_utt = plan->setidx_valid ? plan->s_futt.as<int32_t>() : nullptr;
   if (own_stream) begin_timing(plan);
   if (plan->kind == SNF_KIND_PLP) {
     const int nb = plan->o.mel.num_bins;

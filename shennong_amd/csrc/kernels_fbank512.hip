@@ -638,10 +638,12 @@ __global__ void build_frame_start_kernel(const int64_t* __restrict__ frame_offse
                                          const int64_t* __restrict__ sample_offsets, int64_t n_utts,
                                          int64_t total_frames, int win_shift, int win_len,
                                          int snip_edges, int64_t* __restrict__ frame_start,
-                                         int32_t* __restrict__ frame_edge) {
+                                         int32_t* __restrict__ frame_edge,
+                                         int32_t* __restrict__ frame_utt) {
   const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (g >= total_frames) return;
   const int64_t u = find_utt(frame_offsets, n_utts, g);
+  frame_utt[g] = static_cast<int32_t>(u);
   const int64_t s0 = sample_offsets[u], n = sample_offsets[u + 1] - s0;
   const int64_t f = g - frame_offsets[u];
   if (snip_edges) {
@@ -659,12 +661,12 @@ __global__ void build_frame_start_kernel(const int64_t* __restrict__ frame_offse
 int launch_build_frame_start(const int64_t* d_frame_offsets, const int64_t* d_sample_offsets,
                              int64_t n_utts, int64_t total_frames, int win_shift, int win_len,
                              int snip_edges, int64_t* d_frame_start, int32_t* d_frame_edge,
-                             hipStream_t stream) {
+                             int32_t* d_frame_utt, hipStream_t stream) {
   if (total_frames <= 0) return SNF_OK;
   hipLaunchKernelGGL(build_frame_start_kernel,
                      dim3(static_cast<unsigned>((total_frames + 255) / 256)), dim3(256), 0, stream,
                      d_frame_offsets, d_sample_offsets, n_utts, total_frames, win_shift, win_len,
-                     snip_edges, d_frame_start, d_frame_edge);
+                     snip_edges, d_frame_start, d_frame_edge, d_frame_utt);
   SNF_HIP_CHECK(hipGetLastError());
   return SNF_OK;
 }

@@ -82,7 +82,7 @@ __device__ __forceinline__ int bit_reverse(int v, int bits) {
 
 }  // namespace
 
-__global__ __launch_bounds__(kWaves * 64) void mel_features_generic_kernel(
+__global__ __launch_bounds__(kWaves * 64, 8) void mel_features_generic_kernel(
     const MelParams p, const BatchArgs b, float* __restrict__ out, const int out_cols,
     double* __restrict__ energy_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -103,7 +103,9 @@ __global__ __launch_bounds__(kWaves * 64) void mel_features_generic_kernel(
   for (int64_t g = static_cast<int64_t>(blockIdx.x) * kWaves + wid; g < b.total_frames;
        g += stride) {
     // ---- which utterance / which frame ---------------------------------------------------------
-    const int64_t u = find_utt(b.frame_offsets, b.n_utts, g);
+    // (frame -> utterance table when the host built one: the binary search is a chain of ~14
+    // dependent loads per frame)
+    const int64_t u = b.frame_utt ? b.frame_utt[g] : find_utt(b.frame_offsets, b.n_utts, g);
     const int64_t f = g - b.frame_offsets[u];
     const int64_t s0 = b.sample_offsets[u];
     const int64_t n = b.sample_offsets[u + 1] - s0;
@@ -305,7 +307,7 @@ int launch_mel_features(const MelParams& p, const BatchArgs& b, float* out, int 
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(lds)));
   int64_t blocks = (b.total_frames + kWaves - 1) / kWaves;
-  const int64_t max_blocks = 256 * 8;  // 256 CUs x 8 resident workgroups of 4 waves
+  const int64_t max_blocks = 256 * 16;  // 256 CUs x resident workgroups of 4 waves x depth
   if (blocks > max_blocks) blocks = max_blocks;
   hipLaunchKernelGGL(mel_features_generic_kernel, dim3(static_cast<unsigned>(blocks)),
                      dim3(kWaves * 64), lds, stream, p, b, out, out_cols, energy_out);

@@ -112,6 +112,7 @@ struct BatchArgs {
   const int32_t* utt_warp;        // [n_utts] index into the plan's warp tables, or nullptr
   const int64_t* frame_start;     // [total_frames] first sample of every frame (fast path only)
   const int32_t* frame_edge;      // [total_frames] snip_edges = false: utterance + 1 of edge frames
+  const int32_t* frame_utt;       // [total_frames] utterance of every frame (generic kernel)
   const int32_t* blk_utt;         // [n_blocks] fast path with VTLN warps: utterance of every workgroup
   const int32_t* blk_set0;        // [n_blocks] ... and its first frame set inside that utterance
   int64_t n_blocks;
@@ -177,7 +178,7 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
 int launch_build_frame_start(const int64_t* d_frame_offsets, const int64_t* d_sample_offsets,
                              int64_t n_utts, int64_t total_frames, int win_shift, int win_len,
                              int snip_edges, int64_t* d_frame_start, int32_t* d_frame_edge,
-                             hipStream_t stream);
+                             int32_t* d_frame_utt, hipStream_t stream);
 int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int out_cols,
                     double* energy_out, hipStream_t stream);
 
