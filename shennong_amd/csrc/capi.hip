@@ -1121,7 +1121,10 @@ int snf_cmvn_apply_device(snf_plan* plan, const float* d_in, int32_t cols,
     d_group = plan->s_uwarp.as<int32_t>();
   }
   begin_timing(plan);
-  if ((rc = launch_cmvn_apply(d_in, cols, plan->s_foff.as<int64_t>(), n_utts, total_frames, d_group,
+  int64_t max_frames = 0;
+  for (int64_t k = 0; k < n_utts; ++k)
+    max_frames = std::max(max_frames, frame_offsets[k + 1] - frame_offsets[k]);
+  if ((rc = launch_cmvn_apply(d_in, cols, plan->s_foff.as<int64_t>(), n_utts, max_frames, d_group,
                               plan->s_mel.as<float>(), norm_vars ? 1 : 0, d_out, s)))
     return rc;
   mark_kernel(plan, "cmvn_apply_kernel");

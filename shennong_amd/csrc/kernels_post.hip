@@ -475,9 +475,97 @@ __global__ void pitch_post_kernel(const PitchPostParams p, const float* __restri
   if (o.add_raw_log_pitch) row[idx++] = log_pitch;
 }
 
+// Tiled variant of the same arithmetic: the POV weight and the log-pitch of a frame are evaluated
+// ONCE (by the workgroup that needs them, into LDS) instead of once per window position - the POV
+// mapping costs four double-precision exponentials, and the +-75-frame normalisation window made the
+// kernel above evaluate it 151 times per frame.
+constexpr int kPostRows = 256;
+__global__ __launch_bounds__(kPostRows) void pitch_post_tiled_kernel(
+    const PitchPostParams p, const float* __restrict__ in, const int halo_l, const int halo_r,
+    const int64_t* __restrict__ frame_offsets, const int64_t n_utts, const int64_t total_frames,
+    float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_pov = reinterpret_cast<float*>(smem);        // [kPostRows + halo_l + halo_r]
+  float* s_lp = s_pov + (kPostRows + halo_l + halo_r);  // log-pitch
+  const int64_t g0 = static_cast<int64_t>(blockIdx.x) * kPostRows;
+  const int64_t t0 = g0 - halo_l;
+  const int tile = kPostRows + halo_l + halo_r;
+  for (int i = threadIdx.x; i < tile; i += blockDim.x) {
+    const int64_t t = t0 + i;
+    float pov = 0.0f, lp = 0.0f;
+    if (t >= 0 && t < total_frames) {
+      pov = nccf_to_pov(in[t * 2]);
+      lp = logf(in[t * 2 + 1]);
+    }
+    s_pov[i] = pov;
+    s_lp[i] = lp;
+  }
+  __syncthreads();
+  const int64_t g = g0 + threadIdx.x;
+  if (g >= total_frames) return;
+  const int64_t u = find_utt(frame_offsets, n_utts, g);
+  const int64_t f0 = frame_offsets[u], f1 = frame_offsets[u + 1];
+  const snf_pitch_post_options& o = p.o;
+  float* __restrict__ row = out + g * p.ndims;
+  int idx = 0;
+  const float nccf = in[g * 2];
+  const float log_pitch = s_lp[g - t0];
+  if (o.add_pov_feature) row[idx++] = o.pov_scale * nccf_to_pov_feature(nccf) + o.pov_offset;
+  if (o.add_normalized_log_pitch) {
+    int64_t wb = g - o.normalization_left_context, we = g + o.normalization_right_context + 1;
+    if (wb < f0) wb = f0;
+    if (we > f1) we = f1;
+    double sum_pov = 0.0, sum_lp = 0.0;
+    for (int64_t t = wb; t < we; ++t) {
+      const float pov = s_pov[t - t0], lp = s_lp[t - t0];
+      sum_pov += pov;
+      sum_lp += pov * lp;
+    }
+    const float avg = static_cast<float>(sum_lp / sum_pov);
+    row[idx++] = (log_pitch - avg) * o.pitch_scale;
+  }
+  if (o.add_delta_pitch) {
+    const int w = o.delta_window;
+    float normalizer = 0.0f;
+    for (int j = -w; j <= w; ++j) normalizer += static_cast<float>(j * j);
+    const float inv = static_cast<float>(1.0 / normalizer);
+    int64_t lo = g - w, hi = g + w;
+    if (lo < f0) lo = f0;
+    if (hi > f1 - 1) hi = f1 - 1;
+    float acc = 0.0f;
+    for (int j = -w; j <= w; ++j) {
+      int64_t t = g + j;
+      t = t < lo ? lo : (t > hi ? hi : t);
+      const float sc = static_cast<float>(j) * inv;
+      if (sc != 0.0f) acc += sc * s_lp[t - t0];
+    }
+    float noise = 0.0f;
+    if (o.delta_pitch_noise_stddev != 0.0f)
+      noise = gauss(p.seed, static_cast<uint64_t>(g)) * o.delta_pitch_noise_stddev;
+    row[idx++] = (acc + noise) * o.delta_pitch_scale;
+  }
+  if (o.add_raw_log_pitch) row[idx++] = log_pitch;
+}
+
 int launch_pitch_post(const PitchPostParams& p, const float* in, const int64_t* frame_offsets,
                       int64_t n_utts, int64_t total_frames, float* out, hipStream_t stream) {
   if (total_frames <= 0) return SNF_OK;
+  {
+    int halo_l = p.o.normalization_left_context, halo_r = p.o.normalization_right_context;
+    if (p.o.delta_window > halo_l) halo_l = p.o.delta_window;
+    if (p.o.delta_window > halo_r) halo_r = p.o.delta_window;
+    if (halo_l < 0) halo_l = 0;
+    if (halo_r < 0) halo_r = 0;
+    const size_t lds = sizeof(float) * 2 * static_cast<size_t>(kPostRows + halo_l + halo_r);
+    if (lds <= 48 * 1024) {
+      hipLaunchKernelGGL(pitch_post_tiled_kernel,
+                         dim3(static_cast<unsigned>((total_frames + kPostRows - 1) / kPostRows)),
+                         dim3(kPostRows), lds, stream, p, in, halo_l, halo_r, frame_offsets, n_utts,
+                         total_frames, out);
+      SNF_HIP_CHECK(hipGetLastError());
+      return SNF_OK;
+    }
+  }
   const int threads = 128;
   hipLaunchKernelGGL(pitch_post_kernel,
                      dim3(static_cast<unsigned>((total_frames + threads - 1) / threads)),
@@ -635,15 +723,17 @@ int launch_cmvn_stats(const float* in, int in_cols, const int64_t* frame_offsets
 // out = in * scale + offset with two roundings (Kaldi MulColsVec then AddVecToRows);
 // norm[group][2][D] = {offset, scale} in float.
 __global__ void cmvn_apply_kernel(const float* __restrict__ in, const int D,
-                                  const int64_t* __restrict__ frame_offsets, const int64_t n_utts,
-                                  const int64_t total_frames, const int32_t* __restrict__ group,
+                                  const int64_t* __restrict__ frame_offsets, const int64_t u0,
+                                  const int32_t* __restrict__ group,
                                   const float* __restrict__ norm, const int scale_it,
                                   float* __restrict__ out) {
-  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (idx >= total_frames * D) return;
-  const int64_t g = idx / D;
-  const int c = static_cast<int>(idx - g * D);
-  const int64_t u = find_utt(frame_offsets, n_utts, g);
+  // blockIdx.y = utterance (no per-element search), blockIdx.x = 256-element chunk of its block
+  const int64_t u = u0 + blockIdx.y;
+  const int64_t e0 = frame_offsets[u] * D, ne = (frame_offsets[u + 1] - frame_offsets[u]) * D;
+  const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (k >= ne) return;
+  const int64_t idx = e0 + k;
+  const int c = static_cast<int>(k % D);
   const float* __restrict__ nm = norm + static_cast<int64_t>(group ? group[u] : 0) * 2 * D;
   float x = in[idx];
   if (scale_it) x = __fmul_rn(x, nm[D + c]);
@@ -651,14 +741,17 @@ __global__ void cmvn_apply_kernel(const float* __restrict__ in, const int D,
 }
 
 int launch_cmvn_apply(const float* in, int in_cols, const int64_t* frame_offsets, int64_t n_utts,
-                      int64_t total_frames, const int32_t* group, const float* norm, int scale_it,
+                      int64_t max_frames, const int32_t* group, const float* norm, int scale_it,
                       float* out, hipStream_t stream) {
-  const int64_t total = total_frames * in_cols;
-  if (total <= 0) return SNF_OK;
-  hipLaunchKernelGGL(cmvn_apply_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
-                     stream, in, in_cols, frame_offsets, n_utts, total_frames, group, norm, scale_it,
-                     out);
-  SNF_HIP_CHECK(hipGetLastError());
+  const int64_t per_utt = max_frames * in_cols;
+  if (per_utt <= 0 || n_utts <= 0) return SNF_OK;
+  for (int64_t u0 = 0; u0 < n_utts; u0 += 65535) {  // grid.y limit
+    const int64_t nu = n_utts - u0 < 65535 ? n_utts - u0 : 65535;
+    hipLaunchKernelGGL(cmvn_apply_kernel,
+                       dim3(static_cast<unsigned>((per_utt + 255) / 256), static_cast<unsigned>(nu)),
+                       dim3(256), 0, stream, in, in_cols, frame_offsets, u0, group, norm, scale_it, out);
+    SNF_HIP_CHECK(hipGetLastError());
+  }
   return SNF_OK;
 }
 

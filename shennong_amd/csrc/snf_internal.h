@@ -217,7 +217,7 @@ int launch_vad(const snf_vad_options& o, const float* in, int in_cols, const int
 int launch_cmvn_stats(const float* in, int in_cols, const int64_t* frame_offsets,
                       const float* weights, int64_t n_utts, double* stats, hipStream_t stream);
 int launch_cmvn_apply(const float* in, int in_cols, const int64_t* frame_offsets, int64_t n_utts,
-                      int64_t total_frames, const int32_t* group, const float* norm, int scale_it,
+                      int64_t max_frames, const int32_t* group, const float* norm, int scale_it,
                       float* out, hipStream_t stream);
 int launch_concat_columns(const float* a, int cols_a, const int64_t* d_off_a, const float* b, int cols_b,
                           const int64_t* d_off_b, int64_t n_utts, float* out, const int64_t* d_off_out,
