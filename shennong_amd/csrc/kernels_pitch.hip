@@ -505,26 +505,37 @@ __device__ __forceinline__ float trans_cost(int j, float fi, float factor, float
   return __fadd_rn(__fmul_rn(d * d, factor), fwd_j);
 }
 
-// exact argmin over j in [lo, hi] (lowest index wins ties), 4 candidates in flight per step
+// exact argmin over j in [lo, hi] (lowest index wins ties), 4 candidates in flight per step.  The
+// last step may look at up to 3 states beyond `hi`: the argmin is monotone in i, so none of them can
+// beat the optimum inside the range (an equal cost loses to the lower index), and the forward costs
+// are padded with FLT_MAX beyond the last state.
 __device__ __forceinline__ void scan_range(const float* __restrict__ fwd, int lo, int hi, float fi,
                                            float factor, float& best, int& best_j) {
-  best = trans_cost(lo, fi, factor, fwd[lo]);
-  best_j = lo;
-  for (int j = lo + 1; j <= hi; j += 4) {
-    const int j1 = j + 1 <= hi ? j + 1 : hi, j2 = j + 2 <= hi ? j + 2 : hi, j3 = j + 3 <= hi ? j + 3 : hi;
-    const float f0 = fwd[j], f1 = fwd[j1], f2 = fwd[j2], f3 = fwd[j3];
-    const float c0 = trans_cost(j, fi, factor, f0), c1 = trans_cost(j1, fi, factor, f1);
-    const float c2 = trans_cost(j2, fi, factor, f2), c3 = trans_cost(j3, fi, factor, f3);
-    // (clamped duplicates of `hi` can never win: strict comparison against an equal cost)
-    if (c0 < best) { best = c0; best_j = j; }
-    if (c1 < best) { best = c1; best_j = j1; }
-    if (c2 < best) { best = c2; best_j = j2; }
-    if (c3 < best) { best = c3; best_j = j3; }
+  float fj = static_cast<float>(lo);
+  {
+    const float d = fj - fi;
+    best = __fadd_rn(__fmul_rn(d * d, factor), fwd[lo]);
   }
+  float best_f = fj;
+  for (int j = lo + 1; j <= hi; j += 4) {
+    const float f0 = fwd[j], f1 = fwd[j + 1], f2 = fwd[j + 2], f3 = fwd[j + 3];
+    const float d0 = (fj + 1.0f) - fi, d1 = (fj + 2.0f) - fi, d2 = (fj + 3.0f) - fi, d3 = (fj + 4.0f) - fi;
+    const float c0 = __fadd_rn(__fmul_rn(d0 * d0, factor), f0);
+    const float c1 = __fadd_rn(__fmul_rn(d1 * d1, factor), f1);
+    const float c2 = __fadd_rn(__fmul_rn(d2 * d2, factor), f2);
+    const float c3 = __fadd_rn(__fmul_rn(d3 * d3, factor), f3);
+    if (c0 < best) { best = c0; best_f = fj + 1.0f; }
+    if (c1 < best) { best = c1; best_f = fj + 2.0f; }
+    if (c2 < best) { best = c2; best_f = fj + 3.0f; }
+    if (c3 < best) { best = c3; best_f = fj + 4.0f; }
+    fj += 4.0f;
+  }
+  best_j = static_cast<int>(best_f);
 }
 
 constexpr int kLagGroup = 5;  // lags per work item of the correlation
 constexpr int kCorrChunks = 4;  // window quarters per lag group (the 4 lanes of a quad)
+constexpr int kFwdPad = 36;    // FLT_MAX entries behind the forward costs (unclamped scan steps)
 constexpr int kLongRange = 8;  // candidate ranges at least this long are scanned by a 16-lane row
 
 __device__ void forward_pass_wave(const PitchDevTables& t, const float* __restrict__ x, int64_t nd,
@@ -535,6 +546,7 @@ __device__ void forward_pass_wave(const PitchDevTables& t, const float* __restri
                                   const float* __restrict__ st_lag, const int lane) {
   const int S = t.num_states, L = t.num_lags, W = t.win_size;
   for (int s = lane; s < S; s += 64) sh.fwd[s] = 0.0f;
+  for (int s = S + lane; s < S + kFwdPad; s += 64) sh.fwd[s] = FLT_MAX;  // scan read-ahead padding
   for (int i = lane; i < 8; i += 64) sh.win[t.full_len + i] = 0.0f;  // read-ahead padding
   for (int i = lane; i < kWaveMaxTaps; i += 64) sh.nccf[L + i] = 0.0f;  // (taps are zero-padded)
   const float ballast1 = static_cast<float>(pow(ms1 * W, 2.0) * static_cast<double>(t.nccf_ballast));
@@ -672,19 +684,21 @@ __device__ void forward_pass_wave(const PitchDevTables& t, const float* __restri
       int best_j = 0x7fffffff;
       if (i_rep < S) {
         const float fi = static_cast<float>(i_rep);
+        // (the forward costs are padded with FLT_MAX up to a multiple of 32 states)
+        float fj = static_cast<float>(sub), best_f = 0.0f;
         for (int j = sub; j < S; j += 32) {
-          int jj[8];
           float ff[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) jj[u] = j + 4 * u < S ? j + 4 * u : j;  // duplicates never win
-#pragma unroll
-          for (int u = 0; u < 8; ++u) ff[u] = sh.fwd[jj[u]];
+          for (int u = 0; u < 8; ++u) ff[u] = sh.fwd[j + 4 * u];
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const float c = trans_cost(jj[u], fi, factor, ff[u]);
-            if (c < best) { best = c; best_j = jj[u]; }
+            const float d = (fj + static_cast<float>(4 * u)) - fi;
+            const float c = __fadd_rn(__fmul_rn(d * d, factor), ff[u]);
+            if (c < best) { best = c; best_f = fj + static_cast<float>(4 * u); }
           }
+          fj += 32.0f;
         }
+        best_j = static_cast<int>(best_f);
       }
       quad_argmin(best, best_j);
       wave_sync();  // local costs (nxt) written above are read below
@@ -795,13 +809,13 @@ __global__ __launch_bounds__(kWaveTrackWaves * 64, 4) void pitch_track_wave_kern
   const int64_t d0 = b.down_offsets[u], nd = b.down_offsets[u + 1] - d0, nd1 = b.down_phase1[u];
   const float* __restrict__ x = down + d0;
   const int per_wave = ((t.full_len + 8 + 3) & ~3) + ((L + kWaveMaxTaps + 3) & ~3) + ((L + 3) & ~3) +
-                       3 * ((S + 3) & ~3);
+                       3 * ((S + 3) & ~3) + kFwdPad;
   WaveShared sh;
   sh.win = st_lag + S4 + wid * per_wave;
   sh.nccf = sh.win + ((t.full_len + 8 + 3) & ~3);
   sh.norm = sh.nccf + ((L + kWaveMaxTaps + 3) & ~3);
   sh.fwd = sh.norm + ((L + 3) & ~3);
-  sh.nxt = sh.fwd + ((S + 3) & ~3);
+  sh.nxt = sh.fwd + ((S + 3) & ~3) + kFwdPad;
   sh.bpw = reinterpret_cast<int*>(sh.nxt + ((S + 3) & ~3));
   int16_t* __restrict__ bp = backptr + f0 * S;
   float* __restrict__ pov_nccf = pov_all + f0 * L;
@@ -888,7 +902,7 @@ int launch_pitch(const PitchDevTables& t, const PitchBatch& b, float* down, doub
                          !getenv("SNF_PITCH_BLOCK_KERNEL");
   if (wave_path) {
     const int per_wave = ((t.full_len + 8 + 3) & ~3) + ((t.num_lags + kWaveMaxTaps + 3) & ~3) +
-                         ((t.num_lags + 3) & ~3) + 3 * ((t.num_states + 3) & ~3);
+                         ((t.num_lags + 3) & ~3) + 3 * ((t.num_states + 3) & ~3) + kFwdPad;
     const size_t lds_w = sizeof(float) * (((t.num_states * kWaveMaxTaps + 3) & ~3) +
                                           2 * ((t.num_states + 3) & ~3) +
                                           static_cast<size_t>(kWaveTrackWaves) * per_wave);
