@@ -330,7 +330,7 @@ __global__ void delta_kernel(const DeltaParams p, const float* __restrict__ in, 
 // Tiled variant: a workgroup stages kDeltaRows + 2*halo input rows in LDS once (each HBM row is read
 // ~1.1x instead of 9x through the caches) and writes its output rows fully coalesced.  The edge clamp
 // is per utterance; a clamped neighbour is never farther than the unclamped one, so it is in the tile.
-constexpr int kDeltaRows = 64;
+constexpr int kDeltaRows = 256;
 
 __global__ __launch_bounds__(256) void delta_tiled_kernel(
     const DeltaParams p, const float* __restrict__ in, const int D, const int halo,
