@@ -677,12 +677,17 @@ int launch_build_frame_start(const int64_t* d_frame_offsets, const int64_t* d_sa
 bool fast512_eligible(const MelParams& mp, bool any_warp) {
   if (getenv("SNF_DISABLE_FAST512")) return false;
   if (any_warp) return false;
-  if (mp.padded != 512 || !mp.pow2) return false;
+  // Frames that pad to 256 or 128 samples (8 kHz audio, short windows) run as the same 512-point
+  // transform of the zero-extended frame: X512[s k] = X_N[k] with s = 512 / N, so the mel taps sit
+  // on every s-th bin (fast512_build interleaves zero weights).  Twice the FFT arithmetic the frame
+  // needs, still several times faster than the LDS radix-2 kernel.  The spectrogram needs the N/2+1
+  // bins themselves and stays on the generic kernel for those sizes.
+  if ((mp.padded != 512 && mp.padded != 256 && mp.padded != 128) || !mp.pow2) return false;
   if (mp.win_len & 1) return false;
-  if (mp.win_len <= 256) return false;  // (pads to 512 samples, see above: 257..512)
   if (mp.kind != SNF_KIND_FBANK && mp.kind != SNF_KIND_MFCC && mp.kind != SNF_KIND_PLP &&
       mp.kind != SNF_KIND_SPECTROGRAM && mp.kind != SNF_KIND_ENERGY)
     return false;
+  if (mp.kind == SNF_KIND_SPECTROGRAM && mp.padded != 512) return false;
   if (mp.kind == SNF_KIND_FBANK && !mp.use_power) return false;
   if (mp.num_bins > 16 * kMaxRounds) return false;
   if (mp.kind == SNF_KIND_MFCC && mp.num_ceps > 16) return false;
@@ -690,10 +695,29 @@ bool fast512_eligible(const MelParams& mp, bool any_warp) {
 }
 
 // Builds the packed LDS table blob from the plan's host tables (warp 1.0 mel banks).
-int fast512_build(const MelParams& mp, const std::vector<float>& window, const MelBanksHost& mb,
+int fast512_build(const MelParams& mp, const std::vector<float>& window, const MelBanksHost& mb_in,
                   const std::vector<float>& dct, const std::vector<float>& lifter,
                   std::vector<float>* blob, Fast512Params* out) {
   constexpr double kTwoPi = 6.283185307179586476925286766559005;
+  // frames shorter than 512 samples: spread the taps of every bin over the bins of the 512-point
+  // spectrum of the zero-extended frame (see fast512_eligible)
+  MelBanksHost spread;
+  const int bin_stride = 512 / mp.padded;
+  if (bin_stride > 1 && mb_in.num_bins > 0) {
+    spread.num_bins = mb_in.num_bins;
+    spread.num_fft_bins = mb_in.num_fft_bins * bin_stride;
+    spread.center_freqs = mb_in.center_freqs;
+    for (int m = 0; m < mb_in.num_bins; ++m) {
+      spread.first.push_back(mb_in.first[m] * bin_stride);
+      spread.size.push_back(mb_in.size[m] > 0 ? (mb_in.size[m] - 1) * bin_stride + 1 : 0);
+      spread.offset.push_back(static_cast<int>(spread.w.size()));
+      for (int k = 0; k < mb_in.size[m]; ++k) {
+        spread.w.push_back(mb_in.w[mb_in.offset[m] + k]);
+        if (k + 1 < mb_in.size[m]) spread.w.insert(spread.w.end(), bin_stride - 1, 0.0f);
+      }
+    }
+  }
+  const MelBanksHost& mb = bin_stride > 1 && mb_in.num_bins > 0 ? spread : mb_in;
   Fast512Params p{};
   p.win_len = mp.win_len;
   p.win_shift = mp.win_shift;

@@ -4,6 +4,7 @@ Tolerance: rtol 1e-4 (BASELINE.json north_star) + atol 2e-3 on log-domain output
 shapes bit-exact; delta is compared at 1e-5; pitch frame-by-frame (see test_pitch)."""
 
 import itertools
+import os
 
 import numpy as np
 import pytest
@@ -210,6 +211,52 @@ def test_full_size_properties(gpu):
     f1 = proc.process(Audio(half, 16000)).data
     f2 = proc.process(Audio((half * 2).astype(np.int16), 16000)).data
     np.testing.assert_allclose(f2, 4 * f1, rtol=2e-5)
+
+
+@pytest.fixture(scope='module')
+def full_workload():
+    """BASELINE.json configs[1]: 10 000 unique synthetic 16 kHz 3 s utterances (the bench batch)"""
+    from concurrent.futures import ProcessPoolExecutor
+    jobs = [(1000 + i, 625, 48000) for i in range(0, 10000, 625)]
+    with ProcessPoolExecutor(min(16, os.cpu_count() or 1)) as pool:
+        parts = list(pool.map(_synth_job, jobs))
+    return np.concatenate(parts, axis=0)
+
+
+def _synth_job(args):
+    return synth.utterances(*args)
+
+
+@pytest.mark.parametrize('kind', ['fbank40', 'mfcc13', 'mfcc13_delta'])
+def test_full_workload_every_frame(gpu, full_workload, kind):
+    """The whole bench workload (2.98 M frames), EVERY frame against the oracle, through the same
+    batched entry point the bench times; then order independence: the batch reversed gives the same
+    rows bit for bit."""
+    waves = full_workload
+    proc = (FilterbankProcessor(num_bins=40, dither=0) if kind == 'fbank40'
+            else MfccProcessor(dither=0))
+    opts = proc._build_options()
+    plan = _backend.get_plan(opts)
+    got = plan.run(list(waves))
+    assert len(got) == 10000 and all(g.shape == (298, plan.ndims) for g in got[::997])
+    got = np.concatenate(got)
+    want = orc.compute_batch(opts, waves, os.cpu_count() or 1)
+    if kind == 'mfcc13_delta':
+        foff = np.arange(10001, dtype=np.int64) * 298
+        dproc = DeltaPostProcessor(order=2)
+        dplan = _backend.get_plan(dproc._build_options())
+        got39 = np.concatenate(dplan.run_post(list(got.reshape(10000, 298, 13))))
+        # the delta kernel on the GPU's own MFCC vs the oracle's delta of the same matrix: exact
+        # up to float32 summation order; edge clamping is per utterance
+        for u in (0, 1, 4999, 9999):
+            ref = orc.deltas(got[foff[u]:foff[u + 1]], 2, 2)
+            assert_close(got39[foff[u]:foff[u + 1]], ref, rtol=1e-5, atol=1e-5, what=f'delta {u}')
+        assert np.array_equal(got39[:, :13], got)
+        return
+    assert got.shape == want.shape == (2980000, plan.ndims)
+    assert_close(got, want, what=kind)
+    rev = np.concatenate(plan.run(list(waves[::-1]))).reshape(10000, 298, -1)[::-1]
+    assert np.array_equal(rev.reshape(got.shape), got)
 
 
 @pytest.mark.parametrize('snip_edges', [True, False])  # fast 512-point kernel / generic kernel
@@ -485,3 +532,54 @@ def test_fast_kernel_vtln(gpu, synth_waves, cls, snip_edges):
         if want.size:
             assert_close(f.data, want, rtol=2e-4, what=f'{cls.__name__} warp {wf}')
         assert f.properties[proc.name]['vtln_warp'] == wf
+
+
+@pytest.mark.parametrize('snip_edges', [True, False])
+@pytest.mark.parametrize('cls, sample_rate, opts', [
+    (FilterbankProcessor, 8000, dict(num_bins=40)),           # telephone speech: 200 samples -> 256
+    (FilterbankProcessor, 8000, dict(num_bins=23, use_energy=True, raw_energy=False)),
+    (MfccProcessor, 8000, dict()),
+    (PlpProcessor, 8000, dict()),
+    (MfccProcessor, 16000, dict(frame_length=0.01, frame_shift=0.005)),  # 160 samples -> 256
+    (FilterbankProcessor, 16000, dict(frame_length=0.008, frame_shift=0.004, num_bins=15)),  # -> 128
+    (MfccProcessor, 8000, dict(frame_length=0.016)),          # 128 samples -> 128
+])
+def test_fast_kernel_short_frames(gpu, cls, sample_rate, opts, snip_edges):
+    """frames that pad to 256 / 128 samples run on the register-resident kernel as the 512-point
+    transform of the zero-extended frame (mel taps on every 2nd / 4th bin)"""
+    n = int(0.7 * sample_rate)
+    waves = [synth.utterances(11 + i, 1, n + 37 * i, sample_rate)[0] for i in range(3)]
+    proc = cls(sample_rate=sample_rate, dither=0, snip_edges=snip_edges, **opts)
+    warps = [1.0, 1.0, 1.0]
+    feats = proc._process_batch([Audio(w, sample_rate) for w in waves], vtln_warp=warps)
+    plan = _backend.get_plan(proc._build_options())
+    assert plan.kernel_name(1) == 'fbank512_kernel'
+    for w, f in zip(waves, feats):
+        want = _oracle(proc, w)
+        assert f.shape == want.shape
+        assert_close(f.data, want, rtol=2e-4, what=f'{cls.__name__} {sample_rate} {opts}')
+    # with VTLN warps (per-utterance tables), same kernel
+    warps = [0.9, 1.0, 1.15]
+    feats = proc._process_batch([Audio(w, sample_rate) for w in waves], vtln_warp=warps)
+    assert plan.kernel_name(1) == 'fbank512_kernel'
+    for w, wf, f in zip(waves, warps, feats):
+        assert_close(f.data, _oracle(proc, w, wf), rtol=2e-4, what=f'warp {wf} {opts}')
+
+
+def test_short_frames_spectrogram_and_energy(gpu):
+    """the spectrogram of a 256-sample frame needs its own 129 bins: generic kernel; the frame
+    energy has no spectrum at all: fast kernel"""
+    wave = synth.utterances(5, 1, 6000, 8000)[0]
+    proc = SpectrogramProcessor(sample_rate=8000, dither=0)
+    got = proc.process(Audio(wave, 8000))
+    assert got.shape[1] == 129
+    assert_close(got.data, _oracle(proc, wave), rtol=1e-4, atol=2e-2)
+    plan = _backend.get_plan(proc._build_options())
+    plan.run([wave])
+    assert plan.kernel_name(1) == 'mel_features_generic_kernel'
+    eproc = EnergyProcessor(sample_rate=8000, dither=0)
+    got = eproc.process(Audio(wave, 8000))
+    np.testing.assert_allclose(got.data, _oracle(eproc, wave), rtol=1e-6)
+    plan = _backend.get_plan(eproc._build_options())
+    plan.run([wave])
+    assert plan.kernel_name(1) == 'fbank512_kernel'
