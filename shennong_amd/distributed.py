@@ -17,13 +17,17 @@ import numpy as np
 
 
 def shard_utterances(lengths, world_size):
-    """Greedy longest-first partition of utterance indices by sample count.
+    """Greedy longest-first partition of utterance indices by length (sample counts or durations in
+    seconds: any non-negative numbers).
 
     Returns `world_size` lists of indices (each sorted ascending); deterministic, every index appears
-    exactly once, the per-rank sample totals differ by at most the longest utterance."""
-    lengths = np.asarray(lengths, dtype=np.int64)
+    exactly once, the per-rank totals differ by at most the longest utterance."""
+    lengths = np.asarray(lengths)
+    if lengths.dtype.kind not in 'iu':
+        lengths = lengths.astype(np.float64)  # (durations: truncating them would send every
+                                              # sub-second utterance to rank 0)
     order = np.argsort(-lengths, kind='stable')
-    totals = np.zeros(world_size, dtype=np.int64)
+    totals = np.zeros(world_size, dtype=lengths.dtype if lengths.size else np.int64)
     shards = [[] for _ in range(world_size)]
     for idx in order:
         r = int(np.argmin(totals))
@@ -254,3 +258,42 @@ def extract_features_sharded(configuration, utterances, warps=None, dst=0, group
         times, properties = everything[u.name]
         out[u.name] = Features(merged[u.name], times, properties=properties, validate=False)
     return out
+
+
+def extract_features_streamed_sharded(configuration, utterances, sink, warps=None,
+                                      max_batch_duration=3600.0, group=None, log=None):
+    """``pipeline.extract_features_streamed`` over the ranks of one node (BASELINE config 5): every
+    rank passes the same `utterances`, streams its length-balanced shard batch by batch through the
+    device-resident pipeline and hands the batches to ITS OWN `sink` (e.g. one
+    ``KaldiStreamWriter('feats.<rank>.ark')`` per rank: no features travel between the ranks).  The
+    only exchange is the sum of the per-speaker CMVN statistics after the first pass (a few KB,
+    `reduce_named_stats`).  Returns the number of utterances this rank wrote."""
+    import torch.distributed as dist
+    from shennong_amd import pipeline
+    from shennong_amd.logger import get_logger
+    from shennong_amd.utterances import Utterances
+    log = log or get_logger('pipeline', 'warning')
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    config = pipeline._init_config(configuration, log=log)
+    if warps:
+        warps = pipeline._init_warps(warps, config, utterances, log)
+    utts = list(utterances)
+    shards = shard_utterances([u.duration for u in utts], world)
+    mine = [utts[i] for i in sorted(shards[rank])]
+    by_speaker = 'cmvn' in config and config['cmvn']['by_speaker']
+    if by_speaker and not utterances.has_speakers():
+        raise ValueError(
+            'cmvn normalization by speaker requested '
+            'but no speaker information provided')
+
+    def reduce(names, stats):
+        return reduce_named_stats(names, stats, group=group)
+
+    if not mine:
+        if by_speaker:  # still take part in the reduction
+            reduce([], np.zeros((0, 2, 1), dtype=np.float64))
+        return 0
+    return pipeline.extract_features_streamed(
+        configuration, Utterances(mine), sink,
+        warps={u.name: warps[u.name] for u in mine} if warps else None,
+        max_batch_duration=max_batch_duration, stats_reduce=reduce if by_speaker else None, log=log)

@@ -311,6 +311,85 @@ def extract_features(configuration, utterances, warps=None, njobs=1,
     return _extract_features(config, utterances, warps, log)
 
 
+def _batches(utterances, max_duration):
+    """Consecutive runs of `utterances` (order kept) of at most `max_duration` seconds of audio each;
+    an utterance longer than that is a batch of its own"""
+    batch, total = [], 0.0
+    for utt in utterances:
+        duration = utt.duration
+        if batch and total + duration > max_duration:
+            yield batch
+            batch, total = [], 0.0
+        batch.append(utt)
+        total += duration
+    if batch:
+        yield batch
+
+
+def extract_features_streamed(configuration, utterances, sink, warps=None,
+                              max_batch_duration=3600.0, njobs=1, stats_reduce=None,
+                              log=get_logger('pipeline', 'warning')):
+    """:func:`extract_features` for a corpus that must not sit in memory at once (BASELINE config 5)
+
+    The utterances are processed in consecutive batches of at most `max_batch_duration` seconds of
+    audio (one hour of 16 kHz audio is 115 MB of int16 up and, for 123 columns, 177 MB of float32
+    down); each batch goes through the device-resident pipeline and its FeaturesCollection is
+    handed to `sink` (a callable, e.g. ``KaldiStreamWriter.write``) and dropped.  The results are
+    those of :func:`extract_features` on the whole corpus, bit for bit: with CMVN by speaker the
+    statistics need every utterance of a speaker before any can be normalised, so a first pass over
+    the batches accumulates them (features + VAD only, summed in utterance order like the one-shot
+    pipeline does) and the second pass recomputes the features instead of keeping them - on this
+    hardware the features are cheaper to recompute than to store.
+
+    `stats_reduce(names, stats) -> stats` sums the speakers' statistics across processes when the
+    corpus is sharded (see shennong_amd.distributed.extract_features_streamed_sharded).
+
+    Returns the number of utterances written."""
+    from shennong_amd.utterances import Utterances
+    get_njobs(njobs, log=log)
+    config = _init_config(configuration, log=log)
+    if not max_batch_duration > 0:
+        raise ValueError('max_batch_duration must be strictly positive')
+    if warps:
+        warps = _init_warps(warps, config, utterances, log)
+    by_speaker = 'cmvn' in config and config['cmvn']['by_speaker']
+    if by_speaker and not utterances.has_speakers():
+        raise ValueError(
+            'cmvn normalization by speaker requested '
+            'but no speaker information provided')
+    utts = list(utterances)
+
+    def sub(batch):
+        return {u.name: warps[u.name] for u in batch} if warps else None
+
+    hook = None
+    if by_speaker:
+        total = {}
+        for batch in _batches(utts, max_batch_duration):
+            speakers, per_utt = _extract_features(
+                config, Utterances(batch), sub(batch), log, stats_only=True)
+            for speaker, stats in zip(speakers, per_utt):
+                if speaker in total:
+                    total[speaker] += stats
+                else:
+                    total[speaker] = stats.copy()
+        if stats_reduce is not None:
+            names = list(total)
+            reduced = stats_reduce(names, np.stack([total[k] for k in names]) if names
+                                   else np.zeros((0, 2, 1), dtype=np.float64))
+            total = dict(zip(names, reduced))
+
+        def hook(names, _partial):
+            return np.stack([total[k] for k in names])
+
+    count = 0
+    for batch in _batches(utts, max_batch_duration):
+        features = _extract_features(config, Utterances(batch), sub(batch), log, stats_hook=hook)
+        sink(features)
+        count += len(features)
+    return count
+
+
 class _Meta:
     """What the post-processors' `get_properties` need to know about features that live in HBM.
     The properties of a stage are the same for every utterance that went through the same processors
@@ -332,11 +411,16 @@ class _Meta:
                      self.times if times is None else times, key)
 
 
-def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=None):
+def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=None,
+                      stats_only=False):
     """The whole pipeline with the intermediate features resident in HBM: the waveforms go up once,
     every stage is one batched launch on device buffers (features, energy -> VAD, CMVN statistics and
     apply, delta, pitch and its post-processing, column concatenation), the final matrices come down
-    once.  Stage order, arithmetic and properties are those of reference pipeline.py:525-643."""
+    once.  Stage order, arithmetic and properties are those of reference pipeline.py:525-643.
+
+    `stats_only` (first pass of :func:`extract_features_streamed`): stop after the CMVN accumulation
+    and return ``(group name of every utterance, per-utterance statistics [n, 2, dim + 1])``; the
+    pitch stage, which the statistics do not depend on, is skipped."""
     features_name = [k for k in config.keys() if k in valid_features()][0]
     with_cmvn = 'cmvn' in config
     if with_cmvn and config['cmvn']['by_speaker'] and not utterances.has_speakers():
@@ -439,7 +523,7 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             d_energy.free()
             st['d_vad'] = d_vad
 
-        if 'pitch' in config:
+        if 'pitch' in config and not stats_only:
             params = {k: v for k, v in config['pitch'].items()
                       if k not in ('processor', 'postprocessing')}
             params['sample_rate'] = rate
@@ -491,6 +575,10 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             per_utt[st['idx']] = local
             if 'd_vad' in st:
                 st['d_vad'].free()
+        if stats_only:
+            for st in groups_state:
+                st['d_feat'].free()
+            return [names[g] for g in group_of], per_utt
         stats = np.zeros((len(names), 2, dim + 1), dtype=np.float64)
         for i in range(n):
             stats[group_of[i]] += per_utt[i]
@@ -647,7 +735,7 @@ def _extract_features_by_stage(config, utterances, warps, log, tolerance=2):
             for i, v in zip(idx, decisions):
                 weights[i] = v.data.reshape((v.shape[0], ))
 
-        if 'pitch' in config:
+        if 'pitch' in config and not stats_only:
             params = {k: v for k, v in config['pitch'].items()
                       if k not in ('processor', 'postprocessing')}
             params['sample_rate'] = rate

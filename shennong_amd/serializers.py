@@ -264,19 +264,25 @@ class PickleSerializer(FeaturesSerializer):
 
 
 # ---- Kaldi binary archives ------------------------------------------------------------------------------
+def _write_kaldi_matrix(stream, key, mat):
+    """One table entry; returns the offset an scp line points to (just after ``<key> ``)"""
+    mat = np.ascontiguousarray(mat, dtype=np.float64)
+    stream.write(key.encode('utf-8') + b' ')
+    offset = stream.tell()
+    stream.write(b'\0BDM ')
+    stream.write(b'\4' + struct.pack('<i', mat.shape[0]))
+    stream.write(b'\4' + struct.pack('<i', mat.shape[1]))
+    stream.write(mat.tobytes())
+    return offset
+
+
 def _write_kaldi_ark(ark, matrices, scp=None):
     """Binary table of double matrices: ``<key> \\0B DM \\4<rows>\\4<cols><float64 row-major>``
     ([KALDI-UPSTREAM] util/kaldi-holder-inl.h, matrix/kaldi-matrix.cc Write)"""
     index = []
     with open(ark, 'wb') as stream:
         for key, mat in matrices.items():
-            mat = np.ascontiguousarray(mat, dtype=np.float64)
-            stream.write(key.encode('utf-8') + b' ')
-            index.append((key, stream.tell()))
-            stream.write(b'\0BDM ')
-            stream.write(b'\4' + struct.pack('<i', mat.shape[0]))
-            stream.write(b'\4' + struct.pack('<i', mat.shape[1]))
-            stream.write(mat.tobytes())
+            index.append((key, _write_kaldi_matrix(stream, key, mat)))
     if scp:
         with open(scp, 'w', encoding='utf-8') as stream:
             for key, offset in index:
@@ -359,13 +365,18 @@ class KaldiSerializer(FeaturesSerializer):
         if not os.path.isfile(ark):
             raise IOError('file not found: {}'.format(ark))
         times = _read_kaldi_ark(ark)
-        for key, value in times.items():
-            if value.shape[0] == 1:
-                times[key] = value.reshape((value.shape[1]))
 
         ark = self._fileroot + '.ark'
         self._log.info('loading %s', ark)
         data = _read_kaldi_ark(ark)
+
+        # 1-D times were written as one row: back to 1-D (reference serializers.py does this for
+        # every one-row matrix, which breaks the [1, 2] times of a single-frame item: those are told
+        # apart by the number of frames of the data)
+        for key, value in times.items():
+            single_frame = (key in data and data[key].shape[0] == 1 and value.shape[1] == 2)
+            if value.shape[0] == 1 and not single_frame:
+                times[key] = value.reshape((value.shape[1]))
 
         if properties.keys() != data.keys():
             raise ValueError(
@@ -382,6 +393,74 @@ class KaldiSerializer(FeaturesSerializer):
                     if '__dtype_' not in k},
                 validate=False)
                for k in data.keys()})
+
+
+class KaldiStreamWriter:
+    """Incremental writer of the Kaldi layout above (``<root>.ark``, ``<root>.times.ark``,
+    optional ``.scp`` indexes, ``<root>.properties.json`` at close) for features that are produced
+    batch by batch (pipeline.extract_features_streamed): the archives are appended to as the
+    batches arrive, so the corpus never sits in host memory.  What it writes loads back with
+    ``FeaturesCollection.load(filename)`` / `KaldiSerializer` and is byte-identical to
+    ``FeaturesCollection.save`` of the same items in the same order.
+
+    >>> with KaldiStreamWriter('corpus.ark', scp=True) as writer:       # doctest: +SKIP
+    ...     extract_features_streamed(config, utterances, writer.write)
+    """
+    def __init__(self, filename, scp=False, with_properties=True, log=None):
+        root, ext = os.path.splitext(filename)
+        if ext != '.ark':
+            raise ValueError(
+                'when saving to Kaldi ark format, the file extension must be '
+                '".ark", it is "{}"'.format(ext))
+        self._root = root
+        self._with_properties = with_properties
+        self._log = log
+        self._properties = {}
+        self._files = [root + '.ark', root + '.times.ark', root + '.properties.json']
+        if scp:
+            self._files += [root + '.scp', root + '.times.scp']
+        for name in self._files:
+            if os.path.exists(name):
+                raise IOError('file already exists: {}'.format(name))
+        self._data = open(root + '.ark', 'wb')
+        self._times = open(root + '.times.ark', 'wb')
+        self._data_scp = open(root + '.scp', 'w', encoding='utf-8') if scp else None
+        self._times_scp = open(root + '.times.scp', 'w', encoding='utf-8') if scp else None
+
+    def write(self, features):
+        """Appends the items of a FeaturesCollection (or any ``name -> Features`` mapping)"""
+        if self._data is None:
+            raise ValueError('writer is closed')
+        for key, feat in features.items():
+            if key in self._properties:
+                raise ValueError('item already written: {}'.format(key))
+            offset = _write_kaldi_matrix(self._data, key, feat.data)
+            if self._data_scp:
+                self._data_scp.write(f'{key} {self._root}.ark:{offset}\n')
+            offset = _write_kaldi_matrix(self._times, key, np.atleast_2d(feat.times))
+            if self._times_scp:
+                self._times_scp.write(f'{key} {self._root}.times.ark:{offset}\n')
+            props = copy.deepcopy(feat.properties) if self._with_properties else {}
+            props['__dtype_data__'] = str(feat.dtype)
+            props['__dtype_times__'] = str(feat.times.dtype)
+            self._properties[key] = props
+
+    def close(self):
+        if self._data is None:
+            return
+        for stream in (self._data, self._times, self._data_scp, self._times_scp):
+            if stream is not None:
+                stream.close()
+        self._data = None
+        with open(self._root + '.properties.json', 'wt', encoding='utf-8') as stream:
+            stream.write(_json_dumps(self._properties))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
 
 class CsvSerializer(FeaturesSerializer):

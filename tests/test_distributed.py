@@ -22,6 +22,8 @@ def test_shard_utterances_balanced():
         assert max(totals) - min(totals) <= lengths.max()
     assert shard_utterances([], 2) == [[], []]
     assert shard_utterances([5, 5, 5], 4) == [[0], [1], [2], []]
+    # durations in seconds are not truncated (sub-second utterances would all land on rank 0)
+    assert shard_utterances([0.3, 0.4, 0.5, 0.6, 0.2], 2) == [[0, 3, 4], [1, 2]]
 
 
 def _worker(rank, world, port, tmpdir):
@@ -173,4 +175,55 @@ def test_reduce_named_stats_gloo(tmp_path):
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     mp.spawn(_named_stats_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert [open(tmp_path / f'ok{r}').read() for r in range(2)] == ['1', '1']
+
+
+def _streamed_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    from conftest import GOLDEN
+    from shennong_amd import Utterances, pipeline
+    from shennong_amd.distributed import extract_features_streamed_sharded
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    wav = os.path.join(GOLDEN, 'test.wav')
+    index = Utterances([(f'u{i}', wav, f's{i % 3}', 0.1 * (i % 4), 0.1 * (i % 4) + 0.3 + 0.1 * (i % 5))
+                        for i in range(1, 10)])
+
+    def fake(config, utterances, warps, log, tolerance=2, stats_hook=None, stats_only=False):
+        # stand-in for the device pipeline (no GPU on the CPU ranks): the "statistics" of utterance
+        # u<i> are i, the "features" of an utterance are its speaker's global statistics
+        utts = list(utterances)
+        per_utt = np.stack([np.full((2, 3), float(int(u.name[1:]))) for u in utts])
+        if stats_only:
+            return [u.speaker for u in utts], per_utt
+        names = list(dict.fromkeys(u.speaker for u in utts))
+        stats = stats_hook(names, np.zeros((len(names), 2, 3)))
+        return {u.name: float(stats[names.index(u.speaker)][0, 0]) for u in utts}
+
+    pipeline._extract_features = fake
+    config = pipeline.get_default_config('mfcc', with_cmvn=True)
+    out = {}
+    n = extract_features_streamed_sharded(config, index, out.update, max_batch_duration=1.0)
+    want = {f's{k}': float(sum(i for i in range(1, 10) if i % 3 == k)) for k in range(3)}
+    ok = n == len(out) and 0 < n < 9
+    ok = ok and all(v == want[f's{int(k[1:]) % 3}'] for k, v in out.items())
+    counts = [None, None]
+    dist.all_gather_object(counts, sorted(out))
+    ok = ok and sorted(counts[0] + counts[1]) == [f'u{i}' for i in range(1, 10)]
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmpdir, f'ok{rank}'), 'w').write('1' if ok else f'0 {n} {out} {counts}')  # noqa
+
+
+@pytest.mark.timeout(120)
+def test_streamed_sharded_gloo(tmp_path):
+    """streamed extraction over two ranks: each rank streams its shard into its own sink, the
+    speakers' statistics are summed over all batches of all ranks before the second pass"""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_streamed_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert [open(tmp_path / f'ok{r}').read() for r in range(2)] == ['1', '1']

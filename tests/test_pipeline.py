@@ -369,3 +369,116 @@ def test_utterances_file_and_duration(tmp_path):
         utts.fit_to_duration(0)
     with pytest.raises(ValueError):
         Utterances([('x', WAV)]).fit_to_duration(1)
+
+
+# ---- streamed extraction (BASELINE config 5: a corpus that does not sit in memory at once) ------------
+def _segments_index():
+    return Utterances([
+        ('u1', WAV, 's1', 0, 0.9), ('u2', WAV, 's2', 0.2, 1.3), ('u3', WAV, 's1', 0.5, 1.4),
+        ('u4', WAV, 's2', 0.1, 0.6), ('u5', WAV, 's3', 0.3, 1.2), ('u6', WAV, 's1', 0.7, 1.4)])
+
+
+def test_batches():
+    index = _segments_index()
+    utts = list(index)
+    durations = [u.duration for u in utts]
+    got = list(pipeline._batches(utts, 2.0))
+    assert [u.name for b in got for u in b] == [u.name for u in utts]  # order kept, nothing lost
+    for b in got:
+        assert sum(u.duration for u in b) <= 2.0 or len(b) == 1
+    assert len(got) > 1
+    assert list(pipeline._batches(utts, sum(durations) + 1)) == [utts]
+    assert [len(b) for b in pipeline._batches(utts, 1e-3)] == [1] * len(utts)
+    with pytest.raises(ValueError, match='max_batch_duration'):
+        pipeline.extract_features_streamed(
+            pipeline.get_default_config('mfcc'), index, lambda f: None, max_batch_duration=0)
+    with pytest.raises(ValueError, match='no speaker information'):
+        pipeline.extract_features_streamed(
+            pipeline.get_default_config('mfcc', with_cmvn=True),
+            Utterances([('a', WAV), ('b', WAV)]), lambda f: None)
+
+
+def test_streamed_driver_logic(monkeypatch):
+    """host logic of the two passes with the device pipeline replaced by a stand-in: every speaker's
+    statistics are the sum over ALL batches (in utterance order) before any batch is normalised, and
+    a cross-process reduction is applied exactly once, after the first pass"""
+    index = _segments_index()
+    calls = []
+
+    def fake(config, utterances, warps, log, tolerance=2, stats_hook=None, stats_only=False):
+        utts = list(utterances)
+        per_utt = np.stack([np.full((2, 3), float(int(u.name[1]))) for u in utts])
+        if stats_only:
+            calls.append(('stats', [u.name for u in utts]))
+            return [u.speaker for u in utts], per_utt
+        names = list(dict.fromkeys(u.speaker for u in utts))
+        partial = np.stack([sum(per_utt[i] for i, u in enumerate(utts) if u.speaker == s)
+                            for s in names])
+        stats = stats_hook(names, partial) if stats_hook else partial
+        calls.append(('apply', [u.name for u in utts]))
+        return {u.name: stats[names.index(u.speaker)][0, 0] for u in utts}
+
+    monkeypatch.setattr(pipeline, '_extract_features', fake)
+    config = pipeline.get_default_config('mfcc', with_cmvn=True)
+    out = {}
+    n = pipeline.extract_features_streamed(config, index, out.update, max_batch_duration=2.0)
+    assert n == 6
+    # s1 = u1 + u3 + u6, s2 = u2 + u4, s3 = u5 whatever the batch boundaries are
+    assert out == {'u1': 10.0, 'u3': 10.0, 'u6': 10.0, 'u2': 6.0, 'u4': 6.0, 'u5': 5.0}
+    kinds = [k for k, _ in calls]
+    assert kinds == ['stats'] * (len(kinds) // 2) + ['apply'] * (len(kinds) // 2) and len(kinds) > 2
+    assert [x for k, b in calls if k == 'stats' for x in b] == ['u1', 'u2', 'u3', 'u4', 'u5', 'u6']
+
+    reduced = []
+
+    def reduce(names, stats):
+        reduced.append(list(names))
+        return stats * 2
+
+    out = {}
+    pipeline.extract_features_streamed(config, index, out.update, max_batch_duration=2.0,
+                                       stats_reduce=reduce)
+    assert reduced == [['s1', 's2', 's3']]
+    assert out['u1'] == 20.0 and out['u5'] == 10.0
+
+    # CMVN by utterance (or no CMVN): a single pass, no statistics carried between the batches
+    calls.clear()
+    config['cmvn']['by_speaker'] = False
+    pipeline.extract_features_streamed(config, index, out.update, max_batch_duration=2.0)
+    assert all(k == 'apply' for k, _ in calls)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('by_speaker', [True, False, None])
+def test_pipeline_streamed(gpu, tmp_path, by_speaker):
+    """the streamed pipeline (several batches, speaker statistics from a first pass, features
+    recomputed in the second) returns exactly the one-shot pipeline's features, and the incremental
+    Kaldi writer stores them like FeaturesCollection.save does"""
+    from shennong_amd import FeaturesCollection
+    from shennong_amd.serializers import KaldiStreamWriter
+    index = _segments_index()
+    config = pipeline.get_default_config(
+        'mfcc', with_cmvn=by_speaker is not None, with_delta=True, with_pitch='kaldi')
+    config['mfcc']['dither'] = 0
+    config['pitch']['postprocessing']['delta_pitch_noise_stddev'] = 0
+    if by_speaker is not None:
+        config['cmvn']['by_speaker'] = by_speaker
+        config['cmvn']['with_vad'] = False  # (the VAD energy is dithered per batch position)
+    warps = {'s1': 1.1, 's2': 0.9, 's3': 1.0}
+    whole = pipeline.extract_features(config, index, warps=warps)
+    got = FeaturesCollection()
+    name = str(tmp_path / 'corpus.ark')
+    with KaldiStreamWriter(name, scp=True) as writer:
+        def sink(feats):
+            got.update(feats)
+            writer.write(feats)
+        n = pipeline.extract_features_streamed(config, index, sink, warps=warps,
+                                               max_batch_duration=1.5)
+    assert n == 6 and list(got.keys()) == list(whole.keys())
+    for k in whole:
+        assert got[k] == whole[k], k
+    assert FeaturesCollection.load(name) == whole
+    whole.save(str(tmp_path / 'oneshot.ark'), scp=True)
+    for suffix in ('.ark', '.times.ark'):
+        assert open(str(tmp_path / 'corpus') + suffix, 'rb').read() == \
+            open(str(tmp_path / 'oneshot') + suffix, 'rb').read()

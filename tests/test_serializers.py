@@ -225,3 +225,51 @@ def test_partition_and_trim(mfcc):
         col.trim({'a': vad['a']})
     with pytest.raises(ValueError):
         col.trim({k: v.astype(int) for k, v in vad.items()})
+
+
+@pytest.mark.parametrize('scp', [True, False])
+@pytest.mark.parametrize('with_properties', [True, False])
+def test_kaldi_stream_writer(tmpdir, mfcc, scp, with_properties):
+    """batches appended one after the other give byte for byte the files of one
+    FeaturesCollection.save of all the items, and load back equal"""
+    rng = np.random.default_rng(1)
+    items = FeaturesCollection()
+    for i, n in enumerate((140, 3, 77, 1, 25)):
+        proc = MfccProcessor()
+        items[f'utt{i}-é'] = Features(
+            rng.standard_normal((n, 13)).astype(np.float32), proc.times(n),
+            properties=proc.get_properties(vtln_warp=1.0 + i / 10))
+    items['times1d'] = Features(np.ones((4, 2), np.float64), np.arange(4.0), validate=True)
+    keys = list(items)
+    streamed = str(tmpdir.join('streamed.ark'))
+    with serializers.KaldiStreamWriter(streamed, scp=scp, with_properties=with_properties) as w:
+        w.write({k: items[k] for k in keys[:2]})
+        w.write({})
+        w.write({k: items[k] for k in keys[2:5]})
+        w.write({keys[5]: items[keys[5]]})
+        with pytest.raises(ValueError, match='already written'):
+            w.write({keys[0]: items[keys[0]]})
+    with pytest.raises(ValueError, match='closed'):
+        w.write({})
+    w.close()  # idempotent
+    items.save(str(tmpdir.join('oneshot.ark')), scp=scp, with_properties=with_properties)
+    suffixes = ['.ark', '.times.ark', '.properties.json'] + (['.scp', '.times.scp'] if scp else [])
+    for suffix in suffixes:
+        a = open(str(tmpdir.join('streamed' + suffix)), 'rb').read()
+        b = open(str(tmpdir.join('oneshot' + suffix)), 'rb').read()
+        if suffix.endswith('.scp'):
+            b = b.replace(b'oneshot', b'streamed')
+        assert a == b, suffix
+    assert not os.path.exists(str(tmpdir.join('streamed.scp'))) or scp
+    loaded = FeaturesCollection.load(streamed)
+    assert list(loaded.keys()) == keys
+    for k in keys:
+        assert np.array_equal(loaded[k].data, items[k].data) and loaded[k].dtype == items[k].dtype
+        assert np.array_equal(loaded[k].times, items[k].times)
+        assert (loaded[k].properties == items[k].properties) is with_properties or \
+            not items[k].properties
+    # never overwrites, wrong extension refused
+    with pytest.raises(IOError, match='already exists'):
+        serializers.KaldiStreamWriter(streamed)
+    with pytest.raises(ValueError, match='extension must be'):
+        serializers.KaldiStreamWriter(str(tmpdir.join('x.npz')))
