@@ -386,6 +386,76 @@ __global__ __launch_bounds__(256) void delta_tiled_kernel(
   }
 }
 
+// The same tile with the order and window known at compile time (the reference's defaults, order 2 /
+// window 2, and order 1): the 2*halo+1 clamped neighbours of an element are read from LDS ONCE for all
+// the orders, the composite scales sit in scalar registers, the tap loops are unrolled.  Same products
+// in the same order as the generic kernel above.
+template <int ORDER, int WINDOW>
+__global__ __launch_bounds__(256) void delta_tiled_fixed_kernel(
+    const DeltaParams p, const float* __restrict__ in, const int D,
+    const int64_t* __restrict__ frame_offsets, const int64_t n_utts, const int64_t total_frames,
+    float* __restrict__ out) {
+  constexpr int kHalo = ORDER * WINDOW;
+  constexpr int kTaps = 2 * kHalo + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* row_lo = reinterpret_cast<int*>(smem);
+  int* row_hi = row_lo + kDeltaRows;
+  float* tile = reinterpret_cast<float*>(row_hi + kDeltaRows);  // [(kDeltaRows + 2 kHalo), D]
+  const int64_t g0 = static_cast<int64_t>(blockIdx.x) * kDeltaRows;
+  const int64_t t0 = g0 - kHalo;
+  constexpr int tile_rows = kDeltaRows + 2 * kHalo;
+  const int64_t first = t0 * D, limit = total_frames * D;
+  for (int i = threadIdx.x; i < tile_rows * D; i += blockDim.x) {
+    const int64_t a = first + i;
+    tile[i] = (a >= 0 && a < limit) ? in[a] : 0.0f;
+  }
+  if (threadIdx.x < kDeltaRows) {
+    const int64_t g = g0 + threadIdx.x;
+    if (g < total_frames) {
+      const int64_t u = find_utt(frame_offsets, n_utts, g);
+      const int64_t lo = frame_offsets[u] - t0, hi = frame_offsets[u + 1] - 1 - t0;
+      row_lo[threadIdx.x] = lo < 0 ? 0 : static_cast<int>(lo);
+      row_hi[threadIdx.x] = hi > tile_rows - 1 ? tile_rows - 1 : static_cast<int>(hi);
+    }
+  }
+  // composite scales of every order, concatenated like DeltaParams::scales (uniform: scalar loads)
+  constexpr int kScales = (ORDER + 1) * (ORDER * WINDOW + 1);  // sum of 2 i WINDOW + 1, i <= ORDER
+  float sc[kScales];
+#pragma unroll
+  for (int i = 0; i < kScales; ++i) sc[i] = p.scales[i];
+  __syncthreads();
+  const int OD = D * (ORDER + 1);
+  const int rows_here = static_cast<int>(total_frames - g0 < kDeltaRows ? total_frames - g0 : kDeltaRows);
+  int r = threadIdx.x / D, c = threadIdx.x - r * D;
+  const int dr = blockDim.x / D, dc = blockDim.x - dr * D;
+  float* __restrict__ obase = out + g0 * OD;
+  for (; r < rows_here; r += dr, c += dc) {
+    if (c >= D) { c -= D; ++r; if (r >= rows_here) break; }
+    const int lo = row_lo[r], hi = row_hi[r], centre = r + kHalo;
+    float x[kTaps];
+#pragma unroll
+    for (int j = 0; j < kTaps; ++j) {
+      int t = centre + j - kHalo;
+      t = t < lo ? lo : (t > hi ? hi : t);
+      x[j] = tile[t * D + c];
+    }
+    float* __restrict__ orow = obase + static_cast<int64_t>(r) * OD + c;
+    int soff = 0;
+#pragma unroll
+    for (int i = 0; i <= ORDER; ++i) {
+      const int max_off = i * WINDOW;
+      float acc = 0.0f;
+#pragma unroll
+      for (int j = -max_off; j <= max_off; ++j) {
+        const float s = sc[soff + j + max_off];
+        if (s != 0.0f) acc += s * x[j + kHalo];
+      }
+      orow[i * D] = acc;
+      soff += 2 * max_off + 1;
+    }
+  }
+}
+
 int launch_deltas(const DeltaParams& p, const float* in, int in_cols, const int64_t* frame_offsets,
                   int64_t n_utts, int64_t total_frames, float* out, hipStream_t stream) {
   const int64_t total = total_frames * in_cols;
@@ -393,6 +463,19 @@ int launch_deltas(const DeltaParams& p, const float* in, int in_cols, const int6
   const int halo = p.order * p.window;
   const size_t lds = 2 * sizeof(int) * kDeltaRows + sizeof(float) * ((p.n_scales + 3) & ~3) +
                      sizeof(float) * static_cast<size_t>(kDeltaRows + 2 * halo) * in_cols;
+  const unsigned tiles = static_cast<unsigned>((total_frames + kDeltaRows - 1) / kDeltaRows);
+  if (lds <= 48 * 1024 && in_cols <= 256 && p.window == 2 && (p.order == 2 || p.order == 1)) {
+    const size_t lds_fixed = 2 * sizeof(int) * kDeltaRows +
+                             sizeof(float) * static_cast<size_t>(kDeltaRows + 2 * halo) * in_cols;
+    if (p.order == 2)
+      hipLaunchKernelGGL((delta_tiled_fixed_kernel<2, 2>), dim3(tiles), dim3(256), lds_fixed, stream, p,
+                         in, in_cols, frame_offsets, n_utts, total_frames, out);
+    else
+      hipLaunchKernelGGL((delta_tiled_fixed_kernel<1, 2>), dim3(tiles), dim3(256), lds_fixed, stream, p,
+                         in, in_cols, frame_offsets, n_utts, total_frames, out);
+    SNF_HIP_CHECK(hipGetLastError());
+    return SNF_OK;
+  }
   if (lds <= 48 * 1024 && in_cols <= 256) {
     hipLaunchKernelGGL(delta_tiled_kernel,
                        dim3(static_cast<unsigned>((total_frames + kDeltaRows - 1) / kDeltaRows)),

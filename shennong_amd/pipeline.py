@@ -13,6 +13,7 @@ Not provided by this backend (out of scope): VTLN *training* (`with
 configuration entry; precomputed `warps` are supported), CREPE pitch, bottleneck features.
 """
 
+import copy
 import os
 
 import numpy as np
@@ -309,6 +310,22 @@ def extract_features(configuration, utterances, warps=None, njobs=1,
     if warps:
         warps = _init_warps(warps, config, utterances, log)
     return _extract_features(config, utterances, warps, log)
+
+
+def _copy_properties(value):
+    """Independent copy of a properties tree (dicts / lists of strings, numbers and arrays): what
+    ``copy.deepcopy`` returns for these, several times faster - with one Features per utterance the
+    generic deepcopy was half of the pipeline's wall time"""
+    kind = type(value)
+    if kind is dict:
+        return {k: _copy_properties(v) for k, v in value.items()}
+    if kind is list:
+        return [_copy_properties(v) for v in value]
+    if kind is np.ndarray:
+        return value.copy()
+    if kind in (str, int, float, bool, type(None)) or isinstance(value, np.generic):
+        return value
+    return copy.deepcopy(value)
 
 
 def _batches(utterances, max_duration):
@@ -651,9 +668,8 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
         st['d_feat'].free()
         for k, i in enumerate(idx):
             results[i] = host[st['foff'][k]:st['foff'][k + 1]].copy()
-    import copy
     for i, utt in enumerate(utts):
-        props = copy.deepcopy(meta[i].properties)
+        props = _copy_properties(meta[i].properties)
         if utt.speaker:
             props['speaker'] = utt.speaker
         props['audio'] = {
@@ -735,7 +751,7 @@ def _extract_features_by_stage(config, utterances, warps, log, tolerance=2):
             for i, v in zip(idx, decisions):
                 weights[i] = v.data.reshape((v.shape[0], ))
 
-        if 'pitch' in config and not stats_only:
+        if 'pitch' in config:
             params = {k: v for k, v in config['pitch'].items()
                       if k not in ('processor', 'postprocessing')}
             params['sample_rate'] = rate

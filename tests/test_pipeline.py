@@ -482,3 +482,21 @@ def test_pipeline_streamed(gpu, tmp_path, by_speaker):
     for suffix in ('.ark', '.times.ark'):
         assert open(str(tmp_path / 'corpus') + suffix, 'rb').read() == \
             open(str(tmp_path / 'oneshot') + suffix, 'rb').read()
+
+
+def test_copy_properties():
+    """the pipeline's properties copy is a deep copy: equal, nothing mutable shared"""
+    import copy
+    props = {'pipeline': [{'name': 'mfcc', 'columns': [0, 12]}, {'name': 'cmvn', 'columns': [0, 12]}],
+             'mfcc': {'dither': np.float32(0.0), 'window_type': 'povey', 'snip_edges': True,
+                      'vtln_warp': 1.1, 'num_ceps': 13, 'none': None},
+             'cmvn': {'stats': np.arange(28.0).reshape(2, 14)}, 'other': (1, [2])}
+    got = pipeline._copy_properties(props)
+    want = copy.deepcopy(props)
+    assert got.keys() == want.keys() and got['mfcc'] == want['mfcc'] and got['pipeline'] == want['pipeline']
+    assert np.array_equal(got['cmvn']['stats'], props['cmvn']['stats'])
+    assert got['cmvn']['stats'] is not props['cmvn']['stats']
+    assert got['pipeline'] is not props['pipeline'] and got['pipeline'][0] is not props['pipeline'][0]
+    assert got['pipeline'][0]['columns'] is not props['pipeline'][0]['columns']
+    assert type(got['mfcc']['dither']) is np.float32
+    assert got['other'] == props['other'] and got['other'][1] is not props['other'][1]
