@@ -583,3 +583,64 @@ def test_short_frames_spectrogram_and_energy(gpu):
     plan = _backend.get_plan(eproc._build_options())
     plan.run([wave])
     assert plan.kernel_name(1) == 'fbank512_kernel'
+
+
+def test_more_than_2g_output_elements(gpu):
+    """maximum sizes: a batch whose output has more than 2^31 elements (8.4 M spectrogram frames of
+    257 bins, 8.6 GB) and whose waveform has more than 2^31 bytes - every row index is 64-bit.  Device
+    resident; rows on both sides of the 2^31-element boundary and the last rows are compared with
+    the same utterances processed alone."""
+    import ctypes as C
+    block = synth.utterances(77, 100, 48000)
+    n_utts, nsamp, nfr = 28200, 48000, 298
+    assert n_utts * nfr * 257 > 2**31 and n_utts * nsamp * 2 > 2**31
+    proc = SpectrogramProcessor(dither=0)
+    plan = _backend.get_plan(proc._build_options())
+    soff = np.arange(n_utts + 1, dtype=np.int64) * nsamp
+    foff = np.arange(n_utts + 1, dtype=np.int64) * nfr
+    d_wave = _backend.DeviceBuffer(n_utts * nsamp * 2)
+    flat = np.ascontiguousarray(block.reshape(-1))
+    for k in range(n_utts // 100):  # utterance u holds block[u % 100]
+        _backend.check(_backend.lib().snf_memcpy_h2d(
+            C.c_void_p(d_wave.ptr + k * flat.nbytes), flat.ctypes.data_as(C.c_void_p), flat.nbytes))
+    d_out = _backend.DeviceBuffer(n_utts * nfr * 257 * 4)
+    plan.run_device(d_wave.ptr, soff, foff, d_out.ptr)
+    assert plan.kernel_name(1) == 'fbank512_kernel'
+    boundary = 2**31 // (nfr * 257)  # the utterance whose rows straddle element 2^31
+    for u in (0, boundary - 1, boundary, boundary + 1, n_utts - 1):
+        got = np.empty((nfr, 257), dtype=np.float32)
+        _backend.check(_backend.lib().snf_memcpy_d2h(
+            got.ctypes.data_as(C.c_void_p), C.c_void_p(d_out.ptr + u * nfr * 257 * 4), got.nbytes))
+        alone = plan.run([block[u % 100]])[0]
+        assert np.array_equal(got, alone), u
+    d_out.free()
+    # the same batch through a mel kind with a small row (delta on top): > 2^31 BYTES of samples
+    mproc = MfccProcessor(dither=0)
+    mplan = _backend.get_plan(mproc._build_options())
+    d_mfcc = _backend.DeviceBuffer(n_utts * nfr * 13 * 4)
+    mplan.run_device(d_wave.ptr, soff, foff, d_mfcc.ptr)
+    dplan = _backend.get_plan(DeltaPostProcessor()._build_options())
+    d_delta = _backend.DeviceBuffer(n_utts * nfr * 39 * 4)
+    dplan.run_post_device(d_mfcc.ptr, 13, foff, d_delta.ptr)
+    for u in (0, n_utts // 2, n_utts - 1):
+        got = np.empty((nfr, 39), dtype=np.float32)
+        _backend.check(_backend.lib().snf_memcpy_d2h(
+            got.ctypes.data_as(C.c_void_p), C.c_void_p(d_delta.ptr + u * nfr * 39 * 4), got.nbytes))
+        alone = dplan.run_post([mplan.run([block[u % 100]])[0]])[0]
+        assert np.array_equal(got, alone), u
+    for buf in (d_wave, d_mfcc, d_delta):
+        buf.free()
+
+
+def test_long_utterance(gpu):
+    """one 10-minute utterance (9.6 M samples, 59 998 frames): fbank / MFCC / pitch against the oracle
+    (the pitch tracker walks the whole utterance with one wavefront)"""
+    wave = synth.utterances(5, 1, 9600000)[0]
+    for proc in (FilterbankProcessor(num_bins=40, dither=0), MfccProcessor(dither=0)):
+        got = proc.process(Audio(wave, 16000))
+        want = _oracle(proc, wave)
+        assert got.shape == want.shape == (59998, want.shape[1])
+        assert_close(got.data, want, what=proc.name)
+    pproc = KaldiPitchProcessor()
+    got = pproc.process(Audio(wave, 16000))
+    _pitch_close(got.data, orc.pitch(pproc._options, wave))
