@@ -206,14 +206,15 @@ class Plan:
         return name.decode() if name else None
 
     # -- Audio -> Features --
-    def run(self, waves, vtln_warps=None):
-        """`waves`: list of 1-D int16 arrays -> list of float32 [nframes, ndims]"""
+    def run(self, waves, vtln_warps=None, check_finite=False):
+        """`waves`: list of 1-D int16 arrays -> list of float32 [nframes, ndims]; `check_finite`:
+        ONE validation of the whole batch (what Features.validate checks per utterance)"""
         n = len(waves)
         lengths = np.fromiter((w.shape[0] for w in waves), np.int64, n)
         soff = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(lengths, out=soff[1:])
-        nfr = np.fromiter(
-            (self.num_frames(x) for x in lengths), np.int64, n)
+        frames_of = {int(x): self.num_frames(int(x)) for x in np.unique(lengths)}
+        nfr = np.fromiter((frames_of[int(x)] for x in lengths), np.int64, n)
         foff = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(nfr, out=foff[1:])
         if n == 1:
@@ -238,6 +239,8 @@ class Plan:
             else None,
             out.ctypes.data_as(C.POINTER(C.c_float)),
             foff.ctypes.data_as(C.POINTER(C.c_int64))))
+        if check_finite:
+            _check_finite(out)
         res = []
         for u in range(n):
             if nfr[u] == 0:
@@ -250,7 +253,7 @@ class Plan:
         return res
 
     # -- Features -> Features --
-    def run_post(self, mats):
+    def run_post(self, mats, check_finite=False):
         """`mats`: list of float32 [nframes, cols] -> list of float32 [nframes, out_cols]"""
         n = len(mats)
         if n == 0:
@@ -272,6 +275,8 @@ class Plan:
             self.handle, data.ctypes.data_as(C.POINTER(C.c_float)), cols,
             foff.ctypes.data_as(C.POINTER(C.c_int64)), n,
             out.ctypes.data_as(C.POINTER(C.c_float))))
+        if check_finite:
+            _check_finite(out)
         if n == 1:
             return [out]
         return [out[foff[u]:foff[u + 1]].copy() for u in range(n)]
@@ -316,7 +321,7 @@ class Plan:
         return stats
 
     def cmvn_apply(self, mats, stats, groups=None, norm_vars=True,
-                   reverse=False):
+                   reverse=False, check_finite=False):
         """Kaldi ApplyCmvn / ApplyCmvnReverse of mats[u] with stats[groups[u]]"""
         n = len(mats)
         if n == 0:
@@ -333,6 +338,8 @@ class Plan:
             g.ctypes.data_as(C.POINTER(C.c_int32)) if g is not None else None,
             stats.shape[0], int(bool(norm_vars)), int(bool(reverse)),
             out.ctypes.data_as(C.POINTER(C.c_float))))
+        if check_finite:
+            _check_finite(out)
         if n == 1:
             return [out]
         return [out[foff[u]:foff[u + 1]].copy() for u in range(n)]
@@ -413,6 +420,13 @@ def clear_plans():
 
 
 # ---- raw device memory (for hosts that keep batches resident in HBM) ----------
+def _check_finite(out):
+    """Features.validate's data check for a whole batch at once (NaN propagates through min / max,
+    an infinity is the min or the max)"""
+    if out.size and not (np.isfinite(out.min()) and np.isfinite(out.max())):
+        raise ValueError('data contains non-finite numbers (nan of infinity)')
+
+
 class DeviceBuffer:
     def __init__(self, nbytes):
         ptr = C.c_void_p()

@@ -13,7 +13,6 @@ Not provided by this backend (out of scope): VTLN *training* (`with
 configuration entry; precomputed `warps` are supported), CREPE pitch, bottleneck features.
 """
 
-import copy
 import os
 
 import numpy as np
@@ -24,7 +23,7 @@ from shennong_amd.features import Features, FeaturesCollection
 from shennong_amd.logger import get_logger
 from shennong_amd.postprocessor.cmvn import (
     CmvnPostProcessor, _fake_stats_for_dims)  # noqa: F401
-from shennong_amd.utils import get_njobs
+from shennong_amd.utils import copy_properties, get_njobs
 
 
 _PROCESSORS = {
@@ -310,22 +309,6 @@ def extract_features(configuration, utterances, warps=None, njobs=1,
     if warps:
         warps = _init_warps(warps, config, utterances, log)
     return _extract_features(config, utterances, warps, log)
-
-
-def _copy_properties(value):
-    """Independent copy of a properties tree (dicts / lists of strings, numbers and arrays): what
-    ``copy.deepcopy`` returns for these, several times faster - with one Features per utterance the
-    generic deepcopy was half of the pipeline's wall time"""
-    kind = type(value)
-    if kind is dict:
-        return {k: _copy_properties(v) for k, v in value.items()}
-    if kind is list:
-        return [_copy_properties(v) for v in value]
-    if kind is np.ndarray:
-        return value.copy()
-    if kind in (str, int, float, bool, type(None)) or isinstance(value, np.generic):
-        return value
-    return copy.deepcopy(value)
 
 
 def _batches(utterances, max_duration):
@@ -669,7 +652,7 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
         for k, i in enumerate(idx):
             results[i] = host[st['foff'][k]:st['foff'][k + 1]].copy()
     for i, utt in enumerate(utts):
-        props = _copy_properties(meta[i].properties)
+        props = copy_properties(meta[i].properties)
         if utt.speaker:
             props['speaker'] = utt.speaker
         props['audio'] = {

@@ -2,9 +2,9 @@
 (mirror of reference shennong/postprocessor/base.py:15-32)"""
 
 import abc
-import copy
 
 from shennong_amd.processor.base import FeaturesProcessor
+from shennong_amd.utils import copy_properties
 
 
 class FeaturesPostProcessor(FeaturesProcessor):
@@ -14,7 +14,7 @@ class FeaturesPostProcessor(FeaturesProcessor):
         """Returns features post-processed from input `features`"""
 
     def get_properties(self, features):
-        properties = copy.deepcopy(features.properties)
+        properties = copy_properties(features.properties)
         properties[self.name] = self.get_params()
         if 'pipeline' not in properties:
             properties['pipeline'] = []

@@ -7,13 +7,13 @@ host (or all-reduced over ranks, see shennong_amd/distributed.py), and applied b
 (Kaldi SlidingWindowCmn).
 """
 
-import copy
 
 import numpy as np
 
 from shennong_amd import _abi, _backend
 from shennong_amd.features import Features, FeaturesCollection
 from shennong_amd.postprocessor.base import FeaturesPostProcessor
+from shennong_amd.utils import copy_properties
 
 
 def _cmvn_plan():
@@ -302,7 +302,7 @@ class SlidingWindowCmvnPostProcessor(FeaturesPostProcessor):
         self._normalize_variance = bool(value)
 
     def get_properties(self, features):
-        properties = copy.deepcopy(features.properties)
+        properties = copy_properties(features.properties)
         properties[self.name] = self.get_params()
         if 'pipeline' not in properties:
             properties['pipeline'] = []
@@ -325,6 +325,6 @@ class SlidingWindowCmvnPostProcessor(FeaturesPostProcessor):
 
     def _process_batch(self, features_list):
         datas = _backend.get_plan(self._build_options()).run_post(
-            [np.asarray(f.data, dtype=np.float32) for f in features_list])
-        return [Features(d, f.times, self.get_properties(f))
+            [np.asarray(f.data, dtype=np.float32) for f in features_list], check_finite=True)
+        return [Features(d, f.times, self.get_properties(f), validate=False)
                 for d, f in zip(datas, features_list)]

@@ -1,13 +1,13 @@
 """Delta / delta-delta: Features ---> DeltaPostProcessor ---> Features
 (mirror of reference shennong/postprocessor/delta.py:53-136 over the HIP backend)"""
 
-import copy
 
 import numpy as np
 
 from shennong_amd import _abi, _backend
 from shennong_amd.features import Features
 from shennong_amd.postprocessor.base import FeaturesPostProcessor
+from shennong_amd.utils import copy_properties
 
 
 class DeltaPostProcessor(FeaturesPostProcessor):
@@ -51,7 +51,7 @@ class DeltaPostProcessor(FeaturesPostProcessor):
 
     def get_properties(self, features):
         ndims = (self.order + 1) * features.ndims
-        properties = copy.deepcopy(features.properties)
+        properties = copy_properties(features.properties)
         properties[self.name] = {
             'order': self.order,
             'window': self.window}
@@ -76,6 +76,6 @@ class DeltaPostProcessor(FeaturesPostProcessor):
 
     def _process_batch(self, features_list):
         datas = _backend.get_plan(self._build_options()).run_post(
-            [np.asarray(f.data, dtype=np.float32) for f in features_list])
-        return [Features(d, f.times, self.get_properties(f))
+            [np.asarray(f.data, dtype=np.float32) for f in features_list], check_finite=True)
+        return [Features(d, f.times, self.get_properties(f), validate=False)
                 for d, f in zip(datas, features_list)]

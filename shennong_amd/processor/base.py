@@ -15,7 +15,7 @@ import numpy as np
 from shennong_amd import _abi, _backend
 from shennong_amd.base import BaseProcessor
 from shennong_amd.features import Features, FeaturesCollection
-from shennong_amd.utils import get_njobs
+from shennong_amd.utils import copy_properties, get_njobs
 
 
 def check_signal(processor, signal, what='signal', dims='one dimension'):
@@ -29,6 +29,24 @@ def check_signal(processor, signal, what='signal', dims='one dimension'):
         raise ValueError(
             'processor and signal mismatch in sample rates: '
             '{} != {}'.format(processor.sample_rate, signal.sample_rate))
+
+
+def batch_features(datas, times_of, properties_of, keys=None):
+    """The Features of one batched launch, with the per-utterance host work reduced to what differs
+    between utterances: the matrices were validated once for the whole batch (``check_finite`` of the
+    plan's run call), generated times are sorted by construction, and times / properties are built
+    once per distinct (frame count) / (key, e.g. the VTLN warp) and copied"""
+    times_cache, props_cache, out = {}, {}, []
+    for i, data in enumerate(datas):
+        key = None if keys is None else keys[i]
+        nframes = data.shape[0]
+        if nframes not in times_cache:
+            times_cache[nframes] = times_of(nframes)
+        if key not in props_cache:
+            props_cache[key] = properties_of(key)
+        out.append(Features(data, times_cache[nframes].copy(),
+                            properties=copy_properties(props_cache[key]), validate=False))
+    return out
 
 
 class FeaturesProcessor(BaseProcessor, metaclass=abc.ABCMeta):
@@ -218,7 +236,7 @@ class FramesProcessor(FeaturesProcessor, metaclass=abc.ABCMeta):
 
     def _run(self, opts, signals, vtln_warps=None):
         waves = [s.astype(np.int16).data for s in signals]  # force 16 bits integers
-        return _backend.get_plan(opts).run(waves, vtln_warps)
+        return _backend.get_plan(opts).run(waves, vtln_warps, check_finite=True)
 
 
 class MelFeaturesProcessor(FramesProcessor):
@@ -320,7 +338,5 @@ class MelFeaturesProcessor(FramesProcessor):
             check_signal(self, signal)
         warps = [1.0] * len(signals) if vtln_warp is None else list(vtln_warp)
         datas = self._run(self._build_options(), signals, warps)
-        return [
-            Features(d, self.times(d.shape[0]),
-                     properties=self.get_properties(vtln_warp=w))
-            for d, w in zip(datas, warps)]
+        return batch_features(
+            datas, self.times, lambda w: self.get_properties(vtln_warp=w), warps)

@@ -8,7 +8,7 @@ rounded once to float32 (what every Kaldi consumer downstream, e.g. the VAD, wor
 
 from shennong_amd import _abi
 from shennong_amd.features import Features
-from shennong_amd.processor.base import FramesProcessor, check_signal
+from shennong_amd.processor.base import FramesProcessor, batch_features, check_signal
 
 
 class EnergyProcessor(FramesProcessor):
@@ -82,6 +82,5 @@ class EnergyProcessor(FramesProcessor):
         for signal in signals:
             check_signal(self, signal)
         datas = self._run(self._build_options(), signals)
-        return [Features(d if d.shape[0] else d.reshape((0, 1)),
-                         self.times(d.shape[0]),
-                         properties=self.get_properties()) for d in datas]
+        return batch_features([d if d.shape[0] else d.reshape((0, 1)) for d in datas],
+                              self.times, lambda _: self.get_properties())

@@ -10,7 +10,7 @@ import numpy as np
 
 from shennong_amd import _abi, _backend
 from shennong_amd.features import Features
-from shennong_amd.processor.base import FeaturesProcessor
+from shennong_amd.processor.base import FeaturesProcessor, batch_features
 from shennong_amd.postprocessor.base import FeaturesPostProcessor
 
 
@@ -196,9 +196,8 @@ class KaldiPitchProcessor(FeaturesProcessor):
         for signal in signals:
             self._check(signal)
         waves = [s.astype(np.int16).data for s in signals]
-        datas = _backend.get_plan(self._build_options()).run(waves)
-        return [Features(d, self.times(d.shape[0]),
-                         properties=self.get_properties()) for d in datas]
+        datas = _backend.get_plan(self._build_options()).run(waves, check_finite=True)
+        return batch_features(datas, self.times, lambda _: self.get_properties())
 
 
 class KaldiPitchPostProcessor(FeaturesPostProcessor):
@@ -326,6 +325,6 @@ class KaldiPitchPostProcessor(FeaturesPostProcessor):
         for raw in raw_pitches:
             self._check(raw)
         datas = _backend.get_plan(self._build_options()).run_post(
-            [raw.data for raw in raw_pitches])
-        return [Features(d, raw.times, properties=self.get_properties(raw))
+            [raw.data for raw in raw_pitches], check_finite=True)
+        return [Features(d, raw.times, properties=self.get_properties(raw), validate=False)
                 for d, raw in zip(datas, raw_pitches)]

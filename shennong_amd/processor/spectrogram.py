@@ -5,7 +5,7 @@ Mirror of reference shennong/processor/spectrogram.py:40-143 over the HIP backen
 
 from shennong_amd import _abi
 from shennong_amd.features import Features
-from shennong_amd.processor.base import FramesProcessor, check_signal
+from shennong_amd.processor.base import FramesProcessor, batch_features, check_signal
 
 
 class SpectrogramProcessor(FramesProcessor):
@@ -74,5 +74,4 @@ class SpectrogramProcessor(FramesProcessor):
         for signal in signals:
             check_signal(self, signal)
         datas = self._run(self._build_options(), signals)
-        return [Features(d, self.times(d.shape[0]),
-                         properties=self.get_properties()) for d in datas]
+        return batch_features(datas, self.times, lambda _: self.get_properties())

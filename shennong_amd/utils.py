@@ -1,5 +1,6 @@
 """Small host utilities (mirrors reference shennong/utils.py:18-96)"""
 
+import copy
 import multiprocessing
 
 import numpy as np
@@ -30,6 +31,22 @@ def array2list(seq):
     if isinstance(seq, np.ndarray):
         return seq.tolist()
     return seq
+
+
+def copy_properties(value):
+    """Independent copy of a properties tree (dicts / lists of strings, numbers and arrays): what
+    ``copy.deepcopy`` returns for these, several times faster - with one Features per utterance the
+    generic deepcopy dominated the host time of a batched launch"""
+    kind = type(value)
+    if kind is dict:
+        return {k: copy_properties(v) for k, v in value.items()}
+    if kind is list:
+        return [copy_properties(v) for v in value]
+    if kind is np.ndarray:
+        return value.copy()
+    if kind in (str, int, float, bool, type(None)) or isinstance(value, np.generic):
+        return value
+    return copy.deepcopy(value)
 
 
 def dict_equal(dict1, dict2):

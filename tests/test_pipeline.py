@@ -491,7 +491,7 @@ def test_copy_properties():
              'mfcc': {'dither': np.float32(0.0), 'window_type': 'povey', 'snip_edges': True,
                       'vtln_warp': 1.1, 'num_ceps': 13, 'none': None},
              'cmvn': {'stats': np.arange(28.0).reshape(2, 14)}, 'other': (1, [2])}
-    got = pipeline._copy_properties(props)
+    got = pipeline.copy_properties(props)
     want = copy.deepcopy(props)
     assert got.keys() == want.keys() and got['mfcc'] == want['mfcc'] and got['pipeline'] == want['pipeline']
     assert np.array_equal(got['cmvn']['stats'], props['cmvn']['stats'])
