@@ -298,6 +298,16 @@ int snf_free(void* dptr);
 int snf_memcpy_h2d(void* dst, const void* src, uint64_t bytes);
 int snf_memcpy_d2h(void* dst, const void* src, uint64_t bytes);
 int snf_memset(void* dst, int value, uint64_t bytes);
+/* Page-locked host staging memory for the host-pointer entry points (snf_plan_run_batch, ...): a
+   batch assembled in it (the reference hands over one numpy array per utterance, processor/base.py:428)
+   crosses the link at full rate and its pages are faulted in once, not once per call.  Plain host
+   memory as far as the caller is concerned. */
+int snf_host_malloc(void** hptr, uint64_t bytes);
+int snf_host_free(void* hptr);
+/* Test aid: fills the LDS of every CU of the current device with `pattern` (e.g. 0xFFFFFFFF, a NaN).
+   LDS is not cleared between workgroups, so a kernel that reads a word it did not write sees whatever
+   the previous kernel left there; the parity tests poison it before they compare against the oracle. */
+int snf_debug_fill_lds(uint32_t pattern);
 /* Duration in milliseconds of the kernels launched by the last run call on this plan, measured
    with HIP events on the stream the kernels were launched on.  `which` selects a kernel slot:
    0 = whole call, 1.. = per-kernel; returns <0 if the slot was not recorded. */

@@ -32,6 +32,7 @@ EXPORTS = [
     'snf_cmvn_accumulate', 'snf_cmvn_apply', 'snf_cmvn_accumulate_device',
     'snf_cmvn_apply_device', 'snf_concat_columns_device',
     'snf_malloc', 'snf_free', 'snf_memcpy_h2d', 'snf_memcpy_d2h', 'snf_memset',
+    'snf_host_malloc', 'snf_host_free', 'snf_debug_fill_lds',
     'snf_plan_last_kernel_ms', 'snf_plan_kernel_name']
 
 
@@ -97,6 +98,9 @@ def lib():
         L.snf_memcpy_h2d.argtypes = [vp, vp, C.c_uint64]
         L.snf_memcpy_d2h.argtypes = [vp, vp, C.c_uint64]
         L.snf_memset.argtypes = [vp, i32, C.c_uint64]
+        L.snf_host_malloc.argtypes = [C.POINTER(vp), C.c_uint64]
+        L.snf_host_free.argtypes = [vp]
+        L.snf_debug_fill_lds.argtypes = [C.c_uint32]
         L.snf_plan_last_kernel_ms.argtypes = [vp, i32]
         L.snf_plan_last_kernel_ms.restype = f32
         L.snf_plan_kernel_name.argtypes = [vp, i32]
@@ -217,14 +221,6 @@ class Plan:
         nfr = np.fromiter((frames_of[int(x)] for x in lengths), np.int64, n)
         foff = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(nfr, out=foff[1:])
-        if n == 1:
-            wave = np.ascontiguousarray(waves[0], dtype=np.int16)
-        else:
-            wave = np.concatenate(
-                [np.asarray(w, dtype=np.int16) for w in waves]) \
-                if n else np.zeros(0, np.int16)
-        d = self.ndims
-        out = np.empty((int(foff[-1]), d), dtype=np.float32)
         warp = None
         if vtln_warps is not None:
             warp = np.ascontiguousarray(vtln_warps, dtype=np.float32)
@@ -232,24 +228,33 @@ class Plan:
                 raise ValueError('one vtln_warp per utterance is required')
             if np.all(warp == 1.0):
                 warp = None
-        check(lib().snf_plan_run_batch(
-            self.handle, wave.ctypes.data_as(C.POINTER(C.c_int16)),
-            soff.ctypes.data_as(C.POINTER(C.c_int64)), n,
-            warp.ctypes.data_as(C.POINTER(C.c_float)) if warp is not None
-            else None,
-            out.ctypes.data_as(C.POINTER(C.c_float)),
-            foff.ctypes.data_as(C.POINTER(C.c_int64))))
-        if check_finite:
-            _check_finite(out)
-        res = []
-        for u in range(n):
-            if nfr[u] == 0:
-                # Kaldi returns an empty (0, 0) matrix when no frame fits
-                res.append(np.zeros((0, 0), dtype=np.float32))
-            elif n == 1:
-                res.append(out)
-            else:
-                res.append(out[foff[u]:foff[u + 1]].copy())
+        if n == 0:
+            return []
+        wave, wave_token = stage_rows(waves, np.int16)
+        out, out_token = STAGING.array((int(foff[-1]), self.ndims), np.float32)
+        try:
+            check(lib().snf_plan_run_batch(
+                self.handle, wave.ctypes.data_as(C.POINTER(C.c_int16)),
+                soff.ctypes.data_as(C.POINTER(C.c_int64)), n,
+                warp.ctypes.data_as(C.POINTER(C.c_float)) if warp is not None
+                else None,
+                out.ctypes.data_as(C.POINTER(C.c_float)),
+                foff.ctypes.data_as(C.POINTER(C.c_int64))))
+            if check_finite:
+                _check_finite(out)
+            res = []
+            for u in range(n):
+                if nfr[u] == 0:
+                    # Kaldi returns an empty (0, 0) matrix when no frame fits
+                    res.append(np.zeros((0, 0), dtype=np.float32))
+                elif n == 1 and out_token is None:
+                    res.append(out)
+                else:
+                    res.append(out[foff[u]:foff[u + 1]].copy())
+        finally:
+            del wave, out
+            STAGING.release(wave_token)
+            STAGING.release(out_token)
         return res
 
     # -- Features -> Features --
@@ -262,24 +267,27 @@ class Plan:
         nfr = np.fromiter((m.shape[0] for m in mats), np.int64, n)
         foff = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(nfr, out=foff[1:])
-        if n == 1:
-            data = np.ascontiguousarray(mats[0], dtype=np.float32)
-        else:
-            data = np.ascontiguousarray(
-                np.concatenate(mats, axis=0), dtype=np.float32)
         ocols = self.post_ndims(cols)
         if ocols <= 0:
             raise ValueError('bad column count for this post-processor')
-        out = np.empty((int(foff[-1]), ocols), dtype=np.float32)
-        check(lib().snf_post_run_batch(
-            self.handle, data.ctypes.data_as(C.POINTER(C.c_float)), cols,
-            foff.ctypes.data_as(C.POINTER(C.c_int64)), n,
-            out.ctypes.data_as(C.POINTER(C.c_float))))
-        if check_finite:
-            _check_finite(out)
-        if n == 1:
-            return [out]
-        return [out[foff[u]:foff[u + 1]].copy() for u in range(n)]
+        data, data_token = stage_rows(mats, np.float32)
+        out, out_token = STAGING.array((int(foff[-1]), ocols), np.float32)
+        try:
+            check(lib().snf_post_run_batch(
+                self.handle, data.ctypes.data_as(C.POINTER(C.c_float)), cols,
+                foff.ctypes.data_as(C.POINTER(C.c_int64)), n,
+                out.ctypes.data_as(C.POINTER(C.c_float))))
+            if check_finite:
+                _check_finite(out)
+            if n == 1 and out_token is None:
+                res = [out]
+            else:
+                res = [out[foff[u]:foff[u + 1]].copy() for u in range(n)]
+        finally:
+            del data, out
+            STAGING.release(data_token)
+            STAGING.release(out_token)
+        return res
 
     # -- CMVN (plan kind CMVN): statistics on the GPU, per-speaker sums on the host --
     @staticmethod
@@ -289,12 +297,8 @@ class Plan:
         nfr = np.fromiter((m.shape[0] for m in mats), np.int64, n)
         foff = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(nfr, out=foff[1:])
-        if n == 1:
-            data = np.ascontiguousarray(mats[0], dtype=np.float32)
-        else:
-            data = np.ascontiguousarray(
-                np.concatenate(mats, axis=0), dtype=np.float32)
-        return data, cols, foff
+        data, token = stage_rows(mats, np.float32)
+        return data, cols, foff, token
 
     def cmvn_accumulate(self, mats, stats, weights=None, groups=None):
         """stats[groups[u]] += CMVN statistics of mats[u]; `stats` is float64
@@ -302,22 +306,26 @@ class Plan:
         n = len(mats)
         if n == 0:
             return stats
-        data, cols, foff = self._pack(mats)
         assert stats.dtype == np.float64 and stats.flags.c_contiguous
-        assert stats.shape[1:] == (2, cols + 1)
+        assert stats.shape[1:] == (2, mats[0].shape[1] + 1)
         w = None
         if weights is not None:
             w = np.ascontiguousarray(np.concatenate(
                 [np.asarray(x, dtype=np.float32).ravel() for x in weights]))
-            if w.shape[0] != foff[-1]:
+            if w.shape[0] != sum(m.shape[0] for m in mats):
                 raise ValueError('one weight per frame is required')
         g = None if groups is None else np.ascontiguousarray(groups, np.int32)
-        check(lib().snf_cmvn_accumulate(
-            self.handle, data.ctypes.data_as(C.POINTER(C.c_float)), cols,
-            foff.ctypes.data_as(C.POINTER(C.c_int64)), n,
-            w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None,
-            g.ctypes.data_as(C.POINTER(C.c_int32)) if g is not None else None,
-            stats.shape[0], stats.ctypes.data_as(C.POINTER(C.c_double))))
+        data, cols, foff, token = self._pack(mats)
+        try:
+            check(lib().snf_cmvn_accumulate(
+                self.handle, data.ctypes.data_as(C.POINTER(C.c_float)), cols,
+                foff.ctypes.data_as(C.POINTER(C.c_int64)), n,
+                w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None,
+                g.ctypes.data_as(C.POINTER(C.c_int32)) if g is not None else None,
+                stats.shape[0], stats.ctypes.data_as(C.POINTER(C.c_double))))
+        finally:
+            del data
+            STAGING.release(token)
         return stats
 
     def cmvn_apply(self, mats, stats, groups=None, norm_vars=True,
@@ -326,23 +334,30 @@ class Plan:
         n = len(mats)
         if n == 0:
             return []
-        data, cols, foff = self._pack(mats)
         stats = np.ascontiguousarray(stats, dtype=np.float64)
-        assert stats.shape[1:] == (2, cols + 1)
+        assert stats.shape[1:] == (2, mats[0].shape[1] + 1)
         g = None if groups is None else np.ascontiguousarray(groups, np.int32)
-        out = np.empty_like(data)
-        check(lib().snf_cmvn_apply(
-            self.handle, data.ctypes.data_as(C.POINTER(C.c_float)), cols,
-            foff.ctypes.data_as(C.POINTER(C.c_int64)), n,
-            stats.ctypes.data_as(C.POINTER(C.c_double)),
-            g.ctypes.data_as(C.POINTER(C.c_int32)) if g is not None else None,
-            stats.shape[0], int(bool(norm_vars)), int(bool(reverse)),
-            out.ctypes.data_as(C.POINTER(C.c_float))))
-        if check_finite:
-            _check_finite(out)
-        if n == 1:
-            return [out]
-        return [out[foff[u]:foff[u + 1]].copy() for u in range(n)]
+        data, cols, foff, token = self._pack(mats)
+        out, out_token = STAGING.array(data.shape, np.float32)
+        try:
+            check(lib().snf_cmvn_apply(
+                self.handle, data.ctypes.data_as(C.POINTER(C.c_float)), cols,
+                foff.ctypes.data_as(C.POINTER(C.c_int64)), n,
+                stats.ctypes.data_as(C.POINTER(C.c_double)),
+                g.ctypes.data_as(C.POINTER(C.c_int32)) if g is not None else None,
+                stats.shape[0], int(bool(norm_vars)), int(bool(reverse)),
+                out.ctypes.data_as(C.POINTER(C.c_float))))
+            if check_finite:
+                _check_finite(out)
+            if n == 1 and out_token is None:
+                res = [out]
+            else:
+                res = [out[foff[u]:foff[u + 1]].copy() for u in range(n)]
+        finally:
+            del data, out
+            STAGING.release(token)
+            STAGING.release(out_token)
+        return res
 
     def cmvn_accumulate_device(self, d_in, cols, foff, stats, d_weights=None, groups=None):
         """device-resident `cmvn_accumulate` (d_in / d_weights are device pointers)"""
@@ -420,6 +435,73 @@ def clear_plans():
 
 
 # ---- raw device memory (for hosts that keep batches resident in HBM) ----------
+class _Staging:
+    """Page-locked host staging buffers for the host-pointer entry points (snf_host_malloc), pooled:
+    a batch is assembled directly in one (no page faults after the first use, full link rate), the
+    result comes back into another and is cut into per-utterance arrays from there.  Below
+    `_MIN_BYTES` plain numpy memory is used (a single utterance is not worth a pinned buffer); a
+    failed pinned allocation falls back to plain memory as well - this only concerns the KIND of host
+    memory, the arithmetic always runs on the GPU."""
+    _MIN_BYTES = 1 << 20
+    _MAX_POOLED = 4
+    _MAX_POOLED_BYTES = 8 << 30
+
+    def __init__(self):
+        self._free = []  # (capacity, pointer)
+        self._lock = threading.Lock()
+
+    def array(self, shape, dtype):
+        """-> (numpy array of `shape` / `dtype`, token to pass to :func:`release`)"""
+        dtype = np.dtype(dtype)
+        count = int(np.prod(shape))
+        nbytes = count * dtype.itemsize
+        if nbytes < self._MIN_BYTES:
+            return np.empty(shape, dtype=dtype), None
+        token = None
+        with self._lock:
+            fits = [b for b in self._free if b[0] >= nbytes]
+            if fits:
+                token = min(fits)
+                self._free.remove(token)
+        if token is None:
+            capacity = (nbytes + nbytes // 8 + (1 << 21) - 1) & ~((1 << 21) - 1)
+            ptr = C.c_void_p()
+            if lib().snf_host_malloc(C.byref(ptr), capacity) != 0 or not ptr.value:
+                return np.empty(shape, dtype=dtype), None
+            token = (capacity, ptr.value)
+        raw = (C.c_char * nbytes).from_address(token[1])
+        return np.frombuffer(raw, dtype=dtype, count=count).reshape(shape), token
+
+    def release(self, token):
+        if token is None:
+            return
+        drop = None
+        with self._lock:
+            self._free.append(token)
+            if len(self._free) > self._MAX_POOLED or \
+                    sum(b[0] for b in self._free) > self._MAX_POOLED_BYTES:
+                drop = max(self._free) if sum(b[0] for b in self._free) > self._MAX_POOLED_BYTES \
+                    else min(self._free)
+                self._free.remove(drop)
+        if drop is not None:
+            lib().snf_host_free(C.c_void_p(drop[1]))
+
+
+STAGING = _Staging()
+
+
+def stage_rows(mats, dtype):
+    """Concatenation of `mats` along axis 0 in a staging buffer -> (array, token)"""
+    first = np.asarray(mats[0])
+    shape = (int(sum(m.shape[0] for m in mats)),) + tuple(first.shape[1:])
+    staged, token = STAGING.array(shape, dtype)
+    if len(mats) == 1:
+        staged[...] = first
+    elif shape[0]:
+        np.concatenate([np.asarray(m, dtype=dtype) for m in mats], axis=0, out=staged)
+    return staged, token
+
+
 def _check_finite(out):
     """Features.validate's data check for a whole batch at once (NaN propagates through min / max,
     an infinity is the min or the max)"""

@@ -55,6 +55,8 @@ struct snf_plan {
   int device = 0;
   hipStream_t stream = nullptr;
   std::mutex mu;
+  std::mutex host_mu;  // a host-pointer call owns the plan's staging scratch (s_wave / s_in / s_out)
+                       // from its upload to its download: whole-call lock, taken before `mu`
   int kind = 0, ndims = 0;
 
   // mel family
@@ -848,6 +850,7 @@ int snf_plan_run_batch(snf_plan* plan, const int16_t* wave, const int64_t* sampl
                        int64_t n_utts, const float* vtln_warp, float* out,
                        const int64_t* frame_offsets) {
   if (!plan) return set_error(SNF_E_INVALID, "null plan");
+  std::lock_guard<std::mutex> host_lock(plan->host_mu);
   if (n_utts <= 0) return n_utts == 0 ? SNF_OK : set_error(SNF_E_INVALID, "n_utts < 0");
   if (!sample_offsets || !frame_offsets) return set_error(SNF_E_INVALID, "null offsets table");
   const int64_t total_samples = sample_offsets[n_utts] - sample_offsets[0];
@@ -867,15 +870,17 @@ int snf_plan_run_batch(snf_plan* plan, const int16_t* wave, const int64_t* sampl
     d_wave = plan->s_wave.as<int16_t>();
     d_out = plan->s_out.as<float>();
     if (total_samples > 0)
-      SNF_HIP_CHECK(hipMemcpy(d_wave, wave, sizeof(int16_t) * total_samples, hipMemcpyHostToDevice));
+      SNF_HIP_CHECK(hipMemcpyAsync(d_wave, wave, sizeof(int16_t) * total_samples, hipMemcpyHostToDevice,
+                                   plan->stream));
   }
   int rc = snf_plan_run_batch_device(plan, d_wave, sample_offsets, n_utts, vtln_warp, d_out,
                                      frame_offsets, nullptr);
   if (rc) return rc;
   if (total_frames > 0) {
     std::lock_guard<std::mutex> lock(plan->mu);
-    SNF_HIP_CHECK(hipMemcpy(out, d_out, sizeof(float) * total_frames * plan->ndims,
-                            hipMemcpyDeviceToHost));
+    SNF_HIP_CHECK(hipMemcpyAsync(out, d_out, sizeof(float) * total_frames * plan->ndims,
+                                 hipMemcpyDeviceToHost, plan->stream));
+    SNF_HIP_CHECK(hipStreamSynchronize(plan->stream));
   }
   return SNF_OK;
 }
@@ -946,6 +951,7 @@ int snf_post_run_batch_device(snf_plan* plan, const float* d_in, int32_t in_cols
 int snf_post_run_batch(snf_plan* plan, const float* in, int32_t in_cols,
                        const int64_t* frame_offsets, int64_t n_utts, float* out) {
   if (!plan) return set_error(SNF_E_INVALID, "null plan");
+  std::lock_guard<std::mutex> host_lock(plan->host_mu);
   if (n_utts <= 0) return n_utts == 0 ? SNF_OK : set_error(SNF_E_INVALID, "n_utts < 0");
   if (!frame_offsets) return set_error(SNF_E_INVALID, "null offsets table");
   const int64_t total_frames = frame_offsets[n_utts];
@@ -961,12 +967,15 @@ int snf_post_run_batch(snf_plan* plan, const float* in, int32_t in_cols,
     if ((rc = plan->s_out.ensure(sizeof(float) * static_cast<size_t>(total_frames) * out_cols))) return rc;
     d_in = plan->s_in.as<float>();
     d_out = plan->s_out.as<float>();
-    SNF_HIP_CHECK(hipMemcpy(d_in, in, sizeof(float) * total_frames * in_cols, hipMemcpyHostToDevice));
+    SNF_HIP_CHECK(hipMemcpyAsync(d_in, in, sizeof(float) * total_frames * in_cols, hipMemcpyHostToDevice,
+                                 plan->stream));
   }
   int rc = snf_post_run_batch_device(plan, d_in, in_cols, frame_offsets, n_utts, d_out, nullptr);
   if (rc) return rc;
   std::lock_guard<std::mutex> lock(plan->mu);
-  SNF_HIP_CHECK(hipMemcpy(out, d_out, sizeof(float) * total_frames * out_cols, hipMemcpyDeviceToHost));
+  SNF_HIP_CHECK(hipMemcpyAsync(out, d_out, sizeof(float) * total_frames * out_cols, hipMemcpyDeviceToHost,
+                               plan->stream));
+  SNF_HIP_CHECK(hipStreamSynchronize(plan->stream));
   return SNF_OK;
 }
 
@@ -1034,18 +1043,19 @@ int snf_cmvn_accumulate(snf_plan* plan, const float* in, int32_t cols, const int
   const int64_t total_frames = frame_offsets[n_utts];
   if (total_frames == 0) return SNF_OK;
   if (!in) return set_error(SNF_E_INVALID, "null input");
+  std::lock_guard<std::mutex> host_lock(plan->host_mu);
   const float *d_in, *d_w = nullptr;
   {
     std::lock_guard<std::mutex> lock(plan->mu);
     if ((rc = guard_device(plan))) return rc;
     if ((rc = plan->s_in.ensure(sizeof(float) * static_cast<size_t>(total_frames) * cols))) return rc;
-    SNF_HIP_CHECK(hipMemcpy(plan->s_in.p, in, sizeof(float) * total_frames * cols,
-                            hipMemcpyHostToDevice));
+    SNF_HIP_CHECK(hipMemcpyAsync(plan->s_in.p, in, sizeof(float) * total_frames * cols,
+                                 hipMemcpyHostToDevice, plan->stream));
     d_in = plan->s_in.as<float>();
     if (weights) {
       if ((rc = plan->s_energy.ensure(sizeof(float) * static_cast<size_t>(total_frames)))) return rc;
-      SNF_HIP_CHECK(hipMemcpy(plan->s_energy.p, weights, sizeof(float) * total_frames,
-                              hipMemcpyHostToDevice));
+      SNF_HIP_CHECK(hipMemcpyAsync(plan->s_energy.p, weights, sizeof(float) * total_frames,
+                                   hipMemcpyHostToDevice, plan->stream));
       d_w = plan->s_energy.as<float>();
     }
   }
@@ -1141,6 +1151,7 @@ int snf_cmvn_apply(snf_plan* plan, const float* in, int32_t cols, const int64_t*
   const int64_t total_frames = frame_offsets[n_utts];
   if (total_frames == 0) return SNF_OK;
   if (!in || !out) return set_error(SNF_E_INVALID, "null buffer");
+  std::lock_guard<std::mutex> host_lock(plan->host_mu);
   const size_t bytes = sizeof(float) * static_cast<size_t>(total_frames) * cols;
   float *d_in, *d_out;
   {
@@ -1148,7 +1159,7 @@ int snf_cmvn_apply(snf_plan* plan, const float* in, int32_t cols, const int64_t*
     if ((rc = guard_device(plan))) return rc;
     if ((rc = plan->s_in.ensure(bytes))) return rc;
     if ((rc = plan->s_out.ensure(bytes))) return rc;
-    SNF_HIP_CHECK(hipMemcpy(plan->s_in.p, in, bytes, hipMemcpyHostToDevice));
+    SNF_HIP_CHECK(hipMemcpyAsync(plan->s_in.p, in, bytes, hipMemcpyHostToDevice, plan->stream));
     d_in = plan->s_in.as<float>();
     d_out = plan->s_out.as<float>();
   }
@@ -1156,7 +1167,8 @@ int snf_cmvn_apply(snf_plan* plan, const float* in, int32_t cols, const int64_t*
                              reverse, d_out);
   if (rc) return rc;
   std::lock_guard<std::mutex> lock(plan->mu);
-  SNF_HIP_CHECK(hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost));
+  SNF_HIP_CHECK(hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, plan->stream));
+  SNF_HIP_CHECK(hipStreamSynchronize(plan->stream));
   return SNF_OK;
 }
 
@@ -1214,6 +1226,41 @@ int snf_memcpy_d2h(void* dst, const void* src, uint64_t bytes) {
 }
 int snf_memset(void* dst, int value, uint64_t bytes) {
   SNF_HIP_CHECK(hipMemset(dst, value, bytes));
+  return SNF_OK;
+}
+namespace {
+__global__ __launch_bounds__(256) void lds_fill_kernel(unsigned pattern, int words, unsigned* sink) {
+  extern __shared__ unsigned fill[];
+  for (int i = threadIdx.x; i < words; i += blockDim.x) fill[i] = pattern;
+  __syncthreads();
+  // (a dependent read keeps the stores from being optimised away)
+  if (fill[(threadIdx.x * 97) % words] != pattern) sink[0] = 1;
+}
+}  // namespace
+
+int snf_debug_fill_lds(uint32_t pattern) {
+  // two 80 KB workgroups cover the 160 KB of a CU; many more workgroups than CUs so that every CU
+  // (and both halves of its LDS) is visited
+  const int bytes = 80 * 1024 - 256;
+  unsigned* sink = nullptr;
+  SNF_HIP_CHECK(hipMalloc(&sink, sizeof(unsigned)));
+  SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_fill_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  hipLaunchKernelGGL(lds_fill_kernel, dim3(256 * 32), dim3(256), bytes, nullptr, pattern, bytes / 4, sink);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  (void)hipFree(sink);
+  if (e != hipSuccess) return snf::set_error(SNF_E_HIP, std::string("lds fill: ") + hipGetErrorString(e));
+  return SNF_OK;
+}
+
+int snf_host_malloc(void** hptr, uint64_t bytes) {
+  if (!hptr) return set_error(SNF_E_INVALID, "null pointer");
+  SNF_HIP_CHECK(hipHostMalloc(hptr, bytes > 0 ? bytes : 1, hipHostMallocDefault));
+  return SNF_OK;
+}
+int snf_host_free(void* hptr) {
+  if (hptr) SNF_HIP_CHECK(hipHostFree(hptr));
   return SNF_OK;
 }
 

@@ -479,9 +479,13 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             check_signal(proc, audios[i])
         waves = [audios[i].astype(np.int16).data for i in idx]
         soff = offsets([w.shape[0] for w in waves])
-        wave = np.concatenate(waves) if len(waves) > 1 else np.ascontiguousarray(waves[0])
+        wave, token = _backend.stage_rows(waves, np.int16)  # (page-locked staging: full link rate)
         d_wave = DB(max(wave.nbytes, 16))
-        d_wave.upload(wave)
+        try:
+            d_wave.upload(wave)
+        finally:
+            del wave
+            _backend.STAGING.release(token)
         st = {'idx': idx, 'soff': soff, 'd_wave': d_wave}
 
         opts = proc._build_options()
@@ -645,12 +649,16 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             st['d_feat'].free()
             st['d_pitch'].free()
             st['d_feat'], st['dim'], st['foff'] = d_out, odim, ooff
-        host = np.empty((int(st['foff'][-1]), st['dim']), dtype=np.float32)
-        if host.size:
-            st['d_feat'].download(host)
-        st['d_feat'].free()
-        for k, i in enumerate(idx):
-            results[i] = host[st['foff'][k]:st['foff'][k + 1]].copy()
+        host, token = _backend.STAGING.array((int(st['foff'][-1]), st['dim']), np.float32)
+        try:
+            if host.size:
+                st['d_feat'].download(host)
+            st['d_feat'].free()
+            for k, i in enumerate(idx):
+                results[i] = host[st['foff'][k]:st['foff'][k + 1]].copy()
+        finally:
+            del host
+            _backend.STAGING.release(token)
     for i, utt in enumerate(utts):
         props = copy_properties(meta[i].properties)
         if utt.speaker:

@@ -51,12 +51,21 @@ def synth_waves():
 
 
 @pytest.fixture(scope='session')
-def gpu():
-    """Skips when no device is visible; on the GPU box a missing library is an error"""
+def _gpu_backend():
     from shennong_amd import _backend
     if _backend.device_count() < 1:
         pytest.skip('no HIP device visible')
     return _backend
+
+
+@pytest.fixture()
+def gpu(_gpu_backend):
+    """Skips when no device is visible; on the GPU box a missing library is an error.  Every GPU
+    test starts from LDS filled with NaN bit patterns: LDS is not cleared between kernels, and a
+    kernel that multiplies a word it never wrote by a zero weight is correct only as long as the
+    previous tenant of that CU left something finite there (this bit the last mel bin once)."""
+    _gpu_backend.check(_gpu_backend.lib().snf_debug_fill_lds(0xFFFFFFFF))
+    return _gpu_backend
 
 
 def assert_close(got, want, rtol=1e-4, atol=2e-3, what=''):

@@ -444,3 +444,25 @@ def test_cmvn_params_and_errors():
     assert 'dimension for sliding window CMVN processor depends on input' in str(err.value)
     o = s._build_options()
     assert (o.sliding_cmvn.center, o.sliding_cmvn.normalize_variance) == (0, 1)
+
+
+def test_staging_rows_without_device():
+    """the staging helper of the host-pointer path: concatenation semantics, and plain memory when a
+    page-locked buffer cannot be had (no device here) - only the KIND of host memory changes"""
+    import numpy as np
+    from shennong_amd import _backend
+    mats = [np.arange(6, dtype=np.float64).reshape(3, 2), np.zeros((0, 2)), np.ones((2, 2), np.float32)]
+    staged, token = _backend.stage_rows(mats, np.float32)
+    assert staged.dtype == np.float32 and staged.shape == (5, 2)
+    assert np.array_equal(staged, np.concatenate(mats).astype(np.float32))
+    _backend.STAGING.release(token)
+    waves = [np.arange(5, dtype=np.int16), np.arange(3, dtype=np.int16)]
+    staged, token = _backend.stage_rows(waves, np.int16)
+    assert staged.tolist() == [0, 1, 2, 3, 4, 0, 1, 2]
+    _backend.STAGING.release(token)
+    single, token = _backend.stage_rows([np.arange(4, dtype=np.int32)], np.int16)
+    assert single.dtype == np.int16 and single.tolist() == [0, 1, 2, 3]
+    # a large request without a device falls back to plain memory (token None)
+    big, token = _backend.STAGING.array((1 << 19, 2), np.float32)
+    assert big.shape == (1 << 19, 2)
+    _backend.STAGING.release(token)
