@@ -231,7 +231,9 @@ class Plan:
         if n == 0:
             return []
         wave, wave_token = stage_rows(waves, np.int16)
-        out, out_token = STAGING.array((int(foff[-1]), self.ndims), np.float32)
+        # the per-utterance results are views of ONE array (cutting 4 000 fresh copies out of it
+        # cost more than the launch and both transfers together)
+        out = np.empty((int(foff[-1]), self.ndims), dtype=np.float32)
         try:
             check(lib().snf_plan_run_batch(
                 self.handle, wave.ctypes.data_as(C.POINTER(C.c_int16)),
@@ -247,14 +249,13 @@ class Plan:
                 if nfr[u] == 0:
                     # Kaldi returns an empty (0, 0) matrix when no frame fits
                     res.append(np.zeros((0, 0), dtype=np.float32))
-                elif n == 1 and out_token is None:
+                elif n == 1:
                     res.append(out)
                 else:
-                    res.append(out[foff[u]:foff[u + 1]].copy())
+                    res.append(out[foff[u]:foff[u + 1]])
         finally:
-            del wave, out
+            del wave
             STAGING.release(wave_token)
-            STAGING.release(out_token)
         return res
 
     # -- Features -> Features --
@@ -271,7 +272,7 @@ class Plan:
         if ocols <= 0:
             raise ValueError('bad column count for this post-processor')
         data, data_token = stage_rows(mats, np.float32)
-        out, out_token = STAGING.array((int(foff[-1]), ocols), np.float32)
+        out = np.empty((int(foff[-1]), ocols), dtype=np.float32)
         try:
             check(lib().snf_post_run_batch(
                 self.handle, data.ctypes.data_as(C.POINTER(C.c_float)), cols,
@@ -279,14 +280,10 @@ class Plan:
                 out.ctypes.data_as(C.POINTER(C.c_float))))
             if check_finite:
                 _check_finite(out)
-            if n == 1 and out_token is None:
-                res = [out]
-            else:
-                res = [out[foff[u]:foff[u + 1]].copy() for u in range(n)]
+            res = [out] if n == 1 else [out[foff[u]:foff[u + 1]] for u in range(n)]
         finally:
-            del data, out
+            del data
             STAGING.release(data_token)
-            STAGING.release(out_token)
         return res
 
     # -- CMVN (plan kind CMVN): statistics on the GPU, per-speaker sums on the host --
@@ -338,7 +335,7 @@ class Plan:
         assert stats.shape[1:] == (2, mats[0].shape[1] + 1)
         g = None if groups is None else np.ascontiguousarray(groups, np.int32)
         data, cols, foff, token = self._pack(mats)
-        out, out_token = STAGING.array(data.shape, np.float32)
+        out = np.empty(data.shape, dtype=np.float32)
         try:
             check(lib().snf_cmvn_apply(
                 self.handle, data.ctypes.data_as(C.POINTER(C.c_float)), cols,
@@ -349,14 +346,10 @@ class Plan:
                 out.ctypes.data_as(C.POINTER(C.c_float))))
             if check_finite:
                 _check_finite(out)
-            if n == 1 and out_token is None:
-                res = [out]
-            else:
-                res = [out[foff[u]:foff[u + 1]].copy() for u in range(n)]
+            res = [out] if n == 1 else [out[foff[u]:foff[u + 1]] for u in range(n)]
         finally:
-            del data, out
+            del data
             STAGING.release(token)
-            STAGING.release(out_token)
         return res
 
     def cmvn_accumulate_device(self, d_in, cols, foff, stats, d_weights=None, groups=None):

@@ -649,16 +649,12 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             st['d_feat'].free()
             st['d_pitch'].free()
             st['d_feat'], st['dim'], st['foff'] = d_out, odim, ooff
-        host, token = _backend.STAGING.array((int(st['foff'][-1]), st['dim']), np.float32)
-        try:
-            if host.size:
-                st['d_feat'].download(host)
-            st['d_feat'].free()
-            for k, i in enumerate(idx):
-                results[i] = host[st['foff'][k]:st['foff'][k + 1]].copy()
-        finally:
-            del host
-            _backend.STAGING.release(token)
+        host = np.empty((int(st['foff'][-1]), st['dim']), dtype=np.float32)
+        if host.size:
+            st['d_feat'].download(host)
+        st['d_feat'].free()
+        for k, i in enumerate(idx):
+            results[i] = host[st['foff'][k]:st['foff'][k + 1]]  # views of the one downloaded array
     for i, utt in enumerate(utts):
         props = copy_properties(meta[i].properties)
         if utt.speaker:
