@@ -507,7 +507,10 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             key = (features_name, rate, extra.get('vtln_warp'))
             if key not in cache:
                 cache[key] = proc.get_properties(**extra)
-            meta[i] = _Meta(cache[key], dim, t, proc.times(t), key)
+            tkey = ('times', features_name, rate, t)
+            if tkey not in cache:
+                cache[tkey] = proc.times(t)
+            meta[i] = _Meta(cache[key], dim, t, cache[tkey], key)
 
         if with_cmvn and config['cmvn']['with_vad']:
             energy = _processor_class('energy')()
@@ -550,7 +553,10 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
                 key = ('pitch', rate)
                 if key not in cache:
                     cache[key] = pproc.get_properties()
-                raw_meta = _Meta(cache[key], 2, t, pproc.times(t), key)
+                tkey = ('times', 'pitch', rate, t)
+                if tkey not in cache:
+                    cache[tkey] = pproc.times(t)
+                raw_meta = _Meta(cache[key], 2, t, cache[tkey], key)
                 pmeta[i] = raw_meta.derive(cache, 'post', post.get_properties, ndims=pdim)
         d_wave.free()
         groups_state.append(st)
@@ -630,9 +636,12 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
         if 'd_pitch' in st:
             rows = []
             for k, i in enumerate(idx):
-                r, times, _ = Features._concatenate_meta(
-                    meta[i].nframes, meta[i].ndims, meta[i].times, {},
-                    pmeta[i].nframes, pmeta[i].times, {}, tolerance, log)
+                ckey = ('rows', meta[i].nframes, pmeta[i].nframes, id(meta[i].times), id(pmeta[i].times))
+                if ckey not in cache:  # (same frame counts and times: same trimming, checked once)
+                    cache[ckey] = Features._concatenate_meta(
+                        meta[i].nframes, meta[i].ndims, meta[i].times, {},
+                        pmeta[i].nframes, pmeta[i].times, {}, tolerance, log)[:2]
+                r, times = cache[ckey]
                 rows.append(r)
                 meta[i] = meta[i].derive(
                     cache, ('concat', pmeta[i].key),
@@ -652,6 +661,7 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
         host = np.empty((int(st['foff'][-1]), st['dim']), dtype=np.float32)
         if host.size:
             st['d_feat'].download(host)
+            _backend._check_finite(host)  # (Features.validate's data check, once for the batch)
         st['d_feat'].free()
         for k, i in enumerate(idx):
             results[i] = host[st['foff'][k]:st['foff'][k + 1]]  # views of the one downloaded array
@@ -667,7 +677,8 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             props['audio']['tstart'] = utt.tstart
             props['audio']['tstop'] = utt.tstop
         props['audio']['duration'] = utt.duration
-        out[utt.name] = Features(results[i], meta[i].times, properties=props)
+        # (times are generated, hence sorted; the data were checked above: no per-utterance validate)
+        out[utt.name] = Features(results[i], meta[i].times.copy(), properties=props, validate=False)
     return out
 
 

@@ -273,3 +273,15 @@ def test_kaldi_stream_writer(tmpdir, mfcc, scp, with_properties):
         serializers.KaldiStreamWriter(streamed)
     with pytest.raises(ValueError, match='extension must be'):
         serializers.KaldiStreamWriter(str(tmpdir.join('x.npz')))
+
+
+def test_kaldi_stream_writer_float_matrices(tmpdir, mfcc):
+    """double=False: Kaldi float matrices (FM), half the bytes, float32 features round-trip exactly"""
+    name = str(tmpdir.join('f32.ark'))
+    with serializers.KaldiStreamWriter(name, double=False) as w:
+        w.write({'a': mfcc, 'b': mfcc})
+    blob = open(name, 'rb').read()
+    assert blob.count(b'\0BFM ') == 2 and b'\0BDM ' not in blob
+    assert len(blob) < 2 * (mfcc.data.size * 4 + 64)
+    loaded = FeaturesCollection.load(name)
+    assert loaded['a'] == mfcc and loaded['b'].dtype == np.float32

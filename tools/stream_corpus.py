@@ -31,7 +31,10 @@ hours = n_utts * 3.0 / 3600.0
 
 for label, make_sink in (('null sink', lambda: (None, lambda f: None)),
                          ('kaldi ark', lambda: (KaldiStreamWriter(os.path.join(out_dir, 'corpus.ark')),
-                                                None))):
+                                                None)),
+                         ('kaldi ark, float matrices',
+                          lambda: (KaldiStreamWriter(os.path.join(out_dir, 'corpus32.ark'), double=False),
+                                   None))):
     writer, sink = make_sink()
     if writer is not None:
         sink = writer.write
@@ -43,7 +46,7 @@ for label, make_sink in (('null sink', lambda: (None, lambda f: None)),
     dt = time.perf_counter() - t0
     size = ''
     if writer is not None:
-        size = ' %.2f GB written' % (os.path.getsize(os.path.join(out_dir, 'corpus.ark')) / 1e9)
+        size = ' %.2f GB written' % (os.path.getsize(writer._root + '.ark') / 1e9)
     print(f'{label}: {n} utterances ({hours:.2f} h of audio) in {dt:.2f} s wall = '
           f'{hours / dt:.3f} h of audio per second ({hours * 3600 / dt:.0f} x real time), '
           f'batches of {batch_seconds:.0f} s{size}')
