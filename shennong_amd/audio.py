@@ -1,16 +1,21 @@
 """Audio container: the input of every features processor
 
-Only what the hot path needs from reference shennong/audio.py: ``data / sample_rate / nchannels /
-nsamples / dtype``, ``astype`` (int16 <-> float scaling by 2**15, audio.py:469-518), ``segment``
-(audio.py:520-561) and wav loading through scipy (audio.py:243-286 without the pydub fallback,
-resampling and sox scanning, which are file-format plumbing and out of scope here).
+Mirror of reference shennong/audio.py for WAV files: ``data / sample_rate / nchannels / nsamples /
+dtype``, ``astype`` (int16 <-> float scaling by 2**15, audio.py:469-518), ``segment``
+(audio.py:520-561), ``channel`` (audio.py:328-357), ``load`` / ``save`` / ``scan`` through scipy
+(audio.py:179-320; the reference falls back to pydub / ffmpeg and sox for flac, mp3, ...: neither
+exists offline, those formats raise a ValueError that says so) and ``resample`` with the reference's
+scipy backend (audio.py:358-425; the sox backend is the same call here).
 """
 
 import collections
+import functools
+import os
 import warnings
 
 import numpy as np
 import scipy.io.wavfile
+import scipy.signal
 
 
 class Audio:
@@ -62,14 +67,75 @@ class Audio:
     def precision(self):
         return self.dtype.itemsize * 8
 
+    # the pipeline loads a file once for its metadata and again for every segment of it: like the
+    # reference (audio.py:240-243) keep the last two decoded files
     @classmethod
+    @functools.lru_cache(maxsize=2)
     def load(cls, filename):
-        """Loads a wav file (16/32 bits PCM or float) with scipy"""
+        """Creates an `Audio` instance from a WAV file (16/32 bits PCM or float)
+
+        Raises ValueError if `filename` does not exist or is not a WAV file."""
+        filename = str(filename)
+        if not os.path.isfile(filename):
+            raise ValueError(f'{filename}: file not found')
         try:
             sample_rate, data = scipy.io.wavfile.read(filename)
         except Exception as err:  # noqa
-            raise ValueError(f'{filename}: cannot read file: {err}') from None
+            raise ValueError(
+                f'{filename}: cannot read file, Decoding failed ({err}); only WAV files are '
+                f'supported here (the reference decodes other formats with pydub/ffmpeg)') from None
         return cls(data, sample_rate, validate=False)
+
+    def save(self, filename):
+        """Saves the audio data to a WAV `filename`
+
+        Raises ValueError if the file already exists, has no extension or is not ``.wav``."""
+        filename = str(filename)
+        if os.path.isfile(filename):
+            raise ValueError(f'{filename}: file already exists')
+        if '.' not in filename:
+            raise ValueError(
+                f'{filename}: cannot write audio file without extension')
+        extension = filename.split('.')[-1]
+        if extension.lower() != 'wav':
+            raise ValueError(
+                f'{filename}: cannot write file, only WAV files are supported here '
+                f'(the reference encodes other formats with pydub/ffmpeg)')
+        try:
+            scipy.io.wavfile.write(filename, self.sample_rate, self.data)
+        except ValueError as err:  # pragma: nocover
+            raise ValueError(f'{filename}: cannot write file, {err}') from None
+
+    def channel(self, index):
+        """Builds a mono signal from channel `index` of a multi-channel one"""
+        if index == 0 and self.nchannels == 1:
+            return self
+        if index >= self.nchannels:
+            raise ValueError(
+                f'not enough channels ({self.nchannels}) to extract '
+                f'the index {index} (indices count starts at 0)')
+        return Audio(self.data[:, index], self.sample_rate)
+
+    def resample(self, sample_rate, backend='sox'):
+        """Returns the audio signal resampled at the given `sample_rate`
+
+        `backend` must be 'sox' or 'scipy' like in the reference; sox is not available here, so both
+        run the reference's scipy backend (Fourier-domain `scipy.signal.resample`)."""
+        if backend not in ('sox', 'scipy'):
+            raise ValueError(f'backend must be sox or scipy, it is {backend}')
+        if sample_rate == self.sample_rate:
+            return self
+        try:
+            nsamples = int(self.nsamples * sample_rate / self.sample_rate)
+            if nsamples <= 0:
+                raise ValueError('no sample left')
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore', category=FutureWarning)
+                data = scipy.signal.resample(self.data, nsamples)
+        except (ValueError, TypeError, ZeroDivisionError):
+            raise ValueError(f'resampling at {sample_rate} failed!') from None
+        # resampling casts to float64: back to the original dtype
+        return Audio(data.astype(self.dtype), sample_rate, validate=False)
 
     _metadata = collections.namedtuple(
         '_metadata', 'nchannels sample_rate nsamples duration')
@@ -82,10 +148,13 @@ class Audio:
         if isinstance(filename, Audio):
             return cls._metadata(filename.nchannels, filename.sample_rate,
                                  filename.nsamples, filename.duration)
+        filename = str(filename)
+        if not os.path.isfile(filename):
+            raise ValueError(f'{filename}: file not found')
         try:
             sample_rate, data = scipy.io.wavfile.read(filename, mmap=True)
         except Exception as err:  # noqa
-            raise ValueError(f'{filename}: cannot read file: {err}') from None
+            raise ValueError(f'{filename}: cannot scan audio file: {err}') from None
         nchannels = 1 if data.ndim == 1 else data.shape[1]
         return cls._metadata(nchannels, sample_rate, data.shape[0],
                              data.shape[0] / sample_rate)
