@@ -644,3 +644,48 @@ def test_long_utterance(gpu):
     pproc = KaldiPitchProcessor()
     got = pproc.process(Audio(wave, 16000))
     _pitch_close(got.data, orc.pitch(pproc._options, wave))
+
+
+# ---- reference test/processor/test_stability.py and test_parallel.py ------------------------------------
+@pytest.mark.parametrize('same', [True, False])
+@pytest.mark.parametrize('make', [
+    lambda: EnergyProcessor(), lambda: FilterbankProcessor(), lambda: MfccProcessor(),
+    lambda: PlpProcessor(), lambda: PlpProcessor(rasta=True), lambda: KaldiPitchProcessor(),
+    lambda: SpectrogramProcessor()], ids=['energy', 'fbank', 'mfcc', 'plp', 'rasta-plp', 'pitch', 'spec'])
+def test_stable(gpu, audio, make, same):
+    """the features are exactly the same across computations (dither off), with one processor
+    instance or two"""
+    p1 = make()
+    p2 = p1 if same else make()
+    for p in (p1, p2):
+        if hasattr(p, 'dither'):
+            p.dither = 0
+    assert p1.process(audio) == p2.process(audio)
+
+
+def test_process_all_like_reference(gpu, wav_file, capsys):
+    import multiprocessing
+    from shennong_amd import Utterances
+    utterances = Utterances([('u1', wav_file, 0, 0.2), ('u2', wav_file, 0, 0.2), ('u3', wav_file, 0, 0.2)])
+    features = MfccProcessor().process_all(utterances)
+    values = list(features.values())
+    assert utterances.by_name().keys() == features.keys() and len(values) == 3
+    assert all(values[0].is_close(v, atol=10) for v in values[1:])  # (dither is on: close, not equal)
+    features = MfccProcessor().process_all(utterances, vtln_warp={f'u{n + 1}': 1.0 for n in range(3)})
+    assert utterances.by_name().keys() == features.keys()
+    with pytest.raises(TypeError):
+        MfccProcessor().process_all(utterances, bad_name={f'u{n + 1}': 1.0 for n in range(3)})
+    with pytest.raises(ValueError, match='is not a dict'):
+        MfccProcessor().process_all(utterances, vtln_warp=1.0)
+    with pytest.raises(ValueError, match='have different names'):
+        MfccProcessor().process_all(utterances, vtln_warp={f'{n}': 1.0 for n in range(2)})
+    proc = MfccProcessor()
+    proc.set_logger('debug')
+    with pytest.raises(ValueError, match='must be strictly positive'):
+        proc.process_all(utterances, njobs=0)
+    for njobs in (1, 2, 1000):
+        capsys.readouterr()
+        features = proc.process_all(utterances, njobs=njobs)
+        if njobs > multiprocessing.cpu_count():
+            assert 'CPU cores but reducing to' in capsys.readouterr().err
+        assert utterances.by_name().keys() == features.keys()
