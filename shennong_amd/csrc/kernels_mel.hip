@@ -173,19 +173,44 @@ __global__ __launch_bounds__(kWaves * 64, 8) void mel_features_generic_kernel(
     }
 
     if (p.pow2) {
-      // ---- complex FFT of size M = N/2 on the packed frame (radix-2 DIT, data stays in LDS) -------
-      for (int s = 0; s < p.log2_half; ++s) {
+      // ---- complex FFT of size M = N/2 on the packed frame (DIT on bit-reversed data, in LDS) -------
+      // Two radix-2 stages per pass over the data (radix-4 butterflies, half the LDS traffic); one
+      // plain radix-2 stage first when log2(M) is odd.  Same butterflies in the same order as the
+      // stage-by-stage form: the results are bit-identical to it.
+      int s = 0;
+      if (p.log2_half & 1) {
+        wave_lds_sync();
+        for (int j = lane; j < (M >> 1); j += 64) {  // stage 0: half = 1, twiddle 1
+          const float2 a = zs[2 * j], c = zs[2 * j + 1];
+          zs[2 * j] = make_float2(a.x + c.x, a.y + c.y);
+          zs[2 * j + 1] = make_float2(a.x - c.x, a.y - c.y);
+        }
+        s = 1;
+      }
+      for (; s + 2 <= p.log2_half; s += 2) {
         wave_lds_sync();
         const int half = 1 << s;
-        const int tw_stride = M >> (s + 1);
-        for (int j = lane; j < (M >> 1); j += 64) {
+        const int stride_a = M >> (s + 1), stride_b = M >> (s + 2);
+        for (int j = lane; j < (M >> 2); j += 64) {
           const int k = j & (half - 1);
-          const int i0 = ((j >> s) << (s + 1)) + k, i1 = i0 + half;
-          const float2 a = zs[i0], c = zs[i1];
-          const float2 t = p.tw_fft[k * tw_stride];
-          const float xr = c.x * t.x - c.y * t.y, xi = c.x * t.y + c.y * t.x;
-          zs[i0] = make_float2(a.x + xr, a.y + xi);
-          zs[i1] = make_float2(a.x - xr, a.y - xi);
+          const int i0 = ((j >> s) << (s + 2)) + k;
+          const float2 x0 = zs[i0], x1 = zs[i0 + half], x2 = zs[i0 + 2 * half], x3 = zs[i0 + 3 * half];
+          const float2 ta = p.tw_fft[k * stride_a];  // W_{2 half}^k
+          const float2 tb = p.tw_fft[k * stride_b];  // W_{4 half}^k
+          // stage s on (x0, x1) and (x2, x3)
+          const float ar = x1.x * ta.x - x1.y * ta.y, ai = x1.x * ta.y + x1.y * ta.x;
+          const float br = x3.x * ta.x - x3.y * ta.y, bi = x3.x * ta.y + x3.y * ta.x;
+          const float2 y0 = make_float2(x0.x + ar, x0.y + ai), y1 = make_float2(x0.x - ar, x0.y - ai);
+          const float2 y2 = make_float2(x2.x + br, x2.y + bi), y3 = make_float2(x2.x - br, x2.y - bi);
+          // stage s + 1 on (y0, y2) with W^k and (y1, y3) with W^(k + half) = -i W^k... the table
+          // holds that twiddle too: read it so that the products match the radix-2 form bit for bit
+          const float2 tc = p.tw_fft[(k + half) * stride_b];
+          const float cr = y2.x * tb.x - y2.y * tb.y, ci = y2.x * tb.y + y2.y * tb.x;
+          const float dr = y3.x * tc.x - y3.y * tc.y, di = y3.x * tc.y + y3.y * tc.x;
+          zs[i0] = make_float2(y0.x + cr, y0.y + ci);
+          zs[i0 + 2 * half] = make_float2(y0.x - cr, y0.y - ci);
+          zs[i0 + half] = make_float2(y1.x + dr, y1.y + di);
+          zs[i0 + 3 * half] = make_float2(y1.x - dr, y1.y - di);
         }
       }
       wave_lds_sync();
