@@ -689,3 +689,32 @@ def test_process_all_like_reference(gpu, wav_file, capsys):
         if njobs > multiprocessing.cpu_count():
             assert 'CPU cores but reducing to' in capsys.readouterr().err
         assert utterances.by_name().keys() == features.keys()
+
+
+def test_threaded_callers(gpu, synth_waves):
+    """the reference's callers are joblib THREADS (processor/base.py:104-107, pipeline.py:545-565):
+    concurrent `process` / `process_all` calls on one shared plan and on different plans return what
+    the sequential calls return (a host-pointer call owns the plan's staging scratch for its whole
+    duration; staging buffers come from a locked pool)"""
+    from concurrent.futures import ThreadPoolExecutor
+    audios = [Audio(w, 16000) for w in synth_waves] * 4
+    procs = [FilterbankProcessor(num_bins=40, dither=0), MfccProcessor(dither=0),
+             FilterbankProcessor(num_bins=40, dither=0)]  # the first and the last share a plan
+    want = [[p.process(a).data for a in audios] for p in procs]
+
+    def work(job):
+        k, i = job
+        return procs[k].process(audios[i]).data
+
+    jobs = [(k, i) for i in range(len(audios)) for k in range(len(procs))]
+    with ThreadPoolExecutor(8) as pool:
+        got = list(pool.map(work, jobs))
+    for (k, i), g in zip(jobs, got):
+        assert np.array_equal(g, want[k][i]), (k, i)
+    # whole batches from several threads (pinned staging buffers are pooled)
+    big = [Audio(w, 16000) for w in synth.utterances(3, 40, 48000)]
+    ref = [f.data for f in procs[0]._process_batch(big)]
+    with ThreadPoolExecutor(4) as pool:
+        outs = list(pool.map(lambda _: [f.data for f in procs[0]._process_batch(big)], range(8)))
+    for out in outs:
+        assert all(np.array_equal(a, b) for a, b in zip(out, ref))
