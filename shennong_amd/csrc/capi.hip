@@ -530,6 +530,20 @@ int run_pitch_device(snf_plan* plan, const int16_t* d_wave, const int64_t* sampl
   if ((rc = plan->s_doff.upload(doff, s))) return rc;
   if ((rc = plan->s_dp1.upload(dp1, s))) return rc;
   if ((rc = plan->s_fp1.upload(fp1, s))) return rc;
+  // ragged batches: the tracker walks one utterance per wavefront, so a workgroup lasts as long as
+  // its longest utterance - hand the utterances out longest first (ties keep the batch order)
+  std::vector<int32_t> order;
+  bool ragged = false;
+  for (int64_t u = 1; u < n_utts && !ragged; ++u)
+    ragged = (foff[u + 1] - foff[u]) != (foff[1] - foff[0]);
+  if (ragged && n_utts < (int64_t{1} << 31)) {
+    order.resize(static_cast<size_t>(n_utts));
+    for (int64_t u = 0; u < n_utts; ++u) order[u] = static_cast<int32_t>(u);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+      return foff[x + 1] - foff[x] > foff[y + 1] - foff[y];
+    });
+    if ((rc = plan->s_uwarp.upload(order, s))) return rc;
+  }
   if ((rc = plan->s_down.ensure(sizeof(float) * static_cast<size_t>(total_down > 0 ? total_down : 1)))) return rc;
   if ((rc = plan->s_stats.ensure(sizeof(double) * 4 * static_cast<size_t>(n_utts)))) return rc;
   if ((rc = plan->s_bp.ensure(sizeof(int16_t) * static_cast<size_t>(total_frames) * plan->pd.num_states))) return rc;
@@ -543,6 +557,7 @@ int run_pitch_device(snf_plan* plan, const int16_t* d_wave, const int64_t* sampl
   b.frame_offsets = plan->s_foff.as<int64_t>();
   b.down_offsets = plan->s_doff.as<int64_t>();
   b.down_phase1 = plan->s_dp1.as<int64_t>();
+  b.order = order.empty() ? nullptr : plan->s_uwarp.as<int32_t>();
   b.frames_phase1 = plan->s_fp1.as<int64_t>();
   b.n_utts = n_utts;
   b.total_frames = total_frames;

@@ -801,8 +801,9 @@ __global__ __launch_bounds__(kWaveTrackWaves * 64, 4) void pitch_track_wave_kern
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int64_t u = static_cast<int64_t>(blockIdx.x) * kWaveTrackWaves + wid;
-  if (u >= b.n_utts) return;
+  const int64_t slot = static_cast<int64_t>(blockIdx.x) * kWaveTrackWaves + wid;
+  if (slot >= b.n_utts) return;
+  const int64_t u = b.order ? b.order[slot] : slot;
   const int64_t f0 = b.frame_offsets[u], T = b.frame_offsets[u + 1] - f0;
   if (T <= 0) return;
   const int64_t T1 = b.frames_phase1[u];

@@ -202,6 +202,7 @@ struct PitchBatch {
   const int64_t* down_offsets;    // [n_utts+1] offsets into the downsampled scratch
   const int64_t* down_phase1;     // [n_utts] samples available before the flush
   const int64_t* frames_phase1;   // [n_utts] frames processed before the flush
+  const int32_t* order;           // [n_utts] utterance handled by every tracker slot (longest first), or nullptr
   int64_t n_utts, total_frames, total_down;
   int64_t max_down;               // longest downsampled utterance
 };
