@@ -550,6 +550,9 @@ ORC_API int orc_compute(const snf_options* o, const int16_t* wave16, int64_t n, 
   int64_t T = orc_num_frames(fo, n);
   int D = orc_ndims(o);
   if (len < 2) return orc_fail("window size too small");
+  /* [KALDI-UPSTREAM] RealFft / SplitRadixRealFft assert an even transform size (matrix-functions.cc);
+     the frame energy (reference processor/energy.py) has no transform */
+  if (padded % 2 != 0 && kind != SNF_KIND_ENERGY) return orc_fail("padded window size must be even");
   melbanks_t mb; memset(&mb, 0, sizeof(mb));
   int nb = o->mel.num_bins;
   float *dct = NULL, *lift = NULL, *eql = NULL, *idft = NULL;
@@ -557,9 +560,12 @@ ORC_API int orc_compute(const snf_options* o, const int16_t* wave16, int64_t n, 
     /* Kaldi constructs the computer (mel banks for warp 1.0, DCT...) before checking frames */
     if (kind == SNF_KIND_MFCC && o->num_ceps > nb)
       return orc_fail("num-ceps cannot be larger than num-mel-bins");
-    int rc = melbanks_init(&mb, &o->mel, fo, kind == SNF_KIND_PLP ? vtln_warp : 1.0f);
+    /* ... the banks of a warp factor other than 1 are built lazily by the first frame
+       ([KALDI-UPSTREAM] MfccComputer::GetMelBanks from Compute; reference plp.py:521-522 returns
+       before _compute_frame): an utterance without frames never sees their option errors */
+    int rc = melbanks_init(&mb, &o->mel, fo, (kind == SNF_KIND_PLP && T > 0) ? vtln_warp : 1.0f);
     if (rc) return rc;
-    if (kind != SNF_KIND_PLP && vtln_warp != 1.0f) {
+    if (kind != SNF_KIND_PLP && vtln_warp != 1.0f && T > 0) {
       melbanks_free(&mb);
       rc = melbanks_init(&mb, &o->mel, fo, vtln_warp);
       if (rc) return rc;

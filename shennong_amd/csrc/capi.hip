@@ -137,7 +137,9 @@ int build_mel_plan(snf_plan* plan) {
   p.padded = padded_window_size(fo);
   if (p.win_shift <= 0) return set_error(SNF_E_RUNTIME, "frame shift is shorter than one sample");
   if (p.win_len < 2) return set_error(SNF_E_RUNTIME, "frame length must be at least 2 samples");
-  if (p.padded % 2 != 0)
+  // (the frame energy has no spectrum: an odd window - e.g. 25 ms at 22.05 kHz without rounding to a
+  // power of two - is fine for it; Kaldi's RealFft asserts an even size for everything else)
+  if (p.padded % 2 != 0 && plan->kind != SNF_KIND_ENERGY)
     return set_error(SNF_E_RUNTIME, "padded window size must be even (real FFT)");
   p.half = p.padded / 2;
   p.pow2 = (p.padded & (p.padded - 1)) == 0;
@@ -373,12 +375,16 @@ int sync_fast_warp_tables(snf_plan* plan) {
 }
 
 // map per-utterance warp factors to table ids, creating tables on demand
-int resolve_warps(snf_plan* plan, const float* vtln_warp, int64_t n_utts,
+int resolve_warps(snf_plan* plan, const float* vtln_warp, const int64_t* frame_offsets, int64_t n_utts,
                   std::vector<int32_t>* ids, bool* any) {
   *any = false;
   if (!vtln_warp || plan->kind == SNF_KIND_SPECTROGRAM) return SNF_OK;
   ids->assign(n_utts, 0);
   for (int64_t u = 0; u < n_utts; ++u) {
+    // Kaldi builds the banks of a warp factor when the first frame asks for them
+    // ([KALDI-UPSTREAM] MfccComputer::GetMelBanks): an utterance without frames never does, and
+    // never sees the option errors of its warp factor
+    if (frame_offsets[u + 1] == frame_offsets[u]) continue;
     const float wf = vtln_warp[u];
     int id = -1;
     for (size_t k = 0; k < plan->warps.size(); ++k)
@@ -755,7 +761,7 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
 
   std::vector<int32_t> warp_ids;
   bool any_warp = false;
-  if ((rc = resolve_warps(plan, vtln_warp, n_utts, &warp_ids, &any_warp))) return rc;
+  if ((rc = resolve_warps(plan, vtln_warp, frame_offsets, n_utts, &warp_ids, &any_warp))) return rc;
   if ((rc = sync_warp_tables(plan))) return rc;
 
   if (!same_tables) {

@@ -1,0 +1,120 @@
+"""Randomised differential test of the HIP path against the CPU oracle (developer tool, run on the
+GPU box): random processor kinds and options, ragged batches with per-utterance VTLN warps, LDS
+poisoned with NaNs before every case.  Prints the failing case (seed + options) and exits non-zero.
+
+    python tools/fuzz_parity.py [n_cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as orc  # noqa: E402  (test infrastructure: the checker)
+from shennong_amd import Audio, _backend, synth  # noqa: E402
+from shennong_amd.processor import (  # noqa: E402
+    EnergyProcessor, FilterbankProcessor, MfccProcessor, PlpProcessor, SpectrogramProcessor)
+
+
+def random_case(rng):
+    sample_rate = int(rng.choice([8000, 16000, 16000, 16000, 22050]))
+    frame = dict(
+        sample_rate=sample_rate, dither=0,
+        frame_length=float(rng.choice([0.008, 0.01, 0.016, 0.02, 0.025, 0.025, 0.03, 0.032, 0.05])),
+        frame_shift=float(rng.choice([0.005, 0.01, 0.01, 0.0125, 0.02])),
+        preemph_coeff=float(rng.choice([0.0, 0.5, 0.97])),
+        remove_dc_offset=bool(rng.integers(2)), snip_edges=bool(rng.integers(2)),
+        window_type=str(rng.choice(['povey', 'hamming', 'hanning', 'rectangular', 'blackman'])),
+        round_to_power_of_two=bool(rng.integers(8) > 0))
+    kind = str(rng.choice(['fbank', 'fbank', 'mfcc', 'mfcc', 'plp', 'spectrogram', 'energy']))
+    nyquist = sample_rate / 2
+    mel = dict(num_bins=int(rng.integers(8, 65)), low_freq=float(rng.choice([0, 20, 100])),
+               high_freq=float(rng.choice([0, -200, nyquist - 300])))
+    if kind == 'fbank':
+        proc = FilterbankProcessor(use_energy=bool(rng.integers(2)), raw_energy=bool(rng.integers(2)),
+                                   htk_compat=bool(rng.integers(2)), use_log_fbank=bool(rng.integers(4) > 0),
+                                   use_power=bool(rng.integers(4) > 0), **frame, **mel)
+    elif kind == 'mfcc':
+        mel['num_bins'] = max(mel['num_bins'], 13)
+        proc = MfccProcessor(num_ceps=int(rng.integers(2, 14)), use_energy=bool(rng.integers(2)),
+                             raw_energy=bool(rng.integers(2)), htk_compat=bool(rng.integers(2)),
+                             cepstral_lifter=float(rng.choice([0, 22])), **frame, **mel)
+    elif kind == 'plp':
+        mel['num_bins'] = int(rng.integers(15, 41))
+        proc = PlpProcessor(num_ceps=int(rng.integers(2, 14)), use_energy=bool(rng.integers(2)),
+                            raw_energy=bool(rng.integers(2)), htk_compat=bool(rng.integers(2)),
+                            rasta=bool(rng.integers(3) == 0), **frame, **mel)
+    elif kind == 'spectrogram':
+        proc = SpectrogramProcessor(raw_energy=bool(rng.integers(2)), **frame)
+    else:
+        proc = EnergyProcessor(raw_energy=bool(rng.integers(2)),
+                               compression=str(rng.choice(['log', 'sqrt', 'off'])), **frame)
+    n = int(rng.integers(1, 12))
+    lengths = [int(rng.integers(int(0.02 * sample_rate), int(1.5 * sample_rate))) for _ in range(n)]
+    if rng.integers(3) == 0:
+        lengths[int(rng.integers(n))] = int(rng.integers(1, 64))  # shorter than any frame
+    warps = None
+    if kind in ('fbank', 'mfcc', 'plp') and rng.integers(2):
+        warps = [float(rng.choice([1.0, 0.85, 0.93, 1.1, 1.25])) for _ in range(n)]
+    return kind, proc, sample_rate, lengths, warps
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    kernels = {}
+    for case in range(n_cases):
+        kind, proc, sample_rate, lengths, warps = random_case(rng)
+        waves = [synth.utterances(1000 * case + i, 1, n, sample_rate)[0] for i, n in enumerate(lengths)]
+        _backend.check(_backend.lib().snf_debug_fill_lds(0xFFFFFFFF))
+        what = f'case {case} (seed {seed}): {kind} {proc.get_params()} lengths {lengths} warps {warps}'
+        try:
+            audios = [Audio(w, sample_rate) for w in waves]
+            feats = proc._process_batch(audios, vtln_warp=warps) if warps else proc._process_batch(audios)
+        except RuntimeError as err:  # Kaldi-class option errors must be errors of the oracle too
+            try:
+                for w, warp in zip(waves, warps or [1.0] * len(waves)):
+                    orc.compute(proc._build_options(), w, warp)
+            except RuntimeError:
+                continue
+            print('FAIL (device raised, oracle did not)', what, err)
+            return 1
+        plan = _backend.get_plan(proc._build_options())
+        name = plan.kernel_name(1)
+        kernels[name] = kernels.get(name, 0) + 1
+        log_domain = kind in ('mfcc', 'plp', 'spectrogram') or \
+            (kind == 'fbank' and proc.use_log_fbank) or (kind == 'energy' and proc.compression == 'log')
+        for i, (w, f) in enumerate(zip(waves, feats)):
+            try:
+                want = orc.compute(proc._build_options(), w, warps[i] if warps else 1.0)
+            except RuntimeError as err:
+                print('FAIL (oracle raised, device did not)', what, 'utterance', i, err)
+                return 1
+            if f.data.shape != want.shape and not (want.size == 0 and f.data.size == 0):
+                print('FAIL shape', f.data.shape, want.shape, what)
+                return 1
+            if not want.size:
+                continue
+            if kind == 'spectrogram':
+                # single-bin log powers: a bin far below the frame's strongest bin sits under the
+                # float32 noise floor of BOTH transforms - compare the powers against the row maximum
+                pg, pw = np.exp(f.data[:, 1:].astype(np.float64)), np.exp(want[:, 1:].astype(np.float64))
+                ok = np.all(np.abs(pg - pw) <= 2e-4 * pw + 2e-6 * pw.max(axis=1, keepdims=True)) and \
+                    np.allclose(f.data[:, 0], want[:, 0], rtol=2e-4, atol=5e-3)
+            elif log_domain:
+                ok = np.allclose(f.data, want, rtol=2e-4, atol=5e-3)
+            else:
+                ok = np.allclose(f.data, want, rtol=5e-4, atol=1e-6 * float(np.abs(want).max()) + 1e-6)
+            if not ok:
+                bad = np.argwhere(~np.isclose(f.data, want, rtol=2e-4, atol=3e-2))
+                print('FAIL values', what, 'utterance', i, 'first bad', bad[:3].tolist(),
+                      'got', f.data[tuple(bad[0])] if len(bad) else None,
+                      'want', want[tuple(bad[0])] if len(bad) else None,
+                      'max abs', float(np.abs(f.data - want).max()))
+                return 1
+    print(f'{n_cases} random cases agree with the oracle (seed {seed}); kernels used: {kernels}')
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
