@@ -193,14 +193,36 @@ class MatlabSerializer(FeaturesSerializer):
         features = self._features_collection()
         for k, v in data.items():
             if k not in ('__header__', '__version__', '__globals__'):
+                mat, times = self._unsqueeze(v['data'], v['times'])
                 if 'properties' in v:
                     features[k] = Features(
-                        v['data'], v['times'],
+                        mat, times,
                         self._make_list(self._check_keys(v['properties'])),
                         validate=False)
                 else:
-                    features[k] = Features(v['data'], v['times'], validate=False)
+                    features[k] = Features(mat, times, validate=False)
         return features
+
+    @staticmethod
+    def _unsqueeze(data, times):
+        """`loadmat(squeeze_me=True)` (needed for the properties, as in the reference) also collapses
+        a single frame or a single column of the matrices: give them their two dimensions back"""
+        data, times = np.asarray(data), np.asarray(times)
+        if data.ndim == 2:
+            if data.shape[0] == 1 and times.ndim < 2:
+                times = times.reshape((1, 2)) if times.size == 2 else times.reshape((1,))
+            return data, times
+        if data.ndim == 0:
+            return data.reshape((1, 1)), (times.reshape((1, 2)) if times.size == 2 else times.reshape((1,)))
+        if times.ndim == 2:  # several frames of one column
+            return data.reshape((times.shape[0], -1)), times
+        if times.ndim == 0:  # one frame, 1-D times
+            return data.reshape((1, -1)), times.reshape((1,))
+        if times.shape[0] == data.shape[0] and times.shape[0] != 2:  # one column, 1-D times
+            return data.reshape((-1, 1)), times
+        if times.shape[0] == 2:  # one frame, (start, stop) times
+            return data.reshape((1, -1)), times.reshape((1, 2))
+        return data.reshape((-1, 1)), times
 
     @staticmethod
     def _is_struct(obj):

@@ -25,9 +25,12 @@ def get_njobs(njobs=None, log=null_logger()):
 
 
 def array2list(seq):
-    """Converts numpy arrays in `seq` into lists"""
+    """Converts numpy arrays in `seq` into lists (reference utils.py:65-73, which stops at lists: an
+    array inside a list of dicts made `dict_equal` raise there; lists are walked as well here)"""
     if isinstance(seq, dict):
         return {k: array2list(v) for k, v in seq.items()}
+    if isinstance(seq, (list, tuple)):
+        return [array2list(v) for v in seq]
     if isinstance(seq, np.ndarray):
         return seq.tolist()
     return seq

@@ -285,3 +285,58 @@ def test_kaldi_stream_writer_float_matrices(tmpdir, mfcc):
     assert len(blob) < 2 * (mfcc.data.size * 4 + 64)
     loaded = FeaturesCollection.load(name)
     assert loaded['a'] == mfcc and loaded['b'].dtype == np.float32
+
+
+def _random_properties(rng, depth=0):
+    def leaf():
+        kind = int(rng.integers(9))
+        return [lambda: int(rng.integers(-1000, 1000)), lambda: float(rng.standard_normal()),
+                lambda: bool(rng.integers(2)), lambda: 'str%d é' % int(rng.integers(100)),
+                lambda: np.float32(rng.standard_normal()), lambda: np.int64(rng.integers(1000)),
+                lambda: rng.standard_normal((int(rng.integers(1, 4)), int(rng.integers(1, 5)))),
+                lambda: [int(x) for x in rng.integers(0, 50, size=int(rng.integers(0, 4)))],
+                lambda: rng.standard_normal(int(rng.integers(1, 6))).astype(np.float32)][kind]()
+    out = {}
+    for k in range(int(rng.integers(1, 6))):
+        if depth < 2 and rng.integers(3) == 0:
+            out[f'k{k}'] = _random_properties(rng, depth + 1)
+        elif rng.integers(6) == 0:
+            out[f'k{k}'] = [_random_properties(rng, 2) for _ in range(int(rng.integers(1, 3)))]
+        else:
+            out[f'k{k}'] = leaf()
+    return out
+
+
+@pytest.mark.parametrize('serializer', SERIALIZERS)
+@pytest.mark.parametrize('seed', range(6))
+def test_random_collections_round_trip(tmpdir, serializer, seed):
+    """random collections (ragged frame counts incl. one frame, float32 / float64 data, 1-D and 2-D
+    times, nested properties with arrays, numpy scalars, lists, unicode) survive every file format"""
+    rng = np.random.default_rng(100 + seed)
+    coll = FeaturesCollection()
+    cols = int(rng.integers(1, 20))
+    for i in range(int(rng.integers(1, 6))):
+        n = int(rng.integers(1, 60))
+        data = rng.standard_normal((n, cols)).astype(rng.choice([np.float32, np.float64]))
+        start = np.arange(n) * 0.01
+        times = start if rng.integers(2) else np.stack([start, start + 0.025], axis=1)
+        # (the .mat format squeezes arrays and turns lists into arrays - in the reference too: it gets
+        # the kind of properties the processors really write)
+        props = ({'mfcc': {'dither': 0.0, 'window_type': 'povey', 'snip_edges': True, 'num_ceps': 13},
+                  'pipeline': [{'name': 'mfcc', 'columns': [0, cols - 1]}]}
+                 if serializer is serializers.MatlabSerializer else _random_properties(rng))
+        coll[f'item-{i}-ü'] = Features(data, times, properties=props)
+    name = str(tmpdir.join(_name(serializer)))
+    coll.save(name, serializer=serializer.__name__.replace('Serializer', '').lower())
+    loaded = FeaturesCollection.load(name, serializer=serializer.__name__.replace('Serializer', '').lower())
+    assert list(sorted(loaded.keys())) == list(sorted(coll.keys()))
+    for k in coll:
+        assert loaded[k].shape == coll[k].shape, k
+        if serializer is not serializers.MatlabSerializer:
+            assert loaded[k].dtype == coll[k].dtype, k
+        assert np.array_equal(loaded[k].data, coll[k].data), k
+        assert np.array_equal(loaded[k].times, coll[k].times) and loaded[k].times.shape == coll[k].times.shape
+        if serializer is serializers.MatlabSerializer:  # (.mat holds doubles)
+            assert loaded[k].is_close(coll[k].copy(dtype=np.float64))
+            continue
+        assert loaded[k] == coll[k], (k, loaded[k].properties, coll[k].properties)
