@@ -205,3 +205,8 @@ def default_options(kind):
 def options_key(opts):
     """Hashable identity of an options record (plan cache key)"""
     return bytes(opts)
+
+
+def copy_options(opts):
+    """An independent copy of an options record (nested records included)"""
+    return Options.from_buffer_copy(opts)

@@ -1,98 +1,86 @@
-"""Base class of all processors: sklearn-like get_params / set_params
+"""Base class of all processors: parameters as constructor keywords
 
-Mirrors reference shennong/base.py:59-150 (parameters are the explicit keyword arguments of
-``__init__``; nested ``a__b`` keys are forwarded to sub-processors).
+Every processor declares its parameters as explicit keyword arguments of ``__init__`` and exposes
+them as attributes of the same names; ``get_params`` / ``set_params`` (the scikit-learn estimator
+protocol, as in reference shennong/base.py:59-150) read and write them by name, ``a__b`` addressing
+parameter ``b`` of the processor stored in parameter ``a``.
 """
 
-import abc
-import collections
 import inspect
 
 from shennong_amd.logger import get_logger
 
+_FORMAT = '%(levelname)s - %(name)s - %(message)s'
+
 
 class BaseProcessor:
     """Base class for all processors"""
+    name = None  # every processor class names itself
+
     def __init__(self):
         self._logger = get_logger(self.name, level='info')
 
     def __repr__(self):
-        return self.__class__.__name__
-
-    @abc.abstractproperty
-    def name(self):
-        """Processor name"""
+        return type(self).__name__
 
     @property
     def log(self):
-        """Processor logger"""
-        if not hasattr(self, '_logger'):
+        """Processor logger (created on first use when a subclass did not call ``__init__``)"""
+        if '_logger' not in self.__dict__:
             self._logger = get_logger(self.name, level='info')
         return self._logger
 
-    def set_logger(self, level,
-                   formatter='%(levelname)s - %(name)s - %(message)s'):
+    def set_logger(self, level, formatter=_FORMAT):
         """Change level and/or format of the processor's logger"""
         self._logger = get_logger(self.name, level=level, formatter=formatter)
 
+    # ---- parameters -------------------------------------------------------------------------------
     @classmethod
     def _get_param_names(cls):
-        cached = cls.__dict__.get('_param_names_cache')
-        if cached is not None:
-            return cached
-        names = cls._inspect_param_names()
-        cls._param_names_cache = names
+        """Sorted names of the constructor's keyword parameters (cached per class: the pipeline asks
+        once per utterance)"""
+        names = cls.__dict__.get('_param_names')
+        if names is None:
+            names = []
+            for param in inspect.signature(cls.__init__).parameters.values():
+                if param.kind is param.VAR_POSITIONAL:
+                    raise RuntimeError(
+                        f'processors should always specify their parameters in the signature of '
+                        f'their __init__ (no varargs): {cls} does not')
+                if param.name != 'self' and param.kind is not param.VAR_KEYWORD:
+                    names.append(param.name)
+            names = cls._param_names = sorted(names)
         return names
 
-    @classmethod
-    def _inspect_param_names(cls):
-        init = getattr(cls.__init__, 'deprecated_original', cls.__init__)
-        if init is object.__init__:  # pragma: nocover
-            return []
-        signature = inspect.signature(init)
-        parameters = [p for p in signature.parameters.values()
-                      if p.name != 'self' and p.kind != p.VAR_KEYWORD]
-        for param in parameters:
-            if param.kind == param.VAR_POSITIONAL:
-                raise RuntimeError(
-                    f'processors should always specify their parameters in '
-                    f'the signature of their __init__ (no varargs). {cls} '
-                    f'with constructor {signature} does not follow this '
-                    f'convention.')
-        return sorted([p.name for p in parameters])
-
     def get_params(self, deep=True):
-        """Get parameters for this processor as a dict name -> value"""
-        out = dict()
-        for key in self._get_param_names():
-            value = getattr(self, key, None)
+        """Parameters of this processor as a dict name -> value; with `deep`, the parameters of
+        processor-valued parameters appear too, as ``name__subname``"""
+        params = {}
+        for name in self._get_param_names():
+            value = params[name] = getattr(self, name, None)
             if deep and hasattr(value, 'get_params'):
-                out.update((key + '__' + k, val)
-                           for k, val in value.get_params().items())
-            out[key] = value
-        return out
+                for sub_name, sub_value in value.get_params().items():
+                    params[f'{name}__{sub_name}'] = sub_value
+        return params
 
     def set_params(self, **params):
-        """Set the parameters of this processor, returns self"""
-        if not params:
-            return self
-        valid_params = self.get_params(deep=True)
-        nested_params = collections.defaultdict(dict)
+        """Set parameters by name (``name__subname`` reaches into a processor-valued parameter);
+        returns self.  Raises ValueError for a name that is not a parameter."""
+        known = self.get_params(deep=False) if params else {}
+        nested = {}
         for key, value in params.items():
-            key, delim, sub_key = key.partition('__')
-            if key not in valid_params:
+            name, _, sub_name = key.partition('__')
+            if name not in known:
                 raise ValueError(
-                    f'invalid parameter {key} for processor {self}, '
-                    f'check the list of available parameters '
-                    f'with `processor.get_params().keys()`.')
-            if delim:
-                nested_params[key][sub_key] = value
-            else:
-                try:
-                    setattr(self, key, value)
-                except AttributeError:
-                    raise ValueError(f'cannot set attribute {key} for {self}')
-                valid_params[key] = value
-        for key, sub_params in nested_params.items():
-            valid_params[key].set_params(**sub_params)
+                    f'invalid parameter {name} for processor {self}, check the list of available '
+                    f'parameters with `processor.get_params().keys()`.')
+            if sub_name:
+                nested.setdefault(name, {})[sub_name] = value
+                continue
+            try:
+                setattr(self, name, value)
+            except AttributeError:
+                raise ValueError(f'cannot set attribute {name} for {self}') from None
+        for name, sub_params in nested.items():
+            getattr(self, name).set_params(**sub_params)
         return self

@@ -1,67 +1,34 @@
 """Frames: extract overlapping frames from raw (sampled) signals
 
-Mirror of reference shennong/frames.py:42-249.  The frame count is Kaldi's NumFrames (through the
-C ABI, snf_num_frames, replacing kaldi.feat.window.num_frames at frames.py:137); note that
-``make_frames`` starts every frame at ``frame * shift`` and mirrors only the tail when
-``snip_edges=False`` (frames.py:213-215), unlike Kaldi's centred framing used by the processors.
+Counterpart of reference shennong/frames.py:42-249.  The frame count is Kaldi's NumFrames (through
+the C ABI, snf_num_frames, replacing kaldi.feat.window.num_frames at frames.py:137).  Note the
+reference's own convention, kept here: ``make_frames`` starts every frame at ``frame * shift`` and
+mirrors only the tail when ``snip_edges=False`` (frames.py:213-215), unlike Kaldi's centred framing
+used by the processors.
 """
 
 import numpy as np
 
 from shennong_amd import _abi, _backend
+from shennong_amd._options import FLAG, SECONDS, Configurable, Option
 from shennong_amd.base import BaseProcessor
 
 
-class Frames(BaseProcessor):
+class Frames(Configurable, BaseProcessor):
     """Extract frames from raw signals"""
+    _kind = _abi.KIND_SPECTROGRAM  # (only the framing part of the option record is used)
+    name = 'frames'
+
     def __init__(self, sample_rate=16000,
                  frame_shift=0.01, frame_length=0.025,
                  snip_edges=True):
-        self._options = _abi.default_frame_options()
-        self.sample_rate = sample_rate
-        self.frame_shift = frame_shift
-        self.frame_length = frame_length
-        self.snip_edges = snip_edges
+        self._configure(locals())
 
-    @property
-    def name(self):
-        return 'frames'
-
-    @property
-    def sample_rate(self):
-        """Waveform sample frequency in Hertz"""
-        return self._options.samp_freq
-
-    @sample_rate.setter
-    def sample_rate(self, value):
-        self._options.samp_freq = value
-
-    @property
-    def frame_shift(self):
-        """Frame shift in seconds"""
-        return self._options.frame_shift_ms / 1000.0
-
-    @frame_shift.setter
-    def frame_shift(self, value):
-        self._options.frame_shift_ms = value * 1000.0
-
-    @property
-    def frame_length(self):
-        """Frame length in seconds"""
-        return self._options.frame_length_ms / 1000.0
-
-    @frame_length.setter
-    def frame_length(self, value):
-        self._options.frame_length_ms = value * 1000.0
-
-    @property
-    def snip_edges(self):
-        """If true, output only frames that completely fit in the file"""
-        return bool(self._options.snip_edges)
-
-    @snip_edges.setter
-    def snip_edges(self, value):
-        self._options.snip_edges = bool(value)
+    sample_rate = Option('frame.samp_freq', 'Waveform sample frequency in Hertz')
+    frame_shift = Option('frame.frame_shift_ms', 'Frame shift in seconds', SECONDS)
+    frame_length = Option('frame.frame_length_ms', 'Frame length in seconds', SECONDS)
+    snip_edges = Option(
+        'frame.snip_edges', 'If true, output only frames that completely fit in the file', FLAG)
 
     @property
     def samples_per_frame(self):
@@ -77,7 +44,7 @@ class Frames(BaseProcessor):
         """Returns the number of frames extracted from `nsamples`"""
         if self.samples_per_shift == 0:
             raise ValueError('cannot compute nframes: sample rate too low')
-        return _backend.num_frames(self._options, nsamples)
+        return _backend.num_frames(self._record.frame, nsamples)
 
     def first_sample_of_frame(self, frame):
         """Returns the index of the first sample of frame indexed `frame`"""
@@ -85,45 +52,29 @@ class Frames(BaseProcessor):
 
     def last_sample_of_frame(self, frame):
         """Returns the index+1 of the last sample of frame indexed `frame`"""
-        return int(self.first_sample_of_frame(frame) + self.samples_per_frame)
+        return self.first_sample_of_frame(frame) + self.samples_per_frame
 
     def times(self, nsamples):
         """Returns an array of (tstart, tstop) times of each frames of a signal"""
-        nframes = self.nframes(nsamples)
-        return np.vstack((
-            np.arange(nframes) * self.frame_shift,
-            np.arange(nframes) * self.frame_shift + self.frame_length)).T
+        start = np.arange(self.nframes(nsamples)) * self.frame_shift
+        return np.vstack((start, start + self.frame_length)).T
 
     def boundaries(self, nframes):
-        """Returns an array of (istart, istop) index boundaries of frames"""
-        first = [self.first_sample_of_frame(i) for i in range(nframes)]
-        return (np.asarray(first, dtype=np.int64).repeat(2).reshape(nframes, 2)
-                + (0, self.samples_per_frame)).astype(int)
+        """Returns an array [nframes, 2] of (istart, istop) sample indices of the frames"""
+        first = np.arange(nframes, dtype=np.int64) * self.samples_per_shift
+        return np.stack((first, first + self.samples_per_frame), axis=1).astype(int)
 
     def make_frames(self, array, writeable=False):
-        """Returns an `array` divided in frames, shape [nframes, samples_per_frame, ...]"""
+        """Returns `array` divided in frames, shape [nframes, samples_per_frame, ...]: a read-only
+        strided view, or a copy when `writeable`"""
         nframes = self.nframes(array.shape[0])
         if not self.snip_edges:
-            # mirror the data in the last frames
-            n = self.last_sample_of_frame(nframes-1) - array.shape[0]
-            array = np.concatenate((array, array[-n-1:-1][::-1]))
-        if writeable is True:
-            return self._make_frames_by_copy(array, nframes)
-        return self._make_frames_by_view(array, nframes)
-
-    def _make_frames_by_view(self, array, nframes):
-        shape = (nframes, self.samples_per_frame) + array.shape[1:]
-        strides = (array.strides[0] * self.samples_per_shift,
-                   array.strides[0]) + array.strides[1:]
-        return np.lib.stride_tricks.as_strided(
-            array, shape=shape, strides=strides, writeable=False)
-
-    def _make_frames_by_copy(self, array, nframes):
-        boundaries = self.boundaries(nframes)
-        nsamples = self.samples_per_frame
-        framed = np.empty(
-            (nframes, nsamples) + array.shape[1:], dtype=array.dtype)
-        for i, (start, stop) in enumerate(boundaries):
-            assert stop - start == nsamples
-            framed[i] = array[start:stop]
-        return framed
+            # the last frames reach beyond the data: mirror its tail
+            missing = self.last_sample_of_frame(nframes - 1) - array.shape[0]
+            array = np.concatenate((array, array[-missing - 1:-1][::-1]))
+        step, width = self.samples_per_shift, self.samples_per_frame
+        view = np.lib.stride_tricks.as_strided(
+            array, shape=(nframes, width) + array.shape[1:],
+            strides=(array.strides[0] * step, array.strides[0]) + array.strides[1:],
+            writeable=False)
+        return view.copy() if writeable is True else view

@@ -11,6 +11,7 @@ host (or all-reduced over ranks, see shennong_amd/distributed.py), and applied b
 import numpy as np
 
 from shennong_amd import _abi, _backend
+from shennong_amd._options import FLAG, Configurable, Option
 from shennong_amd.features import Features, FeaturesCollection
 from shennong_amd.postprocessor.base import FeaturesPostProcessor
 from shennong_amd.utils import copy_properties
@@ -222,66 +223,29 @@ def apply_cmvn(feats_collection, by_collection=True, norm_vars=True,
     return out
 
 
-class SlidingWindowCmvnPostProcessor(FeaturesPostProcessor):
-    """Compute sliding-window normalization on speech features
+class SlidingWindowCmvnPostProcessor(Configurable, FeaturesPostProcessor):
+    """Sliding-window mean (and variance) normalisation of speech features (Kaldi
+    SlidingWindowCmn; same parameters and defaults as reference postprocessor/cmvn.py:400-500;
+    plan kind SLIDING_CMVN on the HIP backend)
 
-    Parameters
-    ----------
-    center : bool, optional
-        Whether to center the window on the current frame, default to True
-    cmn_window : int, optional
-        Window size for average CMN computation, default to 600
-    min_window : int, optional
-        Minimum CMN window used at start of decoding, default to 100
-    max_warnings : int, optional
-        Maximum warning to report per utterance, default to 5
-    normalize_variance : bool, optional
-        Whether to normalize variance to one, default to False
-    """
+    `max_warnings` is accepted for compatibility: the reference passes it to Kaldi, which only uses
+    it to limit log messages."""
+    _kind = _abi.KIND_SLIDING_CMVN
+    name = 'sliding_window_cmvn'
+
     def __init__(self, center=True, cmn_window=600, min_window=100,
                  max_warnings=5, normalize_variance=False):
         super().__init__()
-        self.center = center
-        self.cmn_window = cmn_window
-        self.max_warnings = max_warnings
-        self.min_window = min_window
-        self.normalize_variance = normalize_variance
+        self._max_warnings = 5
+        self._configure(locals())
 
-    @property
-    def name(self):
-        return 'sliding_window_cmvn'
-
-    @property
-    def ndims(self):
-        raise ValueError('output dimension for sliding '
-                         'window CMVN processor depends on input')
-
-    @property
-    def center(self):
-        """Whether to center the window on the current frame"""
-        return self._center
-
-    @center.setter
-    def center(self, value):
-        self._center = bool(value)
-
-    @property
-    def cmn_window(self):
-        """Window size for average CMN computation"""
-        return self._cmn_window
-
-    @cmn_window.setter
-    def cmn_window(self, value):
-        self._cmn_window = int(value)
-
-    @property
-    def min_window(self):
-        """Minimum CMN window used at start of decoding"""
-        return self._min_window
-
-    @min_window.setter
-    def min_window(self, value):
-        self._min_window = int(value)
+    center = Option(
+        'sliding_cmvn.center', 'Whether to center the window on the current frame', FLAG)
+    cmn_window = Option('sliding_cmvn.cmn_window', 'Window size for average CMN computation')
+    min_window = Option(
+        'sliding_cmvn.min_window', 'Minimum CMN window used at start of decoding')
+    normalize_variance = Option(
+        'sliding_cmvn.normalize_variance', 'Whether to normalize variance to one', FLAG)
 
     @property
     def max_warnings(self):
@@ -293,31 +257,14 @@ class SlidingWindowCmvnPostProcessor(FeaturesPostProcessor):
         self._max_warnings = int(value)
 
     @property
-    def normalize_variance(self):
-        """Whether to normalize variance to one"""
-        return self._normalize_variance
-
-    @normalize_variance.setter
-    def normalize_variance(self, value):
-        self._normalize_variance = bool(value)
+    def ndims(self):
+        raise ValueError('output dimension for sliding '
+                         'window CMVN processor depends on input')
 
     def get_properties(self, features):
-        properties = copy_properties(features.properties)
+        properties = self._extend_properties(features, features.ndims)
         properties[self.name] = self.get_params()
-        if 'pipeline' not in properties:
-            properties['pipeline'] = []
-        properties['pipeline'].append({
-            'name': self.name,
-            'columns': [0, features.ndims - 1]})
         return properties
-
-    def _build_options(self):
-        opts = _abi.default_options(_abi.KIND_SLIDING_CMVN)
-        opts.sliding_cmvn = _abi.SlidingCmvnOptions(
-            center=int(self.center), cmn_window=self.cmn_window,
-            min_window=self.min_window,
-            normalize_variance=int(self.normalize_variance))
-        return opts
 
     def process(self, features):
         """Applies sliding-window cepstral mean and/or variance normalization"""

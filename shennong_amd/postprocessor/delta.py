@@ -1,48 +1,32 @@
 """Delta / delta-delta: Features ---> DeltaPostProcessor ---> Features
-(mirror of reference shennong/postprocessor/delta.py:53-136 over the HIP backend)"""
 
+Same parameters, outputs and error messages as reference shennong/postprocessor/delta.py:53-136
+(Kaldi ComputeDeltas; plan kind DELTA on the HIP backend).
+"""
 
 import numpy as np
 
 from shennong_amd import _abi, _backend
+from shennong_amd._options import Configurable, Option, require
 from shennong_amd.features import Features
 from shennong_amd.postprocessor.base import FeaturesPostProcessor
-from shennong_amd.utils import copy_properties
 
 
-class DeltaPostProcessor(FeaturesPostProcessor):
+class DeltaPostProcessor(Configurable, FeaturesPostProcessor):
+    """Appends the time derivatives of the input columns, up to `order`"""
+    _kind = _abi.KIND_DELTA
+    name = 'delta'
+
     def __init__(self, order=2, window=2):
         super().__init__()
-        self._order = 2
-        self._window = 2
-        self.order = order
-        self.window = window
+        self._configure(locals())
 
-    @property
-    def name(self):
-        return 'delta'
-
-    @property
-    def order(self):
-        """Order of delta computation"""
-        return self._order
-
-    @order.setter
-    def order(self, value):
-        self._order = int(value)
-
-    @property
-    def window(self):
-        """The actual window size for each delta order is 1 + 2 * `window`; edges replicate
-        the first or last frame"""
-        return self._window
-
-    @window.setter
-    def window(self, value):
-        if not 0 < value < 1000:
-            raise ValueError(
-                'window must be in [1, 999], it is {}'.format(value))
-        self._window = int(value)
+    order = Option('delta_order', 'Order of delta computation')
+    window = Option(
+        'delta_window',
+        'The actual window size for each delta order is 1 + 2 * `window`; edges replicate the '
+        'first or last frame',
+        check=require(lambda v: 0 < v < 1000, 'window must be in [1, 999], it is {}'))
 
     @property
     def ndims(self):
@@ -50,29 +34,15 @@ class DeltaPostProcessor(FeaturesPostProcessor):
             'output dimension for delta processor depends on input')
 
     def get_properties(self, features):
-        ndims = (self.order + 1) * features.ndims
-        properties = copy_properties(features.properties)
-        properties[self.name] = {
-            'order': self.order,
-            'window': self.window}
-        if 'pipeline' not in properties:
-            properties['pipeline'] = []
-        properties['pipeline'].append({
-            'name': self.name,
-            'columns': [0, ndims - 1]})
+        """The input's properties + this processor's parameters + one more pipeline stage covering
+        the (order + 1) * ndims output columns"""
+        properties = self._extend_properties(features, (self.order + 1) * features.ndims)
+        properties[self.name] = {'order': self.order, 'window': self.window}
         return properties
-
-    def _build_options(self):
-        opts = _abi.default_options(_abi.KIND_DELTA)
-        opts.delta_order = self.order
-        opts.delta_window = self.window
-        return opts
 
     def process(self, features):
         """Compute deltas on `features`: [nframes, ncols] -> [nframes, ncols * (order + 1)]"""
-        data = _backend.get_plan(self._build_options()).run_post(
-            [np.asarray(features.data, dtype=np.float32)])[0]
-        return Features(data, features.times, self.get_properties(features))
+        return self._process_batch([features])[0]
 
     def _process_batch(self, features_list):
         datas = _backend.get_plan(self._build_options()).run_post(

@@ -1,85 +1,41 @@
 """Voice activity detection: Features ---> VadPostProcessor ---> Features
 
-Mirror of reference shennong/postprocessor/vad.py:74-191 over the HIP backend (plan kind VAD,
-Kaldi ComputeVadEnergy on the first column of the features).
+Same parameters, outputs and error messages as reference shennong/postprocessor/vad.py:74-191 (Kaldi
+ComputeVadEnergy on the first column of the features; plan kind VAD on the HIP backend).
 """
 
 import numpy as np
 
 from shennong_amd import _abi, _backend
+from shennong_amd._options import F32, Configurable, Option, require
 from shennong_amd.features import Features
 from shennong_amd.postprocessor.base import FeaturesPostProcessor
 
 
-class VadPostProcessor(FeaturesPostProcessor):
+class VadPostProcessor(Configurable, FeaturesPostProcessor):
     """Computes VAD on speech features"""
+    _kind = _abi.KIND_VAD
+    name = 'vad'
+    ndims = 1
+
     def __init__(self, energy_threshold=5.0, energy_mean_scale=0.5,
                  frames_context=0, proportion_threshold=0.6):
         super().__init__()
-        self._options = _abi.default_options(_abi.KIND_VAD).vad
-        self.energy_threshold = energy_threshold
-        self.energy_mean_scale = energy_mean_scale
-        self.frames_context = frames_context
-        self.proportion_threshold = proportion_threshold
+        self._configure(locals())
 
-    @property
-    def name(self):
-        return 'vad'
-
-    @property
-    def energy_threshold(self):
-        """Constant term in energy threshold for MFCC0 for VAD"""
-        return np.float32(self._options.energy_threshold)
-
-    @energy_threshold.setter
-    def energy_threshold(self, value):
-        self._options.energy_threshold = value
-
-    @property
-    def energy_mean_scale(self):
-        """Scale factor of the mean log-energy: the threshold is `s * mean + energy_threshold`"""
-        return np.float32(self._options.energy_mean_scale)
-
-    @energy_mean_scale.setter
-    def energy_mean_scale(self, value):
-        if value < 0:
-            raise ValueError(
-                'Energy mean scale must be >= 0, it is {}'.format(value))
-        self._options.energy_mean_scale = value
-
-    @property
-    def frames_context(self):
-        """Number of frames of context on each side of central frame"""
-        return self._options.frames_context
-
-    @frames_context.setter
-    def frames_context(self, value):
-        if value < 0:
-            raise ValueError(
-                'frames_context must be >= 0, it is {}'.format(value))
-        self._options.frames_context = value
-
-    @property
-    def proportion_threshold(self):
-        """Proportion of frames of the window that must exceed the threshold, in ]0, 1["""
-        return np.float32(self._options.proportion_threshold)
-
-    @proportion_threshold.setter
-    def proportion_threshold(self, value):
-        if value <= 0 or value >= 1:
-            raise ValueError(
-                'proportion_threshold must be in ]0, 1[, it is {}'
-                .format(value))
-        self._options.proportion_threshold = value
-
-    @property
-    def ndims(self):
-        return 1
-
-    def _build_options(self):
-        opts = _abi.default_options(_abi.KIND_VAD)
-        opts.vad = _abi.VadOptions.from_buffer_copy(bytes(self._options))
-        return opts
+    energy_threshold = Option(
+        'vad.energy_threshold', 'Constant term in energy threshold for MFCC0 for VAD', F32)
+    energy_mean_scale = Option(
+        'vad.energy_mean_scale',
+        'Scale factor of the mean log-energy: the threshold is `s * mean + energy_threshold`', F32,
+        check=require(lambda v: v >= 0, 'Energy mean scale must be >= 0, it is {}'))
+    frames_context = Option(
+        'vad.frames_context', 'Number of frames of context on each side of central frame',
+        check=require(lambda v: v >= 0, 'frames_context must be >= 0, it is {}'))
+    proportion_threshold = Option(
+        'vad.proportion_threshold',
+        'Proportion of frames of the window that must exceed the threshold, in ]0, 1[', F32,
+        check=require(lambda v: 0 < v < 1, 'proportion_threshold must be in ]0, 1[, it is {}'))
 
     def process(self, features):
         """VAD decisions (uint8, 1 = voiced) [nframes, 1] from features whose first column

@@ -13,6 +13,7 @@ import abc
 import numpy as np
 
 from shennong_amd import _abi, _backend
+from shennong_amd._options import F32, FLAG, SECONDS_F32, Configurable, Option
 from shennong_amd.base import BaseProcessor
 from shennong_amd.features import Features, FeaturesCollection
 from shennong_amd.utils import copy_properties, get_njobs
@@ -102,87 +103,38 @@ class FeaturesProcessor(BaseProcessor, metaclass=abc.ABCMeta):
             (u.name, f) for u, f in zip(utts, feats))
 
 
-class FramesProcessor(FeaturesProcessor, metaclass=abc.ABCMeta):
-    """A base class for frame based features processors (Kaldi FrameExtractionOptions)"""
+class FramesProcessor(Configurable, FeaturesProcessor, metaclass=abc.ABCMeta):
+    """Base of the frame based processors: the ten framing parameters (Kaldi
+    FrameExtractionOptions; reference processor/base.py:110-268) as views on the `frame` part of
+    the option record, the `times` of the output rows and the batched device call"""
     def __init__(self, sample_rate=16000, frame_shift=0.01,
                  frame_length=0.025, dither=1.0, preemph_coeff=0.97,
                  remove_dc_offset=True, window_type='povey',
                  round_to_power_of_two=True, blackman_coeff=0.42,
                  snip_edges=True):
         super().__init__()
-        self._frame_options = _abi.default_frame_options()
-        self._window_type = 'povey'
-        self.sample_rate = sample_rate
-        self.frame_shift = frame_shift
-        self.frame_length = frame_length
-        self.dither = dither
-        self.preemph_coeff = preemph_coeff
-        self.remove_dc_offset = remove_dc_offset
-        self.window_type = window_type
-        self.round_to_power_of_two = round_to_power_of_two
-        self.blackman_coeff = blackman_coeff
-        self.snip_edges = snip_edges
+        self._configure(locals())
 
-    # float options round-trip through a C float like the reference's Kaldi structs do, so the
-    # getters return np.float32 (reference processor/base.py:150-243)
-    @property
-    def sample_rate(self):
-        """Waveform sample frequency in Hertz"""
-        return np.float32(self._frame_options.samp_freq)
-
-    @sample_rate.setter
-    def sample_rate(self, value):
-        self._frame_options.samp_freq = value
-
-    @property
-    def frame_shift(self):
-        """Frame shift in seconds"""
-        return np.float32(self._frame_options.frame_shift_ms / 1000.0)
-
-    @frame_shift.setter
-    def frame_shift(self, value):
-        self._frame_options.frame_shift_ms = value * 1000.0
-
-    @property
-    def frame_length(self):
-        """Frame length in seconds"""
-        return np.float32(self._frame_options.frame_length_ms / 1000.0)
-
-    @frame_length.setter
-    def frame_length(self, value):
-        self._frame_options.frame_length_ms = value * 1000.0
-
-    @property
-    def dither(self):
-        """Amount of dithering, 0.0 means no dither"""
-        return np.float32(self._frame_options.dither)
-
-    @dither.setter
-    def dither(self, value):
-        self._frame_options.dither = value
-
-    @property
-    def preemph_coeff(self):
-        """Coefficient for use in signal preemphasis"""
-        return np.float32(self._frame_options.preemph_coeff)
-
-    @preemph_coeff.setter
-    def preemph_coeff(self, value):
-        self._frame_options.preemph_coeff = value
-
-    @property
-    def remove_dc_offset(self):
-        """If True, subtract mean from waveform on each frame"""
-        return bool(self._frame_options.remove_dc_offset)
-
-    @remove_dc_offset.setter
-    def remove_dc_offset(self, value):
-        self._frame_options.remove_dc_offset = bool(value)
+    sample_rate = Option('frame.samp_freq', 'Waveform sample frequency in Hertz', F32)
+    frame_shift = Option('frame.frame_shift_ms', 'Frame shift in seconds', SECONDS_F32)
+    frame_length = Option('frame.frame_length_ms', 'Frame length in seconds', SECONDS_F32)
+    dither = Option('frame.dither', 'Amount of dithering, 0.0 means no dither', F32)
+    preemph_coeff = Option('frame.preemph_coeff', 'Coefficient for use in signal preemphasis', F32)
+    remove_dc_offset = Option(
+        'frame.remove_dc_offset', 'If True, subtract mean from waveform on each frame', FLAG)
+    round_to_power_of_two = Option(
+        'frame.round_to_power_of_two',
+        'If true, round window size to power of two by zero-padding the FFT input', FLAG)
+    blackman_coeff = Option(
+        'frame.blackman_coeff', 'Constant coefficient for generalized Blackman window', F32)
+    snip_edges = Option(
+        'frame.snip_edges', 'If true, output only frames that completely fit in the file', FLAG)
 
     @property
     def window_type(self):
         """'hamming', 'hanning', 'povey', 'rectangular' or 'blackman'"""
-        return self._window_type
+        code = self._record.frame.window_type
+        return next(name for name, value in _abi.WINDOW_TYPES.items() if value == code)
 
     @window_type.setter
     def window_type(self, value):
@@ -190,135 +142,41 @@ class FramesProcessor(FeaturesProcessor, metaclass=abc.ABCMeta):
         if value not in windows:
             raise ValueError(
                 'window type must be in {}, it is {}'.format(windows, value))
-        self._window_type = value
-        self._frame_options.window_type = _abi.WINDOW_TYPES[value]
-
-    @property
-    def round_to_power_of_two(self):
-        """If true, round window size to power of two by zero-padding the FFT input"""
-        return bool(self._frame_options.round_to_power_of_two)
-
-    @round_to_power_of_two.setter
-    def round_to_power_of_two(self, value):
-        self._frame_options.round_to_power_of_two = bool(value)
-
-    @property
-    def blackman_coeff(self):
-        """Constant coefficient for generalized Blackman window"""
-        return np.float32(self._frame_options.blackman_coeff)
-
-    @blackman_coeff.setter
-    def blackman_coeff(self, value):
-        self._frame_options.blackman_coeff = value
-
-    @property
-    def snip_edges(self):
-        """If true, output only frames that completely fit in the file"""
-        return bool(self._frame_options.snip_edges)
-
-    @snip_edges.setter
-    def snip_edges(self, value):
-        self._frame_options.snip_edges = bool(value)
+        self._record.frame.window_type = _abi.WINDOW_TYPES[value]
 
     def times(self, nframes):
-        """Returns the times label for the rows given by :func:`process`
-        (float64 multiples of the float32 shift, reference processor/base.py:264-268)"""
-        return np.vstack((
-            np.arange(nframes) * self.frame_shift,
-            np.arange(nframes) * self.frame_shift + self.frame_length)).T
-
-    # -- shared device path --------------------------------------------------------
-    def _options(self, kind):
-        """A by-value copy of the option structs (reference processor/base.py:421-425)"""
-        opts = _abi.default_options(kind)
-        opts.frame = self._frame_options
-        return opts
+        """(start, stop) of every output row in seconds: float64 multiples of the float32 shift,
+        which is what the reference produces (processor/base.py:264-268)"""
+        start = np.arange(nframes) * self.frame_shift
+        return np.vstack((start, start + self.frame_length)).T
 
     def _run(self, opts, signals, vtln_warps=None):
-        waves = [s.astype(np.int16).data for s in signals]  # force 16 bits integers
+        """One batched launch over `signals` (forced to 16 bits integers like the reference does
+        before Kaldi, processor/base.py:428); the batch is validated once"""
+        waves = [s.astype(np.int16).data for s in signals]
         return _backend.get_plan(opts).run(waves, vtln_warps, check_finite=True)
 
 
 class MelFeaturesProcessor(FramesProcessor):
-    """A base class for mel-based features processors (Kaldi MelBanksOptions)"""
-    _kind = None
-
+    """Base of the mel based processors: adds the five mel-bank parameters (Kaldi MelBanksOptions;
+    reference processor/base.py:271-436) and `process(signal, vtln_warp)`"""
     def __init__(self, sample_rate=16000, frame_shift=0.01,
                  frame_length=0.025, dither=1.0, preemph_coeff=0.97,
                  remove_dc_offset=True, window_type='povey',
                  round_to_power_of_two=True, blackman_coeff=0.42,
                  snip_edges=True, num_bins=23, low_freq=20,
                  high_freq=0, vtln_low=100, vtln_high=-500):
-        super().__init__(
-            sample_rate=sample_rate,
-            frame_shift=frame_shift,
-            frame_length=frame_length,
-            dither=dither,
-            preemph_coeff=preemph_coeff,
-            remove_dc_offset=remove_dc_offset,
-            window_type=window_type,
-            round_to_power_of_two=round_to_power_of_two,
-            blackman_coeff=blackman_coeff,
-            snip_edges=snip_edges)
-        self._mel_options = _abi.default_mel_options()
-        self.num_bins = num_bins
-        self.low_freq = low_freq
-        self.high_freq = high_freq
-        self.vtln_low = vtln_low
-        self.vtln_high = vtln_high
+        FeaturesProcessor.__init__(self)
+        self._configure(locals())
 
-    @property
-    def num_bins(self):
-        """Number of triangular mel-frequency bins (minimum 3)"""
-        return self._mel_options.num_bins
-
-    @num_bins.setter
-    def num_bins(self, value):
-        self._mel_options.num_bins = value
-
-    @property
-    def low_freq(self):
-        """Low cutoff frequency for mel bins in Hertz"""
-        return np.float32(self._mel_options.low_freq)
-
-    @low_freq.setter
-    def low_freq(self, value):
-        self._mel_options.low_freq = value
-
-    @property
-    def high_freq(self):
-        """High cutoff frequency for mel bins in Hertz (< 0: offset from Nyquist)"""
-        return np.float32(self._mel_options.high_freq)
-
-    @high_freq.setter
-    def high_freq(self, value):
-        self._mel_options.high_freq = value
-
-    @property
-    def vtln_low(self):
-        """Low inflection point in piecewise linear VTLN warping function"""
-        return np.float32(self._mel_options.vtln_low)
-
-    @vtln_low.setter
-    def vtln_low(self, value):
-        self._mel_options.vtln_low = value
-
-    @property
-    def vtln_high(self):
-        """High inflection point in piecewise linear VTLN warping function"""
-        return np.float32(self._mel_options.vtln_high)
-
-    @vtln_high.setter
-    def vtln_high(self, value):
-        self._mel_options.vtln_high = value
-
-    def _options(self, kind):
-        opts = super()._options(kind)
-        opts.mel = self._mel_options
-        return opts
-
-    def _build_options(self):  # pragma: nocover
-        raise NotImplementedError
+    num_bins = Option('mel.num_bins', 'Number of triangular mel-frequency bins (minimum 3)')
+    low_freq = Option('mel.low_freq', 'Low cutoff frequency for mel bins in Hertz', F32)
+    high_freq = Option(
+        'mel.high_freq', 'High cutoff frequency for mel bins in Hertz (< 0: offset from Nyquist)', F32)
+    vtln_low = Option(
+        'mel.vtln_low', 'Low inflection point in piecewise linear VTLN warping function', F32)
+    vtln_high = Option(
+        'mel.vtln_high', 'High inflection point in piecewise linear VTLN warping function', F32)
 
     def process(self, signal, vtln_warp=1.0):
         """Compute features with the specified options
@@ -327,11 +185,7 @@ class MelFeaturesProcessor(FramesProcessor):
         Raises ValueError if `signal` is not mono or sample rates mismatch, RuntimeError for
         Kaldi-class option errors (num_bins < 3, num_ceps > num_bins, bad frequencies...).
         """
-        check_signal(self, signal)
-        data = self._run(self._build_options(), [signal], [vtln_warp])[0]
-        return Features(
-            data, self.times(data.shape[0]),
-            properties=self.get_properties(vtln_warp=vtln_warp))
+        return self._process_batch([signal], vtln_warp=[vtln_warp])[0]
 
     def _process_batch(self, signals, vtln_warp=None):
         for signal in signals:

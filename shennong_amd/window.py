@@ -1,35 +1,33 @@
 """Window functions: rectangular, hanning, hamming, povey, blackman
 
-Mirror of reference shennong/window.py:59-114; the values come from the C ABI
-(snf_window_function, replacing kaldi.feat.window.FeatureWindowFunction at window.py:107-114).
+Counterpart of reference shennong/window.py:59-114; the coefficients come from the C ABI
+(snf_window_function, in place of kaldi.feat.window.FeatureWindowFunction at window.py:107-114).
 """
 
 import numpy as np
 
 from shennong_amd import _abi, _backend
 
+_ONES_AT_LENGTH_TWO = ('povey', 'blackman', 'hanning')  # cos(0) and cos(2 pi): both ends are 0 -> Kaldi
+#                                                        would return zeros; the reference returns ones
+
 
 def types():
     """Returns the supported window functions as a list"""
-    return sorted(['povey', 'hanning', 'hamming', 'rectangular', 'blackman'])
+    return sorted(_abi.WINDOW_TYPES)
 
 
 def window(length, type='povey', blackman_coeff=0.42):
-    """Returns a float32 window of the given `type` and `length`"""
+    """Returns a window of the given `type` and `length` (float32; the two degenerate cases below are
+    float64 ones, as in the reference, window.py:97-105)"""
     if int(length) <= 0:
-        raise ValueError(
-            'length must be strictly positive but is {}'.format(length))
+        raise ValueError(f'length must be strictly positive but is {length}')
     if type not in types():
-        raise ValueError(
-            'type must be in {} but is {}'.format(types, type))
-    # special cases, see reference window.py:97-105
-    if length == 1:
-        return np.ones((1,))
-    if length == 2 and type in ('povey', 'blackman', 'hanning'):
-        return np.ones((2,))
-    opt = _abi.default_frame_options()
-    opt.samp_freq = 1000
-    opt.frame_length_ms = length  # samp_freq * 0.001 * length
-    opt.window_type = _abi.WINDOW_TYPES[type]
-    opt.blackman_coeff = blackman_coeff
-    return _backend.window_function(opt)
+        raise ValueError(f'type must be in {types()} but is {type}')
+    if length == 1 or (length == 2 and type in _ONES_AT_LENGTH_TWO):
+        return np.ones((int(length),))
+    # a 1 kHz "signal" makes the frame length in milliseconds the length in samples
+    opts = _abi.default_frame_options()
+    opts.samp_freq, opts.frame_length_ms = 1000, length
+    opts.window_type, opts.blackman_coeff = _abi.WINDOW_TYPES[type], blackman_coeff
+    return _backend.window_function(opts)
