@@ -1,11 +1,12 @@
 """Audio container: the input of every features processor
 
-Mirror of reference shennong/audio.py for WAV files: ``data / sample_rate / nchannels / nsamples /
-dtype``, ``astype`` (int16 <-> float scaling by 2**15, audio.py:469-518), ``segment``
-(audio.py:520-561), ``channel`` (audio.py:328-357), ``load`` / ``save`` / ``scan`` through scipy
-(audio.py:179-320; the reference falls back to pydub / ffmpeg and sox for flac, mp3, ...: neither
-exists offline, those formats raise a ValueError that says so) and ``resample`` with the reference's
-scipy backend (audio.py:358-425; the sox backend is the same call here).
+Counterpart of reference shennong/audio.py for WAV files.  An :class:`Audio` is a numpy array of
+samples (one column per channel) and a sample rate; the sample type is one of int16, int32, float32
+or float64 and each type has a full scale (2**15, 2**30 and 1.0): ``astype`` rescales between them
+(audio.py:469-518), the processors ask for int16.  Files are read and written with scipy
+(audio.py:179-320; the reference falls back to pydub / ffmpeg and to sox for flac, mp3, ...:
+neither exists offline, those formats raise a ValueError that says so); ``resample`` is the
+reference's scipy backend (audio.py:358-425; its sox backend is the same call here).
 """
 
 import collections
@@ -17,57 +18,51 @@ import numpy as np
 import scipy.io.wavfile
 import scipy.signal
 
+# sample type -> (log2 of the full scale, smallest and largest valid sample)
+_FORMATS = {
+    np.dtype(np.int16): (15, -2**15, 2**15 - 1),
+    np.dtype(np.int32): (30, -2**31, 2**31 - 1),
+    np.dtype(np.float32): (0, -1, 1),
+    np.dtype(np.float64): (0, -1, 1),
+}
+_Metadata = collections.namedtuple('_metadata', 'nchannels sample_rate nsamples duration')
+
+
+def _read_wav(filename, what, **kwargs):
+    filename = str(filename)
+    if not os.path.isfile(filename):
+        raise ValueError(f'{filename}: file not found')
+    try:
+        return scipy.io.wavfile.read(filename, **kwargs)
+    except Exception as err:  # noqa (scipy raises ValueError and others on non-WAV content)
+        raise ValueError(
+            f'{filename}: {what} ({err}); only WAV files are supported here (the reference '
+            f'decodes other formats with pydub/ffmpeg)') from None
+
 
 class Audio:
     """An audio signal with the given `data` and `sample_rate`"""
     def __init__(self, data, sample_rate, validate=True):
+        # a single channel given as a column is a vector (the kernels take vectors)
+        self._data = data[:, 0] if data.ndim == 2 and data.shape[1] == 1 else data
         self._sample_rate = int(sample_rate)
-        # force shape (n, 1) to be (n,)
-        self._data = (
-            data[:, 0] if data.ndim > 1 and data.shape[1] == 1 else data)
         if validate and not self.is_valid():
             raise ValueError(f'invalid audio data for type {self.dtype}')
 
+    data = property(lambda self: self._data, doc='The samples, [nsamples] or [nsamples, nchannels]')
+    sample_rate = property(lambda self: self._sample_rate, doc='Samples per second')
+    shape = property(lambda self: self._data.shape)
+    dtype = property(lambda self: self._data.dtype)
+    nsamples = property(lambda self: self._data.shape[0])
+    nchannels = property(lambda self: 1 if self._data.ndim == 1 else self._data.shape[1])
+    duration = property(lambda self: self.nsamples / self.sample_rate, doc='Duration in seconds')
+    precision = property(lambda self: self.dtype.itemsize * 8, doc='Bits per sample')
+
     def __eq__(self, other):
-        if self.sample_rate != other.sample_rate:
-            return False
-        return np.array_equal(self.data, other.data)
+        return self.sample_rate == other.sample_rate and np.array_equal(self.data, other.data)
 
-    @property
-    def data(self):
-        return self._data
-
-    @property
-    def sample_rate(self):
-        return self._sample_rate
-
-    @property
-    def duration(self):
-        return self.nsamples / self.sample_rate
-
-    @property
-    def nchannels(self):
-        if self.data.ndim == 1:
-            return 1
-        return self.data.shape[1]
-
-    @property
-    def nsamples(self):
-        return self.data.shape[0]
-
-    @property
-    def shape(self):
-        return self.data.shape
-
-    @property
-    def dtype(self):
-        return self.data.dtype
-
-    @property
-    def precision(self):
-        return self.dtype.itemsize * 8
-
-    # the pipeline loads a file once for its metadata and again for every segment of it: like the
+    # ---- files ------------------------------------------------------------------------------------
+    # the pipeline reads a file once for its metadata and again for every segment of it: like the
     # reference (audio.py:240-243) keep the last two decoded files
     @classmethod
     @functools.lru_cache(maxsize=2)
@@ -75,16 +70,20 @@ class Audio:
         """Creates an `Audio` instance from a WAV file (16/32 bits PCM or float)
 
         Raises ValueError if `filename` does not exist or is not a WAV file."""
-        filename = str(filename)
-        if not os.path.isfile(filename):
-            raise ValueError(f'{filename}: file not found')
-        try:
-            sample_rate, data = scipy.io.wavfile.read(filename)
-        except Exception as err:  # noqa
-            raise ValueError(
-                f'{filename}: cannot read file, Decoding failed ({err}); only WAV files are '
-                f'supported here (the reference decodes other formats with pydub/ffmpeg)') from None
+        sample_rate, data = _read_wav(filename, 'cannot read file, Decoding failed')
         return cls(data, sample_rate, validate=False)
+
+    @classmethod
+    def scan(cls, filename):
+        """Returns (nchannels, sample_rate, nsamples, duration) without decoding the samples
+        (reference audio.py:179-240 asks sox; the WAV header is read through a memory map here).
+        An in-memory :class:`Audio` is accepted too (benchmark / tests)."""
+        if isinstance(filename, Audio):
+            audio = filename
+            return _Metadata(audio.nchannels, audio.sample_rate, audio.nsamples, audio.duration)
+        sample_rate, data = _read_wav(filename, 'cannot scan audio file', mmap=True)
+        return _Metadata(1 if data.ndim == 1 else data.shape[1], sample_rate, data.shape[0],
+                         data.shape[0] / sample_rate)
 
     def save(self, filename):
         """Saves the audio data to a WAV `filename`
@@ -93,28 +92,23 @@ class Audio:
         filename = str(filename)
         if os.path.isfile(filename):
             raise ValueError(f'{filename}: file already exists')
-        if '.' not in filename:
-            raise ValueError(
-                f'{filename}: cannot write audio file without extension')
-        extension = filename.split('.')[-1]
-        if extension.lower() != 'wav':
+        extension = os.path.splitext(filename)[1]
+        if not extension:
+            raise ValueError(f'{filename}: cannot write audio file without extension')
+        if extension.lower() != '.wav':
             raise ValueError(
                 f'{filename}: cannot write file, only WAV files are supported here '
                 f'(the reference encodes other formats with pydub/ffmpeg)')
-        try:
-            scipy.io.wavfile.write(filename, self.sample_rate, self.data)
-        except ValueError as err:  # pragma: nocover
-            raise ValueError(f'{filename}: cannot write file, {err}') from None
+        scipy.io.wavfile.write(filename, self.sample_rate, self.data)
 
+    # ---- views and conversions --------------------------------------------------------------------
     def channel(self, index):
         """Builds a mono signal from channel `index` of a multi-channel one"""
-        if index == 0 and self.nchannels == 1:
-            return self
         if index >= self.nchannels:
             raise ValueError(
                 f'not enough channels ({self.nchannels}) to extract '
                 f'the index {index} (indices count starts at 0)')
-        return Audio(self.data[:, index], self.sample_rate)
+        return self if self.nchannels == 1 else Audio(self.data[:, index], self.sample_rate)
 
     def resample(self, sample_rate, backend='sox'):
         """Returns the audio signal resampled at the given `sample_rate`
@@ -125,110 +119,66 @@ class Audio:
             raise ValueError(f'backend must be sox or scipy, it is {backend}')
         if sample_rate == self.sample_rate:
             return self
-        try:
-            nsamples = int(self.nsamples * sample_rate / self.sample_rate)
-            if nsamples <= 0:
-                raise ValueError('no sample left')
-            with warnings.catch_warnings():
-                warnings.simplefilter('ignore', category=FutureWarning)
-                data = scipy.signal.resample(self.data, nsamples)
-        except (ValueError, TypeError, ZeroDivisionError):
-            raise ValueError(f'resampling at {sample_rate} failed!') from None
-        # resampling casts to float64: back to the original dtype
-        return Audio(data.astype(self.dtype), sample_rate, validate=False)
-
-    _metadata = collections.namedtuple(
-        '_metadata', 'nchannels sample_rate nsamples duration')
-
-    @classmethod
-    def scan(cls, filename):
-        """Returns (nchannels, sample_rate, nsamples, duration) without decoding the samples
-        (reference audio.py:179-240 asks sox; wav headers are read with scipy here).  An
-        in-memory :class:`Audio` is accepted too (benchmark / tests)."""
-        if isinstance(filename, Audio):
-            return cls._metadata(filename.nchannels, filename.sample_rate,
-                                 filename.nsamples, filename.duration)
-        filename = str(filename)
-        if not os.path.isfile(filename):
-            raise ValueError(f'{filename}: file not found')
-        try:
-            sample_rate, data = scipy.io.wavfile.read(filename, mmap=True)
-        except Exception as err:  # noqa
-            raise ValueError(f'{filename}: cannot scan audio file: {err}') from None
-        nchannels = 1 if data.ndim == 1 else data.shape[1]
-        return cls._metadata(nchannels, sample_rate, data.shape[0],
-                             data.shape[0] / sample_rate)
+        nsamples = int(self.nsamples * sample_rate / self.sample_rate) if sample_rate > 0 else 0
+        if nsamples <= 0:
+            raise ValueError(f'resampling at {sample_rate} failed!')
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', category=FutureWarning)
+            data = scipy.signal.resample(self.data, nsamples)
+        return Audio(data.astype(self.dtype), sample_rate, validate=False)  # (scipy returns float64)
 
     @staticmethod
     def _is_valid_dtype(dtype):
-        return dtype in (np.dtype(t) for t in (
-            np.int16, np.int32, np.float32, np.float64))
+        try:
+            return np.dtype(dtype) in _FORMATS
+        except TypeError:
+            return False
 
     def is_valid(self):
-        """True if dtype is supported and samples are within the type's range"""
-        if not self._is_valid_dtype(self.dtype):
+        """True if the sample type is supported and the samples lie within its full scale (warns
+        and returns False otherwise)"""
+        if self.dtype not in _FORMATS:
             warnings.warn(f'unsupported audio data type: {self.dtype}')
             return False
-        if self.dtype is np.dtype(np.int16):
-            emin, emax = -2**15, 2**15 - 1
-        elif self.dtype is np.dtype(np.int32):
-            emin, emax = -2**31, 2**31 - 1
-        else:
-            emin, emax = -1, 1
         if self.data.size == 0:
             return True
-        dmin, dmax = np.amin(self.data), np.amax(self.data)
-        if dmin < emin or dmax > emax:
+        _, lowest, highest = _FORMATS[self.dtype]
+        dmin, dmax = self.data.min(), self.data.max()
+        if dmin < lowest or dmax > highest:
             warnings.warn(
                 f'invalid audio for type {self.dtype}: boundaries must be in '
-                f'({emin}, {emax}) but are ({dmin}, {dmax})')
+                f'({lowest}, {highest}) but are ({dmin}, {dmax})')
             return False
         return True
 
     def astype(self, dtype):
-        """Returns the signal converted to `dtype` (reference audio.py:469-518)"""
-        if self.dtype is np.dtype(dtype):
-            return self
+        """Returns the signal converted to `dtype`, rescaled from the full scale of the current
+        sample type to the full scale of the new one (reference audio.py:469-518)"""
         if not self._is_valid_dtype(dtype):
             raise ValueError(f'unsupported audio data type: {dtype}')
-        if self.dtype is np.dtype(np.int16):
-            if dtype is np.int32:
-                # `data * 2**15` under the reference's numpy 1.x value-based casting
-                data = self.data.astype(np.int32) * 2**15
-            else:
-                data = self.data / 2**15
-        elif self.dtype is np.dtype(np.int32):
-            if dtype is np.int16:
-                data = self.data / 2**15
-            else:
-                data = self.data / 2**30
+        dtype = np.dtype(dtype)
+        if dtype == self.dtype:
+            return self
+        shift = _FORMATS[dtype][0] - _FORMATS[self.dtype][0]
+        if shift >= 0 and self.dtype.kind == 'i' and dtype.kind == 'i':
+            data = self.data.astype(dtype) << shift  # integer up-scaling is exact
         else:
-            if dtype is np.int16:
-                data = self.data * 2**15
-            elif dtype is np.int32:
-                data = self.data * 2**30
-            else:
-                data = self.data
+            # float arithmetic with a power of two, then the C cast of the reference: truncation
+            # toward zero, out-of-range values wrap (no clipping)
+            data = self.data * 2.0 ** shift
         with np.errstate(invalid='ignore'):
-            # out-of-range floats wrap exactly like the reference's C cast
             return Audio(data.astype(dtype), self.sample_rate, validate=False)
 
     def segment(self, segments):
-        """Returns audio chunks for a list of (tstart, tstop) pairs in seconds"""
+        """Returns one :class:`Audio` per (tstart, tstop) pair of `segments`, in seconds"""
         if not isinstance(segments, list):
             raise ValueError('segments must be a list')
-        for segment in segments:
-            try:
-                if not len(segment) == 2:
-                    raise ValueError('segments elements must be pairs')
-            except TypeError:
+        bounds = []
+        for pair in segments:
+            if not hasattr(pair, '__len__') or len(pair) != 2:
                 raise ValueError('segments elements must be pairs')
-            if segment[0] >= segment[1]:
+            if not pair[0] < pair[1]:
                 raise ValueError('time indices in segments must be sorted')
-        chunks = []
-        for segment in segments:
-            istart = int(segment[0] * self.sample_rate)
-            istop = int(segment[1] * self.sample_rate)
-            chunks.append(Audio(
-                self.data[istart:istop], self.sample_rate, validate=False))
-        return chunks
+            bounds.append((int(pair[0] * self.sample_rate), int(pair[1] * self.sample_rate)))
+        return [Audio(self.data[start:stop], self.sample_rate, validate=False)
+                for start, stop in bounds]
