@@ -1,11 +1,22 @@
-"""Features post-processors"""
+"""Features post-processors, loaded on first use (see shennong_amd.processor)"""
 
-import shennong_amd.processor  # noqa: F401 (import order: the processors define the base classes)
+import importlib
 
-from shennong_amd.postprocessor.cmvn import (
-    CmvnPostProcessor, SlidingWindowCmvnPostProcessor, apply_cmvn)
-from shennong_amd.postprocessor.delta import DeltaPostProcessor
-from shennong_amd.postprocessor.vad import VadPostProcessor
+_HOME = {
+    'CmvnPostProcessor': 'cmvn',
+    'SlidingWindowCmvnPostProcessor': 'cmvn',
+    'apply_cmvn': 'cmvn',
+    'DeltaPostProcessor': 'delta',
+    'VadPostProcessor': 'vad',
+}
+__all__ = sorted(_HOME)
 
-__all__ = ['CmvnPostProcessor', 'DeltaPostProcessor',
-           'SlidingWindowCmvnPostProcessor', 'VadPostProcessor', 'apply_cmvn']
+
+def __getattr__(name):
+    if name in _HOME:
+        return getattr(importlib.import_module(f'{__name__}.{_HOME[name]}'), name)
+    raise AttributeError(f'module {__name__!r} has no attribute {name!r}')
+
+
+def __dir__():
+    return __all__

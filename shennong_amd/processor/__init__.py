@@ -1,13 +1,28 @@
-"""Features extraction processors (same names as reference shennong/processor/__init__.py)"""
+"""Features extraction processors, loaded on first use
 
-from shennong_amd.processor.energy import EnergyProcessor
-from shennong_amd.processor.filterbank import FilterbankProcessor
-from shennong_amd.processor.mfcc import MfccProcessor
-from shennong_amd.processor.plp import PlpProcessor
-from shennong_amd.processor.spectrogram import SpectrogramProcessor
-from shennong_amd.processor.pitch_kaldi import (
-    KaldiPitchProcessor, KaldiPitchPostProcessor)
+``from shennong_amd.processor import MfccProcessor`` works as in the reference package; the class
+is imported from its module when it is first asked for.
+"""
 
-__all__ = [
-    'EnergyProcessor', 'FilterbankProcessor', 'MfccProcessor', 'PlpProcessor',
-    'SpectrogramProcessor', 'KaldiPitchProcessor', 'KaldiPitchPostProcessor']
+import importlib
+
+_HOME = {
+    'EnergyProcessor': 'energy',
+    'FilterbankProcessor': 'filterbank',
+    'MfccProcessor': 'mfcc',
+    'PlpProcessor': 'plp',
+    'SpectrogramProcessor': 'spectrogram',
+    'KaldiPitchProcessor': 'pitch_kaldi',
+    'KaldiPitchPostProcessor': 'pitch_kaldi',
+}
+__all__ = sorted(_HOME)
+
+
+def __getattr__(name):
+    if name in _HOME:
+        return getattr(importlib.import_module(f'{__name__}.{_HOME[name]}'), name)
+    raise AttributeError(f'module {__name__!r} has no attribute {name!r}')
+
+
+def __dir__():
+    return __all__
