@@ -14,6 +14,7 @@ import copyreg
 import json
 import os
 import pickle
+import re
 import struct
 
 import numpy as np
@@ -23,53 +24,43 @@ from shennong_amd.features import Features
 from shennong_amd.utils import array2list
 
 
+_BY_NAME, _BY_EXTENSION = {}, {}
+
+
+def _file_format(name, extension):
+    """Class decorator: registers a serializer under its `name` and file `extension`"""
+    def register(cls):
+        _BY_NAME[name] = _BY_EXTENSION[extension] = cls
+        return cls
+    return register
+
+
 def supported_extensions():
     """File extensions mapped to their serializer class"""
-    return {
-        '.npz': NumpySerializer,
-        '.mat': MatlabSerializer,
-        '.pkl': PickleSerializer,
-        '.ark': KaldiSerializer,
-        '': CsvSerializer}
+    return dict(_BY_EXTENSION)
 
 
 def supported_serializers():
     """Serializers names mapped to their class"""
-    return {
-        'numpy': NumpySerializer,
-        'matlab': MatlabSerializer,
-        'pickle': PickleSerializer,
-        'kaldi': KaldiSerializer,
-        'csv': CsvSerializer}
+    return dict(_BY_NAME)
 
 
 def get_serializer(cls, filename, log, serializer=None):
-    """Returns the file serializer from filename extension or serializer name
+    """The serializer instance for `filename`: the one named `serializer`, or the one registered for
+    the file extension
 
-    Raises
-    ------
-    ValueError
-        If the serializer class cannot be guessed, or if `cls` is not FeaturesCollection
-    """
+    Raises ValueError for an unknown name / extension, or if `cls` is not FeaturesCollection."""
     if cls.__name__ != 'FeaturesCollection':
         raise ValueError(
             'The `cls` parameter must be shennong.features.FeaturesCollection')
+    filename = str(filename)
     if serializer is None:
-        ext = os.path.splitext(str(filename))[1]
-        try:
-            serializer = supported_extensions()[ext]
-        except KeyError:
-            raise ValueError(
-                'invalid extension {}, must be in {}'.format(
-                    ext, list(supported_extensions().keys()))) from None
+        what, key, table = 'extension', os.path.splitext(filename)[1], _BY_EXTENSION
     else:
-        try:
-            serializer = supported_serializers()[serializer]
-        except KeyError:
-            raise ValueError(
-                'invalid serializer {}, must be in {}'.format(
-                    serializer, list(supported_serializers().keys()))) from None
-    return serializer(cls, str(filename), log)
+        what, key, table = 'serializer', serializer, _BY_NAME
+    if key not in table:
+        raise ValueError(f'invalid {what} {key}, must be in {list(table)}')
+    return table[key](cls, filename, log)
 
 
 # ---- JSON with numpy support (json_tricks-compatible encoding) ---------------------------------------
@@ -99,24 +90,29 @@ def _json_loads(text):
 
 
 class FeaturesSerializer(metaclass=abc.ABCMeta):
-    """Base class of a features file serializer"""
+    """Base class of a features file serializer: `save` / `load` do the checks common to every
+    format, the subclasses read and write the files (`_save`, `_load`)"""
     def __init__(self, cls, filename, log):
-        self._features_collection = cls
-        self._filename = filename
-        self._log = log
+        self._features_collection, self._filename, self._log = cls, filename, log
 
-    @property
-    def filename(self):
-        """Name of the file to read or write"""
-        return self._filename
+    filename = property(lambda self: self._filename, doc='Name of the file to read or write')
 
     @abc.abstractmethod
     def _save(self, features, with_properties):  # pragma: nocover
-        pass
+        """Writes the (valid) collection"""
+
+    @abc.abstractmethod
+    def _load(self):  # pragma: nocover
+        """Reads the collection back"""
 
     def _check_save(self):
         if os.path.isfile(self.filename):
             raise IOError(f'file already exists: {self.filename}')
+
+    def _check_load(self):
+        for test, problem in ((os.path.isfile, 'found'), (lambda f: os.access(f, os.R_OK), 'readable')):
+            if not test(self.filename):
+                raise IOError(f'file not {problem}: {self.filename}')
 
     def save(self, features, with_properties=True, **kwargs):
         """Saves a collection of `features` to a file
@@ -124,24 +120,13 @@ class FeaturesSerializer(metaclass=abc.ABCMeta):
         Raises IOError if the output file already exists, ValueError if the features are not a
         valid FeaturesCollection."""
         self._check_save()
-        if not isinstance(features, self._features_collection):
+        expected = self._features_collection
+        if not isinstance(features, expected):
             raise ValueError(
-                'features must be {} but are {}'.format(
-                    self._features_collection.__name__,
-                    features.__class__.__name__))
+                f'features must be {expected.__name__} but are {type(features).__name__}')
         if not features.is_valid():
             raise ValueError('features are not valid')
         self._save(features, with_properties, **kwargs)
-
-    @abc.abstractmethod
-    def _load(self):  # pragma: nocover
-        pass
-
-    def _check_load(self):
-        if not os.path.isfile(self.filename):
-            raise IOError(f'file not found: {self.filename}')
-        if not os.access(self.filename, os.R_OK):
-            raise IOError(f'file not readable: {self.filename}')
 
     def load(self, **kwargs):
         """Returns the collection of features stored in the file
@@ -154,54 +139,67 @@ class FeaturesSerializer(metaclass=abc.ABCMeta):
             raise ValueError(f'features not valid in "{self.filename}"')
         return features
 
-
-class NumpySerializer(FeaturesSerializer):
-    """Saves and loads features to/from the numpy '.npz' format"""
-    def _save(self, features, with_properties, compress=True):
+    def _as_dicts(self, features, with_properties):
+        """name -> {'data', 'times'[, 'properties']}: what the array container formats store"""
         self._log.info('writing %s', self.filename)
-        data = {k: v._to_dict(with_properties=with_properties)
-                for k, v in features.items()}
-        save = np.savez_compressed if compress is True else np.savez
+        return {name: feats._to_dict(with_properties=with_properties)
+                for name, feats in features.items()}
+
+
+@_file_format('numpy', '.npz')
+class NumpySerializer(FeaturesSerializer):
+    """Saves and loads features to/from the numpy '.npz' format (one pickled dictionary under the
+    key 'features', like the reference)"""
+    def _save(self, features, with_properties, compress=True):
+        write = np.savez_compressed if compress is True else np.savez
         with open(self.filename, 'wb') as stream:
-            save(stream, features=data, allow_pickle=True)
+            write(stream, features=self._as_dicts(features, with_properties), allow_pickle=True)
 
     def _load(self):
         self._log.info('loading %s', self.filename)
         with open(self.filename, 'rb') as stream:
-            data = np.load(stream, allow_pickle=True)['features'].tolist()
-        features = self._features_collection()
-        for k, v in data.items():
-            features[k] = Features._from_dict(v, validate=False)
-        return features
+            stored = np.load(stream, allow_pickle=True)['features'].item()
+        return self._features_collection(
+            (name, Features._from_dict(entry, validate=False)) for name, entry in stored.items())
 
 
+@_file_format('matlab', '.mat')
 class MatlabSerializer(FeaturesSerializer):
-    """Saves and loads features to/from the matlab '.mat' format"""
+    """Saves and loads features to/from the matlab '.mat' format (one struct per item)"""
+    _BOOKKEEPING = ('__header__', '__version__', '__globals__')
+
     def _save(self, features, with_properties, compress=True):
-        self._log.info('writing %s', self.filename)
-        data = {k: v._to_dict(with_properties=with_properties)
-                for k, v in features.items()}
         scipy.io.savemat(
-            self.filename, data, long_field_names=True,
+            self.filename, self._as_dicts(features, with_properties), long_field_names=True,
             appendmat=False, do_compression=compress)
 
     def _load(self):
         self._log.info('loading %s', self.filename)
-        data = self._check_keys(scipy.io.loadmat(
-            self.filename, appendmat=False, squeeze_me=True,
-            mat_dtype=True, struct_as_record=False))
+        stored = scipy.io.loadmat(
+            self.filename, appendmat=False, squeeze_me=True, mat_dtype=True, struct_as_record=False)
         features = self._features_collection()
-        for k, v in data.items():
-            if k not in ('__header__', '__version__', '__globals__'):
-                mat, times = self._unsqueeze(v['data'], v['times'])
-                if 'properties' in v:
-                    features[k] = Features(
-                        mat, times,
-                        self._make_list(self._check_keys(v['properties'])),
-                        validate=False)
-                else:
-                    features[k] = Features(mat, times, validate=False)
+        for name, entry in stored.items():
+            if name in self._BOOKKEEPING:
+                continue
+            entry = self._plain(entry)
+            data, times = self._unsqueeze(entry['data'], entry['times'])
+            properties = entry.get('properties')
+            if properties is not None and 'pipeline' in properties:
+                # a one-stage pipeline comes back as the stage itself, arrays as arrays
+                stages = properties['pipeline']
+                stages = stages if isinstance(stages, list) else [stages]
+                properties['pipeline'] = [array2list(stage) for stage in stages]
+            features[name] = Features(data, times, properties, validate=False)
         return features
+
+    @classmethod
+    def _plain(cls, value):
+        """scipy's mat_struct objects (and object arrays of them) as dicts (and lists of dicts)"""
+        if type(value).__name__ == 'mat_struct':
+            return {field: cls._plain(getattr(value, field)) for field in value._fieldnames}
+        if isinstance(value, np.ndarray) and value.dtype == object:
+            return [cls._plain(item) for item in value.ravel()]
+        return value
 
     @staticmethod
     def _unsqueeze(data, times):
@@ -224,45 +222,6 @@ class MatlabSerializer(FeaturesSerializer):
             return data.reshape((1, -1)), times.reshape((1, 2))
         return data.reshape((-1, 1)), times
 
-    @staticmethod
-    def _is_struct(obj):
-        return obj.__class__.__name__ == 'mat_struct'
-
-    @classmethod
-    def _check_keys(cls, data):
-        for key in data:
-            if cls._is_struct(data[key]):
-                data[key] = cls._todict(data[key])
-            elif isinstance(data[key], (list, np.ndarray)) and any(
-                    cls._is_struct(d) for d in np.atleast_1d(data[key]).ravel()):
-                data[key] = [cls._todict(dd) for dd in data[key]]
-        return data
-
-    @classmethod
-    def _todict(cls, matobj):
-        data = {}
-        for strg in matobj._fieldnames:
-            elem = matobj.__dict__[strg]
-            if cls._is_struct(elem):
-                data[strg] = cls._todict(elem)
-            elif isinstance(elem, np.ndarray) and elem.dtype == object and any(
-                    cls._is_struct(d) for d in elem.ravel()):
-                data[strg] = [cls._todict(d) for d in elem.ravel()]
-            else:
-                data[strg] = elem
-        return data
-
-    @staticmethod
-    def _make_list(properties):
-        if 'pipeline' in properties:
-            # the matlab format collapses a list of a single element into that element
-            if isinstance(properties['pipeline'], list):
-                properties['pipeline'] = [
-                    array2list(p) for p in properties['pipeline']]
-            else:
-                properties['pipeline'] = [array2list(properties['pipeline'])]
-        return properties
-
 
 class _NoPropertiesPickler(pickle.Pickler):
     """Implements the with_properties=False for PickleSerializer"""
@@ -271,6 +230,7 @@ class _NoPropertiesPickler(pickle.Pickler):
         obj.__class__, (obj.data, obj.times, None, False))
 
 
+@_file_format('pickle', '.pkl')
 class PickleSerializer(FeaturesSerializer):
     """Saves and loads features to/from the Python pickle format"""
     def _save(self, features, with_properties):
@@ -341,6 +301,7 @@ def _read_kaldi_ark(ark):
     return out
 
 
+@_file_format('kaldi', '.ark')
 class KaldiSerializer(FeaturesSerializer):
     """Saves and loads features to/from the Kaldi ark/scp format"""
     def __init__(self, cls, filename, log):
@@ -489,8 +450,14 @@ class KaldiStreamWriter:
         return False
 
 
+_CSV_HEADER = re.compile(r'^# data_dtype = (\S+), times_dtype = (\S+), features_ndims = (\d+)$')
+
+
+@_file_format('csv', '')
 class CsvSerializer(FeaturesSerializer):
-    """Saves and loads features to/from the CSV format (one csv/json pair per item in a directory)"""
+    """Saves and loads features to/from the CSV format: a directory with, per item, a ``.csv`` file
+    (one row per frame: the times then the data; the first line records the dtypes and the number of
+    data columns) and, when it has properties, a ``.json`` file"""
     def _check_load(self):
         if not os.path.isdir(self.filename):
             raise IOError(f'directory not found: {self.filename}')
@@ -499,65 +466,50 @@ class CsvSerializer(FeaturesSerializer):
         if os.path.exists(self.filename):
             raise IOError(f'already exists: {self.filename}')
 
+    def _path(self, name, extension):
+        return os.path.join(self.filename, name + extension)
+
     def _save(self, features, with_properties):
         os.makedirs(self.filename)
         self._log.info('writing directory "%s"', self.filename)
-        for name, feat in features.items():
-            csv_file = os.path.join(self.filename, name + '.csv')
-            self._log.debug('writing %s', csv_file)
+        for name, feats in features.items():
+            self._log.debug('writing %s', self._path(name, '.csv'))
+            times = feats.times if feats.times.ndim == 2 else feats.times[:, np.newaxis]
             np.savetxt(
-                csv_file,
-                np.hstack((
-                    feat.times.reshape((feat.nframes, 1))
-                    if feat.times.ndim == 1 else feat.times,
-                    feat.data)),
-                header=(
-                    f'data_dtype = {feat.dtype}, '
-                    f'times_dtype = {feat.times.dtype}, '
-                    f'features_ndims = {feat.ndims}'),
-                comments='# ')
-            if with_properties and feat.properties:
-                json_file = os.path.join(self.filename, name + '.json')
-                self._log.debug('writing %s', json_file)
-                with open(json_file, 'wt', encoding='utf-8') as stream:
-                    stream.write(_json_dumps(feat.properties))
+                self._path(name, '.csv'), np.hstack((times, feats.data)), comments='# ',
+                header=f'data_dtype = {feats.dtype}, times_dtype = {feats.times.dtype}, '
+                       f'features_ndims = {feats.ndims}')
+            if with_properties and feats.properties:
+                self._log.debug('writing %s', self._path(name, '.json'))
+                with open(self._path(name, '.json'), 'wt', encoding='utf-8') as stream:
+                    stream.write(_json_dumps(feats.properties))
 
     @staticmethod
     def _parse_header(csv_file):
+        """(data dtype, times dtype, number of data columns) from the first line of `csv_file`"""
         with open(csv_file, 'r', encoding='utf-8') as stream:
-            header = stream.readline().strip()
-        if not header or header[0] != '#':
-            raise ValueError(f'failed to parse header from {csv_file}')
-        header = header.split(', ')
+            match = _CSV_HEADER.match(stream.readline().strip())
         try:
-            data_dtype = np.dtype(header[0].split('= ')[1])
-            times_dtype = np.dtype(header[1].split('= ')[1])
-            ndims = int(header[2].split('= ')[1])
-        except (IndexError, TypeError):
+            return np.dtype(match.group(1)), np.dtype(match.group(2)), int(match.group(3))
+        except (AttributeError, TypeError):
             raise ValueError(f'failed to parse header from {csv_file}') from None
-        return data_dtype, times_dtype, ndims
 
     def _load(self):
         self._log.info('loading directory "%s"', self.filename)
-        names = sorted(os.listdir(self.filename))
-        csv_files = [os.path.join(self.filename, n) for n in names if n.endswith('.csv')]
-        json_files = [os.path.join(self.filename, n) for n in names if n.endswith('.json')]
+        present = set(os.listdir(self.filename))
         features = self._features_collection()
-        for csv in csv_files:
-            self._log.debug('loading %s', csv)
-            data_dtype, times_dtype, ndims = self._parse_header(csv)
-            data = np.atleast_2d(np.loadtxt(csv))
-            times = data[:, :data.shape[1] - ndims].astype(times_dtype)
-            if times.shape[1] == 1:
-                times = times.flatten()
-            data = data[:, data.shape[1] - ndims:].astype(data_dtype)
+        for csv_name in sorted(n for n in present if n.endswith('.csv')):
+            name = csv_name[:-len('.csv')]
+            self._log.debug('loading %s', self._path(name, '.csv'))
+            data_dtype, times_dtype, ndims = self._parse_header(self._path(name, '.csv'))
+            table = np.atleast_2d(np.loadtxt(self._path(name, '.csv')))
+            times = table[:, :-ndims].astype(times_dtype)
             properties = {}
-            json_file = csv[:-len('.csv')] + '.json'
-            if json_file in json_files:
-                self._log.debug('loading %s', json_file)
-                with open(json_file, 'r', encoding='utf-8') as stream:
+            if name + '.json' in present:
+                self._log.debug('loading %s', self._path(name, '.json'))
+                with open(self._path(name, '.json'), 'r', encoding='utf-8') as stream:
                     properties = dict(_json_loads(stream.read()))
-            name = os.path.basename(csv)[:-len('.csv')]
             features[name] = Features(
-                data, times, properties=properties, validate=False)
+                table[:, -ndims:].astype(data_dtype),
+                times[:, 0] if times.shape[1] == 1 else times, properties=properties, validate=False)
         return features

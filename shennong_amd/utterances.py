@@ -19,42 +19,37 @@ VALID_FORMATS = {
     4: '<utterance-id> <audio-file> <speaker-id> <tstart> <tstop>'}
 
 
-class Utterance:
-    def __init__(self, *args):
-        if len(args) < 2 or len(args) > 5:
-            raise ValueError(f'invalid utterance format: {args}')
-        self._format = len(args) - 1
-        self._name, self._audio = args[0], args[1]
-        self._speaker = self._tstart = self._tstop = None
-        if len(args) == 3:
-            self._speaker = args[2]
-        elif len(args) == 4:
-            self._tstart, self._tstop = args[2], args[3]
-        elif len(args) == 5:
-            self._speaker = args[2]
-            self._tstart, self._tstop = args[3], args[4]
+# optional fields after ``<id> <audio>``, by number of fields
+_LAYOUTS = {2: (), 3: ('speaker',), 4: ('tstart', 'tstop'), 5: ('speaker', 'tstart', 'tstop')}
 
-        if self._tstart is not None:
-            try:
-                self._tstart = float(self._tstart)
-            except ValueError:
-                raise ValueError(
-                    f'cannot cast tstart as float: {self._tstart}') from None
-        if self._tstop is not None:
-            try:
-                self._tstop = float(self._tstop)
-            except ValueError:
-                raise ValueError(
-                    f'cannot cast tstop as float: {self._tstop}') from None
-        if (self._tstart is None) != (self._tstop is None):
+
+def _seconds(value, what):
+    try:
+        return None if value is None else float(value)
+    except ValueError:
+        raise ValueError(f'cannot cast {what} as float: {value}') from None
+
+
+class Utterance:
+    """One line of the index: a name, an audio file (or an in-memory :class:`Audio`), optionally a
+    speaker and a (tstart, tstop) interval of the file in seconds"""
+    def __init__(self, *fields):
+        if len(fields) not in _LAYOUTS:
+            raise ValueError(f'invalid utterance format: {fields}')
+        self._format = len(fields) - 1
+        self._name, self._audio = fields[:2]
+        optional = dict(zip(_LAYOUTS[len(fields)], fields[2:]))
+        self._speaker = optional.get('speaker')
+        if ('tstart' in optional) and (optional['tstart'] is None) != (optional['tstop'] is None):
             raise ValueError('both tstart and tstop must be defined or None')
-        if self._tstart is not None and (
-                self._tstart < 0 or self._tstart >= self._tstop):
+        self._tstart = _seconds(optional.get('tstart'), 'tstart')
+        self._tstop = _seconds(optional.get('tstop'), 'tstop')
+        if self._tstart is not None and not 0 <= self._tstart < self._tstop:
             raise ValueError(
                 'we must have 0 <= tstart < tstop, but '
                 f'(tstart, tstop)=({self._tstart}, {self._tstop})')
-
-        # utterance duration; scanning raises if the file is not found nor valid
+        # the duration comes from the file itself (scanning raises if it is missing or not audio);
+        # an interval that runs past the end of the file is cut there
         self._duration = Audio.scan(self._audio).duration
         if self._tstart is not None:
             if self._tstop > self._duration:
@@ -65,12 +60,6 @@ class Utterance:
                 self._tstop = self._duration
             self._duration = self._tstop - self._tstart
 
-    def __eq__(self, other):
-        return str(self) == str(other)
-
-    def __hash__(self):
-        return hash(str(self))
-
     name = property(lambda self: self._name)
     audio_file = property(lambda self: self._audio)
     speaker = property(lambda self: self._speaker)
@@ -80,21 +69,23 @@ class Utterance:
     duration = property(lambda self: self._duration)
 
     def __str__(self):
-        if self._format == 1:
-            return f'{self.name} {self.audio_file}'
-        if self._format == 2:
-            return f'{self.name} {self.audio_file} {self.speaker}'
-        if self._format == 3:
-            return f'{self.name} {self.audio_file} {self.tstart} {self.tstop}'
-        return (f'{self.name} {self.audio_file} {self.speaker} '
-                f'{self.tstart} {self.tstop}')
+        """The index line of this utterance"""
+        fields = [self.name, self.audio_file]
+        fields += [getattr(self, field) for field in _LAYOUTS[self._format + 1]]
+        return ' '.join(str(field) for field in fields)
+
+    def __eq__(self, other):
+        return str(self) == str(other)
+
+    def __hash__(self):
+        return hash(str(self))
 
     def load_audio(self):
-        data = (self._audio if isinstance(self._audio, Audio)
-                else Audio.load(self._audio))
+        """The audio of the utterance: the file, or its (tstart, tstop) interval"""
+        audio = self._audio if isinstance(self._audio, Audio) else Audio.load(self._audio)
         if self.tstart or self.tstop:
-            data = data.segment([(self.tstart, self.tstop)])[0]
-        return data
+            audio = audio.segment([(self.tstart, self.tstop)])[0]
+        return audio
 
 
 class Utterances:
@@ -158,32 +149,26 @@ class Utterances:
         if duration <= 0:
             raise ValueError(
                 f'duration must be a positive number, it is {duration}')
-        segments = []
+        kept = []
         for speaker, utterances in self.by_speaker().items():
             if shuffle:
                 random.shuffle(utterances)
-            remaining_duration = duration
+            missing = duration  # seconds still to collect for this speaker
             for utt in utterances:
-                tstart = 0 if utt.tstart is None else utt.tstart
-                tstop = utt.duration - tstart if utt.tstop is None else utt.tstop
-                if utt.duration >= remaining_duration:
-                    segments.append(Utterance(
-                        utt.name, utt.audio_file, utt.speaker, tstart,
-                        tstart + remaining_duration))
-                    remaining_duration = 0
+                if missing <= 0:
                     break
-                segments.append(Utterance(
-                    utt.name, utt.audio_file, utt.speaker, tstart, tstop))
-                remaining_duration -= utt.duration
-            if remaining_duration > 0:
+                tstart = utt.tstart or 0
+                take = min(utt.duration, missing)
+                kept.append(Utterance(utt.name, utt.audio_file, utt.speaker, tstart, tstart + take))
+                missing -= take
+            if missing > 0:
                 message = (
-                    f'speaker {speaker}: only {duration - remaining_duration}s'
+                    f'speaker {speaker}: only {duration - missing}s'
                     f' of audio available but {duration}s requested')
-                if truncate:
-                    warnings.warn(message)
-                else:
+                if not truncate:
                     raise ValueError(message)
-        return Utterances(segments)
+                warnings.warn(message)
+        return Utterances(kept)
 
     def format(self, type=int):
         """The utterances format: its code (`type` int) or its description (`type` str)"""

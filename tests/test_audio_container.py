@@ -1,0 +1,174 @@
+"""The Audio container on WAV files: file round trips, sample formats, channels, segments, resampling.
+
+What is checked is what a user of the reference's Audio class relies on (its own test-suite pins the
+same facts); flac / mp3, which the reference reads through pydub + ffmpeg, must fail with a
+ValueError that says so.  Host-only.
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from shennong_amd import Audio
+
+SAMPLE_TYPES = (np.int16, np.int32, np.float32, np.float64, float)
+RNG = np.random.default_rng(7)
+
+
+def _stereo(n=1000):
+    return Audio(RNG.random((n, 2)), sample_rate=16000)
+
+
+# ---- files ---------------------------------------------------------------------------------------------
+def test_scan_and_load_agree(wav_file, audio):
+    meta, loaded = Audio.scan(wav_file), Audio.load(wav_file)
+    for source in (meta, loaded, audio):
+        assert (source.sample_rate, source.nchannels, source.nsamples) == (16000, 1, 22713)
+        assert source.duration == pytest.approx(1.419, rel=1e-3)
+    assert loaded.shape == (22713,) and loaded.dtype == np.int16 and loaded.precision == 16
+    assert np.array_equal(loaded.data, audio.data)
+    assert Audio.load(wav_file) is loaded, 'the last decoded files are cached'
+    narrow = Audio.scan(os.path.join(GOLDEN, 'test.8k.wav'))
+    assert (narrow.sample_rate, narrow.nchannels) == (8000, 1)
+
+
+@pytest.mark.parametrize('call, path, message', [
+    (Audio.scan, __file__, 'cannot scan audio file'),
+    (Audio.scan, '/path/to/some/lost/place', 'file not found'),
+    (Audio.load, __file__, 'Decoding failed'),
+    (Audio.load, '/spam/spam/with/eggs', 'file not found')])
+def test_unreadable_files(call, path, message):
+    with pytest.raises(ValueError, match=message):
+        call(path)
+
+
+def test_save_rules(tmpdir, audio):
+    target = str(tmpdir.join('copy.wav'))
+    audio.save(target)
+    assert Audio.load(target) == audio
+    for path, message in ((target, 'file already exist'),
+                          ('no_extension', 'cannot write audio file without extension'),
+                          (str(tmpdir.join('copy.flac')), 'only WAV files are supported'),
+                          (str(tmpdir.join('copy.mp3')), 'only WAV files are supported')):
+        with pytest.raises(ValueError, match=message):
+            audio.save(path)
+
+
+@pytest.mark.parametrize('dtype', SAMPLE_TYPES)
+def test_two_channels_round_trip(tmpdir, dtype):
+    original = _stereo().astype(dtype)
+    original.save(tmpdir / 'stereo.wav')
+    assert Audio.load(tmpdir / 'stereo.wav') == original
+
+
+def test_float32_file_keeps_full_scale(tmpdir):
+    signal = np.zeros(1000, dtype=np.float32)
+    signal[10], signal[20] = 1.0, -1.0
+    target = str(tmpdir.join('impulses.wav'))
+    Audio(signal, 1000).save(target)
+    assert Audio.scan(target)[:3] == (1, 1000, 1000)
+    back = Audio.load(target)
+    assert back.dtype == np.float32 and back.nchannels == 1 and back.nsamples == 1000
+    assert (back.data.min(), back.data.max()) == (-1.0, 1.0)
+
+
+# ---- container -----------------------------------------------------------------------------------------
+def test_equality_and_shape(audio):
+    assert audio == audio == Audio(audio.data, audio.sample_rate)
+    assert audio != Audio(audio.data, audio.sample_rate + 1)
+    louder = Audio(audio.data * 2, audio.sample_rate)
+    assert (louder.duration, louder.sample_rate) == (audio.duration, audio.sample_rate)
+    assert audio != louder
+    # a single channel given as a column is a vector
+    assert Audio(RNG.random((100, 1)), 10).shape == Audio(RNG.random(100), 10).shape == (100,)
+
+
+def test_channels(audio):
+    assert audio.nchannels == 1 and audio.shape == (audio.nsamples,)
+    assert audio.channel(0) == audio
+    stereo = _stereo()
+    assert stereo.nchannels == 2 and stereo.shape == (1000, 2)
+    for index in (0, 1):
+        mono = stereo.channel(index)
+        assert mono.nchannels == 1 and mono.shape == (1000,) and mono.duration == stereo.duration
+        assert np.array_equal(mono.data, stereo.data[:, index])
+        assert not np.array_equal(mono.data, stereo.data[:, 1 - index])
+    for source, index in ((audio, 1), (stereo, 2)):
+        with pytest.raises(ValueError, match='not enough channels'):
+            source.channel(index)
+
+
+def test_validity(audio):
+    assert audio.dtype is np.dtype(np.int16) and audio.is_valid()
+    as_float = audio.astype(np.float32)  # rescaled: valid
+    assert as_float.dtype is np.dtype(np.float32) and as_float.is_valid()
+    spike = as_float.data.copy()
+    spike[6] = 1.1
+    for samples in (audio.data.astype(np.float32),   # a bare cast leaves values far above 1
+                    spike,                            # one sample beyond full scale
+                    audio.data.astype(np.uint8)):     # unsupported sample type
+        with pytest.warns(UserWarning):
+            assert not Audio(samples, audio.sample_rate, validate=False).is_valid()
+        with pytest.raises(ValueError, match='invalid audio data for type'):
+            with pytest.warns(UserWarning):
+                Audio(samples, audio.sample_rate)
+
+
+@pytest.mark.parametrize('dtype', SAMPLE_TYPES)
+def test_sample_type_conversions(audio, dtype):
+    few = Audio(audio.data[:10], audio.sample_rate)
+    converted = few.astype(dtype)
+    assert converted.dtype is np.dtype(dtype) and converted.is_valid()
+    assert few.dtype is np.dtype(np.int16), 'the source is not modified'
+    back = converted.astype(np.int16)
+    assert back.dtype is np.dtype(np.int16) and back.data == pytest.approx(few.data)
+    for other in set(SAMPLE_TYPES) - {np.int16, dtype}:
+        hop = converted.astype(other)
+        assert hop.is_valid() and hop.dtype is np.dtype(other)
+        assert hop.astype(np.int16).data == pytest.approx(few.data)
+
+
+@pytest.mark.parametrize('dtype', [np.uint8, np.int64, np.longdouble, str, int])
+def test_unsupported_sample_types(audio, dtype):
+    with pytest.raises(ValueError, match='unsupported audio data type'):
+        audio.astype(dtype)
+
+
+# ---- segments, resampling --------------------------------------------------------------------------------
+@pytest.mark.parametrize('parts', [1, 2, 3])
+def test_segments_tile_the_signal(audio, parts):
+    d = audio.duration
+    chunks = audio.segment([(k * d / parts, (k + 1) * d / parts) for k in range(parts)])
+    assert all(c.duration == pytest.approx(d / parts, rel=1e-3) for c in chunks)
+    assert sum(c.nsamples for c in chunks) == audio.nsamples
+    assert Audio(np.concatenate([c.data for c in chunks]), audio.sample_rate) == audio
+    assert audio.segment([(0., d + 10)])[0] == audio, 'an interval past the end is cut there'
+
+
+@pytest.mark.parametrize('segments, message', [
+    (0, 'segments must be a list'), ([0, 1], 'must be pairs'), ([(0, 1, 2)], 'must be pairs'),
+    ([(1, 0)], 'must be sorted')])
+def test_bad_segments(audio, segments, message):
+    with pytest.raises(ValueError, match=message):
+        audio.segment(segments)
+
+
+@pytest.mark.parametrize('backend', ['sox', 'scipy'])
+@pytest.mark.parametrize('rate', [4000, 8000, 16000, 32000, 44100, 48000])
+def test_resampling(audio, rate, backend):
+    resampled = audio.resample(rate, backend=backend)
+    assert (resampled.nchannels, resampled.sample_rate, resampled.dtype) == (1, rate, audio.dtype)
+    assert resampled.nsamples == pytest.approx(int(audio.nsamples * rate / audio.sample_rate), abs=1)
+    assert resampled.data.mean() == pytest.approx(audio.data.mean(), abs=0.25)
+    if rate >= audio.sample_rate:
+        back = resampled.resample(audio.sample_rate, backend=backend)
+        assert (back.nchannels, back.sample_rate, back.dtype) == (1, audio.sample_rate, audio.dtype)
+
+
+def test_bad_resampling(audio):
+    with pytest.raises(ValueError, match='backend must be sox or scipy, it is'):
+        audio.resample(5, backend='a_bad_one')
+    with pytest.raises(ValueError, match='resampling at 0 failed'):
+        audio.resample(0)
