@@ -36,101 +36,71 @@ def _name(serializer):
     return 'feats.ark' if serializer is serializers.KaldiSerializer else 'feats'
 
 
-@pytest.mark.parametrize('name', serializers.supported_serializers().keys())
-def test_get_serializer_byname(name):
-    filename = 'foo.file'
-    if name == 'kaldi':
+def _serializer_for(name_or_none, filename):
+    return serializers.get_serializer(FeaturesCollection, filename, log, name_or_none)
+
+
+def test_serializer_lookup():
+    """by name, by file extension, and the ways both can fail"""
+    for name, cls in serializers.supported_serializers().items():
+        filename = 'foo.ark' if name == 'kaldi' else 'foo.file'
+        assert isinstance(_serializer_for(name, filename), cls)
+        assert not os.path.isfile(filename), 'nothing is created before save()'
+    for ext, cls in serializers.supported_extensions().items():
+        assert isinstance(_serializer_for(None, 'foo' + ext), cls)
+    for args, message in (
+            ((int, 'foo', log, None), 'must be shennong.features.FeaturesCollection'),
+            ((FeaturesCollection, 'foo.spam', log, None), 'invalid extension .spam'),
+            ((FeaturesCollection, 'foo.spam', log, 'spam'), 'invalid serializer spam'),
+            # (h5features needs a binding this backend does not ship)
+            ((FeaturesCollection, 'foo.h5f', log, None), 'invalid extension .h5f'),
+            ((FeaturesCollection, 'foo.file', log, 'kaldi'),
+             'the file extension must be ".ark", it is ".file"')):
         with pytest.raises(ValueError) as err:
-            serializers.get_serializer(FeaturesCollection, 'foo.file', log, name)
-        assert 'the file extension must be ".ark", it is ".file"' in str(err.value)
-        filename = 'foo.ark'
-    h = serializers.get_serializer(FeaturesCollection, filename, log, name)
-    assert not os.path.isfile(filename)
-    assert isinstance(h, serializers.supported_serializers()[name])
+            serializers.get_serializer(*args)
+        assert message in str(err.value)
 
 
-@pytest.mark.parametrize('ext', serializers.supported_extensions().keys())
-def test_get_serializer_byext(ext):
-    h = serializers.get_serializer(FeaturesCollection, 'foo' + ext, log, None)
-    assert isinstance(h, serializers.supported_extensions()[ext])
+def test_save_and_load_preconditions(tmpdir, mfcc, mfcc_col):
+    with pytest.raises(IOError, match='file not found'):
+        _serializer_for(None, 'foo.npz').load()
+    taken = str(tmpdir.join('foo.npz'))
+    open(taken, 'w').write('something')
+    with pytest.raises(IOError, match='file already exists'):
+        _serializer_for(None, taken).save(mfcc_col)
+    free = _serializer_for(None, str(tmpdir.join('bar.npz')))
+    with pytest.raises(ValueError, match='features must be FeaturesCollection but are Features'):
+        free.save(mfcc)
+    with pytest.raises(ValueError, match='features are not valid'):
+        free.save(FeaturesCollection(mfcc=Features(data=mfcc.data, times=0, validate=False)))
 
 
-def test_get_serializer_bad():
-    with pytest.raises(ValueError) as err:
-        serializers.get_serializer(int, 'foo', log, None)
-    assert 'must be shennong.features.FeaturesCollection' in str(err.value)
-    with pytest.raises(ValueError) as err:
-        serializers.get_serializer(FeaturesCollection, 'foo.spam', log, None)
-    assert 'invalid extension .spam' in str(err.value)
-    with pytest.raises(ValueError) as err:
-        serializers.get_serializer(FeaturesCollection, 'foo.spam', log, 'spam')
-    assert 'invalid serializer spam' in str(err.value)
-    with pytest.raises(ValueError) as err:   # h5features needs a binding this backend does not ship
-        serializers.get_serializer(FeaturesCollection, 'foo.h5f', log, None)
-    assert 'invalid extension .h5f' in str(err.value)
+def _collections(mfcc):
+    """name -> (collection, extra check on what was loaded back)"""
+    wide_text = dict(mfcc.properties, comments='使用人口について正確な統計はないが、日本国')
+    return {
+        'plain': (FeaturesCollection(mfcc=mfcc), lambda c: (
+            c['mfcc'].dtype == np.float32
+            and c['mfcc'].properties['pipeline'] == [{'name': 'mfcc', 'columns': [0, 12]}])),
+        'times_1d': (FeaturesCollection(mfcc=Features(
+            np.random.default_rng(4).random((10, 5)), MfccProcessor().times(10)[:, 1])),
+            lambda c: c['mfcc'].times.shape == (10,)),
+        'utf8': (FeaturesCollection({'æðÐ': Features(mfcc.data, mfcc.times, wide_text)}),
+                 lambda c: 'æðÐ' in c),
+        'two_dtypes': (FeaturesCollection(mfcc32=mfcc, mfcc64=mfcc.copy(dtype=np.float64)),
+                       lambda c: (c['mfcc64'].dtype, c['mfcc32'].dtype) == (np.float64, np.float32)),
+    }
 
 
-def test_load_save_errors(tmpdir, mfcc, mfcc_col):
-    h = serializers.get_serializer(FeaturesCollection, 'foo.npz', log, None)
-    with pytest.raises(IOError) as err:
-        h.load()
-    assert 'file not found' in str(err.value)
-    f = str(tmpdir.join('foo.npz'))
-    open(f, 'w').write('something')
-    h = serializers.get_serializer(FeaturesCollection, f, log, None)
-    with pytest.raises(IOError) as err:
-        h.save(mfcc_col)
-    assert 'file already exists' in str(err.value)
-    h = serializers.get_serializer(FeaturesCollection, str(tmpdir.join('bar.npz')), log, None)
-    with pytest.raises(ValueError) as err:
-        h.save(mfcc)
-    assert 'features must be FeaturesCollection but are Features' in str(err.value)
-    feats = FeaturesCollection(mfcc=Features(data=mfcc.data, times=0, validate=False))
-    with pytest.raises(ValueError) as err:
-        h.save(feats)
-    assert 'features are not valid' in str(err.value)
-
-
+@pytest.mark.parametrize('case', ['plain', 'times_1d', 'utf8', 'two_dtypes'])
 @pytest.mark.parametrize('serializer', SERIALIZERS)
-def test_simple(mfcc_col, serializer, tmpdir):
-    tmpfile = str(tmpdir.join(_name(serializer)))
-    serializer(mfcc_col.__class__, tmpfile, log).save(mfcc_col)
-    assert os.path.exists(tmpfile)
-    mfcc_col2 = serializer(mfcc_col.__class__, tmpfile, log).load()
-    assert mfcc_col2 == mfcc_col
-    assert mfcc_col2['mfcc'].dtype == np.float32
-    assert mfcc_col2['mfcc'].properties['pipeline'] == [{'name': 'mfcc', 'columns': [0, 12]}]
-
-
-@pytest.mark.parametrize('serializer', SERIALIZERS)
-def test_times_1d(serializer, tmpdir):
-    tmpfile = str(tmpdir.join(_name(serializer)))
-    times = MfccProcessor().times(10)[:, 1]
-    assert times.shape == (10,)
-    col = FeaturesCollection(mfcc=Features(np.random.random((10, 5)), times))
-    serializer(col.__class__, tmpfile, log).save(col)
-    assert serializer(col.__class__, tmpfile, log).load() == col
-
-
-@pytest.mark.parametrize('serializer', SERIALIZERS)
-def test_utf8(mfcc, serializer, tmpdir):
-    props = dict(mfcc.properties)
-    props['comments'] = '使用人口について正確な統計はないが、日本国'
-    feats = FeaturesCollection()
-    feats['æðÐ'] = Features(mfcc.data, mfcc.times, props)
-    h = serializer(feats.__class__, str(tmpdir.join(_name(serializer))), log)
-    h.save(feats)
-    assert h.load() == feats
-
-
-@pytest.mark.parametrize('serializer', SERIALIZERS)
-def test_heterogeneous(mfcc, serializer, tmpdir):
-    col = FeaturesCollection(mfcc32=mfcc, mfcc64=mfcc.copy(dtype=np.float64))
-    h = serializer(col.__class__, str(tmpdir.join(_name(serializer))), log)
-    h.save(col)
-    col2 = h.load()
-    assert col2 == col
-    assert col2['mfcc64'].dtype == np.float64 and col2['mfcc32'].dtype == np.float32
+def test_round_trip(mfcc, serializer, case, tmpdir):
+    collection, also = _collections(mfcc)[case]
+    target = str(tmpdir.join(_name(serializer)))
+    serializer(FeaturesCollection, target, log).save(collection)
+    assert os.path.exists(target)
+    loaded = serializer(FeaturesCollection, target, log).load()
+    assert loaded == collection and also(loaded)
 
 
 @pytest.mark.parametrize('scp', [True, False])
