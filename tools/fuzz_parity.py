@@ -49,7 +49,10 @@ def random_case(rng):
         proc = EnergyProcessor(raw_energy=bool(rng.integers(2)),
                                compression=str(rng.choice(['log', 'sqrt', 'off'])), **frame)
     n = int(rng.integers(1, 12))
-    lengths = [int(rng.integers(int(0.02 * sample_rate), int(1.5 * sample_rate))) for _ in range(n)]
+    longest = 1.5
+    if rng.integers(8) == 0:  # now and then a batch of many short utterances (many workgroups, many warps)
+        n, longest = int(rng.integers(100, 400)), 0.4
+    lengths = [int(rng.integers(int(0.02 * sample_rate), int(longest * sample_rate))) for _ in range(n)]
     if rng.integers(3) == 0:
         lengths[int(rng.integers(n))] = int(rng.integers(1, 64))  # shorter than any frame
     warps = None
