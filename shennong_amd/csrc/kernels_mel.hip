@@ -89,14 +89,16 @@ __global__ __launch_bounds__(kWaves * 64, 8) void mel_features_generic_kernel(
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
   const int N = p.padded, M = p.half, L = p.win_len;
-  // wave-private LDS: xs[N+2] (samples, later power spectrum), zs[N] (complex FFT data), mel[nb]
-  const int xs_floats = (N + 2 + 1) & ~1;
+  // wave-private LDS: xs (samples, later power spectrum), zs[N] (complex FFT data), mel[nb]
+  // xs holds the L samples of the frame, later the M + 1 power bins: the larger of the two (zero
+  // padding to N happens on the way into zs), rounded to keep zs 8-byte aligned
+  const int xs_floats = ((L > M + 1 ? L : M + 1) + 1) & ~1;
   const int mel_floats = (p.num_bins + 1) & ~1;
-  const size_t per_wave = static_cast<size_t>(xs_floats + N + mel_floats);
+  const size_t per_wave = static_cast<size_t>(xs_floats + ((N + 1) & ~1) + mel_floats);
   float* xs = reinterpret_cast<float*>(smem) + per_wave * wid;
   float* zsf = xs + xs_floats;
   float2* zs = reinterpret_cast<float2*>(zsf);
-  float* melbuf = zsf + N;
+  float* melbuf = zsf + ((N + 1) & ~1);
   float* ps = xs;
 
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kWaves;
@@ -322,9 +324,11 @@ __global__ __launch_bounds__(kWaves * 64, 8) void mel_features_generic_kernel(
 int launch_mel_features(const MelParams& p, const BatchArgs& b, float* out, int out_cols,
                         double* energy_out, hipStream_t stream) {
   if (b.total_frames <= 0) return SNF_OK;
-  const int xs_floats = (p.padded + 2 + 1) & ~1;
+  const int xs_need = p.win_len > p.half + 1 ? p.win_len : p.half + 1;
+  const int xs_floats = (xs_need + 1) & ~1;
   const int mel_floats = (p.num_bins + 1) & ~1;
-  const size_t lds = sizeof(float) * kWaves * static_cast<size_t>(xs_floats + p.padded + mel_floats);
+  const size_t lds = sizeof(float) * kWaves *
+                     static_cast<size_t>(xs_floats + ((p.padded + 1) & ~1) + mel_floats);
   if (lds > 160 * 1024)
     return set_error(SNF_E_RUNTIME, "frame too long for the LDS-resident FFT (padded window > 4096)");
   if (lds > 64 * 1024)
