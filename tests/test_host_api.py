@@ -466,3 +466,35 @@ def test_staging_rows_without_device():
     big, token = _backend.STAGING.array((1 << 19, 2), np.float32)
     assert big.shape == (1 << 19, 2)
     _backend.STAGING.release(token)
+
+
+def test_option_descriptors():
+    """shennong_amd/_options.py: parameters are views on the processor's one option record"""
+    import numpy as np
+    from shennong_amd import _abi
+    from shennong_amd._options import Option
+    from shennong_amd.processor import FilterbankProcessor, MfccProcessor
+    from shennong_amd.postprocessor import VadPostProcessor
+    proc = MfccProcessor(frame_shift=0.02, dither=0, snip_edges=False, num_ceps=7)
+    record = proc._record
+    assert record.kind == _abi.KIND_MFCC
+    assert (record.frame.frame_shift_ms, record.frame.dither, record.frame.snip_edges, record.num_ceps) \
+        == (20.0, 0.0, 0, 7)
+    assert isinstance(proc.frame_shift, np.float32) and proc.frame_shift == np.float32(0.02)
+    assert proc.snip_edges is False and proc.window_type == 'povey'
+    proc.low_freq = 100
+    assert record.mel.low_freq == 100.0 and isinstance(proc.low_freq, np.float32)
+    # the record handed to the library is a copy: later edits do not reach it
+    sent = proc._build_options()
+    proc.num_ceps = 9
+    assert (sent.num_ceps, proc._build_options().num_ceps) == (7, 9)
+    # two processors never share a record; descriptors live on the class and carry the documentation
+    other = MfccProcessor()
+    assert other.num_ceps == 13 and other._record is not proc._record
+    assert isinstance(MfccProcessor.num_ceps, Option) and 'cepstra' in MfccProcessor.num_ceps.__doc__
+    assert FilterbankProcessor(use_energy=1).use_energy is True
+    # value checks run before anything is stored
+    vad = VadPostProcessor()
+    with pytest.raises(ValueError, match=r'proportion_threshold must be in \]0, 1\['):
+        vad.proportion_threshold = 1.5
+    assert vad.proportion_threshold == np.float32(0.6)
