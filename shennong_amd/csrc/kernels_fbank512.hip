@@ -18,7 +18,7 @@
 // Nothing but the int16 samples and the float32 features ever touches HBM; no workgroup barrier.
 //
 // The dense contractions (mel x frame, DCT-II) are NOT mapped to MFMA here: the mel matrix is 95 %
-// zeros (2 non-zeros per FFT bin), f32 MFMA runs at the f32 VALU rate on gfx950, and a 16-frame MFMA
+// zeros (2 non-zeros per FFT bin), f32 MFMA peaks at 1.4x the measured f32 VALU rate, and a 16-frame MFMA
 // tile would cost more LDS traffic than the sparse form saves in VALU.
 //
 // Restates the same [KALDI-UPSTREAM] per-frame recipe as kernels_mel.hip (feature-window.cc
