@@ -14,7 +14,8 @@ import numpy as np
 from shennong_amd import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, 'libshennong_hip.so')
+# (SHENNONG_AMD_LIB: developer knob for A/B runs of another build of the same ABI)
+_LIB_PATH = os.environ.get('SHENNONG_AMD_LIB') or os.path.join(_HERE, 'libshennong_hip.so')
 _LIB = None
 _LOCK = threading.Lock()
 _PLANS = {}

@@ -9,17 +9,25 @@
 //   B  pass 1: 16-point FFT over j in registers (radix-4 x radix-4, compile-time twiddles), inter-pass
 //      twiddle W256^(l k2), 16x16 transpose through a padded (conflict-free) wave-private LDS tile.
 //   C  pass 2: 16-point FFT over n1 in registers -> lane l holds Z[l + 16 k1].
-//   D  real-FFT unpack + power: bins k and 256-k are paired; the partner Z[256-k] comes through LDS
-//      (half a tile), twiddles W512^k from an LDS table.  Scaled by 4 (the 1/2 factors of the unpack
-//      are folded into the mel weights as an exact power of two).
-//   E  power spectrum to a wave-private LDS tile; F: sparse mel filterbank (one (round, lane) slot per
-//      bin, the widest bins split over two neighbouring lanes), log, row segments to HBM.  MFCC adds
-//      the 13x23 DCT-II and lifter from LDS tables.
+//   D  real-FFT unpack + power: bins k and 256-k are paired; the partner Z[256-k] sits in lane 16-l
+//      of the same frame and comes over two DPP moves (row_mirror, then row_shr:1 whose unwritten
+//      lane 0 keeps its own Z[256 - 16 k1]) - no LDS round trip; twiddles W512^k from an LDS table.
+//      Scaled by 4 (the 1/2 factors of the unpack are folded into the mel weights as an exact power
+//      of two).
+//   E  power spectrum to a wave-private LDS tile [frame][bin].
+//   F  mel filterbank on the MATRIX pipe: v_mfma_f32_4x4x1_16b_f32 computes 16 independent blocks of
+//      (4 mel bins) x (4 frames) x (1 FFT bin) per instruction - exactly the shape of a wave's frame
+//      set.  Block b owns the group of 4 neighbouring mel bins 4 g .. 4 g + 3 (or a run of the FFT
+//      bins of a wide group: partial sums of up to 4 blocks are added through DPP); per instruction t
+//      lane 4 b + i supplies the weight of bin 4 g + i at FFT bin start_b + t (A operand, LDS table)
+//      and lane 4 b + j the power of frame j at that bin (B operand, read as ds_read_b128 runs from
+//      the power tile).  The band structure of the mel matrix is kept (~28 instructions for 40 bins
+//      instead of 256 for the dense product), the arithmetic is exact f32 (a k-ordered fmaf chain),
+//      and the VALU and most of the LDS traffic of the former sparse VALU form are gone: lane 4 b + j
+//      ends up with 4 consecutive mel bins of frame j -> log -> ONE 16-byte store per lane.
+//      MFCC adds the 13 x 23 DCT-II as a second chain on the same instruction (blocks = 4 cepstral
+//      groups x 4 partitions of the mel bins) and the lifter.
 // Nothing but the int16 samples and the float32 features ever touches HBM; no workgroup barrier.
-//
-// The dense contractions (mel x frame, DCT-II) are NOT mapped to MFMA here: the mel matrix is 95 %
-// zeros (2 non-zeros per FFT bin), f32 MFMA peaks at 1.4x the measured f32 VALU rate, and a 16-frame MFMA
-// tile would cost more LDS traffic than the sparse form saves in VALU.
 //
 // Restates the same [KALDI-UPSTREAM] per-frame recipe as kernels_mel.hip (feature-window.cc
 // ProcessWindow order, feature-fbank.cc, feature-mfcc.cc, MelBanks::Compute), reached by the
@@ -40,6 +48,18 @@ namespace {
 // ln(x) for x >= FLT_EPSILON via the hardware log2 (1 ulp): 2 instructions instead of ~15
 __device__ __forceinline__ float fast_log(float x) {
   return __builtin_amdgcn_logf(x) * 0.69314718055994530942f;
+}
+// max(x, FLT_EPSILON) for finite x in one instruction (fmaxf costs a canonicalising v_max first)
+__device__ __forceinline__ float floor_eps(float x) {
+  return __builtin_amdgcn_fmed3f(x, FLT_EPSILON, FLT_MAX);
+}
+// acc += f * (value of src in lane + SHIFT of the same 16-lane row, 0 beyond the row): v_fmac_f32 with
+// the DPP row shift on its first source (the s_nop covers the VALU-write -> DPP-read hazard, which
+// the compiler does not pad inside an asm statement)
+template <int SHIFT>
+__device__ __forceinline__ void fmac_row_shl(float& acc, float src, float f) {
+  asm volatile("s_nop 1\n v_fmac_f32_dpp %0, %1, %2 row_shl:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+               : "+v"(acc) : "v"(src), "v"(f), "n"(SHIFT));
 }
 
 // On gfx950 ds_read2_b64 runs at half the bandwidth of ds_read_b64 / ds_read_b128 (MI355X_MICROARCH
@@ -73,79 +93,15 @@ __device__ __forceinline__ void read16_b64(const void* base, float2 (&d)[16]) {
       : "v"(lds_addr(base))
       : "memory");
 }
-// dst[i] = the float2 at byte offset 128 (7 - i) from `base`, i < 8 (partner rows, reversed)
-__device__ __forceinline__ void read8_b64_rev128(const void* base, float2 (&d)[8]) {
-  asm volatile(
-      "ds_read_b64 %0, %8 offset:896\n ds_read_b64 %1, %8 offset:768\n ds_read_b64 %2, %8 offset:640\n"
-      "ds_read_b64 %3, %8 offset:512\n ds_read_b64 %4, %8 offset:384\n ds_read_b64 %5, %8 offset:256\n"
-      "ds_read_b64 %6, %8 offset:128\n ds_read_b64 %7, %8\n s_waitcnt lgkmcnt(0)"
-      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]),
-        "=&v"(d[7])
-      : "v"(lds_addr(base))
-      : "memory");
-}
 // N float4 (= 2 N complex) contiguous from `base`: plain 16-byte LDS loads (the compiler emits
 // ds_read_b128 - there is no slower merged form for 128-bit reads - and places the waits itself)
 template <int N>
 __device__ __forceinline__ void read_quads(const void* base, float4 (&dst)[N]) {
-  const float4* __restrict__ q = reinterpret_cast<const float4*>(base);
+  const float4* __restrict__ q =
+      reinterpret_cast<const float4*>(__builtin_assume_aligned(base, 16));  // (rows are 16-byte aligned)
 #pragma unroll
   for (int i = 0; i < N; ++i) dst[i] = q[i];
 }
-// acc += sum over `ngroups` (a multiple of 2) groups of 4 taps of w * x; weights [group][16 lanes]
-// float4 at `wbase`, data contiguous at `pbase`.  Four groups (8 x ds_read_b128) or two are in flight
-// per wait; reads and wait are one asm statement (see above).
-__device__ __forceinline__ void fma4(const float4& w, const float4& x, float& acc) {
-  acc += w.x * x.x;
-  acc += w.y * x.y;
-  acc += w.z * x.z;
-  acc += w.w * x.w;
-}
-template <int I>
-__device__ __forceinline__ void read_groups4(const void* wbase, const void* pbase, float4 (&w)[4],
-                                             float4 (&x)[4]) {
-  asm volatile(
-      "ds_read_b128 %0, %8 offset:%10\n ds_read_b128 %4, %9 offset:%14\n"
-      "ds_read_b128 %1, %8 offset:%11\n ds_read_b128 %5, %9 offset:%15\n"
-      "ds_read_b128 %2, %8 offset:%12\n ds_read_b128 %6, %9 offset:%16\n"
-      "ds_read_b128 %3, %8 offset:%13\n ds_read_b128 %7, %9 offset:%17\n s_waitcnt lgkmcnt(0)"
-      : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]),
-        "=&v"(x[3])
-      : "v"(lds_addr(wbase)), "v"(lds_addr(pbase)), "n"((I + 0) * 256), "n"((I + 1) * 256),
-        "n"((I + 2) * 256), "n"((I + 3) * 256), "n"((I + 0) * 16), "n"((I + 1) * 16), "n"((I + 2) * 16),
-        "n"((I + 3) * 16)
-      : "memory");
-}
-template <int I>
-__device__ __forceinline__ void read_groups2(const void* wbase, const void* pbase, float4 (&w)[2],
-                                             float4 (&x)[2]) {
-  asm volatile(
-      "ds_read_b128 %0, %4 offset:%6\n ds_read_b128 %2, %5 offset:%8\n"
-      "ds_read_b128 %1, %4 offset:%7\n ds_read_b128 %3, %5 offset:%9\n s_waitcnt lgkmcnt(0)"
-      : "=&v"(w[0]), "=&v"(w[1]), "=&v"(x[0]), "=&v"(x[1])
-      : "v"(lds_addr(wbase)), "v"(lds_addr(pbase)), "n"((I + 0) * 256), "n"((I + 1) * 256),
-        "n"((I + 0) * 16), "n"((I + 1) * 16)
-      : "memory");
-}
-template <int G, int I = 0>
-__device__ __forceinline__ void mel_groups(const void* wbase, const void* pbase, int ngroups,
-                                           float& acc) {
-  if constexpr (I < G) {
-    if (I + 4 <= ngroups) {  // wave-uniform
-      float4 w[4], x[4];
-      read_groups4<I>(wbase, pbase, w, x);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fma4(w[i], x[i], acc);
-      mel_groups<G, I + 4>(wbase, pbase, ngroups, acc);
-    } else if (I + 2 <= ngroups) {
-      float4 w[2], x[2];
-      read_groups2<I>(wbase, pbase, w, x);
-      fma4(w[0], x[0], acc);
-      fma4(w[1], x[1], acc);
-    }
-  }
-}
-
 // counter-based N(0,1) pair for Kaldi's per-frame dither (statistical stand-in for RandGauss(), which
 // draws from C rand() and is not reproducible): murmur-style 32-bit finalisers + Box-Muller on the
 // hardware log2 / sqrt / sin / cos (v_sin_f32 and v_cos_f32 take revolutions)
@@ -166,13 +122,10 @@ __device__ __forceinline__ float2 gauss_pair(unsigned key_lo, unsigned key_hi, u
   return make_float2(r * __builtin_amdgcn_cosf(u2), r * __builtin_amdgcn_sinf(u2));
 }
 
-constexpr int kMaxGroups = kFast512MaxGroups;  // 4-tap groups per mel round
-
 constexpr int kMaxWaves = 16;             // wavefronts per workgroup: 8 when two workgroups fit the LDS
                                           // of a CU (measured 5 % faster), else one of 16
 constexpr int kTileRow = 17;               // complex per transposed row (16 + 1 pad: conflict-free)
 constexpr int kFrameTileBytes = 16 * kTileRow * 8;  // wave-private LDS per frame (2176 B)
-constexpr int kMaxRounds = kFast512MaxRounds;  // mel bins <= 64
 constexpr int kFastHeaderFloats = 16;          // table header: the mel layout of this warp factor
 constexpr int kSetsPerBlock = 64;              // PERUTT: frame sets (of 4 frames) per workgroup
 
@@ -186,16 +139,26 @@ __device__ __forceinline__ void wave_lds_sync() {
 template <int CTRL>
 __device__ __forceinline__ float dpp_row_ror(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL,
-                                                               0xf, 0xf, false));
+                                                               0xf, 0xf, true));
 }
 template <int CTRL>
 __device__ __forceinline__ double dpp_row_ror_d(double v) {
   const long long bits = __builtin_bit_cast(long long, v);
-  const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(bits), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(bits >> 32), CTRL, 0xf, 0xf, false);
+  const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(bits), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(bits >> 32), CTRL, 0xf, 0xf, true);
   return __builtin_bit_cast(double, (static_cast<long long>(hi) << 32) |
                                         static_cast<long long>(static_cast<unsigned>(lo)));
 }
+// v_mov_b32_dpp: lanes whose source lane does not exist keep `old` (BOUND = false) or read 0
+template <int CTRL, bool BOUND>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                               __builtin_bit_cast(int, v), CTRL, 0xf,
+                                                               0xf, BOUND));
+}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short short2v __attribute__((ext_vector_type(2)));
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // output rows are 4-byte aligned
 __device__ __forceinline__ float row_sum16(float v) {
   v += dpp_row_ror<0x128>(v);  // row_ror:8
   v += dpp_row_ror<0x124>(v);  // row_ror:4
@@ -270,14 +233,9 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
   int64_t pu_u = 0, pu_f0 = 0, pu_T = 0, pu_s0 = 0, pu_n = 0;
   int pu_set0 = 0;
   const float* __restrict__ gtab = p.tables;
-  int h_rounds = p.rounds, h_off_first = p.off_first, h_off_w = p.off_w, h_off_dct = p.off_dct,
+  int h_mm_quads = p.mm_quads, h_mm_levels = p.mm_levels, h_dd_quads = p.dd_quads,
+      h_off_mm_a = p.off_mm_a, h_off_mm_lane = p.off_mm_lane, h_off_dd_a = p.off_dd_a,
       h_off_lifter = p.off_lifter, h_table_floats = p.table_floats;
-  int h_maxcount[kMaxRounds], h_woff[kMaxRounds];
-#pragma unroll
-  for (int r = 0; r < kMaxRounds; ++r) {
-    h_maxcount[r] = p.mel_maxcount[r];
-    h_woff[r] = p.mel_woff[r];
-  }
   if (PERUTT) {
     pu_u = b.blk_utt[blockIdx.x];
     pu_set0 = b.blk_set0[blockIdx.x];
@@ -287,17 +245,14 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     pu_n = b.sample_offsets[pu_u + 1] - pu_s0;
     gtab = p.tables + static_cast<int64_t>(b.utt_warp ? b.utt_warp[pu_u] : 0) * p.table_stride;
     const int* __restrict__ hdr = reinterpret_cast<const int*>(gtab);
-    h_rounds = hdr[0];
-#pragma unroll
-    for (int r = 0; r < kMaxRounds; ++r) {
-      h_maxcount[r] = hdr[1 + r];
-      h_woff[r] = hdr[5 + r];
-    }
-    h_off_first = hdr[9];
-    h_off_w = hdr[10];
-    h_off_dct = hdr[11];
-    h_off_lifter = hdr[12];
-    h_table_floats = hdr[13];
+    h_mm_quads = hdr[0];
+    h_mm_levels = hdr[1];
+    h_dd_quads = hdr[2];
+    h_off_mm_a = hdr[3];
+    h_off_mm_lane = hdr[4];
+    h_off_dd_a = hdr[5];
+    h_off_lifter = hdr[6];
+    h_table_floats = hdr[7];
   }
   // ---- stage the tables into LDS (the only workgroup-wide barrier of the kernel) -------------------
   for (int i = threadIdx.x; i < h_table_floats; i += blockDim.x) tab[i] = gtab[i];
@@ -308,12 +263,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
   const float2* __restrict__ t_win = reinterpret_cast<const float2*>(tab + kFastHeaderFloats);
   const float2* __restrict__ t_tw16 = t_win + 16 * 18;
   const float2* __restrict__ t_tw512 = t_tw16 + 16 * 18;
-  // per mel slot (round, lane): first tap (multiple of 4), output bin (-1: none), split flag
-  const int* __restrict__ t_first = reinterpret_cast<const int*>(tab + h_off_first);
-  const int* __restrict__ t_bin = t_first + 16 * kMaxRounds;
-  const int* __restrict__ t_pair = t_bin + 16 * kMaxRounds;
-  const float* __restrict__ t_w = tab + h_off_w;
-  const float* __restrict__ t_dct = tab + h_off_dct;
+  const float4* __restrict__ t_mm_a = reinterpret_cast<const float4*>(tab + h_off_mm_a);
+  const float4* __restrict__ t_dd_a = reinterpret_cast<const float4*>(tab + h_off_dd_a);
   const float* __restrict__ t_lifter = tab + h_off_lifter;
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -331,7 +282,19 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
   // left there: a NaN bit pattern (e.g. the -1 entries of another plan's slot table) made
   // 0 * NaN = NaN out of the last mel bin of the fourth frame of a wave.  Zero it once.
   tile[l * kTileRow + 16] = make_float2(0.0f, 0.0f);
+  // MFMA view of the wave: lane = 4 b + j, block b (a group of 4 mel bins, or a run of the FFT bins of
+  // one), frame j of the set.  Lane-constant for the whole kernel: where the lane's B operands start
+  // in the power tile of frame j, the first of the 4 output bins it stores (-1: none), and the 0/1
+  // factors with which the partial sums of the next 1..3 blocks are added to its own.
+  const int mj = lane & 3;
+  const float* __restrict__ mm_lane = tab + h_off_mm_lane;
+  const int mm_start = reinterpret_cast<const int*>(mm_lane)[lane];
+  const int mm_out = reinterpret_cast<const int*>(mm_lane)[64 + lane];
+  const float mm_f1 = mm_lane[128 + lane], mm_f2 = mm_lane[192 + lane], mm_f3 = mm_lane[256 + lane];
+  const float* __restrict__ mtile =
+      reinterpret_cast<const float*>(smem + tab_bytes + (wid * 4 + mj) * kFrameTileBytes) + mj * 16;
 
+  const float win_len_f = static_cast<float>(p.win_len), inv_win_len = 1.0f / win_len_f;
   const int n_waves = blockDim.x >> 6;
   // flat mode: sets of 4 consecutive global frames, grid-stride.  PERUTT: sets of 4 consecutive frames
   // of the workgroup's utterance, kSetsPerBlock of them per workgroup.
@@ -387,7 +350,11 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     start_next = start_of(gn);
     if (!SNIP) edge_next = edge_of(g);
   }
-  for (; set < n_sets; set += set_stride) {
+  // output row of the MFMA view (lane 4 b + j -> frame j of the set), advanced by a constant per set
+  float* __restrict__ mrow =
+      out + ((PERUTT ? pu_f0 : 0) + set * 4 + (lane & 3)) * static_cast<int64_t>(p.out_cols);
+  const int64_t mrow_step = set_stride * 4 * static_cast<int64_t>(p.out_cols);
+  for (; set < n_sets; set += set_stride, mrow += mrow_step) {
     const int64_t gl = set * 4 + q;               // frame index (inside the utterance when PERUTT)
     const bool valid = gl <= last_frame;
     const int64_t g = PERUTT ? pu_f0 + gl : gl;   // global output row
@@ -406,10 +373,19 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     }
     float xe[NJ], xo[NJ];
     float part = 0.0f;
+    // Without dither (and away from reflected edges) the samples are integers whose sums stay below
+    // 2^24: the float32 sum Kaldi forms is exact in any order, so v_dot2c_i32_i16 adds both halves of a
+    // dword in one instruction and the result is bit-identical
+    constexpr bool kIntSum = !DITHER && SNIP;
+    int part_i = 0;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       xe[j] = static_cast<float>(static_cast<short>(raw[j] & 0xffff));
       xo[j] = static_cast<float>(raw[j] >> 16);
+      if (kIntSum) {
+        const int both = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, raw[j]), short2v{1, 1}, part_i, false);
+        part_i = in_window(j) ? both : part_i;
+      }
     }
     if (!SNIP && edge_cur != 0 && valid) {
       // [KALDI-UPSTREAM] ExtractWindow, snip_edges = false: samples outside the utterance are
@@ -437,12 +413,21 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
         xe[j] += p.dither * nz.x;
         xo[j] += p.dither * nz.y;
       }
-      const float s2 = xe[j] + xo[j];
-      part += in_window(j) ? s2 : 0.0f;
+      if (!kIntSum) {
+        const float s2 = xe[j] + xo[j];
+        part += in_window(j) ? s2 : 0.0f;
+      }
     }
+    if (kIntSum) part = static_cast<float>(part_i);
+    // the conversions above are the last readers of `raw`: pin them (and the memory order) here so that
+    // the loads of the next set below reuse the same registers instead of being hoisted into fresh ones
+    // that have to be copied at the loop edge
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(xe[j]), "+v"(xo[j]) : : "memory");
+    asm volatile("" : "+v"(part) : : "memory");
     // prefetch: samples of the next set (its start offset arrived during the previous iteration),
     // start offset of the set after it
-    if (set + set_stride < n_sets) {
+    {  // (unconditional: start_of clamps to the last frame, so a wave's final prefetch re-reads it)
       const int16_t* __restrict__ wp = b.wave + start_next;
       const int16_t* __restrict__ wl = wp + 2 * l;
 #pragma unroll
@@ -453,7 +438,18 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
       if (!SNIP) edge_next = edge_of((set + set_stride) * 4 + q);
     }
     float neg_mean = 0.0f;
-    if (p.remove_dc) neg_mean = -row_sum16(part) / static_cast<float>(p.win_len);
+    if (p.remove_dc) {
+      const float sum = row_sum16(part);
+      if (kIntSum) {
+        // sum / N, correctly rounded, without the 12-instruction IEEE division: q = sum * RN(1 / N)
+        // plus one exact-residual correction equals RN(sum / N) for every integer |sum| < 2^24
+        // (checked exhaustively for the window lengths in use; see tests/test_host_api.py)
+        const float qv = sum * inv_win_len;
+        neg_mean = -__builtin_fmaf(__builtin_fmaf(-qv, win_len_f, sum), inv_win_len, qv);
+      } else {
+        neg_mean = -sum / win_len_f;
+      }
+    }
     lds_wait();
     // A2: the left neighbour x[2n-1] is the odd sample of element n-1 = lane l-1 (same j), or lane 15
     // of j-1 for lane 0: one DPP row rotate of the mean-removed value per element
@@ -524,16 +520,23 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     wave_lds_sync();
 
     // ---- D: real-FFT unpack + power (x4) -----------------------------------------------------------
-    // upper half to LDS: xbuf[r][c] = Z[c + 16 (r + 8)], rows 0..7 (+ row 8 scratch for lane 0)
-#pragma unroll
-    for (int r = 0; r < 8; ++r) tile[r * 16 + l] = z[r + 8];
-    wave_lds_sync();
-    const float2* __restrict__ partner = tile + (16 - l);  // Z[256 - k]: row 7-k1, column 16-l
+    // partner of k = l + 16 k1 (k1 < 8) is 256 - k = (16 - l) + 16 (15 - k1): register 15 - k1 of lane
+    // 16 - l of the same frame for l >= 1 (row_mirror gives lane 15 - l, row_shr:1 then lane l - 1 of
+    // that); lane 0 pairs with its own register 16 - k1, which row_shr:1 leaves in place as `old`
     float2 zpart[8];
+    // (ascending k1: register 16 - k1 was the mirror source of the previous step and is dead when it
+    // serves as `old`, so the second move works in place)
+    zpart[0] = make_float2(dpp_mov<0x111, true>(0.0f, dpp_mov<0x140, true>(0.0f, z[15].x)),
+                           dpp_mov<0x111, true>(0.0f, dpp_mov<0x140, true>(0.0f, z[15].y)));
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1) {
+      const float mx = dpp_mov<0x140, true>(0.0f, z[15 - k1].x);  // row_mirror: lane 15 - l
+      const float my = dpp_mov<0x140, true>(0.0f, z[15 - k1].y);
+      zpart[k1] = make_float2(dpp_mov<0x111, false>(z[16 - k1].x, mx),   // row_shr:1, lane 0 keeps old
+                              dpp_mov<0x111, false>(z[16 - k1].y, my));
+    }
     float4 w512q[4];
     read_quads<4>(t_tw512 + l * 10, w512q);     // W512^(l + 16 k1)
-    read8_b64_rev128(partner, zpart);           // zpart[k1] = Z[256 - l - 16 k1]
-    __builtin_amdgcn_sched_barrier(0);
     float pk[8], pm[8];  // 4 P[k], 4 P[256-k] for k = l + 16 k1
 #pragma unroll
     for (int k1 = 0; k1 < 8; ++k1) {
@@ -550,8 +553,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
       pm[k1] = b_re * b_re + b_im * b_im;
     }
     if (l == 0) {
-      // k = 0: DC (and Nyquist, unused by the mel banks); pairs (16 k1, 256 - 16 k1) were computed
-      // above with zp = Z[256 - 16 k1] = row (8 - k1); k1 = 0 read scratch -> overwrite
+      // k = 0: DC (and Nyquist, unused by the mel banks)
       const float dc = z[0].x + z[0].y;
       pk[0] = 4.0f * dc * dc;
       const float ny = z[0].x - z[0].y;
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     }
     // k = 128 (self-paired): Z[128] sits in lane 0, register 8
     const float p128 = 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y);
-    wave_lds_sync();
+    wave_lds_sync();  // (the transposed reads of the tile are complete; keeps the compiler in order)
     // ---- E: power tile ------------------------------------------------------------------------------
     float* __restrict__ pmirror = ptile + (144 - l);
 #pragma unroll
@@ -581,7 +583,6 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
       }
     }
 
-    // ---- F: sparse mel filterbank, log, epilogue ------------------------------------------------------
     float* __restrict__ row = out + g * static_cast<int64_t>(p.out_cols);
     if (KIND == SNF_KIND_SPECTROGRAM) {
       // log power spectrum, 257 bins: lane l stores bins l + 16 i (64-byte segments), bin 0 = energy
@@ -594,58 +595,121 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
         }
         if (l == 0) row[256] = fast_log(fmaxf(0.25f * ptile[256], FLT_EPSILON));
       }
-    }
-    const int mel_col = (KIND == SNF_KIND_FBANK && p.use_energy && !p.htk_compat) ? 1 : 0;
-    float logmel[kMaxRounds];
-    int mbin[kMaxRounds];
+    } else {
+      // ---- F: mel filterbank on the matrix pipe -----------------------------------------------------
+      // lane 4 b + j: frame j of the set (MFMA view), its row in the output
+      const int64_t mgl = set * 4 + mj;
+      const bool mvalid = mgl <= last_frame;
+      const float4* __restrict__ bsrc = reinterpret_cast<const float4*>(mtile + mm_start);
+      f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+      const float4* __restrict__ asrc = t_mm_a + lane;
+      if (h_mm_quads == 8) {
+        // the common shapes (40 or 23 bins at 16 kHz: 32 taps per block): every operand read is issued
+        // before the first instruction of the chain, which then runs at the pace of the matrix pipe
+        float4 a[8], x[8];
 #pragma unroll
-    for (int r = 0; r < kMaxRounds; ++r) {
-      mbin[r] = -1;
-      if (r < h_rounds) {
-        const int start = t_first[r * 16 + l];  // first tap rounded down to a multiple of 4
-        const int m = t_bin[r * 16 + l];        // mel bin stored by this slot, or -1
-        const int pair = t_pair[r * 16 + l];    // this slot and its quad neighbour share a wide bin
-        // taps outside the slot's range carry zero weights and read finite filler in the tile (every
-        // float of the tile is written before it is read: transposes + the zeroed padding column)
-        float acc = 0.0f;
-        mel_groups<kMaxGroups>(t_w + h_woff[r] + 4 * l, ptile + start, h_maxcount[r], acc);
-        // wide bins are split over two neighbouring lanes of the same round (the idle slots of the
-        // last round would otherwise dictate the group count of the whole round)
-        const float other = dpp_row_ror<0xB1>(acc);  // quad_perm [1,0,3,2]: lane l ^ 1
-        if (pair) acc += other;
-        if (KIND == SNF_KIND_FBANK) {
-          const float v = p.use_log ? fast_log(fmaxf(acc, FLT_EPSILON)) : acc;
-          if (valid && m >= 0) row[mel_col + m] = v;
-        } else if (KIND == SNF_KIND_MFCC) {
-          logmel[r] = fast_log(fmaxf(acc, FLT_EPSILON));
-          mbin[r] = m;
-        } else {
-          if (valid && m >= 0) row[m] = acc;
+        for (int t = 0; t < 8; ++t) {
+          a[t] = asrc[t * 64];
+          x[t] = bsrc[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[t].x, x[t].x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[t].y, x[t].y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[t].z, x[t].z, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[t].w, x[t].w, acc1, 0, 0, 0);
+        }
+      } else {
+        // any other chain length: two operand sets in flight.  mm_quads is even and the weight table
+        // ends with a row of zeros, so the last look-ahead read needs no test (the B side reads finite
+        // tile contents).
+        float4 a0 = asrc[0], x0 = bsrc[0];
+        for (int t = 0; t < h_mm_quads; t += 2) {  // wave-uniform trip count
+          const float4 a1 = asrc[(t + 1) * 64], x1 = bsrc[t + 1];
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, x0.x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, x0.y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, x0.z, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, x0.w, acc1, 0, 0, 0);
+          a0 = asrc[(t + 2) * 64];
+          x0 = bsrc[t + 2];
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, x1.x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, x1.y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, x1.z, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, x1.w, acc1, 0, 0, 0);
         }
       }
-    }
-    if (KIND == SNF_KIND_FBANK) {
-      if (p.use_energy && valid && l == 0) row[p.htk_compat ? p.num_bins : 0] = log_energy;
-    }
-    if (KIND == SNF_KIND_MFCC) {
-      // DCT-II + lifter: lane c owns cepstrum c (num_ceps <= 16); log-mel goes through the (now idle)
-      // power tile
-      wave_lds_sync();
+      float mel[4];
 #pragma unroll
-      for (int r = 0; r < kMaxRounds; ++r)
-        if (r < h_rounds && mbin[r] >= 0) ptile[mbin[r]] = logmel[r];
-      wave_lds_sync();
-      float v = 0.0f;
-      mel_groups<16>(t_dct + 4 * l, ptile, ((p.num_bins + 7) >> 3) << 1, v);  // num_bins <= 64
-      v *= t_lifter[l];
-      if (l == 0 && p.use_energy) v = log_energy;
-      int oc = l;
-      if (p.htk_compat) {
-        oc = l == 0 ? p.num_ceps - 1 : l - 1;
-        if (l == 0 && !p.use_energy)
-          v = static_cast<float>(static_cast<double>(v) * 1.4142135623730950488016887);
+      for (int i = 0; i < 4; ++i) mel[i] = acc0[i] + acc1[i];
+      // a wide group is split over up to 4 neighbouring blocks of one 16-lane row: the first block adds
+      // the sums of the others (0 / 1 factors per lane; one v_fmac_f32 with a DPP row shift each)
+      if (h_mm_levels > 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float own = mel[i];
+          fmac_row_shl<4>(mel[i], own, mm_f1);
+          fmac_row_shl<8>(mel[i], own, mm_f2);
+          if (h_mm_levels > 3) fmac_row_shl<12>(mel[i], own, mm_f3);
+        }
       }
-      if (valid && l < p.num_ceps) row[oc] = v;
+      const int mel_col = (KIND == SNF_KIND_FBANK && p.use_energy && !p.htk_compat) ? 1 : 0;
+      if (KIND == SNF_KIND_FBANK || KIND == SNF_KIND_PLP) {
+        if (KIND == SNF_KIND_FBANK && p.use_log) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) mel[i] = fast_log(floor_eps(mel[i]));
+        }
+        if (mvalid && mm_out >= 0) {
+          float* __restrict__ dst = mrow + mel_col + mm_out;
+          if (mm_out + 4 <= p.num_bins) {
+            *reinterpret_cast<f32x4_a4*>(dst) = f32x4_a4{mel[0], mel[1], mel[2], mel[3]};
+          } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+              if (mm_out + i < p.num_bins) dst[i] = mel[i];
+          }
+        }
+        if (KIND == SNF_KIND_FBANK && p.use_energy && valid && l == 0)
+          row[p.htk_compat ? p.num_bins : 0] = log_energy;
+      }
+      if (KIND == SNF_KIND_MFCC) {
+        // log-mel of frame j back to its (now idle) power tile, then the DCT-II as a second chain:
+        // block b = 4 cg + kp owns cepstra 4 cg .. 4 cg + 3 and the mel bins of partition kp
+        wave_lds_sync();
+        if (mm_out >= 0)
+          *reinterpret_cast<float4*>(const_cast<float*>(mtile) + mm_out) =
+              make_float4(fast_log(floor_eps(mel[0])), fast_log(floor_eps(mel[1])),
+                          fast_log(floor_eps(mel[2])), fast_log(floor_eps(mel[3])));
+        wave_lds_sync();
+        const int kp = (lane >> 2) & 3;
+        const float4* __restrict__ dsrc = reinterpret_cast<const float4*>(mtile + kp * 4 * h_dd_quads);
+        f32x4 c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int t = 0; t < h_dd_quads; ++t) {
+          const float4 a = t_dd_a[t * 64 + lane], x = dsrc[t];
+          c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, x.x, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, x.y, c1, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, x.z, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, x.w, c1, 0, 0, 0);
+        }
+        const float4 lift = *reinterpret_cast<const float4*>(t_lifter + 4 * q);
+        const float lf[4] = {lift.x, lift.y, lift.z, lift.w};
+        const int cbase = 4 * q;  // first cepstrum of this lane's group (kp = 0 lanes store)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = c0[i] + c1[i];
+          v += dpp_mov<0x104, true>(0.0f, v);  // kp 0 + 1, 1 + 2, 2 + 3, 3
+          v += dpp_mov<0x108, true>(0.0f, v);  // kp 0: (0 + 1) + (2 + 3)
+          v *= lf[i];
+          const int c = cbase + i;
+          int oc = c;
+          if (p.htk_compat) {
+            oc = c == 0 ? p.num_ceps - 1 : c - 1;
+            if (c == 0 && !p.use_energy)
+              v = static_cast<float>(static_cast<double>(v) * 1.4142135623730950488016887);
+          }
+          if (mvalid && kp == 0 && c < p.num_ceps && !(c == 0 && p.use_energy)) mrow[oc] = v;
+        }
+        if (p.use_energy && valid && l == 0) row[p.htk_compat ? p.num_ceps - 1 : 0] = log_energy;
+      }
     }
     wave_lds_sync();  // the tile is reused by the next frame set
   }
@@ -710,7 +774,7 @@ bool fast512_eligible(const MelParams& mp, bool any_warp) {
     return false;
   if (mp.kind == SNF_KIND_SPECTROGRAM && mp.padded != 512) return false;
   if (mp.kind == SNF_KIND_FBANK && !mp.use_power) return false;
-  if (mp.num_bins > 16 * kMaxRounds) return false;
+  if (mp.num_bins > kFast512MaxBins) return false;
   if (mp.kind == SNF_KIND_MFCC && mp.num_ceps > 16) return false;
   return true;
 }
@@ -758,7 +822,6 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
   p.log_energy_floor = mp.log_energy_floor;
   p.num_bins = mp.num_bins;
   p.num_ceps = mp.num_ceps;
-  p.rounds = (mp.num_bins + 15) / 16;
   blob->clear();
   blob->resize(kFastHeaderFloats, 0.0f);  // header, filled in at the end
   // window pairs, lane-major: row l = elements l + 16 j (j < 16), 2 complex of padding
@@ -782,160 +845,155 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
       blob->push_back(static_cast<float>(std::cos(a)));
       blob->push_back(static_cast<float>(std::sin(a)));
     }
-  // mel: every (round, lane) slot sums one run of 4-tap groups.  A bin is one slot, or - for the
-  // widest bins, as many as there are idle slots - two slots in neighbouring lanes of one round whose
-  // partial sums are added through DPP.  Slots are sorted by size so that the rounds are as short as
-  // possible (a round costs the group count of its longest slot).
-  struct Piece { int bin, start, groups, units, lo; };  // units = 2: pair (two consecutive pieces);
-                                                        // lo: first tap the piece is responsible for
-  std::vector<Piece> singles, pairs;  // pairs hold the first half; the second half follows it
-  {
-    std::vector<int> order(mb.num_bins), groups_of(mb.num_bins), start_of(mb.num_bins);
-    for (int m = 0; m < mb.num_bins; ++m) {
-      order[m] = m;
-      start_of[m] = mb.first[m] & ~3;
-      groups_of[m] = (mb.first[m] + mb.size[m] - start_of[m] + 3) / 4;
+  // ---- mel filterbank as MFMA blocks --------------------------------------------------------------
+  // Group g = mel bins 4 g .. 4 g + 3 spans the FFT bins [glo, ghi); it is cut into parts[g] runs of at
+  // most 4 mm_quads bins, one MFMA block each.  More parts for the widest groups shorten the chain;
+  // the parts of a group must sit in ONE row of 4 blocks (their sums are added through row DPP).
+  const int n_groups = (mb.num_bins + 3) / 4;
+  std::vector<int> glo(n_groups, 0), ghi(n_groups, 0), parts(n_groups, 1);
+  for (int g = 0; g < n_groups; ++g) {
+    int lo = 1 << 30, hi = 0;
+    for (int m = 4 * g; m < 4 * g + 4 && m < mb.num_bins; ++m) {
+      if (mb.size[m] <= 0) continue;
+      lo = std::min(lo, mb.first[m]);
+      hi = std::max(hi, mb.first[m] + mb.size[m]);
     }
-    std::stable_sort(order.begin(), order.end(),
-                     [&](int x, int y) { return groups_of[x] > groups_of[y]; });
-    int spare = 16 * p.rounds - mb.num_bins;
-    std::vector<char> split(mb.num_bins, 0);
-    for (int m : order)
-      if (spare > 0 && groups_of[m] >= 2) { split[m] = 1; --spare; }
-    for (int m = 0; m < mb.num_bins; ++m) {
-      if (split[m]) {
-        const int ga = (groups_of[m] + 1) / 2;
-        pairs.push_back({m, start_of[m], ga, 2, 0});
-        pairs.push_back({-1, start_of[m] + 4 * ga, groups_of[m] - ga, 0, start_of[m] + 4 * ga});
-      } else {
-        singles.push_back({m, start_of[m], groups_of[m], 1, 0});
-      }
-    }
+    if (hi == 0) lo = 0;
+    glo[g] = lo & ~3;
+    ghi[g] = std::max(hi, glo[g]);
   }
-  // units sorted by decreasing size; pairs (2 slots, even lane first) are placed before the singles
-  // of the same round
-  std::vector<std::vector<Piece>> round_slots(p.rounds);
-  {
-    std::vector<std::pair<int, int>> units;  // (groups, index) index < 0: pair -(idx+1), else single
-    for (size_t i = 0; i < pairs.size(); i += 2) units.push_back({pairs[i].groups, -static_cast<int>(i) - 1});
-    for (size_t i = 0; i < singles.size(); ++i) units.push_back({singles[i].groups, static_cast<int>(i)});
-    std::stable_sort(units.begin(), units.end(),
-                     [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first > y.first; });
-    std::vector<char> used(units.size(), 0);
-    for (int r = 0; r < p.rounds; ++r) {
-      std::vector<Piece> pr, sg;
-      int free_slots = 16;
-      for (size_t u = 0; u < units.size() && free_slots > 0; ++u) {
-        if (used[u]) continue;
-        if (units[u].second < 0) {
-          if (free_slots < 2) continue;
-          const size_t i = static_cast<size_t>(-units[u].second - 1);
-          pr.push_back(pairs[i]);
-          pr.push_back(pairs[i + 1]);
-          free_slots -= 2;
-        } else {
-          sg.push_back(singles[units[u].second]);
-          free_slots -= 1;
-        }
-        used[u] = 1;
-      }
-      round_slots[r] = pr;
-      round_slots[r].insert(round_slots[r].end(), sg.begin(), sg.end());
-    }
-    for (char u : used)
-      if (!u) return 1;  // (cannot happen: 16 * rounds slots >= pieces)
-  }
-  // LDS bank conflicts of the 16-byte tap reads: two lanes of a frame collide on every group when
-  // their first taps differ by a multiple of 64 (same 16-byte slot modulo the 64 banks).  A slot that
-  // is shorter than its round may start up to (round length - own length) groups early (the extra
-  // leading taps carry zero weights), which moves its residue: choose the shifts greedily so that
-  // the 16 residues of a round are distinct; idle lanes get one of the free residues.
-  std::vector<std::vector<int>> idle_start(p.rounds, std::vector<int>(16, 0));
-  for (int r = 0; r < p.rounds; ++r) {
-    int round_groups = 0;
-    for (const Piece& pc : round_slots[r]) round_groups = pc.groups > round_groups ? pc.groups : round_groups;
-    round_groups = (round_groups + 1) & ~1;
-    bool taken[16] = {};
-    std::vector<int> order(round_slots[r].size());
+  auto per_part = [&](int g, int np) { return ((ghi[g] - glo[g] + np - 1) / np + 3) & ~3; };
+  // first-fit-decreasing of the part counts into 4 rows of 4 blocks; returns false when they do not fit
+  auto pack = [&](const std::vector<int>& np, std::vector<int>* first_block) {
+    std::vector<int> order(np.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = static_cast<int>(i);
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-      return round_slots[r][x].groups > round_slots[r][y].groups;  // least slack first
-    });
-    for (int i : order) {
-      Piece& pc = round_slots[r][i];
-      const int slack = round_groups - pc.groups;
-      int best = -1;
-      for (int k = 0; k <= slack && best < 0; ++k)
-        if (pc.start - 4 * k >= 0 && !taken[((pc.start - 4 * k) / 4) & 15]) best = k;
-      if (best > 0) {
-        pc.start -= 4 * best;
-        pc.groups += best;
-      }
-      taken[(pc.start / 4) & 15] = true;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return np[x] > np[y]; });
+    int used[4] = {0, 0, 0, 0};
+    if (first_block) first_block->assign(np.size(), -1);
+    for (int g : order) {
+      int r = 0;
+      while (r < 4 && used[r] + np[g] > 4) ++r;
+      if (r == 4) return false;
+      if (first_block) (*first_block)[g] = 4 * r + used[r];
+      used[r] += np[g];
     }
-    for (int l = static_cast<int>(round_slots[r].size()); l < 16; ++l) {
-      int res = 0;
-      while (res < 15 && taken[res]) ++res;
-      taken[res] = true;
-      idle_start[r][l] = 4 * res;
+    return true;
+  };
+  if (n_groups > 0 && !pack(parts, nullptr)) return 1;  // (more than 16 groups: not eligible)
+  for (;;) {
+    int worst = -1, worst_len = 0;
+    for (int g = 0; g < n_groups; ++g)
+      if (per_part(g, parts[g]) > worst_len) {
+        worst_len = per_part(g, parts[g]);
+        worst = g;
+      }
+    if (worst < 0 || parts[worst] >= 4 || per_part(worst, parts[worst] + 1) >= worst_len) break;
+    std::vector<int> trial = parts;
+    ++trial[worst];
+    if (!pack(trial, nullptr)) break;
+    parts = trial;
+  }
+  int chain = 32;  // (at least 8 quads: the kernel unrolls that length)
+  for (int g = 0; g < n_groups; ++g) chain = std::max(chain, per_part(g, parts[g]));
+  chain = (chain + 7) & ~7;  // an even number of quads: the kernel issues them in pairs
+  p.mm_quads = chain / 4;
+  p.mm_levels = 1;
+  for (int g = 0; g < n_groups; ++g) p.mm_levels = std::max(p.mm_levels, parts[g]);
+  std::vector<int> first_block;
+  pack(parts, &first_block);
+  struct Block { int group, part, lo, hi, start; };  // FFT bins [lo, hi) of `group`; operands from `start`
+  std::vector<Block> blocks(16, Block{-1, 0, 0, 0, 0});
+  const int max_start = (260 - chain) & ~3;  // the B operands stay inside the written part of the tile
+  for (int g = 0; g < n_groups; ++g) {
+    const int per = per_part(g, parts[g]);
+    for (int q = 0; q < parts[g]; ++q) {
+      Block& bk = blocks[first_block[g] + q];
+      bk.group = g;
+      bk.part = q;
+      bk.lo = std::min(glo[g] + q * per, ghi[g]);
+      bk.hi = std::min(glo[g] + (q + 1) * per, ghi[g]);
+      bk.start = std::max(0, std::min(bk.lo, max_start)) & ~3;
     }
   }
-  p.off_first = static_cast<int>(blob->size());
+  // LDS banks of the B reads: a ds_read_b128 is served in groups of 16 lanes - the blocks
+  // {0,3,5,6}, {1,2,4,7}, {8,11,13,14}, {9,10,12,15} - and the four frames of a block already sit
+  // on the four 16-byte slots s, s+4, s+8, s+12 (mod 16) of its start: a group is conflict-free when
+  // the starts / 4 of its 4 blocks differ modulo 4.  A block shorter than the chain may start up to its
+  // slack earlier (leading taps carry zero weights): choose the shifts greedily, least slack first.
+  {
+    static const int kGroups[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};
+    for (const auto& grp : kGroups) {
+      bool taken[4] = {false, false, false, false};
+      int order[4] = {grp[0], grp[1], grp[2], grp[3]};
+      auto slack = [&](int bi) {
+        const Block& bk = blocks[bi];
+        if (bk.group < 0) return 1 << 20;
+        return std::min(bk.start / 4, (bk.start + chain - std::max(bk.hi, bk.start)) / 4);
+      };
+      std::stable_sort(order, order + 4, [&](int x, int y) { return slack(x) < slack(y); });
+      for (int bi : order) {
+        Block& bk = blocks[bi];
+        if (bk.group < 0) {  // idle block: any free residue
+          int r = 0;
+          while (r < 3 && taken[r]) ++r;
+          bk.start = 4 * r;
+          taken[r] = true;
+          continue;
+        }
+        const int sl = slack(bi);
+        int best = 0;
+        for (int k = 0; k <= sl && k < 4; ++k)
+          if (!taken[((bk.start / 4) - k) & 3]) {
+            best = k;
+            break;
+          }
+        bk.start -= 4 * best;
+        taken[(bk.start / 4) & 3] = true;
+      }
+    }
+  }
+  while (blob->size() % 4) blob->push_back(0.0f);  // 16-byte alignment of the float4 tables
+  p.off_mm_a = static_cast<int>(blob->size());
+  for (int t = 0; t < p.mm_quads + 1; ++t)  // (+ the row of zeros the last look-ahead read lands on)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int c = 0; c < 4; ++c) {
+        const Block& bk = blocks[lane >> 2];
+        const int m = bk.group < 0 ? -1 : 4 * bk.group + (lane & 3);
+        const int k = bk.start + 4 * t + c;  // FFT bin of this tap
+        float w = 0.0f;
+        if (t < p.mm_quads && m >= 0 && m < mb.num_bins && k >= bk.lo && k < bk.hi && k >= mb.first[m] &&
+            k < mb.first[m] + mb.size[m])
+          w = 0.25f * mb.w[mb.offset[m] + k - mb.first[m]];  // exact power-of-two scaling
+        blob->push_back(w);
+      }
   auto push_int = [&](int v) {
     float as_float;
     std::memcpy(&as_float, &v, 4);
     blob->push_back(as_float);
   };
-  for (int table = 0; table < 3; ++table)  // first tap, output bin, pair flag: [kMaxRounds][16] each
-    for (int r = 0; r < kMaxRounds; ++r)
-      for (int l = 0; l < 16; ++l) {
-        int v = table == 1 ? -1 : 0;
-        if (table == 0 && r < p.rounds) v = idle_start[r][l];
-        if (r < p.rounds && l < static_cast<int>(round_slots[r].size())) {
-          const Piece& pc = round_slots[r][l];
-          const bool second = pc.units == 0;
-          if (table == 0) v = pc.start;
-          else if (table == 1) v = pc.bin;
-          else v = (pc.units == 2 || second) ? 1 : 0;
-        }
-        push_int(v);
-      }
-  for (int r = 0; r < p.rounds; ++r) {
-    int groups = 0;
-    for (const Piece& pc : round_slots[r]) groups = pc.groups > groups ? pc.groups : groups;
-    if (groups > kMaxGroups) return 1;  // a slot is too long for the unrolled tap loop: not eligible
-    p.mel_maxcount[r] = (groups + 1) & ~1;  // 4-tap groups of this round (even: read in batches)
+  p.off_mm_lane = static_cast<int>(blob->size());
+  for (int lane = 0; lane < 64; ++lane) push_int(blocks[lane >> 2].start);
+  for (int lane = 0; lane < 64; ++lane) {
+    const Block& bk = blocks[lane >> 2];
+    push_int(bk.group >= 0 && bk.part == 0 ? 4 * bk.group : -1);
   }
-  while (blob->size() % 4) blob->push_back(0.0f);  // 16-byte alignment of the float4 weights
-  p.off_w = static_cast<int>(blob->size());
-  int woff = 0;
-  for (int r = 0; r < p.rounds; ++r) {
-    p.mel_woff[r] = woff;
-    for (int g = 0; g < p.mel_maxcount[r]; ++g)
-      for (int l = 0; l < 16; ++l)
-        for (int i = 0; i < 4; ++i) {
-          float w = 0.0f;
-          if (l < static_cast<int>(round_slots[r].size())) {
-            const Piece& pc = round_slots[r][l];
-            // the second half of a split bin takes its bin from the slot before it
-            const int m = pc.units == 0 ? round_slots[r][l - 1].bin : pc.bin;
-            const int k = pc.start + 4 * g + i;  // FFT bin of this tap
-            if (g < pc.groups && k >= pc.lo && k >= mb.first[m] && k < mb.first[m] + mb.size[m])
-              w = 0.25f * mb.w[mb.offset[m] + k - mb.first[m]];  // exact power-of-two scaling
-          }
-          blob->push_back(w);
-        }
-    woff += p.mel_maxcount[r] * 64;
-  }
-  p.off_dct = static_cast<int>(blob->size());
+  for (int level = 1; level <= 3; ++level)
+    for (int lane = 0; lane < 64; ++lane) {
+      const Block& bk = blocks[lane >> 2];
+      blob->push_back(bk.group >= 0 && bk.part == 0 && parts[bk.group] > level ? 1.0f : 0.0f);
+    }
+  // ---- DCT-II as MFMA blocks: block 4 cg + kp = cepstra 4 cg .. 4 cg + 3 x mel bins of partition kp --
+  p.dd_quads = 0;
+  p.off_dd_a = static_cast<int>(blob->size());
   if (mp.kind == SNF_KIND_MFCC) {
-    // [group of 4 bins][lane = cepstrum][4]
-    for (int g = 0; g < ((mp.num_bins + 7) / 8) * 2; ++g)
-      for (int c = 0; c < 16; ++c)
-        for (int i = 0; i < 4; ++i) {
-          const int m = 4 * g + i;
-          blob->push_back(c < mp.num_ceps && m < mp.num_bins
-                              ? dct[static_cast<size_t>(c) * mp.num_bins + m] : 0.0f);
+    p.dd_quads = ((mp.num_bins + 3) / 4 + 3) / 4;
+    const int per = 4 * p.dd_quads;
+    for (int t = 0; t < p.dd_quads; ++t)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int c = 0; c < 4; ++c) {
+          const int blk = lane >> 2, cep = 4 * (blk >> 2) + (lane & 3), m = (blk & 3) * per + 4 * t + c;
+          blob->push_back(cep < mp.num_ceps && m < mp.num_bins
+                              ? dct[static_cast<size_t>(cep) * mp.num_bins + m] : 0.0f);
         }
   }
   p.off_lifter = static_cast<int>(blob->size());
@@ -944,16 +1002,14 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
   p.table_floats = static_cast<int>(blob->size());
   {  // header: what the PERUTT kernel needs to know about THIS warp factor's tables
     int hdr[kFastHeaderFloats] = {};
-    hdr[0] = p.rounds;
-    for (int r = 0; r < kMaxRounds; ++r) {
-      hdr[1 + r] = p.mel_maxcount[r];
-      hdr[5 + r] = p.mel_woff[r];
-    }
-    hdr[9] = p.off_first;
-    hdr[10] = p.off_w;
-    hdr[11] = p.off_dct;
-    hdr[12] = p.off_lifter;
-    hdr[13] = p.table_floats;
+    hdr[0] = p.mm_quads;
+    hdr[1] = p.mm_levels;
+    hdr[2] = p.dd_quads;
+    hdr[3] = p.off_mm_a;
+    hdr[4] = p.off_mm_lane;
+    hdr[5] = p.off_dd_a;
+    hdr[6] = p.off_lifter;
+    hdr[7] = p.table_floats;
     std::memcpy(blob->data(), hdr, sizeof(hdr));
   }
   *out = p;

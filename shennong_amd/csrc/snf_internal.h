@@ -151,24 +151,26 @@ int launch_deltas(const DeltaParams& p, const float* in, int in_cols, const int6
 
 
 // ---- register-resident 512-point fast path (kernels_fbank512.hip) ----------------------------------
-constexpr int kFast512MaxRounds = 4;
-constexpr int kFast512MaxGroups = 16;  // 4-tap groups per mel round (bins up to 61 FFT bins wide)
+constexpr int kFast512MaxBins = 64;    // mel bins: 16 MFMA blocks of 4 bins
 struct Fast512Params {
   int win_len, win_shift, remove_dc, snip_edges;
   float preemph, dither;
   unsigned long long seed;
   int kind, out_cols, use_energy, need_raw, need_post, htk_compat, use_log, has_floor;
   float log_energy_floor;
-  int num_bins, num_ceps, rounds, compression;
-  int mel_maxcount[kFast512MaxRounds];
-  int mel_woff[kFast512MaxRounds];
+  int num_bins, num_ceps, compression;
+  // mel filterbank as a chain of v_mfma_f32_4x4x1_16b_f32: 16 blocks of (4 mel bins x 4 frames), one
+  // FFT bin per block and instruction; `mm_quads` = chain length / 4, `mm_levels` = the most blocks a
+  // group of 4 bins is split into along the FFT bins (partial sums are added through DPP)
+  int mm_quads, mm_levels;
+  int dd_quads;              // MFCC: DCT-II chain length / 4 (mel bins per K partition / 4)
   int table_floats;          // total floats of the packed table blob below (warp 1.0)
   int table_stride;          // floats between the blobs of consecutive warp factors (VTLN)
   // one packed blob, copied to LDS at kernel start:
-  //   float2 win[256] | float2 tw16[256] | float2 tw512[128] | int first[rounds*16] |
-  //   int count[rounds*16] | float w[...] | float dct_t[num_bins*16] | float lifter[16]
+  //   header[16] | float2 win[16][18] | float2 tw16[16][18] | float2 tw512[16][10] |
+  //   float4 mm_a[mm_quads][64] | mm_lane[5][64] | float4 dd_a[dd_quads][64] | float lifter[16]
   const float* tables;
-  int off_first, off_w, off_dct, off_lifter;  // float offsets into the blob
+  int off_mm_a, off_mm_lane, off_dd_a, off_lifter;  // float offsets into the blob
 };
 
 bool fast512_eligible(const MelParams& mp, bool any_warp);
