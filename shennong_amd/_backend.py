@@ -125,9 +125,17 @@ def device_count():
 
 
 def set_device(device_id):
-    """Selects the GPU used by plans created afterwards (one process per GPU)"""
+    """Selects the GPU used by plans and device buffers created afterwards (one process per GPU)
+    and makes it the calling thread's current HIP device"""
     global _DEVICE
     _DEVICE = int(device_id)
+    check(lib().snf_set_device(_DEVICE))
+
+
+def bind_device(device_id=None):
+    """hipSetDevice is per thread: every allocation / copy made outside a plan call binds the
+    thread to the selected GPU first (a fresh thread starts on device 0)"""
+    check(lib().snf_set_device(_DEVICE if device_id is None else int(device_id)))
 
 
 def get_device():
@@ -504,7 +512,10 @@ def _check_finite(out):
 
 
 class DeviceBuffer:
-    def __init__(self, nbytes):
+    """HBM allocation on the selected GPU (`set_device` / SHENNONG_AMD_DEVICE)"""
+    def __init__(self, nbytes, device=None):
+        self.device = _DEVICE if device is None else int(device)
+        bind_device(self.device)
         ptr = C.c_void_p()
         check(lib().snf_malloc(C.byref(ptr), int(max(nbytes, 16))))
         self.ptr = ptr.value
@@ -512,11 +523,13 @@ class DeviceBuffer:
 
     def upload(self, array):
         array = np.ascontiguousarray(array)
+        bind_device(self.device)
         check(lib().snf_memcpy_h2d(
             C.c_void_p(self.ptr), array.ctypes.data_as(C.c_void_p),
             array.nbytes))
 
     def download(self, array):
+        bind_device(self.device)
         check(lib().snf_memcpy_d2h(
             array.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
             array.nbytes))

@@ -3,10 +3,10 @@
 Counterpart of reference shennong/audio.py for WAV files.  An :class:`Audio` is a numpy array of
 samples (one column per channel) and a sample rate; the sample type is one of int16, int32, float32
 or float64 and each type has a full scale (2**15, 2**30 and 1.0): ``astype`` rescales between them
-(audio.py:469-518), the processors ask for int16.  Files are read and written with scipy
-(audio.py:179-320; the reference falls back to pydub / ffmpeg and to sox for flac, mp3, ...:
-neither exists offline, those formats raise a ValueError that says so); ``resample`` is the
-reference's scipy backend (audio.py:358-425; its sox backend is the same call here).
+(audio.py:469-518), the processors ask for int16.  WAV files are read with scipy (audio.py:179-320;
+the reference falls back to pydub / ffmpeg and to sox for flac, mp3, ...: neither exists offline,
+those formats raise a ValueError that says so).  Writing and resampling audio are not on the
+features path and are not provided.
 """
 
 import collections
@@ -16,7 +16,6 @@ import warnings
 
 import numpy as np
 import scipy.io.wavfile
-import scipy.signal
 
 # sample type -> (log2 of the full scale, smallest and largest valid sample)
 _FORMATS = {
@@ -85,22 +84,6 @@ class Audio:
         return _Metadata(1 if data.ndim == 1 else data.shape[1], sample_rate, data.shape[0],
                          data.shape[0] / sample_rate)
 
-    def save(self, filename):
-        """Saves the audio data to a WAV `filename`
-
-        Raises ValueError if the file already exists, has no extension or is not ``.wav``."""
-        filename = str(filename)
-        if os.path.isfile(filename):
-            raise ValueError(f'{filename}: file already exists')
-        extension = os.path.splitext(filename)[1]
-        if not extension:
-            raise ValueError(f'{filename}: cannot write audio file without extension')
-        if extension.lower() != '.wav':
-            raise ValueError(
-                f'{filename}: cannot write file, only WAV files are supported here '
-                f'(the reference encodes other formats with pydub/ffmpeg)')
-        scipy.io.wavfile.write(filename, self.sample_rate, self.data)
-
     # ---- views and conversions --------------------------------------------------------------------
     def channel(self, index):
         """Builds a mono signal from channel `index` of a multi-channel one"""
@@ -109,23 +92,6 @@ class Audio:
                 f'not enough channels ({self.nchannels}) to extract '
                 f'the index {index} (indices count starts at 0)')
         return self if self.nchannels == 1 else Audio(self.data[:, index], self.sample_rate)
-
-    def resample(self, sample_rate, backend='sox'):
-        """Returns the audio signal resampled at the given `sample_rate`
-
-        `backend` must be 'sox' or 'scipy' like in the reference; sox is not available here, so both
-        run the reference's scipy backend (Fourier-domain `scipy.signal.resample`)."""
-        if backend not in ('sox', 'scipy'):
-            raise ValueError(f'backend must be sox or scipy, it is {backend}')
-        if sample_rate == self.sample_rate:
-            return self
-        nsamples = int(self.nsamples * sample_rate / self.sample_rate) if sample_rate > 0 else 0
-        if nsamples <= 0:
-            raise ValueError(f'resampling at {sample_rate} failed!')
-        with warnings.catch_warnings():
-            warnings.simplefilter('ignore', category=FutureWarning)
-            data = scipy.signal.resample(self.data, nsamples)
-        return Audio(data.astype(self.dtype), sample_rate, validate=False)  # (scipy returns float64)
 
     @staticmethod
     def _is_valid_dtype(dtype):

@@ -502,6 +502,9 @@ int check_offsets(const snf_plan* plan, const int64_t* sample_offsets, const int
   if (n_utts < 0) return set_error(SNF_E_INVALID, "n_utts < 0");
   if (n_utts == 0) return SNF_OK;
   if (!sample_offsets || !frame_offsets) return set_error(SNF_E_INVALID, "null offsets table");
+  // (rows below offsets[0] would resolve to utterance 0 with a negative local frame)
+  if (sample_offsets[0] != 0 || frame_offsets[0] != 0)
+    return set_error(SNF_E_INVALID, "offsets tables must start at 0");
   for (int64_t u = 0; u < n_utts; ++u) {
     const int64_t n = sample_offsets[u + 1] - sample_offsets[u];
     const int64_t f = frame_offsets[u + 1] - frame_offsets[u];
@@ -921,6 +924,7 @@ int snf_post_run_batch_device(snf_plan* plan, const float* d_in, int32_t in_cols
   if (!plan) return set_error(SNF_E_INVALID, "null plan");
   if (n_utts <= 0) return n_utts == 0 ? SNF_OK : set_error(SNF_E_INVALID, "n_utts < 0");
   if (!frame_offsets) return set_error(SNF_E_INVALID, "null offsets table");
+  if (frame_offsets[0] != 0) return set_error(SNF_E_INVALID, "offsets tables must start at 0");
   for (int64_t u = 0; u < n_utts; ++u)
     if (frame_offsets[u + 1] < frame_offsets[u])
       return set_error(SNF_E_INVALID, "offsets tables must be non-decreasing");

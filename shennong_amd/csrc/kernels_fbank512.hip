@@ -9,9 +9,8 @@
 //   B  pass 1: 16-point FFT over j in registers (radix-4 x radix-4, compile-time twiddles), inter-pass
 //      twiddle W256^(l k2), 16x16 transpose through a padded (conflict-free) wave-private LDS tile.
 //   C  pass 2: 16-point FFT over n1 in registers -> lane l holds Z[l + 16 k1].
-//   D  real-FFT unpack + power: bins k and 256-k are paired; the partner Z[256-k] sits in lane 16-l
-//      of the same frame and comes over two DPP moves (row_mirror, then row_shr:1 whose unwritten
-//      lane 0 keeps its own Z[256 - 16 k1]) - no LDS round trip; twiddles W512^k from an LDS table.
+//   D  real-FFT unpack + power: bins k and 256-k are paired; the partner Z[256-k] comes through LDS
+//      (half a tile), twiddles W512^k from an LDS table.
 //      Scaled by 4 (the 1/2 factors of the unpack are folded into the mel weights as an exact power
 //      of two).
 //   E  power spectrum to a wave-private LDS tile [frame][bin].
@@ -90,6 +89,17 @@ __device__ __forceinline__ void read16_b64(const void* base, float2 (&d)[16]) {
       : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]),
         "=&v"(d[7]), "=&v"(d[8]), "=&v"(d[9]), "=&v"(d[10]), "=&v"(d[11]), "=&v"(d[12]), "=&v"(d[13]),
         "=&v"(d[14]), "=&v"(d[15])
+      : "v"(lds_addr(base))
+      : "memory");
+}
+// dst[i] = the float2 at byte offset 128 (7 - i) from `base`, i < 8 (partner rows, reversed)
+__device__ __forceinline__ void read8_b64_rev128(const void* base, float2 (&d)[8]) {
+  asm volatile(
+      "ds_read_b64 %0, %8 offset:896\n ds_read_b64 %1, %8 offset:768\n ds_read_b64 %2, %8 offset:640\n"
+      "ds_read_b64 %3, %8 offset:512\n ds_read_b64 %4, %8 offset:384\n ds_read_b64 %5, %8 offset:256\n"
+      "ds_read_b64 %6, %8 offset:128\n ds_read_b64 %7, %8\n s_waitcnt lgkmcnt(0)"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]),
+        "=&v"(d[7])
       : "v"(lds_addr(base))
       : "memory");
 }
@@ -520,21 +530,18 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     wave_lds_sync();
 
     // ---- D: real-FFT unpack + power (x4) -----------------------------------------------------------
-    // partner of k = l + 16 k1 (k1 < 8) is 256 - k = (16 - l) + 16 (15 - k1): register 15 - k1 of lane
-    // 16 - l of the same frame for l >= 1 (row_mirror gives lane 15 - l, row_shr:1 then lane l - 1 of
-    // that); lane 0 pairs with its own register 16 - k1, which row_shr:1 leaves in place as `old`
-    float2 zpart[8];
-    // (ascending k1: register 16 - k1 was the mirror source of the previous step and is dead when it
-    // serves as `old`, so the second move works in place)
-    zpart[0] = make_float2(dpp_mov<0x111, true>(0.0f, dpp_mov<0x140, true>(0.0f, z[15].x)),
-                           dpp_mov<0x111, true>(0.0f, dpp_mov<0x140, true>(0.0f, z[15].y)));
+    // partner of k = l + 16 k1 (k1 < 8) is 256 - k = (16 - l) + 16 (15 - k1): the upper half of the
+    // spectrum goes through the tile, xbuf[r][c] = Z[c + 16 (r + 8)], rows 0..7 (+ row 8 scratch for
+    // lane 0).  LDS instructions are free at the margin here (the kernel is bound by the vector pipe),
+    // and two DPP moves per dword - which run at half the rate of plain VALU instructions - are not:
+    // the exchange through DPP (row_mirror + row_shr:1) was measured and costs 4 % more.
+    wave_lds_sync();
 #pragma unroll
-    for (int k1 = 1; k1 < 8; ++k1) {
-      const float mx = dpp_mov<0x140, true>(0.0f, z[15 - k1].x);  // row_mirror: lane 15 - l
-      const float my = dpp_mov<0x140, true>(0.0f, z[15 - k1].y);
-      zpart[k1] = make_float2(dpp_mov<0x111, false>(z[16 - k1].x, mx),   // row_shr:1, lane 0 keeps old
-                              dpp_mov<0x111, false>(z[16 - k1].y, my));
-    }
+    for (int r = 0; r < 8; ++r) tile[r * 16 + l] = z[r + 8];
+    wave_lds_sync();
+    const float2* __restrict__ partner = tile + (16 - l);  // Z[256 - k]: row 7 - k1, column 16 - l
+    float2 zpart[8];
+    read8_b64_rev128(partner, zpart);           // zpart[k1] = Z[256 - l - 16 k1]
     float4 w512q[4];
     read_quads<4>(t_tw512 + l * 10, w512q);     // W512^(l + 16 k1)
     float pk[8], pm[8];  // 4 P[k], 4 P[256-k] for k = l + 16 k1
@@ -553,7 +560,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
       pm[k1] = b_re * b_re + b_im * b_im;
     }
     if (l == 0) {
-      // k = 0: DC (and Nyquist, unused by the mel banks)
+      // k = 0: DC (and Nyquist, unused by the mel banks); pairs (16 k1, 256 - 16 k1) were computed
+      // above with zp = Z[256 - 16 k1] = row (8 - k1); k1 = 0 read scratch -> overwrite
       const float dc = z[0].x + z[0].y;
       pk[0] = 4.0f * dc * dc;
       const float ny = z[0].x - z[0].y;
@@ -1027,6 +1035,10 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
   size_t lds = static_cast<size_t>(tab_bytes) + n_waves * 4 * kFrameTileBytes;
   if (2 * (lds + 512) > 160 * 1024) {  // two 8-wave workgroups do not fit: one of 16 waves
     n_waves = kMaxWaves;
+    lds = static_cast<size_t>(tab_bytes) + n_waves * 4 * kFrameTileBytes;
+  }
+  if (const char* forced = getenv("SNF_FAST512_WAVES")) {  // developer knob: occupancy experiments
+    n_waves = atoi(forced);
     lds = static_cast<size_t>(tab_bytes) + n_waves * 4 * kFrameTileBytes;
   }
   if (lds > 160 * 1024) return set_error(SNF_E_RUNTIME, "fast512: tables do not fit in LDS");

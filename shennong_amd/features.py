@@ -163,19 +163,17 @@ class FeaturesCollection(dict):
     shennong/features_collection.py:80-280)"""
     @classmethod
     def load(cls, filename, serializer=None, log=None):
-        """Loads a FeaturesCollection from a `filename`; the serializer is guessed from the file
-        extension when not specified (see shennong_amd.serializers)"""
-        from shennong_amd.serializers import get_serializer
-        return get_serializer(
-            cls, filename, log or get_logger('serializer', 'warning'), serializer).load()
+        """Loads a FeaturesCollection from a numpy `.npz` or Kaldi `.ark` file (the format is guessed
+        from the extension unless `serializer` names it: 'numpy' or 'kaldi')"""
+        from shennong_amd import serializers
+        return serializers.load(cls, filename, serializer=serializer, log=log)
 
     def save(self, filename, serializer=None, with_properties=True, log=None, **kwargs):
-        """Saves a FeaturesCollection to a `filename` (`compress` for numpy / matlab, `scp` for
-        kaldi); raises IOError if the file already exists"""
-        from shennong_amd.serializers import get_serializer
-        get_serializer(
-            type(self), filename, log or get_logger('serializer', 'warning'), serializer).save(
-                self, with_properties=with_properties, **kwargs)
+        """Saves the collection to a numpy `.npz` (`compress`) or Kaldi `.ark` (`scp`, `double`) file;
+        raises IOError if the file already exists"""
+        from shennong_amd import serializers
+        serializers.save(self, filename, serializer=serializer, with_properties=with_properties,
+                         log=log, **kwargs)
 
     def is_valid(self):
         return all(features.is_valid() for features in self.values())

@@ -1,70 +1,94 @@
-"""Saves and loads features collections to/from various file formats
+"""Features files: numpy ``.npz`` and Kaldi ``.ark`` (+ ``.scp``), nothing else.
 
-Same classes, entry points, file layouts and error behaviour as reference shennong/serializers.py
-(``supported_extensions``:20-36, ``get_serializer``:58-109, ``FeaturesSerializer``:112-221, numpy
-:224-247, matlab :250-330, pickle :333-351, kaldi :392-505, csv :508-600), without its third-party
-bindings: Kaldi's binary archives (`DM` double matrices, optional scp index) are written and read
-directly, and the properties JSON uses json_tricks' array encoding (``{"__ndarray__": ..., "dtype": ...,
-"shape": ...}``) so that files stay readable by the reference.  h5features is not available here.
+At GPU rates the writer decides the wall time of a corpus run (the reference reports 2:30 to write
+38 h of MFCC as npz, features_collection.py:19-26), so the only formats kept are the two the hot path
+needs: one self-contained ``.npz`` per collection, and the Kaldi binary archive, which can be
+appended to batch by batch (`KaldiStreamWriter`) while ``pipeline.extract_features_streamed`` runs.
+Both layouts are the reference's own (reference serializers.py:224-247 and :392-505), so files stay
+interchangeable with it; the matlab / pickle / csv / h5features / json layouts of the reference are
+out of scope here.
+
+Kaldi table entry ([KALDI-UPSTREAM] util/kaldi-holder-inl.h, matrix/kaldi-matrix.cc Write):
+``<key> \\0B`` + ``DM `` (double) or ``FM `` (float) + ``\\4<int32 rows>\\4<int32 cols>`` + row-major
+values.  A collection is three files: ``<root>.ark`` (data), ``<root>.times.ark`` and
+``<root>.properties.json`` (properties + the original dtypes; numpy arrays inside the properties use
+the ``{"__ndarray__": ..., "dtype": ..., "shape": ...}`` encoding the reference's JSON writer uses).
 """
 
-import abc
 import copy
-import copyreg
 import json
 import os
-import pickle
-import re
 import struct
 
 import numpy as np
-import scipy.io
 
 from shennong_amd.features import Features
-from shennong_amd.utils import array2list
 
 
-_BY_NAME, _BY_EXTENSION = {}, {}
+# ---- the two formats ---------------------------------------------------------------------------------
+def _format_of(filename, serializer):
+    """'numpy' or 'kaldi', from the explicit name or the file extension"""
+    by_extension = {'.npz': 'numpy', '.ark': 'kaldi'}
+    if serializer is not None:
+        if serializer not in by_extension.values():
+            raise ValueError(
+                f'invalid serializer {serializer}, must be in {list(by_extension.values())}')
+        return serializer
+    ext = os.path.splitext(str(filename))[1]
+    if ext not in by_extension:
+        raise ValueError(f'invalid extension {ext}, must be in {list(by_extension)}')
+    return by_extension[ext]
 
 
-def _file_format(name, extension):
-    """Class decorator: registers a serializer under its `name` and file `extension`"""
-    def register(cls):
-        _BY_NAME[name] = _BY_EXTENSION[extension] = cls
-        return cls
-    return register
-
-
-def supported_extensions():
-    """File extensions mapped to their serializer class"""
-    return dict(_BY_EXTENSION)
-
-
-def supported_serializers():
-    """Serializers names mapped to their class"""
-    return dict(_BY_NAME)
-
-
-def get_serializer(cls, filename, log, serializer=None):
-    """The serializer instance for `filename`: the one named `serializer`, or the one registered for
-    the file extension
-
-    Raises ValueError for an unknown name / extension, or if `cls` is not FeaturesCollection."""
-    if cls.__name__ != 'FeaturesCollection':
-        raise ValueError(
-            'The `cls` parameter must be shennong.features.FeaturesCollection')
+def save(features, filename, serializer=None, with_properties=True, log=None, **kwargs):
+    """Writes a FeaturesCollection; IOError if the file exists, ValueError if the collection is not
+    valid.  `compress` (numpy, default True), `scp` / `double` (kaldi)."""
     filename = str(filename)
-    if serializer is None:
-        what, key, table = 'extension', os.path.splitext(filename)[1], _BY_EXTENSION
+    fmt = _format_of(filename, serializer)
+    if type(features).__name__ != 'FeaturesCollection':
+        raise ValueError(
+            f'features must be FeaturesCollection but are {type(features).__name__}')
+    if os.path.isfile(filename):
+        raise IOError(f'file already exists: {filename}')
+    if not features.is_valid():
+        raise ValueError('features are not valid')
+    if log:
+        log.info('writing %s', filename)
+    if fmt == 'numpy':
+        entries = {name: f._to_dict(with_properties=with_properties) for name, f in features.items()}
+        write = np.savez_compressed if kwargs.get('compress', True) is True else np.savez
+        with open(filename, 'wb') as stream:
+            write(stream, features=entries, allow_pickle=True)
     else:
-        what, key, table = 'serializer', serializer, _BY_NAME
-    if key not in table:
-        raise ValueError(f'invalid {what} {key}, must be in {list(table)}')
-    return table[key](cls, filename, log)
+        with KaldiStreamWriter(filename, scp=kwargs.get('scp', False),
+                               with_properties=with_properties,
+                               double=kwargs.get('double', True)) as writer:
+            writer.write(features)
 
 
-# ---- JSON with numpy support (json_tricks-compatible encoding) ---------------------------------------
-class _NumpyEncoder(json.JSONEncoder):
+def load(cls, filename, serializer=None, log=None):
+    """Reads a collection back as `cls` (FeaturesCollection)"""
+    filename = str(filename)
+    fmt = _format_of(filename, serializer)
+    for test, problem in ((os.path.isfile, 'found'), (lambda f: os.access(f, os.R_OK), 'readable')):
+        if not test(filename):
+            raise IOError(f'file not {problem}: {filename}')
+    if log:
+        log.info('loading %s', filename)
+    if fmt == 'numpy':
+        with open(filename, 'rb') as stream:
+            stored = np.load(stream, allow_pickle=True)['features'].item()
+        features = cls((name, Features._from_dict(entry, validate=False))
+                       for name, entry in stored.items())
+    else:
+        features = cls(_read_kaldi_collection(filename))
+    if not features.is_valid():  # pragma: nocover
+        raise ValueError(f'features not valid in "{filename}"')
+    return features
+
+
+# ---- properties JSON -----------------------------------------------------------------------------------
+class _ArrayEncoder(json.JSONEncoder):
     def default(self, obj):
         if isinstance(obj, np.ndarray):
             return {'__ndarray__': obj.tolist(), 'dtype': str(obj.dtype),
@@ -74,341 +98,97 @@ class _NumpyEncoder(json.JSONEncoder):
         return super().default(obj)
 
 
-def _json_hook(dct):
+def _decode_arrays(dct):
     if '__ndarray__' in dct:
-        return np.asarray(dct['__ndarray__'], dtype=dct.get('dtype')).reshape(
-            dct.get('shape', -1))
+        return np.asarray(dct['__ndarray__'], dtype=dct.get('dtype')).reshape(dct.get('shape', -1))
     return dct
 
 
-def _json_dumps(data):
-    return json.dumps(data, indent=4, cls=_NumpyEncoder, ensure_ascii=False)
-
-
-def _json_loads(text):
-    return json.loads(text, object_hook=_json_hook)
-
-
-class FeaturesSerializer(metaclass=abc.ABCMeta):
-    """Base class of a features file serializer: `save` / `load` do the checks common to every
-    format, the subclasses read and write the files (`_save`, `_load`)"""
-    def __init__(self, cls, filename, log):
-        self._features_collection, self._filename, self._log = cls, filename, log
-
-    filename = property(lambda self: self._filename, doc='Name of the file to read or write')
-
-    @abc.abstractmethod
-    def _save(self, features, with_properties):  # pragma: nocover
-        """Writes the (valid) collection"""
-
-    @abc.abstractmethod
-    def _load(self):  # pragma: nocover
-        """Reads the collection back"""
-
-    def _check_save(self):
-        if os.path.isfile(self.filename):
-            raise IOError(f'file already exists: {self.filename}')
-
-    def _check_load(self):
-        for test, problem in ((os.path.isfile, 'found'), (lambda f: os.access(f, os.R_OK), 'readable')):
-            if not test(self.filename):
-                raise IOError(f'file not {problem}: {self.filename}')
-
-    def save(self, features, with_properties=True, **kwargs):
-        """Saves a collection of `features` to a file
-
-        Raises IOError if the output file already exists, ValueError if the features are not a
-        valid FeaturesCollection."""
-        self._check_save()
-        expected = self._features_collection
-        if not isinstance(features, expected):
-            raise ValueError(
-                f'features must be {expected.__name__} but are {type(features).__name__}')
-        if not features.is_valid():
-            raise ValueError('features are not valid')
-        self._save(features, with_properties, **kwargs)
-
-    def load(self, **kwargs):
-        """Returns the collection of features stored in the file
-
-        Raises IOError if the file does not exist or cannot be read, ValueError if the features
-        cannot be loaded or are not valid."""
-        self._check_load()
-        features = self._load(**kwargs)
-        if not features.is_valid():  # pragma: nocover
-            raise ValueError(f'features not valid in "{self.filename}"')
-        return features
-
-    def _as_dicts(self, features, with_properties):
-        """name -> {'data', 'times'[, 'properties']}: what the array container formats store"""
-        self._log.info('writing %s', self.filename)
-        return {name: feats._to_dict(with_properties=with_properties)
-                for name, feats in features.items()}
-
-
-@_file_format('numpy', '.npz')
-class NumpySerializer(FeaturesSerializer):
-    """Saves and loads features to/from the numpy '.npz' format (one pickled dictionary under the
-    key 'features', like the reference)"""
-    def _save(self, features, with_properties, compress=True):
-        write = np.savez_compressed if compress is True else np.savez
-        with open(self.filename, 'wb') as stream:
-            write(stream, features=self._as_dicts(features, with_properties), allow_pickle=True)
-
-    def _load(self):
-        self._log.info('loading %s', self.filename)
-        with open(self.filename, 'rb') as stream:
-            stored = np.load(stream, allow_pickle=True)['features'].item()
-        return self._features_collection(
-            (name, Features._from_dict(entry, validate=False)) for name, entry in stored.items())
-
-
-@_file_format('matlab', '.mat')
-class MatlabSerializer(FeaturesSerializer):
-    """Saves and loads features to/from the matlab '.mat' format (one struct per item)"""
-    _BOOKKEEPING = ('__header__', '__version__', '__globals__')
-
-    def _save(self, features, with_properties, compress=True):
-        scipy.io.savemat(
-            self.filename, self._as_dicts(features, with_properties), long_field_names=True,
-            appendmat=False, do_compression=compress)
-
-    def _load(self):
-        self._log.info('loading %s', self.filename)
-        stored = scipy.io.loadmat(
-            self.filename, appendmat=False, squeeze_me=True, mat_dtype=True, struct_as_record=False)
-        features = self._features_collection()
-        for name, entry in stored.items():
-            if name in self._BOOKKEEPING:
-                continue
-            entry = self._plain(entry)
-            data, times = self._unsqueeze(entry['data'], entry['times'])
-            properties = entry.get('properties')
-            if properties is not None and 'pipeline' in properties:
-                # a one-stage pipeline comes back as the stage itself, arrays as arrays
-                stages = properties['pipeline']
-                stages = stages if isinstance(stages, list) else [stages]
-                properties['pipeline'] = [array2list(stage) for stage in stages]
-            features[name] = Features(data, times, properties, validate=False)
-        return features
-
-    @classmethod
-    def _plain(cls, value):
-        """scipy's mat_struct objects (and object arrays of them) as dicts (and lists of dicts)"""
-        if type(value).__name__ == 'mat_struct':
-            return {field: cls._plain(getattr(value, field)) for field in value._fieldnames}
-        if isinstance(value, np.ndarray) and value.dtype == object:
-            return [cls._plain(item) for item in value.ravel()]
-        return value
-
-    @staticmethod
-    def _unsqueeze(data, times):
-        """`loadmat(squeeze_me=True)` (needed for the properties, as in the reference) also collapses
-        a single frame or a single column of the matrices: give them their two dimensions back"""
-        data, times = np.asarray(data), np.asarray(times)
-        if data.ndim == 2:
-            if data.shape[0] == 1 and times.ndim < 2:
-                times = times.reshape((1, 2)) if times.size == 2 else times.reshape((1,))
-            return data, times
-        if data.ndim == 0:
-            return data.reshape((1, 1)), (times.reshape((1, 2)) if times.size == 2 else times.reshape((1,)))
-        if times.ndim == 2:  # several frames of one column
-            return data.reshape((times.shape[0], -1)), times
-        if times.ndim == 0:  # one frame, 1-D times
-            return data.reshape((1, -1)), times.reshape((1,))
-        if times.shape[0] == data.shape[0] and times.shape[0] != 2:  # one column, 1-D times
-            return data.reshape((-1, 1)), times
-        if times.shape[0] == 2:  # one frame, (start, stop) times
-            return data.reshape((1, -1)), times.reshape((1, 2))
-        return data.reshape((-1, 1)), times
-
-
-class _NoPropertiesPickler(pickle.Pickler):
-    """Implements the with_properties=False for PickleSerializer"""
-    dispatch_table = copyreg.dispatch_table.copy()
-    dispatch_table[Features] = lambda obj: (
-        obj.__class__, (obj.data, obj.times, None, False))
-
-
-@_file_format('pickle', '.pkl')
-class PickleSerializer(FeaturesSerializer):
-    """Saves and loads features to/from the Python pickle format"""
-    def _save(self, features, with_properties):
-        self._log.info('writing %s', self.filename)
-        pickler = pickle.Pickler if with_properties else _NoPropertiesPickler
-        with open(self.filename, 'wb') as stream:
-            pickler(stream).dump(features)
-
-    def _load(self):
-        self._log.info('loading %s', self.filename)
-        with open(self.filename, 'rb') as stream:
-            return pickle.load(stream)
-
-
-# ---- Kaldi binary archives ------------------------------------------------------------------------------
-def _write_kaldi_matrix(stream, key, mat, double=True):
-    """One table entry; returns the offset an scp line points to (just after ``<key> ``).  `double`:
-    a Kaldi double matrix (``DM``, what the reference writes) or a float matrix (``FM``, half the
-    bytes; Kaldi tools and this module read both)"""
+# ---- Kaldi binary tables -----------------------------------------------------------------------------
+def _write_matrix(stream, key, mat, double):
+    """Appends one table entry; returns the offset an scp line points to (just after ``<key> ``)"""
     mat = np.ascontiguousarray(mat, dtype=np.float64 if double else np.float32)
     stream.write(key.encode('utf-8') + b' ')
     offset = stream.tell()
     stream.write(b'\0BDM ' if double else b'\0BFM ')
-    stream.write(b'\4' + struct.pack('<i', mat.shape[0]))
-    stream.write(b'\4' + struct.pack('<i', mat.shape[1]))
+    stream.write(b'\4' + struct.pack('<i', mat.shape[0]) + b'\4' + struct.pack('<i', mat.shape[1]))
     stream.write(mat.tobytes())
     return offset
 
 
-def _write_kaldi_ark(ark, matrices, scp=None):
-    """Binary table of double matrices: ``<key> \\0B DM \\4<rows>\\4<cols><float64 row-major>``
-    ([KALDI-UPSTREAM] util/kaldi-holder-inl.h, matrix/kaldi-matrix.cc Write)"""
-    index = []
-    with open(ark, 'wb') as stream:
-        for key, mat in matrices.items():
-            index.append((key, _write_kaldi_matrix(stream, key, mat)))
-    if scp:
-        with open(scp, 'w', encoding='utf-8') as stream:
-            for key, offset in index:
-                stream.write(f'{key} {ark}:{offset}\n')
-
-
-def _read_kaldi_ark(ark):
-    out = {}
+def _read_table(ark):
+    """key -> float64 matrix of a binary archive of double or float matrices"""
     with open(ark, 'rb') as stream:
         blob = stream.read()
-    pos = 0
+    out, pos = {}, 0
     while pos < len(blob):
         end = blob.index(b' ', pos)
-        key = blob[pos:end].decode('utf-8')
-        pos = end + 1
-        if blob[pos:pos + 2] != b'\0B':
-            raise ValueError(f'{ark}: not a binary Kaldi archive')
-        pos += 2
-        token_end = blob.index(b' ', pos)
-        token = blob[pos:token_end]
-        pos = token_end + 1
-        if token not in (b'DM', b'FM'):
-            raise ValueError(f'{ark}: unsupported Kaldi object {token!r}')
-        dtype = np.float64 if token == b'DM' else np.float32
-        rows = struct.unpack('<i', blob[pos + 1:pos + 5])[0]
-        cols = struct.unpack('<i', blob[pos + 6:pos + 10])[0]
-        pos += 10
-        nbytes = rows * cols * np.dtype(dtype).itemsize
+        key, pos = blob[pos:end].decode('utf-8'), end + 1
+        kind = blob[pos:pos + 5]
+        if kind not in (b'\0BDM ', b'\0BFM '):
+            raise ValueError(f'{ark}: not a binary Kaldi archive of float or double matrices')
+        dtype = np.dtype('<f8' if kind == b'\0BDM ' else '<f4')
+        rows, cols = struct.unpack('<xixi', blob[pos + 5:pos + 15])
+        pos += 15
         out[key] = np.frombuffer(blob, dtype=dtype, count=rows * cols, offset=pos).reshape(
-            (rows, cols)).astype(np.float64)
-        pos += nbytes
+            rows, cols).astype(np.float64)
+        pos += rows * cols * dtype.itemsize
     return out
 
 
-@_file_format('kaldi', '.ark')
-class KaldiSerializer(FeaturesSerializer):
-    """Saves and loads features to/from the Kaldi ark/scp format"""
-    def __init__(self, cls, filename, log):
-        super().__init__(cls, filename, log=log)
-        filename_split = os.path.splitext(self.filename)
-        if filename_split[1] != '.ark':
-            raise ValueError(
-                'when saving to Kaldi ark format, the file extension must be '
-                '".ark", it is "{}"'.format(filename_split[1]))
-        self._fileroot = filename_split[0]
-
-    def _save(self, features, with_properties, scp=False):
-        for suffix, get in (('', lambda v: v.data),
-                            ('.times', lambda v: np.atleast_2d(v.times).copy())):
-            ark = self._fileroot + suffix + '.ark'
-            scp_file = self._fileroot + suffix + '.scp' if scp else None
-            if scp:
-                self._log.info('writing %s and %s', ark, scp_file)
-            else:
-                self._log.info('writing %s', ark)
-            _write_kaldi_ark(ark, {k: get(v) for k, v in features.items()}, scp_file)
-
-        # the matrices are written as doubles: the original dtypes go with the properties
-        filename = self._fileroot + '.properties.json'
-        self._log.info('writing %s', filename)
-        if with_properties:
-            data = {k: copy.deepcopy(v.properties) for k, v in features.items()}
-        else:
-            data = {k: {} for k in features}
-        for k in data:
-            data[k]['__dtype_data__'] = str(features[k].dtype)
-            data[k]['__dtype_times__'] = str(features[k].times.dtype)
-        with open(filename, 'wt', encoding='utf-8') as stream:
-            stream.write(_json_dumps(data))
-
-    def _load(self):
-        filename = self._fileroot + '.properties.json'
-        self._log.info('loading %s', filename)
-        if not os.path.isfile(filename):
-            raise IOError('file not found: {}'.format(filename))
-        with open(filename, 'r', encoding='utf-8') as stream:
-            properties = _json_loads(stream.read())
-
-        ark = self._fileroot + '.times.ark'
-        self._log.info('loading %s', ark)
-        if not os.path.isfile(ark):
-            raise IOError('file not found: {}'.format(ark))
-        times = _read_kaldi_ark(ark)
-
-        ark = self._fileroot + '.ark'
-        self._log.info('loading %s', ark)
-        data = _read_kaldi_ark(ark)
-
-        # 1-D times were written as one row: back to 1-D (reference serializers.py does this for
-        # every one-row matrix, which breaks the [1, 2] times of a single-frame item: those are told
-        # apart by the number of frames of the data)
-        for key, value in times.items():
-            single_frame = (key in data and data[key].shape[0] == 1 and value.shape[1] == 2)
-            if value.shape[0] == 1 and not single_frame:
-                times[key] = value.reshape((value.shape[1]))
-
-        if properties.keys() != data.keys():
-            raise ValueError(
-                'invalid features: items differ in data and properties')
-        if times.keys() != data.keys():
-            raise ValueError(
-                'invalid features: items differ in data and times')
-        return self._features_collection(
-            **{k: Features(
-                data[k].astype(properties[k]['__dtype_data__']),
-                times[k].astype(properties[k]['__dtype_times__']),
-                properties={
-                    k: p for k, p in properties[k].items()
-                    if '__dtype_' not in k},
-                validate=False)
-               for k in data.keys()})
+def _read_kaldi_collection(filename):
+    root, ext = os.path.splitext(filename)
+    if ext != '.ark':
+        raise ValueError(
+            'when saving to Kaldi ark format, the file extension must be '
+            '".ark", it is "{}"'.format(ext))
+    sidecars = {'properties': root + '.properties.json', 'times': root + '.times.ark'}
+    for name in sidecars.values():
+        if not os.path.isfile(name):
+            raise IOError('file not found: {}'.format(name))
+    with open(sidecars['properties'], 'r', encoding='utf-8') as stream:
+        properties = json.loads(stream.read(), object_hook=_decode_arrays)
+    times, data = _read_table(sidecars['times']), _read_table(filename)
+    if properties.keys() != data.keys():
+        raise ValueError('invalid features: items differ in data and properties')
+    if times.keys() != data.keys():
+        raise ValueError('invalid features: items differ in data and times')
+    for key in data:
+        props = properties[key]
+        t = times[key]
+        # 1-D times were written as one row; a [1, 2] times of a single-frame item stays 2-D
+        if t.shape[0] == 1 and not (data[key].shape[0] == 1 and t.shape[1] == 2):
+            t = t.reshape(t.shape[1])
+        yield key, Features(
+            data[key].astype(props['__dtype_data__']), t.astype(props['__dtype_times__']),
+            properties={k: v for k, v in props.items() if '__dtype_' not in k}, validate=False)
 
 
 class KaldiStreamWriter:
-    """Incremental writer of the Kaldi layout above (``<root>.ark``, ``<root>.times.ark``,
-    optional ``.scp`` indexes, ``<root>.properties.json`` at close) for features that are produced
-    batch by batch (pipeline.extract_features_streamed): the archives are appended to as the
-    batches arrive, so the corpus never sits in host memory.  What it writes loads back with
-    ``FeaturesCollection.load(filename)`` / `KaldiSerializer` and is byte-identical to
-    ``FeaturesCollection.save`` of the same items in the same order (``double=False`` writes the data
-    as Kaldi float matrices instead: half the bytes, float32 features lose nothing).
+    """Incremental writer of the Kaldi layout (``<root>.ark``, ``<root>.times.ark``, optional
+    ``.scp`` indexes, ``<root>.properties.json`` at close) for features that are produced batch by
+    batch (pipeline.extract_features_streamed): the archives are appended to as the batches arrive,
+    so the corpus never sits in host memory.  ``FeaturesCollection.save('x.ark')`` is one `write` of
+    the whole collection through this class; ``double=False`` writes the data as Kaldi float
+    matrices (half the bytes, float32 features lose nothing; the reference writes doubles).
 
     >>> with KaldiStreamWriter('corpus.ark', scp=True) as writer:       # doctest: +SKIP
     ...     extract_features_streamed(config, utterances, writer.write)
     """
     def __init__(self, filename, scp=False, with_properties=True, double=True, log=None):
-        root, ext = os.path.splitext(filename)
-        self._double = double  # False: float32 data matrices (times stay double)
+        root, ext = os.path.splitext(str(filename))
         if ext != '.ark':
             raise ValueError(
                 'when saving to Kaldi ark format, the file extension must be '
                 '".ark", it is "{}"'.format(ext))
-        self._root = root
-        self._with_properties = with_properties
-        self._log = log
-        self._properties = {}
-        self._files = [root + '.ark', root + '.times.ark', root + '.properties.json']
+        self._root, self._double, self._with_properties, self._log = root, double, with_properties, log
+        names = [root + '.ark', root + '.times.ark', root + '.properties.json']
         if scp:
-            self._files += [root + '.scp', root + '.times.scp']
-        for name in self._files:
+            names += [root + '.scp', root + '.times.scp']
+        for name in names:
             if os.path.exists(name):
                 raise IOError('file already exists: {}'.format(name))
+        self._properties = {}
         self._data = open(root + '.ark', 'wb')
         self._times = open(root + '.times.ark', 'wb')
         self._data_scp = open(root + '.scp', 'w', encoding='utf-8') if scp else None
@@ -421,10 +201,10 @@ class KaldiStreamWriter:
         for key, feat in features.items():
             if key in self._properties:
                 raise ValueError('item already written: {}'.format(key))
-            offset = _write_kaldi_matrix(self._data, key, feat.data, double=self._double)
+            offset = _write_matrix(self._data, key, feat.data, self._double)
             if self._data_scp:
                 self._data_scp.write(f'{key} {self._root}.ark:{offset}\n')
-            offset = _write_kaldi_matrix(self._times, key, np.atleast_2d(feat.times))
+            offset = _write_matrix(self._times, key, np.atleast_2d(feat.times), True)
             if self._times_scp:
                 self._times_scp.write(f'{key} {self._root}.times.ark:{offset}\n')
             props = copy.deepcopy(feat.properties) if self._with_properties else {}
@@ -440,7 +220,7 @@ class KaldiStreamWriter:
                 stream.close()
         self._data = None
         with open(self._root + '.properties.json', 'wt', encoding='utf-8') as stream:
-            stream.write(_json_dumps(self._properties))
+            stream.write(json.dumps(self._properties, indent=4, cls=_ArrayEncoder, ensure_ascii=False))
 
     def __enter__(self):
         return self
@@ -448,68 +228,3 @@ class KaldiStreamWriter:
     def __exit__(self, *exc):
         self.close()
         return False
-
-
-_CSV_HEADER = re.compile(r'^# data_dtype = (\S+), times_dtype = (\S+), features_ndims = (\d+)$')
-
-
-@_file_format('csv', '')
-class CsvSerializer(FeaturesSerializer):
-    """Saves and loads features to/from the CSV format: a directory with, per item, a ``.csv`` file
-    (one row per frame: the times then the data; the first line records the dtypes and the number of
-    data columns) and, when it has properties, a ``.json`` file"""
-    def _check_load(self):
-        if not os.path.isdir(self.filename):
-            raise IOError(f'directory not found: {self.filename}')
-
-    def _check_save(self):
-        if os.path.exists(self.filename):
-            raise IOError(f'already exists: {self.filename}')
-
-    def _path(self, name, extension):
-        return os.path.join(self.filename, name + extension)
-
-    def _save(self, features, with_properties):
-        os.makedirs(self.filename)
-        self._log.info('writing directory "%s"', self.filename)
-        for name, feats in features.items():
-            self._log.debug('writing %s', self._path(name, '.csv'))
-            times = feats.times if feats.times.ndim == 2 else feats.times[:, np.newaxis]
-            np.savetxt(
-                self._path(name, '.csv'), np.hstack((times, feats.data)), comments='# ',
-                header=f'data_dtype = {feats.dtype}, times_dtype = {feats.times.dtype}, '
-                       f'features_ndims = {feats.ndims}')
-            if with_properties and feats.properties:
-                self._log.debug('writing %s', self._path(name, '.json'))
-                with open(self._path(name, '.json'), 'wt', encoding='utf-8') as stream:
-                    stream.write(_json_dumps(feats.properties))
-
-    @staticmethod
-    def _parse_header(csv_file):
-        """(data dtype, times dtype, number of data columns) from the first line of `csv_file`"""
-        with open(csv_file, 'r', encoding='utf-8') as stream:
-            match = _CSV_HEADER.match(stream.readline().strip())
-        try:
-            return np.dtype(match.group(1)), np.dtype(match.group(2)), int(match.group(3))
-        except (AttributeError, TypeError):
-            raise ValueError(f'failed to parse header from {csv_file}') from None
-
-    def _load(self):
-        self._log.info('loading directory "%s"', self.filename)
-        present = set(os.listdir(self.filename))
-        features = self._features_collection()
-        for csv_name in sorted(n for n in present if n.endswith('.csv')):
-            name = csv_name[:-len('.csv')]
-            self._log.debug('loading %s', self._path(name, '.csv'))
-            data_dtype, times_dtype, ndims = self._parse_header(self._path(name, '.csv'))
-            table = np.atleast_2d(np.loadtxt(self._path(name, '.csv')))
-            times = table[:, :-ndims].astype(times_dtype)
-            properties = {}
-            if name + '.json' in present:
-                self._log.debug('loading %s', self._path(name, '.json'))
-                with open(self._path(name, '.json'), 'r', encoding='utf-8') as stream:
-                    properties = dict(_json_loads(stream.read()))
-            features[name] = Features(
-                table[:, -ndims:].astype(data_dtype),
-                times[:, 0] if times.shape[1] == 1 else times, properties=properties, validate=False)
-        return features

@@ -9,6 +9,7 @@ import os
 
 import numpy as np
 import pytest
+import scipy.io.wavfile
 
 from conftest import GOLDEN
 from shennong_amd import Audio
@@ -44,22 +45,14 @@ def test_unreadable_files(call, path, message):
         call(path)
 
 
-def test_save_rules(tmpdir, audio):
-    target = str(tmpdir.join('copy.wav'))
-    audio.save(target)
-    assert Audio.load(target) == audio
-    for path, message in ((target, 'file already exist'),
-                          ('no_extension', 'cannot write audio file without extension'),
-                          (str(tmpdir.join('copy.flac')), 'only WAV files are supported'),
-                          (str(tmpdir.join('copy.mp3')), 'only WAV files are supported')):
-        with pytest.raises(ValueError, match=message):
-            audio.save(path)
+def _write_wav(path, audio):
+    scipy.io.wavfile.write(str(path), audio.sample_rate, audio.data)
 
 
 @pytest.mark.parametrize('dtype', SAMPLE_TYPES)
 def test_two_channels_round_trip(tmpdir, dtype):
     original = _stereo().astype(dtype)
-    original.save(tmpdir / 'stereo.wav')
+    _write_wav(tmpdir / 'stereo.wav', original)
     assert Audio.load(tmpdir / 'stereo.wav') == original
 
 
@@ -67,7 +60,7 @@ def test_float32_file_keeps_full_scale(tmpdir):
     signal = np.zeros(1000, dtype=np.float32)
     signal[10], signal[20] = 1.0, -1.0
     target = str(tmpdir.join('impulses.wav'))
-    Audio(signal, 1000).save(target)
+    _write_wav(target, Audio(signal, 1000))
     assert Audio.scan(target)[:3] == (1, 1000, 1000)
     back = Audio.load(target)
     assert back.dtype == np.float32 and back.nchannels == 1 and back.nsamples == 1000
@@ -153,22 +146,3 @@ def test_segments_tile_the_signal(audio, parts):
 def test_bad_segments(audio, segments, message):
     with pytest.raises(ValueError, match=message):
         audio.segment(segments)
-
-
-@pytest.mark.parametrize('backend', ['sox', 'scipy'])
-@pytest.mark.parametrize('rate', [4000, 8000, 16000, 32000, 44100, 48000])
-def test_resampling(audio, rate, backend):
-    resampled = audio.resample(rate, backend=backend)
-    assert (resampled.nchannels, resampled.sample_rate, resampled.dtype) == (1, rate, audio.dtype)
-    assert resampled.nsamples == pytest.approx(int(audio.nsamples * rate / audio.sample_rate), abs=1)
-    assert resampled.data.mean() == pytest.approx(audio.data.mean(), abs=0.25)
-    if rate >= audio.sample_rate:
-        back = resampled.resample(audio.sample_rate, backend=backend)
-        assert (back.nchannels, back.sample_rate, back.dtype) == (1, audio.sample_rate, audio.dtype)
-
-
-def test_bad_resampling(audio):
-    with pytest.raises(ValueError, match='backend must be sox or scipy, it is'):
-        audio.resample(5, backend='a_bad_one')
-    with pytest.raises(ValueError, match='resampling at 0 failed'):
-        audio.resample(0)

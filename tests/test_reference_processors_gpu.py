@@ -98,7 +98,10 @@ def test_htk_compat(gpu, audio, cls, factor):
 
 @pytest.mark.parametrize('sample_rate', [8000, 44100])
 def test_mfcc_resampled_audio(gpu, audio, sample_rate):
-    resampled = audio.resample(sample_rate)
+    import scipy.signal
+    n = int(audio.nsamples * sample_rate / audio.sample_rate)
+    resampled = Audio(scipy.signal.resample(audio.data, n).astype(audio.dtype), sample_rate,
+                      validate=False)
     assert MfccProcessor(sample_rate=sample_rate).process(resampled).shape == (140, 13)
     with pytest.raises(ValueError, match='mismatch in sample rate'):
         MfccProcessor().process(resampled)
