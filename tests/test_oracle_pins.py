@@ -375,3 +375,47 @@ def test_sliding_cmvn_oracle(wave, norm_vars, center):
     if norm_vars:
         want = want / mfcc[a:b].std(axis=0)
     assert np.all(np.isclose(out[frame], want, atol=1e-6))
+
+
+# ---- closed-form known answers (tests/known_answers.py): no Kaldi, no code of this repository in
+# the expected values; the same cases run against the HIP path in tests/test_parity_gpu.py ----------
+import known_answers  # noqa: E402
+
+
+@pytest.mark.parametrize('case', known_answers.CASES, ids=[c[0] for c in known_answers.CASES])
+def test_known_answer(case):
+    _, make, wave, check = case
+    check(orc.compute(make()._build_options(), wave))
+
+
+def test_known_answer_mel_partition_of_unity():
+    for nb, low, high in ((40, 20.0, 0.0), (23, 20.0, 0.0), (13, 100.0, -500.0)):
+        mo = _abi.default_mel_options()
+        mo.num_bins, mo.low_freq, mo.high_freq = nb, low, high
+        first, size, weights, _ = orc.mel_banks(mo, _frame_opts())
+        known_answers.mel_partition_check(
+            first, [weights[b, first[b]:first[b] + size[b]] for b in range(nb)])
+
+
+def test_known_answer_dct_orthonormal():
+    for n in (13, 23, 40):
+        m = orc.dct_matrix(n, n).astype(np.float64)
+        np.testing.assert_allclose(m @ m.T, np.eye(n), atol=3e-7)
+
+
+def test_known_answer_parseval():
+    from shennong_amd.processor import FilterbankProcessor, MfccProcessor
+    wave = scipy_wave()
+    fbank = orc.compute(FilterbankProcessor(num_bins=23, dither=0)._build_options(), wave)
+    mfcc = orc.compute(MfccProcessor(num_ceps=23, cepstral_lifter=0, use_energy=False,
+                                     dither=0)._build_options(), wave)
+    known_answers.parseval_check(fbank, mfcc)
+
+
+def test_known_answer_delta_ramp():
+    known_answers.ramp_delta_check(orc.deltas)
+
+
+def scipy_wave():
+    import scipy.io.wavfile
+    return scipy.io.wavfile.read(os.path.join(GOLDEN, 'test.wav'))[1]

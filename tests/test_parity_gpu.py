@@ -746,3 +746,49 @@ def test_vtln_option_errors_need_a_frame(gpu, wave):
         proc._process_batch([Audio(wave, 16000), Audio(tiny, 16000)], vtln_warp=[0.85, 1.0])
     with pytest.raises(RuntimeError):
         orc.compute(proc._build_options(), wave, 0.85)
+
+
+# ---- closed-form known answers (tests/known_answers.py), the same cases the oracle is pinned with ------
+import known_answers  # noqa: E402
+
+
+@pytest.mark.parametrize('case', known_answers.CASES, ids=[c[0] for c in known_answers.CASES])
+def test_known_answer(gpu, case):
+    _, make, wave, check = case
+    check(make().process(Audio(wave, 16000)).data)
+
+
+def test_known_answer_parseval(gpu, audio):
+    fbank = FilterbankProcessor(num_bins=23, dither=0).process(audio)
+    mfcc = MfccProcessor(num_ceps=23, cepstral_lifter=0, use_energy=False, dither=0).process(audio)
+    known_answers.parseval_check(fbank.data, mfcc.data)
+
+
+def test_known_answer_delta_ramp(gpu):
+    from shennong_amd import Features
+
+    def deltas(x, order, window):
+        feats = Features(x, np.arange(x.shape[0], dtype=np.float64))
+        return DeltaPostProcessor(order=order, window=window).process(feats).data
+    known_answers.ramp_delta_check(deltas)
+
+
+def test_buffers_from_a_fresh_thread(gpu):
+    """hipSetDevice is per thread: allocations and copies made by a new thread bind it to the selected
+    GPU first (set_device only set a Python global)"""
+    import threading
+    gpu.set_device(gpu.get_device())
+    result = {}
+
+    def work():
+        data = np.arange(1 << 16, dtype=np.float32)
+        buf = gpu.DeviceBuffer(data.nbytes)
+        buf.upload(data)
+        back = np.empty_like(data)
+        buf.download(back)
+        result['ok'] = bool(np.array_equal(back, data)) and buf.device == gpu.get_device()
+        buf.free()
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    assert result.get('ok')

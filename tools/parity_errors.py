@@ -1,0 +1,20 @@
+#!/usr/bin/env python
+"""Summarises the file written by tests/conftest.py::assert_close under SNF_PARITY_LOG: worst measured
+error of every parity test against the oracle, next to the tolerance the test asserts."""
+import collections
+import json
+import sys
+
+rows = collections.OrderedDict()
+for line in open(sys.argv[1]):
+    r = json.loads(line)
+    key = r['test'].split('::')[-1].split('[')[0]
+    cur = rows.setdefault(key, dict(n=0, max_abs=0.0, max_rel=0.0, need=0.0, rtol=r['rtol'], atol=r['atol']))
+    cur['n'] += 1
+    cur['max_abs'] = max(cur['max_abs'], r['max_abs'])
+    cur['max_rel'] = max(cur['max_rel'], r['max_rel'])
+    cur['need'] = max(cur['need'], r['needed_atol_at_rtol'])
+    cur['atol'] = max(cur['atol'], r['atol'])
+print('%-40s %6s %10s %10s %12s %8s %8s' % ('test', 'calls', 'max abs', 'max rel', 'atol needed', 'rtol', 'atol'))
+for key, c in rows.items():
+    print('%-40s %6d %10.2e %10.2e %12.2e %8.0e %8.0e' % (key, c['n'], c['max_abs'], c['max_rel'], c['need'], c['rtol'], c['atol']))
