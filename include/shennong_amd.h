@@ -180,6 +180,12 @@ typedef struct snf_options {
   /* DeltaFeaturesOptions */
   int32_t delta_order;  /* 2 */
   int32_t delta_window; /* 2 */
+  /* mfcc only: non-zero appends the deltas of order `delta_order` / window `delta_window` to every
+     row in the same launch, [cepstra | delta | delta-delta] = what DeltaPostProcessor().process(
+     MfccProcessor().process(audio)) returns (reference postprocessor/delta.py:129-131 chained after
+     processor/mfcc.py:86), without the [T, num_ceps] round trip through HBM.  Order 2 / window 2 on
+     the 512-point path only; anything else is refused at plan creation. */
+  int32_t append_deltas;
   snf_pitch_options pitch;
   snf_pitch_post_options pitch_post;
   snf_vad_options vad;
@@ -298,16 +304,53 @@ int snf_free(void* dptr);
 int snf_memcpy_h2d(void* dst, const void* src, uint64_t bytes);
 int snf_memcpy_d2h(void* dst, const void* src, uint64_t bytes);
 int snf_memset(void* dst, int value, uint64_t bytes);
+/* Streams and stream-ordered copies for callers that overlap the transfers of one batch with the
+   kernels of another (the *_device entry points take the stream; page-locked host memory from
+   snf_host_malloc is required for the copies to be asynchronous). */
+int snf_stream_create(void** stream);
+int snf_stream_destroy(void* stream);
+int snf_stream_synchronize(void* stream);
+int snf_memcpy_h2d_async(void* dst, const void* src, uint64_t bytes, void* stream);
+int snf_memcpy_d2h_async(void* dst, const void* src, uint64_t bytes, void* stream);
 /* Page-locked host staging memory for the host-pointer entry points (snf_plan_run_batch, ...): a
    batch assembled in it (the reference hands over one numpy array per utterance, processor/base.py:428)
    crosses the link at full rate and its pages are faulted in once, not once per call.  Plain host
    memory as far as the caller is concerned. */
 int snf_host_malloc(void** hptr, uint64_t bytes);
 int snf_host_free(void* hptr);
+/* ---- multi-GPU exchange steps (RCCL over xGMI; one process per GPU) --------------------------------
+   The features path shards by utterance and needs no data-path collective; what crosses GPUs is (a)
+   the final gather of the per-rank feature blocks to a root - the counterpart of the reference's
+   thread pool returning every utterance's matrix to one dict (processor/base.py:104-107) - and (b) the
+   sum of the by-speaker CMVN statistics (postprocessor/cmvn.py:145-164).  RCCL is loaded on the first
+   call.  Bootstrap: rank 0 calls snf_comm_unique_id and hands the 128 bytes to the other ranks by any
+   side channel (a socket, a file, MPI ...), then every rank calls snf_comm_init. */
+#define SNF_COMM_ID_BYTES 128
+typedef struct snf_comm snf_comm; /* opaque */
+int snf_comm_unique_id(void* id128);
+int snf_comm_init(const void* id128, int32_t world_size, int32_t rank, int32_t device_id, snf_comm** out);
+int snf_comm_rank(const snf_comm* comm);
+int snf_comm_world_size(const snf_comm* comm);
+int snf_comm_destroy(snf_comm* comm);
+/* Variable-length gather of float blocks to `root`, device pointers in and out: rank r contributes
+   `send_count` floats; on the root they land in `d_recv` in rank order (`recv_counts[world]`, host, root
+   only).  Point-to-point ncclSend / ncclRecv in one group: every peer uses its own xGMI link to the root.
+   `stream` NULL: the communicator's stream, synchronised before returning. */
+int snf_comm_gatherv(snf_comm* comm, const float* d_send, int64_t send_count, float* d_recv,
+                     const int64_t* recv_counts, int32_t root, void* stream);
+/* In-place all-reduce of float64 on the device; op 0 = sum, 1 = max. */
+int snf_comm_allreduce_f64(snf_comm* comm, double* d_buf, int64_t count, int32_t op, void* stream);
+
 /* Test aid: fills the LDS of every CU of the current device with `pattern` (e.g. 0xFFFFFFFF, a NaN).
    LDS is not cleared between workgroups, so a kernel that reads a word it did not write sees whatever
    the previous kernel left there; the parity tests poison it before they compare against the oracle. */
 int snf_debug_fill_lds(uint32_t pattern);
+/* Test aid: device pointers of the intermediates the last run of a pitch plan left in its scratch
+   (resampled signal [total_down], NCCF at the lag of every state [frames, states], NCCF without
+   ballast at the integer lags [frames, lags], Viterbi states [frames]); the parity tests compare
+   them stage by stage with the oracle's.  Valid until the next call on the plan. */
+int snf_debug_pitch_scratch(snf_plan* plan, void** down, void** nccf_res, void** pov_nccf,
+                            void** states);
 /* Duration in milliseconds of the kernels launched by the last run call on this plan, measured
    with HIP events on the stream the kernels were launched on.  `which` selects a kernel slot:
    0 = whole call, 1.. = per-kernel; returns <0 if the slot was not recorded. */

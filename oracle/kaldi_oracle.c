@@ -64,6 +64,43 @@ static float vecsum(const float* a, int n) {
   for (int i = 0; i < n; i++) s += a[i];
   return s;
 }
+/* Summation orders of the pitch tracker.  Kaldi hands these sums to BLAS (cblas_sdot / sgemv), whose
+ * order and use of fused multiply-adds depend on the library build, so NO order is "the" Kaldi one;
+ * the oracle fixes one that a 16-lane group of a GPU wavefront reproduces bit for bit, and the HIP
+ * kernels (csrc/kernels_pitch.hip) implement exactly the same:
+ *   - chain_dot:  s = fmaf(a[i], b[i], s) for i ascending, from 0 (lag correlations, FIR taps)
+ *   - tree16:     16 partial sums p[0..15] added as a balanced binary tree of neighbours
+ *                 ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)) ... (frame mean, frame energy, norm average),
+ *                 where p[l] runs over the elements l, l+16, l+32, ... ascending */
+static float chain_dot(const float* a, const float* b, int n) {
+  float s = 0.0f;
+  for (int i = 0; i < n; i++) s = fmaf(a[i], b[i], s);
+  return s;
+}
+static float tree16(const float* p) {
+  float a[8], b[4];
+  for (int k = 0; k < 8; k++) a[k] = p[2 * k] + p[2 * k + 1];
+  for (int k = 0; k < 4; k++) b[k] = a[2 * k] + a[2 * k + 1];
+  return (b[0] + b[1]) + (b[2] + b[3]);
+}
+static float strided16_sum(const float* x, int n) {
+  float p[16];
+  for (int l = 0; l < 16; l++) {
+    float s = 0.0f;
+    for (int i = l; i < n; i += 16) s += x[i];
+    p[l] = s;
+  }
+  return tree16(p);
+}
+static float strided16_sumsq(const float* x, int n) {
+  float p[16];
+  for (int l = 0; l < 16; l++) {
+    float s = 0.0f;
+    for (int i = l; i < n; i += 16) s = fmaf(x[i], x[i], s);
+    p[l] = s;
+  }
+  return tree16(p);
+}
 /* Whole-signal sums (tens of thousands of terms): Kaldi hands these to BLAS sdot, whose blocked
  * SIMD accumulation is far more accurate than a sequential float loop; a double accumulator
  * rounded to float is the closest portable stand-in. */
@@ -886,14 +923,10 @@ static void linres_apply(const linres_t* r, const float* in, int64_t n, float* o
     int64_t first_in = r->first[wrapped] + unit * r->in_unit;
     const float* w = r->w[wrapped];
     int nw = r->nw[wrapped];
-    float s = 0.0f;
-    if (first_in >= 0 && first_in + nw <= n) {
-      s = vecvec(in + first_in, w, nw);
-    } else {
-      for (int i = 0; i < nw; i++) {
-        int64_t idx = first_in + i;
-        if (idx >= 0 && idx < n) s += w[i] * in[idx];
-      }
+    float s = 0.0f;  /* chain_dot over the taps that fall inside the signal */
+    for (int i = 0; i < nw; i++) {
+      int64_t idx = first_in + i;
+      if (idx >= 0 && idx < n) s = fmaf(w[i], in[idx], s);
     }
     out[k] = s;
   }
@@ -1059,8 +1092,12 @@ static void compute_backtraces(const pitchcfg_t* c, const float* nccf_pitch, con
 }
 
 /* ComputeKaldiPitch, offline single-chunk call (frames_per_chunk = 0): AcceptWaveform(whole wave)
- * without flush, then InputFinished() flushes the resampler and processes the last frames. */
-ORC_API int orc_pitch(const snf_pitch_options* o, const int16_t* wave16, int64_t n, float* out) {
+ * without flush, then InputFinished() flushes the resampler and processes the last frames.
+ * The optional debug outputs receive the intermediates the GPU path can be compared with stage by
+ * stage: the resampled signal [n_down], the lag-resampled NCCF [T, S], the NCCF without ballast at
+ * the integer lags [T, L] and the Viterbi states [T]. */
+static int pitch_impl(const snf_pitch_options* o, const int16_t* wave16, int64_t n, float* out,
+                      float* dbg_down, float* dbg_res, float* dbg_pov, int32_t* dbg_states) {
   pitchcfg_t c;
   int rc = pitchcfg_init(&c, o);
   if (rc) return rc;
@@ -1076,22 +1113,26 @@ ORC_API int orc_pitch(const snf_pitch_options* o, const int16_t* wave16, int64_t
   for (int64_t i = 0; i < n; i++) wave[i] = (float)wave16[i];
   float* down = (float*)malloc(sizeof(float) * (size_t)n_down);
   linres_apply(&lr, wave, n, down, n_down);
+  if (dbg_down) memcpy(dbg_down, down, sizeof(float) * (size_t)n_down);
   /* signal statistics: phase 1 sees down[0:n_down_p1], phase 2 everything (double accumulators
      += float VecVec / Sum of each chunk) */
   double sumsq1 = (double)vecvec_long(down, down, n_down_p1), sum1 = (double)vecsum_long(down, n_down_p1);
   double sumsq2 = sumsq1 + (double)vecvec_long(down + n_down_p1, down + n_down_p1, n_down - n_down_p1);
   double sum2 = sum1 + (double)vecsum_long(down + n_down_p1, n_down - n_down_p1);
+  /* (x * x instead of pow(x, 2.0): both are the correctly rounded square) */
+  double m1 = n_down_p1 > 0 ? sum1 / (double)n_down_p1 : 0.0, m2 = sum2 / (double)n_down;
+  double ms1 = n_down_p1 > 0 ? sumsq1 / (double)n_down_p1 - m1 * m1 : 0.0;
+  double ms2 = sumsq2 / (double)n_down - m2 * m2;
 
-  int S = c.num_states, L = c.num_lags;
-  float* window = (float*)malloc(sizeof(float) * (size_t)c.full_len);
+  int S = c.num_states, L = c.num_lags, W = c.win_size;
+  float* window = (float*)calloc((size_t)c.full_len + 16, sizeof(float));
   float* inner = (float*)malloc(sizeof(float) * (size_t)L);
   float* norm = (float*)malloc(sizeof(float) * (size_t)L);
   float* nccf_pitch = (float*)malloc(sizeof(float) * (size_t)L);
   float* nccf_pov = (float*)malloc(sizeof(float) * (size_t)L);
   float* pitch_res = (float*)malloc(sizeof(float) * (size_t)T * S);
   float* pov_res = (float*)malloc(sizeof(float) * (size_t)T * S);
-  double* ms_frame = (double*)malloc(sizeof(double) * (size_t)T);
-  double* anp_frame = (double*)malloc(sizeof(double) * (size_t)T);
+  float* anp_frame = (float*)malloc(sizeof(float) * (size_t)T);
   int* bp = (int*)malloc(sizeof(int) * (size_t)T * S);
   int* lo = (int*)malloc(sizeof(int) * (size_t)S);
   int* hi = (int*)malloc(sizeof(int) * (size_t)S);
@@ -1099,9 +1140,7 @@ ORC_API int orc_pitch(const snf_pitch_options* o, const int16_t* wave16, int64_t
   float* nfwd = (float*)calloc((size_t)S, sizeof(float));
 
   for (int64_t t = 0; t < T; t++) {
-    int phase1 = t < T1;
-    double cur_sumsq = phase1 ? sumsq1 : sumsq2, cur_sum = phase1 ? sum1 : sum2;
-    double cur_n = (double)(phase1 ? n_down_p1 : n_down);
+    double mean_square = t < T1 ? ms1 : ms2;
     int64_t start;
     if (o->snip_edges) start = t * c.win_shift;
     else start = (int64_t)(((double)t + 0.5) * c.win_shift) - c.full_len / 2;
@@ -1109,33 +1148,41 @@ ORC_API int orc_pitch(const snf_pitch_options* o, const int16_t* wave16, int64_t
       int64_t k = start + i;
       window[i] = (k >= 0 && k < n_down) ? down[k] : 0.0f;
     }
-    double mean_square = cur_sumsq / cur_n - pow(cur_sum / cur_n, 2.0);
-    /* ComputeCorrelation */
-    float m = -vecsum(window, c.win_size) / (float)c.win_size;
+    /* ComputeCorrelation: mean of the first W samples removed from the whole window */
+    float m = -strided16_sum(window, W) / (float)W;
     for (int i = 0; i < c.full_len; i++) window[i] += m;
-    float e1 = vecvec(window, window, c.win_size);
+    float e1 = strided16_sumsq(window, W);
     for (int lag = c.first_lag; lag <= c.last_lag; lag++) {
-      float e2 = vecvec(window + lag, window + lag, c.win_size);
-      float sum = vecvec(window, window + lag, c.win_size);
-      inner[lag - c.first_lag] = sum;
-      norm[lag - c.first_lag] = e1 * e2;
+      inner[lag - c.first_lag] = chain_dot(window, window + lag, W);
+      norm[lag - c.first_lag] = e1 * chain_dot(window + lag, window + lag, W);
     }
-    double ballast_pitch = pow(mean_square * c.win_size, 2) * (double)o->nccf_ballast;
-    double avg_norm_prod = (double)(vecsum(norm, L) / (float)L);
-    float bal = (float)ballast_pitch;
+    /* ComputeNccf: sqrtf == (float)pow((double)x, 0.5) up to the rounding of pow */
+    float bal = (float)((mean_square * W) * (mean_square * W) * (double)o->nccf_ballast);
     for (int l = 0; l < L; l++) {
-      float den = (float)pow((double)(norm[l] + bal), 0.5);
+      float den = sqrtf(norm[l] + bal);
       nccf_pitch[l] = den != 0.0f ? inner[l] / den : 0.0f;
-      float den2 = (float)pow((double)(norm[l] + 0.0f), 0.5);
+      float den2 = sqrtf(norm[l]);
       nccf_pov[l] = den2 != 0.0f ? inner[l] / den2 : 0.0f;
     }
-    ms_frame[t] = mean_square; anp_frame[t] = avg_norm_prod;
+    /* avg_norm_prod: lane l of the 16 owns the lags 5 (l + 16 g) .. + 4, g = 0, 1, ... */
+    {
+      float p[16];
+      for (int l16 = 0; l16 < 16; l16++) {
+        float sacc = 0.0f;
+        for (int g = 0; 5 * (l16 + 16 * g) < L; g++)
+          for (int d = 0; d < 5 && 5 * (l16 + 16 * g) + d < L; d++) sacc += norm[5 * (l16 + 16 * g) + d];
+        p[l16] = sacc;
+      }
+      anp_frame[t] = tree16(p) / (float)L;
+    }
+    if (dbg_pov) memcpy(dbg_pov + t * L, nccf_pov, sizeof(float) * (size_t)L);
     /* ArbitraryResample::Resample (AddMatVec per output column) */
     for (int s = 0; s < S; s++) {
-      pitch_res[t * S + s] = vecvec(nccf_pitch + c.ar_first[s], c.ar_w[s], c.ar_n[s]);
-      pov_res[t * S + s] = vecvec(nccf_pov + c.ar_first[s], c.ar_w[s], c.ar_n[s]);
+      pitch_res[t * S + s] = chain_dot(nccf_pitch + c.ar_first[s], c.ar_w[s], c.ar_n[s]);
+      pov_res[t * S + s] = chain_dot(nccf_pov + c.ar_first[s], c.ar_w[s], c.ar_n[s]);
     }
   }
+  if (dbg_res) memcpy(dbg_res, pitch_res, sizeof(float) * (size_t)T * S);
   /* Viterbi forward */
   for (int64_t t = 0; t < T; t++) {
     compute_backtraces(&c, pitch_res + t * S, fwd, bp + t * S, nfwd, lo, hi);
@@ -1147,21 +1194,21 @@ ORC_API int orc_pitch(const snf_pitch_options* o, const int16_t* wave16, int64_t
   }
   /* InputFinished(): RecomputeBacktraces when the utterance is shorter than recompute_frame */
   if (T < o->recompute_frame) {
-    double num_samp = (double)n_down, mean = sum2 / num_samp;
-    float mean_square = (float)(sumsq2 / num_samp - mean * mean);
+    float mean_square = (float)ms2;
     int must = 0;
     for (int64_t t = 0; t < T; t++) {
       /* ApproxEqual(a, b, 0.01): |a-b| <= 0.01 * (|a|+|b|) */
-      float a = (float)ms_frame[t], b = mean_square;
+      float a = (float)(t < T1 ? ms1 : ms2), b = mean_square;
       if (!(fabsf(a - b) <= 0.01f * (fabsf(a) + fabsf(b)))) must = 1;
     }
     if (must) {
-      float new_ballast = (float)(pow((double)mean_square * c.win_size, 2) * (double)o->nccf_ballast);
+      float new_ballast = (float)(((double)mean_square * W) * ((double)mean_square * W) * (double)o->nccf_ballast);
       for (int s = 0; s < S; s++) fwd[s] = 0.0f;
       for (int64_t t = 0; t < T; t++) {
-        float old_ms = (float)ms_frame[t], anp = (float)anp_frame[t];
-        float old_ballast = (float)(pow((double)old_ms * c.win_size, 2) * (double)o->nccf_ballast);
-        float scale = powf((old_ballast + anp) / (new_ballast + anp), 0.5f);
+        float old_ms = (float)(t < T1 ? ms1 : ms2), anp = anp_frame[t];
+        float old_ballast = (float)(((double)old_ms * W) * ((double)old_ms * W) * (double)o->nccf_ballast);
+        /* sqrtf == powf(x, 0.5f) up to the rounding of powf */
+        float scale = sqrtf((old_ballast + anp) / (new_ballast + anp));
         for (int s = 0; s < S; s++) pitch_res[t * S + s] *= scale;
         compute_backtraces(&c, pitch_res + t * S, fwd, bp + t * S, nfwd, lo, hi);
         float* sw = fwd; fwd = nfwd; nfwd = sw;
@@ -1177,13 +1224,21 @@ ORC_API int orc_pitch(const snf_pitch_options* o, const int16_t* wave16, int64_t
   for (int64_t t = T - 1; t >= 0; t--) {
     out[t * 2 + 0] = pov_res[t * S + best];
     out[t * 2 + 1] = 1.0f / c.lags[best];
+    if (dbg_states) dbg_states[t] = best;
     best = bp[t * S + best];
   }
   free(wave); free(down); free(window); free(inner); free(norm); free(nccf_pitch); free(nccf_pov);
-  free(pitch_res); free(pov_res); free(ms_frame); free(anp_frame); free(bp); free(lo); free(hi);
+  free(pitch_res); free(pov_res); free(anp_frame); free(bp); free(lo); free(hi);
   free(fwd); free(nfwd);
   linres_free(&lr); pitchcfg_free(&c);
   return 0;
+}
+ORC_API int orc_pitch(const snf_pitch_options* o, const int16_t* wave16, int64_t n, float* out) {
+  return pitch_impl(o, wave16, n, out, NULL, NULL, NULL, NULL);
+}
+ORC_API int orc_pitch_debug(const snf_pitch_options* o, const int16_t* wave16, int64_t n, float* out,
+                            float* down, float* res, float* pov, int32_t* states) {
+  return pitch_impl(o, wave16, n, out, down, res, pov, states);
 }
 
 /* exported for tests: lags table, resampled signal */

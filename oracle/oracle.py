@@ -64,6 +64,7 @@ def lib():
     L.orc_pitch_num_frames.argtypes = [PO, i64]
     L.orc_pitch_num_frames.restype = i64
     L.orc_pitch.argtypes = [PO, C.POINTER(C.c_int16), i64, pf]
+    L.orc_pitch_debug.argtypes = [PO, C.POINTER(C.c_int16), i64, pf, pf, pf, pf, C.POINTER(C.c_int32)]
     L.orc_pitch_lags.argtypes = [PO, pf, C.POINTER(i32), C.POINTER(i32)]
     L.orc_linear_resample.argtypes = [i32, i32, f32, i32, pf, i64, pf, i32]
     L.orc_linear_resample.restype = i64
@@ -235,6 +236,26 @@ def pitch(pitch_opts, wave):
     if nframes == 0:
         return np.zeros((0, 0), dtype=np.float32)
     return out
+
+
+def pitch_debug(pitch_opts, wave):
+    """(out, down, nccf_res [T, S], pov_nccf [T, L], states [T]): the intermediates of `pitch`"""
+    wave = np.ascontiguousarray(wave, dtype=np.int16)
+    T = pitch_num_frames(pitch_opts, wave.shape[0])
+    lags, first, last = pitch_lags(pitch_opts)
+    S, L = lags.shape[0], last - first + 1
+    n_down = lib().orc_linear_resample(
+        int(pitch_opts.samp_freq), int(pitch_opts.resample_freq), pitch_opts.lowpass_cutoff,
+        int(pitch_opts.lowpass_filter_width), None, wave.shape[0], None, 1)
+    out = np.zeros((max(T, 0), 2), dtype=np.float32)
+    down = np.zeros(max(n_down, 1), dtype=np.float32)
+    res = np.zeros((max(T, 1), S), dtype=np.float32)
+    pov = np.zeros((max(T, 1), L), dtype=np.float32)
+    states = np.zeros(max(T, 1), dtype=np.int32)
+    _check(lib().orc_pitch_debug(
+        C.byref(pitch_opts), wave.ctypes.data_as(C.POINTER(C.c_int16)), wave.shape[0], _fp(out),
+        _fp(down), _fp(res), _fp(pov), states.ctypes.data_as(C.POINTER(C.c_int32))))
+    return out, down[:n_down], res[:T], pov[:T], states[:T]
 
 
 def pitch_lags(pitch_opts):

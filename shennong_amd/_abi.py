@@ -127,6 +127,7 @@ class Options(C.Structure):
         ('compression', C.c_int32),
         ('delta_order', C.c_int32),
         ('delta_window', C.c_int32),
+        ('append_deltas', C.c_int32),
         ('pitch', PitchOptions),
         ('pitch_post', PitchPostOptions),
         ('vad', VadOptions),
@@ -191,6 +192,7 @@ def default_options(kind):
     opts.compression = COMPRESSION['log']
     opts.delta_order = 2
     opts.delta_window = 2
+    opts.append_deltas = 0
     opts.pitch = default_pitch_options()
     opts.pitch_post = default_pitch_post_options()
     opts.vad = VadOptions(

@@ -33,7 +33,10 @@ EXPORTS = [
     'snf_cmvn_accumulate', 'snf_cmvn_apply', 'snf_cmvn_accumulate_device',
     'snf_cmvn_apply_device', 'snf_concat_columns_device',
     'snf_malloc', 'snf_free', 'snf_memcpy_h2d', 'snf_memcpy_d2h', 'snf_memset',
-    'snf_host_malloc', 'snf_host_free', 'snf_debug_fill_lds',
+    'snf_host_malloc', 'snf_host_free', 'snf_debug_fill_lds', 'snf_debug_pitch_scratch',
+    'snf_stream_create', 'snf_stream_destroy', 'snf_stream_synchronize', 'snf_memcpy_h2d_async',
+    'snf_memcpy_d2h_async', 'snf_comm_unique_id', 'snf_comm_init', 'snf_comm_rank', 'snf_comm_world_size',
+    'snf_comm_destroy', 'snf_comm_gatherv', 'snf_comm_allreduce_f64',
     'snf_plan_last_kernel_ms', 'snf_plan_kernel_name']
 
 
@@ -102,6 +105,19 @@ def lib():
         L.snf_host_malloc.argtypes = [C.POINTER(vp), C.c_uint64]
         L.snf_host_free.argtypes = [vp]
         L.snf_debug_fill_lds.argtypes = [C.c_uint32]
+        L.snf_debug_pitch_scratch.argtypes = [vp] + [C.POINTER(vp)] * 4
+        L.snf_stream_create.argtypes = [C.POINTER(vp)]
+        L.snf_stream_destroy.argtypes = [vp]
+        L.snf_stream_synchronize.argtypes = [vp]
+        L.snf_memcpy_h2d_async.argtypes = [vp, vp, C.c_uint64, vp]
+        L.snf_memcpy_d2h_async.argtypes = [vp, vp, C.c_uint64, vp]
+        L.snf_comm_unique_id.argtypes = [vp]
+        L.snf_comm_init.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+        L.snf_comm_rank.argtypes = [vp]
+        L.snf_comm_world_size.argtypes = [vp]
+        L.snf_comm_destroy.argtypes = [vp]
+        L.snf_comm_gatherv.argtypes = [vp, vp, i64, vp, pi64, i32, vp]
+        L.snf_comm_allreduce_f64.argtypes = [vp, vp, i64, i32, vp]
         L.snf_plan_last_kernel_ms.argtypes = [vp, i32]
         L.snf_plan_last_kernel_ms.restype = f32
         L.snf_plan_kernel_name.argtypes = [vp, i32]

@@ -1,0 +1,189 @@
+"""Torch-free multi-GPU transport: RCCL through the C ABI (``snf_comm_*``, include/shennong_amd.h).
+
+One process per GPU.  The data path (feature blocks, CMVN statistics) goes over RCCL / xGMI with
+device pointers; what little host metadata the ranks need to agree on (names and shapes of the blocks,
+the RCCL unique id) travels over plain TCP sockets to rank 0, opened from the rendezvous variables a
+launcher such as ``torch.distributed.run`` exports (``RANK``, ``WORLD_SIZE``, ``LOCAL_RANK``,
+``MASTER_ADDR``, ``MASTER_PORT``) - the launcher is only a process spawner here, torch is never
+imported.
+
+An ``RcclComm`` can be passed wherever ``shennong_amd.distributed`` takes a ``group``.
+"""
+
+import ctypes as C
+import os
+import pickle
+import socket
+import struct
+import time
+
+import numpy as np
+
+from shennong_amd import _backend
+
+_PORT_OFFSET = 1017   # rendezvous port = MASTER_PORT + this (MASTER_PORT itself belongs to the launcher)
+
+
+def _send_msg(sock, payload):
+    sock.sendall(struct.pack('<Q', len(payload)) + payload)
+
+
+def _recv_msg(sock):
+    def read(n):
+        chunks = []
+        while n:
+            chunk = sock.recv(min(n, 1 << 20))
+            if not chunk:
+                raise ConnectionError('peer closed the rendezvous socket')
+            chunks.append(chunk)
+            n -= len(chunk)
+        return b''.join(chunks)
+    (size,) = struct.unpack('<Q', read(8))
+    return read(size)
+
+
+class RcclComm:
+    """Communicator of `world_size` processes, one GPU each"""
+    def __init__(self, rank, world_size, device=None, addr='127.0.0.1', port=29500, timeout=120.0):
+        self.rank, self.world_size = int(rank), int(world_size)
+        self.device = _backend.get_device() if device is None else int(device)
+        self._peers = {}     # rank 0: rank -> socket; others: {0: socket}
+        self._handle = C.c_void_p()
+        lib = _backend.lib()
+        ident = (C.c_char * 128)()
+        if self.rank == 0:
+            _backend.check(lib.snf_comm_unique_id(ident))
+            if self.world_size > 1:
+                server = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                server.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                server.bind((addr, port))
+                server.listen(self.world_size)
+                server.settimeout(timeout)
+                while len(self._peers) < self.world_size - 1:
+                    conn, _ = server.accept()
+                    conn.settimeout(timeout)
+                    peer = pickle.loads(_recv_msg(conn))
+                    self._peers[peer] = conn
+                server.close()
+                for conn in self._peers.values():
+                    _send_msg(conn, bytes(ident))
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    conn = socket.create_connection((addr, port), timeout=timeout)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            conn.settimeout(timeout)
+            _send_msg(conn, pickle.dumps(self.rank))
+            C.memmove(ident, _recv_msg(conn), 128)
+            self._peers[0] = conn
+        _backend.check(lib.snf_comm_init(ident, self.world_size, self.rank, self.device,
+                                         C.byref(self._handle)))
+
+    @classmethod
+    def from_env(cls, device=None):
+        """Communicator described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT"""
+        rank = int(os.environ.get('RANK', '0'))
+        local = int(os.environ.get('LOCAL_RANK', str(rank)))
+        return cls(rank, int(os.environ.get('WORLD_SIZE', '1')),
+                   device=local if device is None else device,
+                   addr=os.environ.get('MASTER_ADDR', '127.0.0.1'),
+                   port=int(os.environ.get('MASTER_PORT', '29500')) + _PORT_OFFSET)
+
+    def close(self):
+        if self._handle:
+            _backend.lib().snf_comm_destroy(self._handle)
+            self._handle = C.c_void_p()
+        for conn in self._peers.values():
+            conn.close()
+        self._peers = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: nocover
+            pass
+
+    # ---- host metadata (small python objects) over the rendezvous sockets ---------------------------
+    def all_gather_object(self, obj):
+        """[obj of rank 0, obj of rank 1, ...] on every rank"""
+        if self.world_size == 1:
+            return [obj]
+        if self.rank == 0:
+            objs = [obj] + [None] * (self.world_size - 1)
+            for peer, conn in self._peers.items():
+                objs[peer] = pickle.loads(_recv_msg(conn))
+            payload = pickle.dumps(objs)
+            for conn in self._peers.values():
+                _send_msg(conn, payload)
+            return objs
+        _send_msg(self._peers[0], pickle.dumps(obj))
+        return pickle.loads(_recv_msg(self._peers[0]))
+
+    # ---- device data over RCCL -------------------------------------------------------------------------
+    def gatherv_device(self, d_send, send_count, d_recv, recv_counts, root=0):
+        """Device pointers in and out (see snf_comm_gatherv); `recv_counts` is needed on the root"""
+        counts = None
+        if self.rank == root:
+            counts = np.ascontiguousarray(recv_counts, dtype=np.int64)
+        _backend.check(_backend.lib().snf_comm_gatherv(
+            self._handle, C.c_void_p(d_send), int(send_count), C.c_void_p(d_recv),
+            counts.ctypes.data_as(C.POINTER(C.c_int64)) if counts is not None else None,
+            int(root), None))
+
+    def allreduce(self, array, op='sum'):
+        """Element-wise sum / max of a float64 array over the ranks (through a device buffer)"""
+        host = np.ascontiguousarray(array, dtype=np.float64)
+        if host.size == 0:
+            return host.copy()
+        buf = _backend.DeviceBuffer(host.nbytes, device=self.device)
+        try:
+            buf.upload(host)
+            _backend.check(_backend.lib().snf_comm_allreduce_f64(
+                self._handle, C.c_void_p(buf.ptr), host.size, {'sum': 0, 'max': 1}[op], None))
+            out = np.empty_like(host)
+            buf.download(out)
+        finally:
+            buf.free()
+        return out
+
+    def barrier(self):
+        self.allreduce(np.zeros(1), 'max')
+
+    def gather_features(self, local, dst=0):
+        """``{name: float32 [nframes, ndims]}`` of every rank merged on rank `dst` (None elsewhere):
+        one contiguous block per peer, point to point to the root"""
+        names = list(local.keys())
+        shapes = [tuple(local[n].shape) for n in names]
+        meta = self.all_gather_object((names, shapes))
+        sizes = [sum(int(np.prod(s)) for s in m[1]) for m in meta]
+        flat = np.concatenate([np.ascontiguousarray(local[n], dtype=np.float32).reshape(-1)
+                               for n in names]) if names else np.zeros(0, np.float32)
+        d_send = _backend.DeviceBuffer(max(flat.nbytes, 16), device=self.device)
+        d_recv = None
+        try:
+            if flat.size:
+                d_send.upload(flat)
+            if self.rank == dst:
+                d_recv = _backend.DeviceBuffer(max(4 * sum(sizes), 16), device=self.device)
+            self.gatherv_device(d_send.ptr, flat.size, d_recv.ptr if d_recv else None, sizes, dst)
+            if self.rank != dst:
+                return None
+            host = np.empty(sum(sizes), dtype=np.float32)
+            if host.size:
+                d_recv.download(host)
+        finally:
+            d_send.free()
+            if d_recv is not None:
+                d_recv.free()
+        merged, pos = {}, 0
+        for names_r, shapes_r in meta:
+            for name, shape in zip(names_r, shapes_r):
+                n = int(np.prod(shape))
+                merged[name] = host[pos:pos + n].reshape(shape).copy()
+                pos += n
+        return merged

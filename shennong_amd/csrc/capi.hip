@@ -91,6 +91,7 @@ struct snf_plan {
   // scratch (host-pointer entry points and intermediates)
   DevBuf s_wave, s_out, s_in, s_soff, s_foff, s_uwarp, s_mel, s_energy;
   DevBuf s_down, s_stats, s_bp, s_doff, s_dp1, s_fp1, s_states, s_setidx, s_edge, s_futt;
+  DevBuf s_pres, s_anp;  // pitch: NCCF at the lag of every state [frames, states], norm average [frames]
   bool setidx_valid = false;
 
   // last uploaded offsets tables (re-validated / re-uploaded only when they change)
@@ -211,7 +212,9 @@ int build_mel_plan(snf_plan* plan) {
       plan->ndims = o.mel.num_bins + (o.use_energy ? 1 : 0);
       break;
     case SNF_KIND_MFCC:
-      plan->ndims = o.num_ceps;
+      plan->ndims = o.append_deltas ? 3 * o.num_ceps : o.num_ceps;
+      if (o.append_deltas && (o.delta_order != 2 || o.delta_window != 2))
+        return set_error(SNF_E_INVALID, "append_deltas supports delta_order 2 / delta_window 2 only");
       break;
     case SNF_KIND_PLP:
       plan->ndims = o.num_ceps;
@@ -281,6 +284,10 @@ int build_mel_plan(snf_plan* plan) {
     }
   }
   p.ndims = plan->ndims;
+  const bool want_fused = plan->kind == SNF_KIND_MFCC && o.append_deltas;
+  if (want_fused && (!fast512_eligible(p, false) || o.num_ceps > 16))
+    return set_error(SNF_E_INVALID, "append_deltas needs frames that pad to 512 samples (the register-"
+                                    "resident path); chain a delta plan for this configuration");
   if (fast512_eligible(p, false)) {
     std::vector<float> dct_h, lifter_h, blob;
     if (plan->kind == SNF_KIND_MFCC) {
@@ -295,6 +302,14 @@ int build_mel_plan(snf_plan* plan) {
       if ((rc = plan->d_fast_tables.upload(blob, plan->stream))) return rc;
       plan->fp.tables = plan->d_fast_tables.as<float>();
       plan->fast512 = true;
+      if (plan->kind == SNF_KIND_MFCC && o.append_deltas) {
+        std::vector<float> scales;
+        std::vector<int> dims;
+        make_delta_scales(2, 2, &scales, &dims);
+        if ((rc = plan->d_scales.upload(scales, plan->stream))) return rc;
+        plan->fp.fused_delta = 1;
+        plan->fp.delta_scales = plan->d_scales.as<float>();
+      }
       plan->h_window = window;
       plan->h_dct = dct_h;
       plan->h_lifter = lifter_h;
@@ -368,6 +383,8 @@ int sync_fast_warp_tables(snf_plan* plan) {
   int rc;
   if ((rc = plan->d_fast_warp_tables.upload(all, plan->stream))) return rc;
   plan->fp_warp = fp0;
+  plan->fp_warp.fused_delta = plan->fp.fused_delta;
+  plan->fp_warp.delta_scales = plan->fp.delta_scales;
   plan->fp_warp.tables = plan->d_fast_warp_tables.as<float>();
   plan->fp_warp.table_stride = static_cast<int>(stride);
   plan->fast_warps_built = plan->banks.size();
@@ -553,12 +570,15 @@ int run_pitch_device(snf_plan* plan, const int16_t* d_wave, const int64_t* sampl
     });
     if ((rc = plan->s_uwarp.upload(order, s))) return rc;
   }
+  const size_t nf = static_cast<size_t>(total_frames);
   if ((rc = plan->s_down.ensure(sizeof(float) * static_cast<size_t>(total_down > 0 ? total_down : 1)))) return rc;
-  if ((rc = plan->s_stats.ensure(sizeof(double) * 4 * static_cast<size_t>(n_utts)))) return rc;
-  if ((rc = plan->s_bp.ensure(sizeof(int16_t) * static_cast<size_t>(total_frames) * plan->pd.num_states))) return rc;
-  if ((rc = plan->s_states.ensure(sizeof(int32_t) * static_cast<size_t>(total_frames)))) return rc;
-  if ((rc = plan->s_mel.ensure(sizeof(float) * static_cast<size_t>(total_frames) * plan->pd.num_lags)))
-    return rc;
+  if ((rc = plan->s_stats.ensure(sizeof(float) * 6 * static_cast<size_t>(n_utts)))) return rc;
+  if ((rc = plan->s_bp.ensure(sizeof(int16_t) * nf * plan->pd.num_states))) return rc;
+  if ((rc = plan->s_states.ensure(sizeof(int32_t) * nf))) return rc;
+  if ((rc = plan->s_mel.ensure(sizeof(float) * nf * plan->pd.num_lags))) return rc;
+  if ((rc = plan->s_pres.ensure(sizeof(float) * nf * plan->pd.num_states))) return rc;
+  if ((rc = plan->s_anp.ensure(sizeof(float) * nf))) return rc;
+  if ((rc = plan->s_futt.ensure(sizeof(int32_t) * nf))) return rc;
   SNF_HIP_CHECK(hipStreamSynchronize(s));  // host vectors above go out of scope after launch setup
   PitchBatch b{};
   b.wave = d_wave;
@@ -572,9 +592,16 @@ int run_pitch_device(snf_plan* plan, const int16_t* d_wave, const int64_t* sampl
   b.total_frames = total_frames;
   b.total_down = total_down;
   b.max_down = max_down;
-  return launch_pitch(plan->pd, b, plan->s_down.as<float>(), plan->s_stats.as<double>(),
-                      plan->s_bp.as<int16_t>(), plan->s_states.as<int32_t>(), plan->s_mel.as<float>(),
-                      d_out, s);
+  PitchScratch w{};
+  w.down = plan->s_down.as<float>();
+  w.ub = plan->s_stats.as<float>();
+  w.nccf_res = plan->s_pres.as<float>();
+  w.pov_nccf = plan->s_mel.as<float>();
+  w.anp = plan->s_anp.as<float>();
+  w.backptr = plan->s_bp.as<int16_t>();
+  w.states = plan->s_states.as<int32_t>();
+  w.frame_utt = plan->s_futt.as<int32_t>();
+  return launch_pitch(plan->pd, b, w, d_out, s);
 }
 
 }  // namespace
@@ -802,9 +829,13 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
       if (n > 0 && n < plan->mp.win_len) use_fast = false;
     }
   }
-  if (use_fast && any_warp) {
+  const bool fused = plan->fp.fused_delta != 0;
+  if (fused && !use_fast)
+    return set_error(SNF_E_RUNTIME, "append_deltas: this batch cannot run on the 512-point path");
+  if (use_fast && (any_warp || fused)) {
     // workgroup -> (utterance, first frame set) list: every workgroup stages the tables of one warp
-    constexpr int kSetsPerBlock = 64;  // (kernels_fbank512.hip)
+    // (fused deltas: a workgroup owns a run of frames of one utterance + their delta halo)
+    const int kSetsPerBlock = fused ? kFast512FusedSets : 64;  // (kernels_fbank512.hip)
     std::vector<int32_t> blk_utt, blk_set0;
     for (int64_t u = 0; u < n_utts; ++u) {
       const int64_t sets = (frame_offsets[u + 1] - frame_offsets[u] + 3) / 4;
@@ -829,6 +860,8 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
                                        plan->mp.snip_edges, plan->s_setidx.as<int64_t>(),
                                        plan->s_edge.as<int32_t>(), plan->s_futt.as<int32_t>(), s)))
       return rc;
+    // (the tables are cached: a later call may come in on another stream, so they must be complete)
+    if (!own_stream) SNF_HIP_CHECK(hipStreamSynchronize(s));
     plan->setidx_valid = true;
   }
   b.frame_start = plan->s_setidx.as<int64_t>();
@@ -941,8 +974,9 @@ int snf_post_run_batch_device(snf_plan* plan, const float* d_in, int32_t in_cols
   if (own_stream) begin_timing(plan);
   if (plan->kind == SNF_KIND_DELTA) {
     if (in_cols <= 0) return set_error(SNF_E_INVALID, "in_cols must be positive");
+    if ((rc = plan->s_futt.ensure(sizeof(int32_t) * static_cast<size_t>(total_frames / 256 + 2)))) return rc;
     if ((rc = launch_deltas(plan->dp, d_in, in_cols, plan->s_foff.as<int64_t>(), n_utts,
-                            total_frames, d_out, s)))
+                            total_frames, d_out, plan->s_futt.as<int32_t>(), s)))
       return rc;
     if (own_stream) mark_kernel(plan, "delta_kernel");
   } else if (plan->kind == SNF_KIND_PITCH_POST) {
@@ -1249,6 +1283,29 @@ int snf_memcpy_d2h(void* dst, const void* src, uint64_t bytes) {
   SNF_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return SNF_OK;
 }
+int snf_stream_create(void** stream) {
+  if (!stream) return set_error(SNF_E_INVALID, "null pointer");
+  hipStream_t s;
+  SNF_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = s;
+  return SNF_OK;
+}
+int snf_stream_destroy(void* stream) {
+  if (stream) SNF_HIP_CHECK(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+  return SNF_OK;
+}
+int snf_stream_synchronize(void* stream) {
+  SNF_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return SNF_OK;
+}
+int snf_memcpy_h2d_async(void* dst, const void* src, uint64_t bytes, void* stream) {
+  SNF_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+  return SNF_OK;
+}
+int snf_memcpy_d2h_async(void* dst, const void* src, uint64_t bytes, void* stream) {
+  SNF_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+  return SNF_OK;
+}
 int snf_memset(void* dst, int value, uint64_t bytes) {
   SNF_HIP_CHECK(hipMemset(dst, value, bytes));
   return SNF_OK;
@@ -1263,6 +1320,15 @@ __global__ __launch_bounds__(256) void lds_fill_kernel(unsigned pattern, int wor
 }
 }  // namespace
 
+int snf_debug_pitch_scratch(snf_plan* plan, void** down, void** nccf_res, void** pov_nccf,
+                            void** states) {
+  if (!plan || plan->kind != SNF_KIND_PITCH) return set_error(SNF_E_INVALID, "not a pitch plan");
+  if (down) *down = plan->s_down.p;
+  if (nccf_res) *nccf_res = plan->s_pres.p;
+  if (pov_nccf) *pov_nccf = plan->s_mel.p;
+  if (states) *states = plan->s_states.p;
+  return SNF_OK;
+}
 int snf_debug_fill_lds(uint32_t pattern) {
   // two 80 KB workgroups cover the 160 KB of a CU; many more workgroups than CUs so that every CU
   // (and both halves of its LDS) is visited

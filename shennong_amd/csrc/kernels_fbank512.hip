@@ -138,6 +138,10 @@ constexpr int kTileRow = 17;               // complex per transposed row (16 + 1
 constexpr int kFrameTileBytes = 16 * kTileRow * 8;  // wave-private LDS per frame (2176 B)
 constexpr int kFastHeaderFloats = 16;          // table header: the mel layout of this warp factor
 constexpr int kSetsPerBlock = 64;              // PERUTT: frame sets (of 4 frames) per workgroup
+constexpr int kFusedWaves = 14;                // fused deltas: 14 waves x 6 sets = 82 sets + one halo set on
+constexpr int kFusedSets = kFast512FusedSets;                 // each side (the +-4 frames the delta-delta reaches); a 3 s
+                                               // utterance (75 sets) is one workgroup without any halo
+constexpr int kFusedCols = 16;                 // cepstra per row of the LDS buffer (num_ceps <= 16)
 
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -230,13 +234,18 @@ __device__ __forceinline__ void fft16(float2 (&v)[16]) {
 }  // namespace
 
 // ENERGY: 0 = no log-energy column, 1 = raw (before pre-emphasis/window), 2 = after the window
-template <int NJ, int KIND, int ENERGY, bool DITHER, bool SNIP, bool PERUTT>
+template <int NJ, int KIND, int ENERGY, bool DITHER, bool SNIP, int MODE>
 __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast512Params p,
                                                                    const BatchArgs b,
                                                                    float* __restrict__ out,
                                                                    double* __restrict__ energy_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tab = reinterpret_cast<float*>(smem);
+  // MODE 0: flat (sets of 4 consecutive global frames, grid-stride).  MODE 1 / 2: PERUTT scheduling.
+  // MODE 2 (MFCC only) additionally keeps the cepstra of the workgroup's frames in LDS and writes
+  // [cepstra | delta | delta-delta] rows (BASELINE config 3: no [T, 13] round trip through HBM).
+  constexpr bool PERUTT = MODE != 0, FUSED = MODE == 2;
+  const int sets_per_block = FUSED ? kFusedSets : kSetsPerBlock;
   // PERUTT (utterances with VTLN warps): a workgroup works on a run of frame sets of ONE utterance
   // and stages the tables of that utterance's warp factor; its mel layout comes from the table header
   // instead of the kernel arguments.
@@ -312,9 +321,13 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
   int64_t set_stride = static_cast<int64_t>(gridDim.x) * n_waves;
   if (PERUTT) {
     const int64_t utt_sets = (pu_T + 3) >> 2;
-    n_sets = pu_set0 + kSetsPerBlock < utt_sets ? pu_set0 + kSetsPerBlock : utt_sets;
+    const int64_t end = pu_set0 + sets_per_block + (FUSED ? 1 : 0);  // (+ the halo set behind)
+    n_sets = end < utt_sets ? end : utt_sets;
     set_stride = n_waves;
   }
+  // fused deltas: cepstra of the local frames [4 pu_set0 - 4, 4 pu_set0 + 4 kFusedSets + 4)
+  float* cepbuf = reinterpret_cast<float*>(smem + tab_bytes + n_waves * 4 * kFrameTileBytes);
+  const int64_t cep_frame0 = static_cast<int64_t>(pu_set0) * 4 - 4;
   typedef int __attribute__((aligned(2))) int_a2;
   const int64_t last_frame = PERUTT ? pu_T - 1 : b.total_frames - 1;  // (local index when PERUTT)
   // first sample / edge mark of (local) frame index gi, clamped to the last frame
@@ -337,7 +350,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
   // requested while set i is being transformed, so no global-memory latency sits on the critical
   // path of a wave.  frame_start[g] (sample index of the first sample of global frame g) is built
   // once per offsets table by build_frame_start_kernel.
-  int64_t set = PERUTT ? pu_set0 + wid : static_cast<int64_t>(blockIdx.x) * n_waves + wid;
+  int64_t set = PERUTT ? pu_set0 - ((FUSED && pu_set0 > 0) ? 1 : 0) + wid
+                       : static_cast<int64_t>(blockIdx.x) * n_waves + wid;
   // NJ = 13 is the exact shape of the 25 ms / 16 kHz window (only element j = 12 can fall outside the
   // window); NJ = 16 covers every other window length that pads to 512 samples with a per-element test
   const bool in_last = 2 * (l + 16 * (NJ - 1)) < p.win_len;
@@ -714,12 +728,70 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
             if (c == 0 && !p.use_energy)
               v = static_cast<float>(static_cast<double>(v) * 1.4142135623730950488016887);
           }
-          if (mvalid && kp == 0 && c < p.num_ceps && !(c == 0 && p.use_energy)) mrow[oc] = v;
+          if (mvalid && kp == 0 && c < p.num_ceps && !(c == 0 && p.use_energy)) {
+            if (FUSED) cepbuf[(mgl - cep_frame0) * kFusedCols + oc] = v;
+            else mrow[oc] = v;
+          }
         }
-        if (p.use_energy && valid && l == 0) row[p.htk_compat ? p.num_ceps - 1 : 0] = log_energy;
+        if (p.use_energy && valid && l == 0) {
+          if (FUSED) cepbuf[(gl - cep_frame0) * kFusedCols + (p.htk_compat ? p.num_ceps - 1 : 0)] = log_energy;
+          else row[p.htk_compat ? p.num_ceps - 1 : 0] = log_energy;
+        }
       }
     }
     wave_lds_sync();  // the tile is reused by the next frame set
+  }
+  if (FUSED) {
+    // ---- [cepstra | delta | delta-delta] of the workgroup's frames (DeltaPostProcessor order 2, window
+    // 2; [KALDI-UPSTREAM] ComputeDeltas): frame indices clamp at the ends of the utterance, the same
+    // products in the same order as delta_flat_o2w2_kernel (kernels_post.hip), four consecutive floats
+    // of the flat output row block per thread and store --------------------------------------------
+    __syncthreads();
+    const int D = p.num_ceps, OD = 3 * D;
+    const int64_t f_first = static_cast<int64_t>(pu_set0) * 4;
+    const int64_t rows64 = pu_T - f_first < 4 * kFusedSets ? pu_T - f_first : 4 * kFusedSets;
+    const int n_out = static_cast<int>(rows64) * OD;
+    float sc[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) sc[i] = p.delta_scales[i];
+    float* __restrict__ obase = out + (pu_f0 + f_first) * static_cast<int64_t>(p.out_cols);
+    const int last = static_cast<int>(pu_T - 1 - cep_frame0);   // buffer row of the utterance's last frame
+    const int first = static_cast<int>(-cep_frame0);            // ... and of its first frame
+    for (int e0 = 4 * threadIdx.x; e0 < n_out; e0 += 4 * blockDim.x) {
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = e0 + k < n_out ? e0 + k : n_out - 1;
+        const int r = e / OD, col = e - r * OD, order = col / D, c = col - order * D;
+        const int centre = r + 4;
+        float acc = 0.0f;
+        if (order == 0) {
+          acc += sc[0] * cepbuf[centre * kFusedCols + c];
+        } else if (order == 1) {
+#pragma unroll
+          for (int j = -2; j <= 2; ++j) {
+            int t = centre + j;
+            t = t < first ? first : (t > last ? last : t);
+            const float w = sc[1 + j + 2];
+            if (w != 0.0f) acc += w * cepbuf[t * kFusedCols + c];
+          }
+        } else {
+#pragma unroll
+          for (int j = -4; j <= 4; ++j) {
+            int t = centre + j;
+            t = t < first ? first : (t > last ? last : t);
+            const float w = sc[6 + j + 4];
+            if (w != 0.0f) acc += w * cepbuf[t * kFusedCols + c];
+          }
+        }
+        v[k] = acc;
+      }
+      if (e0 + 3 < n_out) {
+        *reinterpret_cast<f32x4_a4*>(obase + e0) = f32x4_a4{v[0], v[1], v[2], v[3]};
+      } else {
+        for (int k = 0; k < 4 && e0 + k < n_out; ++k) obase[e0 + k] = v[k];
+      }
+    }
   }
 }
 
@@ -1029,13 +1101,22 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
   if (b.total_frames <= 0) return SNF_OK;
   Fast512Params q = p;
   q.out_cols = out_cols;
-  const int tab_bytes = ((b.blk_utt ? p.table_stride : p.table_floats) * 4 + 255) & ~255;
   const bool per_utt = b.blk_utt != nullptr;
+  const bool fused = p.fused_delta != 0;  // (MFCC + deltas: always scheduled per utterance)
+  if (per_utt && q.table_stride == 0) q.table_stride = (p.table_floats + 3) & ~3;  // (one blob, warp 1.0)
+  const int tab_bytes = ((per_utt ? q.table_stride : p.table_floats) * 4 + 255) & ~255;
   int n_waves = 8;
   size_t lds = static_cast<size_t>(tab_bytes) + n_waves * 4 * kFrameTileBytes;
   if (2 * (lds + 512) > 160 * 1024) {  // two 8-wave workgroups do not fit: one of 16 waves
     n_waves = kMaxWaves;
     lds = static_cast<size_t>(tab_bytes) + n_waves * 4 * kFrameTileBytes;
+  }
+  if (fused) {
+    if (!per_utt || p.kind != SNF_KIND_MFCC || p.num_ceps > kFusedCols)
+      return set_error(SNF_E_RUNTIME, "fast512: fused deltas need the per-utterance MFCC schedule");
+    n_waves = kFusedWaves;
+    lds = static_cast<size_t>(tab_bytes) + n_waves * 4 * kFrameTileBytes +
+          sizeof(float) * 4 * (kFusedSets + 2) * kFusedCols;
   }
   if (const char* forced = getenv("SNF_FAST512_WAVES")) {  // developer knob: occupancy experiments
     n_waves = atoi(forced);
@@ -1060,10 +1141,12 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
   } while (0)
 #define SNF_LAUNCH5(NJ_, KIND_, EN_, DI_, SN_)                                                       \
   do {                                                                                              \
-    if (per_utt && KIND_ != SNF_KIND_SPECTROGRAM && KIND_ != SNF_KIND_ENERGY)                       \
+    if (fused && KIND_ == SNF_KIND_MFCC)                                                            \
+      SNF_LAUNCH6(NJ_, KIND_, EN_, DI_, SN_, (KIND_ == SNF_KIND_MFCC ? 2 : 0));                     \
+    else if (per_utt && KIND_ != SNF_KIND_SPECTROGRAM && KIND_ != SNF_KIND_ENERGY)                  \
       SNF_LAUNCH6(NJ_, KIND_, EN_, DI_, SN_,                                                        \
-                  (KIND_ != SNF_KIND_SPECTROGRAM && KIND_ != SNF_KIND_ENERGY));                     \
-    else SNF_LAUNCH6(NJ_, KIND_, EN_, DI_, SN_, false);                                             \
+                  ((KIND_ != SNF_KIND_SPECTROGRAM && KIND_ != SNF_KIND_ENERGY) ? 1 : 0));           \
+    else SNF_LAUNCH6(NJ_, KIND_, EN_, DI_, SN_, 0);                                                 \
   } while (0)
 #define SNF_LAUNCH4(NJ_, KIND_, EN_, DI_)                                                           \
   do {                                                                                              \

@@ -6,16 +6,32 @@
 // PitchFrameInfo::ComputeBacktraces) and resample.cc (LinearResample, ArbitraryResample) for the
 // offline single-chunk call the reference makes (frames_per_chunk = 0).
 //
-// Pipeline (three launches per batch):
-//   1. pitch_resample_kernel   one thread per downsampled sample: 16 kHz -> 4 kHz windowed-sinc FIR
-//   2. pitch_stats_kernel      one workgroup per utterance: signal sum / sum of squares (ballast)
-//   3. pitch_track_kernel      one workgroup per utterance: per frame NCCF at the integer lags
-//      (batched-lag correlation in LDS) -> sinc resampling to the log-spaced lags -> Viterbi forward
-//      step over all states in parallel; then traceback and the POV NCCF of the chosen lags.
-// The Viterbi recursion is sequential in time, so an utterance stays on one CU; utterances are the
-// parallel axis (10 000+ per launch).
+// Four launches per batch:
+//   1. pitch_resample_kernel  one thread per downsampled sample: 16 kHz -> 4 kHz windowed-sinc FIR
+//   2. pitch_stats_kernel     one workgroup per utterance: signal sum / sum of squares, from which
+//                             one thread derives the NCCF ballasts of the utterance
+//   3. pitch_nccf_kernel      FRAME-parallel (nothing in it depends on the previous frame): wave64 =
+//                             4 frames x 16 lanes; lane l correlates the lags 5 l .. 5 l + 4 against
+//                             the frame's window in LDS (5 x 5 register blocks), NCCF with and
+//                             without ballast, then the 16 lanes resample the NCCF to the log-spaced
+//                             lags of the Viterbi states (sinc taps in LDS) -> [frames, states] in HBM
+//   4. pitch_viterbi_kernel   the only sequential part: one wavefront per utterance walks the frames,
+//                             local cost from the row of 3, exact argmin of the transition cost with
+//                             the monotone divide-and-conquer search, backpointers to HBM, traceback.
+//
+// Arithmetic contract.  Kaldi hands the sums of this algorithm to BLAS, whose summation order depends
+// on the library build; the CPU oracle (oracle/kaldi_oracle.c, chain_dot / tree16) fixes ONE order and
+// these kernels implement exactly that order, so the tracker agrees with the oracle bit for bit and the
+// Viterbi paths are identical (a one-ulp difference in a cost flips near-ties in unvoiced regions):
+//   - FIR taps, lag correlations, sinc resampling: s = fmaf(a[i], b[i], s), i ascending, from 0;
+//   - frame mean / frame energy / norm average: lane l of 16 sums its elements l, l + 16, ...
+//     ascending, the 16 partial sums are added as a balanced tree of neighbours (DPP quad_perm xor 1,
+//     xor 2, row_half_mirror, row_mirror: every lane ends with the same bits);
+//   - divisions and square roots are IEEE correctly rounded; nothing else is fused: this file is
+//     compiled with -ffp-contract=off and every fused multiply-add is written as one.
 #include <float.h>
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "snf_internal.h"
@@ -34,18 +50,11 @@ __device__ __forceinline__ int64_t find_utt(const int64_t* __restrict__ offsets,
   return lo;
 }
 
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
-
-constexpr int kTrackThreads = 512;
 
 }  // namespace
 
@@ -67,16 +76,19 @@ __global__ void pitch_resample_kernel(const PitchDevTables t, const PitchBatch b
   float s = 0.0f;
   for (int i = 0; i < ntaps; ++i) {
     const int64_t j = first_in + i;
-    if (j >= 0 && j < n) s += wt[i] * static_cast<float>(w[j]);
+    if (j >= 0 && j < n) s = __builtin_fmaf(wt[i], static_cast<float>(w[j]), s);
   }
   down[d0 + k] = s;
 }
 
 // ---- 2. signal statistics for the NCCF ballast -----------------------------------------------------
-// stats[u] = {sumsq_phase1, sum_phase1, sumsq_all, sum_all}: Kaldi accumulates float BLAS dot/sum of
-// each chunk into doubles; phase 1 = what the resampler emitted before the flush.
-__global__ void pitch_stats_kernel(const PitchBatch b, const float* __restrict__ down,
-                                   double* __restrict__ stats) {
+// Kaldi accumulates the float BLAS dot / sum of each chunk into doubles; phase 1 = what the resampler
+// emitted before the flush.  ub[u] = {ballast of the frames of phase 1, of phase 2, the two "old"
+// ballasts RecomputeBacktraces derives from the float mean squares, the new ballast, 1 if
+// RecomputeBacktraces has to run (utterance shorter than recompute_frame whose phase-1 mean square is
+// more than 1 % away from the final one)}
+__global__ void pitch_stats_kernel(const PitchDevTables t, const PitchBatch b,
+                                   const float* __restrict__ down, float* __restrict__ ub) {
   const int64_t u = blockIdx.x;
   const int64_t d0 = b.down_offsets[u], nd = b.down_offsets[u + 1] - d0, nd1 = b.down_phase1[u];
   const float* __restrict__ x = down + d0;
@@ -95,350 +107,27 @@ __global__ void pitch_stats_kernel(const PitchBatch b, const float* __restrict__
     for (int i = 0; i < nw; ++i) { a += red[0][i]; c += red[1][i]; d += red[2][i]; e += red[3][i]; }
     // each chunk's BLAS result is a float that is then added to a double accumulator
     const double fsq1 = static_cast<float>(a), fs1 = static_cast<float>(c);
-    const double fsq2 = static_cast<float>(d), fs2 = static_cast<float>(e);
-    stats[u * 4 + 0] = fsq1;
-    stats[u * 4 + 1] = fs1;
-    stats[u * 4 + 2] = fsq1 + fsq2;
-    stats[u * 4 + 3] = fs1 + fs2;
+    const double sumsq2 = fsq1 + static_cast<double>(static_cast<float>(d));
+    const double sum2 = fs1 + static_cast<double>(static_cast<float>(e));
+    const double n1 = static_cast<double>(nd1), n2 = static_cast<double>(nd);
+    const double m1 = nd1 > 0 ? fs1 / n1 : 0.0, m2 = nd > 0 ? sum2 / n2 : 0.0;
+    const double ms1 = nd1 > 0 ? fsq1 / n1 - m1 * m1 : 0.0;
+    const double ms2 = nd > 0 ? sumsq2 / n2 - m2 * m2 : 0.0;
+    const double W = t.win_size, bal = t.nccf_ballast;
+    float* __restrict__ o = ub + u * 6;
+    o[0] = static_cast<float>((ms1 * W) * (ms1 * W) * bal);
+    o[1] = static_cast<float>((ms2 * W) * (ms2 * W) * bal);
+    const float f1 = static_cast<float>(ms1), f2 = static_cast<float>(ms2);
+    o[2] = static_cast<float>((static_cast<double>(f1) * W) * (static_cast<double>(f1) * W) * bal);
+    o[3] = static_cast<float>((static_cast<double>(f2) * W) * (static_cast<double>(f2) * W) * bal);
+    o[4] = o[3];
+    // ApproxEqual(a, b, 0.01): |a - b| <= 0.01 (|a| + |b|); frames of phase 2 compare equal
+    const bool differ = b.frames_phase1[u] > 0 && !(fabsf(f1 - f2) <= 0.01f * (fabsf(f1) + fabsf(f2)));
+    o[5] = differ ? 1.0f : 0.0f;
   }
 }
 
-// ---- 3. NCCF + Viterbi ------------------------------------------------------------------------------
 namespace {
-
-struct TrackShared {
-  float* win;      // [full_len]
-  float* nccf;     // [num_lags]      nccf_pitch at the integer lags
-  float* norm;     // [num_lags]      e1*e2 (for avg_norm_prod in the recompute pass)
-  float* fwd;      // [num_states]
-  float* nxt;      // [num_states]
-  float* red;      // [16]
-  float* part_e2;  // [chunks][num_lags] partial sums of the lag correlation
-  float* part_ip;  // [chunks][num_lags]
-  float* rep_cost; // [16] Viterbi: best cost of the representative states 0, 32, 64, ...
-  int* rep_bp;     // [16] and their backpointers
-};
-
-__device__ __forceinline__ float block_min(float v, float* red) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  __syncthreads();
-  if (lane == 0) red[wid] = v;
-  __syncthreads();
-  float m = red[0];
-  for (int i = 1; i < nw; ++i) m = fminf(m, red[i]);
-  return m;
-}
-
-// loads frame t of the utterance into sh.win, removes the mean of its first win_size samples and
-// returns e1 = sum of squares of those samples (every wave computes the two reductions redundantly)
-__device__ __forceinline__ float load_frame(const PitchDevTables& t, const float* __restrict__ x,
-                                            int64_t nd, int64_t frame, float* win) {
-  int64_t start;
-  if (t.snip_edges) start = frame * t.win_shift;
-  else start = static_cast<int64_t>((static_cast<double>(frame) + 0.5) * t.win_shift) - t.full_len / 2;
-  __syncthreads();
-  for (int i = threadIdx.x; i < t.full_len; i += blockDim.x) {
-    const int64_t k = start + i;
-    win[i] = (k >= 0 && k < nd) ? x[k] : 0.0f;
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  float s = 0.0f;
-  for (int i = lane; i < t.win_size; i += 64) s += win[i];
-  const float neg_mean = -wave_sum_f(s) / static_cast<float>(t.win_size);
-  __syncthreads();
-  for (int i = threadIdx.x; i < t.full_len; i += blockDim.x) win[i] += neg_mean;
-  __syncthreads();
-  float e = 0.0f;
-  for (int i = lane; i < t.win_size; i += 64) e += win[i] * win[i];
-  return wave_sum_f(e);
-}
-
-// one forward (Viterbi) pass over all frames; returns with sh.fwd = final normalised forward cost
-__device__ void forward_pass(const PitchDevTables& t, const float* __restrict__ x, int64_t nd,
-                             int64_t T, int64_t T1, double ms1, double ms2, bool rescale,
-                             float new_ballast, int16_t* __restrict__ bp, const TrackShared& sh) {
-  const int S = t.num_states, L = t.num_lags, W = t.win_size;
-  for (int s = threadIdx.x; s < S; s += blockDim.x) sh.fwd[s] = 0.0f;
-  // per-state constants of the lag resampler stay in registers across the frame loop when every
-  // thread owns at most one state
-  constexpr int kRegTaps = 12;
-  const bool reg_taps = S <= static_cast<int>(blockDim.x) && t.ar_max_taps <= kRegTaps;
-  float wreg[kRegTaps];
-  int my_first = 0, my_n = 0;
-  float my_lag = 0.0f;
-  if (reg_taps && static_cast<int>(threadIdx.x) < S) {
-    my_first = t.ar_first[threadIdx.x];
-    my_n = t.ar_n[threadIdx.x];
-    my_lag = t.lags[threadIdx.x];
-#pragma unroll
-    for (int j = 0; j < kRegTaps; ++j)
-      wreg[j] = j < my_n ? t.ar_w[threadIdx.x * t.ar_max_taps + j] : 0.0f;
-  }
-  for (int64_t frame = 0; frame < T; ++frame) {
-    const double ms = frame < T1 ? ms1 : ms2;
-    const float ballast = static_cast<float>(pow(ms * W, 2.0) * static_cast<double>(t.nccf_ballast));
-    const float e1 = load_frame(t, x, nd, frame, sh.win);
-    // batched-lag correlation: (lag, sample chunk) pairs over the whole workgroup, then one thread per
-    // lag adds the chunk partials in a fixed order (deterministic)
-    const int chunks = blockDim.x / L > 0 ? blockDim.x / L : 1;
-    const int chunk_len = (W + chunks - 1) / chunks;
-    for (int idx = threadIdx.x; idx < L * chunks; idx += blockDim.x) {
-      const int l = idx % L, c = idx / L;
-      const int i0 = c * chunk_len, i1 = i0 + chunk_len < W ? i0 + chunk_len : W;
-      const float* __restrict__ a = sh.win;
-      const float* __restrict__ cw = sh.win + t.first_lag + l;
-      float e2 = 0.0f, ip = 0.0f;
-      for (int i = i0; i < i1; ++i) {
-        e2 += cw[i] * cw[i];
-        ip += a[i] * cw[i];
-      }
-      sh.part_e2[c * L + l] = e2;
-      sh.part_ip[c * L + l] = ip;
-    }
-    __syncthreads();
-    for (int l = threadIdx.x; l < L; l += blockDim.x) {
-      float e2 = 0.0f, ip = 0.0f;
-      for (int c = 0; c < chunks; ++c) {
-        e2 += sh.part_e2[c * L + l];
-        ip += sh.part_ip[c * L + l];
-      }
-      const float norm = e1 * e2;
-      const float den = static_cast<float>(sqrt(static_cast<double>(norm + ballast)));
-      sh.nccf[l] = den != 0.0f ? ip / den : 0.0f;
-      sh.norm[l] = norm;
-    }
-    __syncthreads();
-    float scale = 1.0f;
-    if (rescale) {
-      float sum = 0.0f;
-      for (int l = 0; l < L; ++l) sum += sh.norm[l];
-      const float avg_norm_prod = sum / static_cast<float>(L);
-      const float old_ms = static_cast<float>(ms);
-      const float old_ballast =
-          static_cast<float>(pow(static_cast<double>(old_ms) * W, 2.0) * static_cast<double>(t.nccf_ballast));
-      scale = powf((old_ballast + avg_norm_prod) / (new_ballast + avg_norm_prod), 0.5f);
-    }
-    // ---- Viterbi step.  cost(i, j) = (j - i)^2 * factor + fwd[j]; its argmin is monotone in i (Kaldi's
-    // search relies on the same property), so: (1) exact argmin for the representative states
-    // 0, 32, 64, ... (32 lanes per representative, strided scan + lane reduction, lowest index wins
-    // ties); (2) every other state scans only between the backpointers of its two neighbouring
-    // representatives.  No FMA contraction: costs must round like Kaldi's.
-    const bool mono = S <= 512 && blockDim.x >= 512;
-    if (mono) {
-      const int rep = threadIdx.x >> 5, lane32 = threadIdx.x & 31;
-      const int i_rep = rep << 5;
-      float best = FLT_MAX;
-      int best_j = 0;
-      if (i_rep < S) {
-        const float fi = static_cast<float>(i_rep);
-        for (int j = lane32; j < S; j += 32) {
-          const float d = static_cast<float>(j) - fi;
-          const float c = __fadd_rn(__fmul_rn(d * d, t.inter_frame_factor), sh.fwd[j]);
-          if (c < best) { best = c; best_j = j; }
-        }
-      }
-#pragma unroll
-      for (int off = 16; off > 0; off >>= 1) {
-        const float oc = __shfl_xor(best, off, 32);
-        const int oj = __shfl_xor(best_j, off, 32);
-        if (oc < best || (oc == best && oj < best_j)) { best = oc; best_j = oj; }
-      }
-      if (lane32 == 0 && i_rep < S) { sh.rep_cost[rep] = best; sh.rep_bp[rep] = best_j; }
-      __syncthreads();
-    }
-    // sinc-resample the NCCF to the log-spaced lags, local cost, Viterbi step
-    for (int s = threadIdx.x; s < S; s += blockDim.x) {
-      float v = 0.0f, lag_s;
-      if (reg_taps) {
-        const float* __restrict__ src = sh.nccf + my_first;
-#pragma unroll
-        for (int j = 0; j < kRegTaps; ++j)
-          if (j < my_n) v += src[j] * wreg[j];
-        lag_s = my_lag;
-      } else {
-        const float* __restrict__ wt = t.ar_w + s * t.ar_max_taps;
-        const float* __restrict__ src = sh.nccf + t.ar_first[s];
-        const int n = t.ar_n[s];
-        for (int j = 0; j < n; ++j) v += src[j] * wt[j];
-        lag_s = t.lags[s];
-      }
-      if (rescale) v *= scale;
-      float local = 1.0f - v;
-      local += t.soft_min_f0 * lag_s * v;
-      const float fs = static_cast<float>(s);
-      float best;
-      int best_j;
-      if (mono) {
-        const int k = s >> 5;
-        if ((s & 31) == 0) {
-          best = sh.rep_cost[k];
-          best_j = sh.rep_bp[k];
-        } else {
-          const int lo = sh.rep_bp[k];
-          const int hi = ((k + 1) << 5) < S ? sh.rep_bp[k + 1] : S - 1;
-          const float d0 = static_cast<float>(lo) - fs;
-          best = __fadd_rn(__fmul_rn(d0 * d0, t.inter_frame_factor), sh.fwd[lo]);
-          best_j = lo;
-          for (int j = lo + 1; j <= hi; ++j) {
-            const float d = static_cast<float>(j) - fs;
-            const float c = __fadd_rn(__fmul_rn(d * d, t.inter_frame_factor), sh.fwd[j]);
-            if (c < best) { best = c; best_j = j; }
-          }
-        }
-      } else {
-        // exact argmin over all states; lowest index wins ties
-        best = __fadd_rn(__fmul_rn(fs * fs, t.inter_frame_factor), sh.fwd[0]);
-        best_j = 0;
-        for (int j = 1; j < S; ++j) {
-          const float d = static_cast<float>(j) - fs;
-          const float c = __fadd_rn(__fmul_rn(d * d, t.inter_frame_factor), sh.fwd[j]);
-          if (c < best) { best = c; best_j = j; }
-        }
-      }
-      sh.nxt[s] = __fadd_rn(best, local);
-      bp[frame * S + s] = static_cast<int16_t>(best_j);
-    }
-    float m = FLT_MAX;
-    __syncthreads();
-    for (int s = threadIdx.x; s < S; s += blockDim.x) m = fminf(m, sh.nxt[s]);
-    m = block_min(m, sh.red);
-    for (int s = threadIdx.x; s < S; s += blockDim.x) sh.fwd[s] = sh.nxt[s] + (-m);
-    __syncthreads();
-  }
-}
-
-}  // namespace
-
-__global__ __launch_bounds__(kTrackThreads) void pitch_track_kernel(
-    const PitchDevTables t, const PitchBatch b, const float* __restrict__ down,
-    const double* __restrict__ stats, int16_t* __restrict__ backptr, int32_t* __restrict__ states,
-    float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int64_t u = blockIdx.x;
-  const int64_t f0 = b.frame_offsets[u], T = b.frame_offsets[u + 1] - f0;
-  if (T <= 0) return;
-  const int64_t T1 = b.frames_phase1[u];
-  const int64_t d0 = b.down_offsets[u], nd = b.down_offsets[u + 1] - d0, nd1 = b.down_phase1[u];
-  const float* __restrict__ x = down + d0;
-  const int S = t.num_states, L = t.num_lags, W = t.win_size;
-  TrackShared sh;
-  sh.win = reinterpret_cast<float*>(smem);
-  sh.nccf = sh.win + ((t.full_len + 3) & ~3);
-  sh.norm = sh.nccf + ((L + 3) & ~3);
-  sh.fwd = sh.norm + ((L + 3) & ~3);
-  sh.nxt = sh.fwd + ((S + 3) & ~3);
-  sh.red = sh.nxt + ((S + 3) & ~3);
-  const int chunks = kTrackThreads / L > 0 ? kTrackThreads / L : 1;
-  sh.part_e2 = sh.red + 16;
-  sh.part_ip = sh.part_e2 + chunks * L;
-  sh.rep_cost = sh.part_ip + chunks * L;
-  sh.rep_bp = reinterpret_cast<int*>(sh.rep_cost + 16);
-  int16_t* __restrict__ bp = backptr + f0 * S;
-
-  const double sq1 = stats[u * 4 + 0], s1 = stats[u * 4 + 1], sq2 = stats[u * 4 + 2],
-               s2 = stats[u * 4 + 3];
-  const double n1 = static_cast<double>(nd1), n2 = static_cast<double>(nd);
-  const double ms1 = nd1 > 0 ? sq1 / n1 - pow(s1 / n1, 2.0) : 0.0;
-  const double ms2 = sq2 / n2 - pow(s2 / n2, 2.0);
-
-  forward_pass(t, x, nd, T, T1, ms1, ms2, false, 0.0f, bp, sh);
-
-  // InputFinished(): RecomputeBacktraces when the utterance is shorter than recompute_frame and some
-  // frame saw a mean-square energy more than 1 % away from the final one
-  if (T < t.recompute_frame && T1 > 0) {
-    const double mean = s2 / n2;
-    const float ms_final = static_cast<float>(sq2 / n2 - mean * mean);
-    const float a = static_cast<float>(ms1);
-    const bool approx_equal = (a == ms_final) || (fabsf(a - ms_final) <= 0.01f * (fabsf(a) + fabsf(ms_final)));
-    if (!approx_equal) {
-      const float new_ballast =
-          static_cast<float>(pow(static_cast<double>(ms_final) * W, 2.0) * static_cast<double>(t.nccf_ballast));
-      __syncthreads();
-      forward_pass(t, x, nd, T, T1, ms1, ms2, true, new_ballast, bp, sh);
-    }
-  }
-
-  // traceback (sequential chain of dependent loads; L2-resident)
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int best = 0;
-    float bv = sh.fwd[0];
-    for (int s = 1; s < S; ++s)
-      if (sh.fwd[s] < bv) { bv = sh.fwd[s]; best = s; }
-    for (int64_t frame = T - 1; frame >= 0; --frame) {
-      states[f0 + frame] = best;
-      best = bp[frame * S + best];
-    }
-  }
-  __syncthreads();
-  __threadfence_block();
-
-  // output rows: (POV NCCF resampled at the chosen lag, 1 / lag); the POV NCCF (ballast 0) is only
-  // needed at the chosen state, so it is recomputed here instead of being stored for all states
-  for (int64_t frame = threadIdx.x; frame < T; frame += blockDim.x) {
-    const int s = states[f0 + frame];
-    int64_t start;
-    if (t.snip_edges) start = frame * t.win_shift;
-    else start = static_cast<int64_t>((static_cast<double>(frame) + 0.5) * t.win_shift) - t.full_len / 2;
-    float sum = 0.0f;
-    for (int i = 0; i < W; ++i) {
-      const int64_t k = start + i;
-      sum += (k >= 0 && k < nd) ? x[k] : 0.0f;
-    }
-    const float neg_mean = -sum / static_cast<float>(W);
-    float e1 = 0.0f;
-    for (int i = 0; i < W; ++i) {
-      const int64_t k = start + i;
-      const float v = ((k >= 0 && k < nd) ? x[k] : 0.0f) + neg_mean;
-      e1 += v * v;
-    }
-    const float* __restrict__ wt = t.ar_w + s * t.ar_max_taps;
-    const int first = t.ar_first[s], n = t.ar_n[s];
-    float pov = 0.0f;
-    for (int j = 0; j < n; ++j) {
-      const int lag = t.first_lag + first + j;
-      float e2 = 0.0f, ip = 0.0f;
-      for (int i = 0; i < W; ++i) {
-        const int64_t ka = start + i, kc = ka + lag;
-        const float va = ((ka >= 0 && ka < nd) ? x[ka] : 0.0f) + neg_mean;
-        const float vc = ((kc >= 0 && kc < nd && i + lag < t.full_len) ? x[kc] : 0.0f) + neg_mean;
-        e2 += vc * vc;
-        ip += va * vc;
-      }
-      const float norm = e1 * e2;
-      const float den = static_cast<float>(sqrt(static_cast<double>(norm + 0.0f)));
-      const float nccf = den != 0.0f ? ip / den : 0.0f;
-      pov += nccf * wt[j];
-    }
-    out[(f0 + frame) * 2 + 0] = pov;
-    out[(f0 + frame) * 2 + 1] = 1.0f / t.lags[s];
-  }
-}
-
-
-// ---- 3b. wave-per-utterance tracker ---------------------------------------------------------------
-// The Viterbi recursion is sequential over the frames of one utterance but utterances are
-// independent, and one frame is only ~30 kflop: a 512-thread workgroup per utterance spends its time
-// in workgroup barriers (11 per frame).  Here ONE wavefront owns an utterance (no workgroup barrier in
-// the frame loop, 16 utterances in flight per CU); the arithmetic of every frame is the same as in
-// pitch_track_kernel above (same summation trees for the frame mean / energy, same Viterbi costs and
-// tie-breaks), only the lag correlation adds its four 25-sample partials in a quad tree.
-namespace {
-
-constexpr int kWaveTrackWaves = 8;   // utterances (= wavefronts) per workgroup
-constexpr int kWaveMaxTaps = 12;
-
-struct WaveShared {
-  float* win;    // [full_len]
-  float* nccf;   // [num_lags]
-  float* norm;   // [num_lags]
-  float* fwd;    // [num_states]
-  float* nxt;    // [num_states]
-  int* bpw;      // [num_states]   backpointers of the current frame
-};
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -452,11 +141,11 @@ __device__ __forceinline__ void wave_sync() {
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf,
-                                                               0xf, false));
+                                                               0xf, true));
 }
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
 }
 __device__ __forceinline__ float lane_f(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
@@ -533,187 +222,303 @@ __device__ __forceinline__ void scan_range(const float* __restrict__ fwd, int lo
   best_j = static_cast<int>(best_f);
 }
 
-constexpr int kLagGroup = 5;  // lags per work item of the correlation
-constexpr int kCorrChunks = 4;  // window quarters per lag group (the 4 lanes of a quad)
+
+// sum of the 16 values of a DPP row as a balanced tree of neighbours; every lane gets the same bits
+__device__ __forceinline__ float tree16(float v) {
+  v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
+  v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
+  v += dpp_f<0x141>(v);  // row_half_mirror: quad 0 <-> 1, 2 <-> 3
+  v += dpp_f<0x140>(v);  // row_mirror: half 0 <-> 1
+  return v;
+}
+
+constexpr int kLagGroup = 5;   // lags per lane and pass of the correlation
+constexpr int kNccfWaves = 4;  // 16 frames per workgroup
 constexpr int kFwdPad = 36;    // FLT_MAX entries behind the forward costs (unclamped scan steps)
 constexpr int kLongRange = 8;  // candidate ranges at least this long are scanned by a 16-lane row
+constexpr int kVitWaves = 8;   // utterances (= wavefronts) per workgroup of the Viterbi kernel
+constexpr int kRowRegs = 8;    // row values per lane held one frame ahead (up to 512 states)
 
-__device__ void forward_pass_wave(const PitchDevTables& t, const float* __restrict__ x, int64_t nd,
-                                  int64_t T, int64_t T1, double ms1, double ms2, bool rescale,
-                                  float new_ballast, int16_t* __restrict__ bp,
-                                  float* __restrict__ pov_nccf, const WaveShared& sh,
-                                  const float* __restrict__ taps, const int* __restrict__ st_first,
-                                  const float* __restrict__ st_lag, const int lane) {
+}  // namespace
+
+// one thread per frame: the utterance it belongs to (a binary search of dependent loads: microseconds
+// when a wave does it at the head of every frame set, nothing when a million threads do it at once)
+__global__ void pitch_frame_utt_kernel(const PitchBatch b, int32_t* __restrict__ frame_utt) {
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g < b.total_frames) frame_utt[g] = static_cast<int32_t>(find_utt(b.frame_offsets, b.n_utts, g));
+}
+
+// ---- 3. NCCF at the integer lags, resampled to the lags of the Viterbi states ------------------------
+__global__ __launch_bounds__(kNccfWaves * 64) void pitch_nccf_kernel(
+    const PitchDevTables t, const PitchBatch b, const float* __restrict__ down,
+    const float* __restrict__ ub, const int32_t* __restrict__ frame_utt, float* __restrict__ nccf_res,
+    float* __restrict__ pov_nccf, float* __restrict__ anp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = t.num_states, L = t.num_lags, W = t.win_size;
-  for (int s = lane; s < S; s += 64) sh.fwd[s] = 0.0f;
-  for (int s = S + lane; s < S + kFwdPad; s += 64) sh.fwd[s] = FLT_MAX;  // scan read-ahead padding
-  for (int i = lane; i < 8; i += 64) sh.win[t.full_len + i] = 0.0f;  // read-ahead padding
-  for (int i = lane; i < kWaveMaxTaps; i += 64) sh.nccf[L + i] = 0.0f;  // (taps are zero-padded)
-  const float ballast1 = static_cast<float>(pow(ms1 * W, 2.0) * static_cast<double>(t.nccf_ballast));
-  const float ballast2 = static_cast<float>(pow(ms2 * W, 2.0) * static_cast<double>(t.nccf_ballast));
-  const int chunk_len = (W + kCorrChunks - 1) / kCorrChunks;
-  const int groups = (L + kLagGroup - 1) / kLagGroup;
-  const int passes = (groups * kCorrChunks + 63) >> 6;
-  const float factor = t.inter_frame_factor;
-  for (int64_t frame = 0; frame < T; ++frame) {
-    const double ms = frame < T1 ? ms1 : ms2;
-    const float ballast = frame < T1 ? ballast1 : ballast2;
-    // ---- frame window, mean removal, e1 ----------------------------------------------------------
+  const int KT = (t.ar_max_taps + 3) & ~3, S4 = (S + 3) & ~3;
+  // sinc taps of every state (zero padded to KT: fmaf(x, 0, v) == v), shared by the workgroup
+  float* taps = reinterpret_cast<float*>(smem);
+  int* st_first = reinterpret_cast<int*>(taps + static_cast<size_t>(S) * KT);
+  for (int i = threadIdx.x; i < S * KT; i += blockDim.x) {
+    const int s = i / KT, j = i - s * KT;
+    taps[i] = (j < t.ar_max_taps && j < t.ar_n[s]) ? t.ar_w[s * t.ar_max_taps + j] : 0.0f;
+  }
+  for (int s = threadIdx.x; s < S; s += blockDim.x) st_first[s] = t.ar_first[s];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int l = lane & 15, q = lane >> 4;
+  const int WL = (t.full_len + 16 + 3) & ~3, LN = (L + KT + 3) & ~3;
+  float* win = reinterpret_cast<float*>(st_first + S4) + (wid * 4 + q) * (WL + LN);
+  float* nccf = win + WL;
+  const int64_t n_sets = (b.total_frames + 3) >> 2;
+  for (int64_t set = static_cast<int64_t>(blockIdx.x) * kNccfWaves + wid; set < n_sets;
+       set += static_cast<int64_t>(gridDim.x) * kNccfWaves) {
+    const int64_t g = set * 4 + q;
+    const bool valid = g < b.total_frames;
+    const int64_t gc = valid ? g : b.total_frames - 1;
+    const int64_t u = frame_utt[gc];
+    const int64_t frame = gc - b.frame_offsets[u];
+    const int64_t d0 = b.down_offsets[u], nd = b.down_offsets[u + 1] - d0;
+    const float* __restrict__ x = down + d0;
+    const float ballast = frame < b.frames_phase1[u] ? ub[u * 6 + 0] : ub[u * 6 + 1];
     int64_t start;
     if (t.snip_edges) start = frame * t.win_shift;
     else start = static_cast<int64_t>((static_cast<double>(frame) + 0.5) * t.win_shift) - t.full_len / 2;
+    // ---- window (zero beyond the signal and in the read-ahead padding), mean removal, e1 -----------
     wave_sync();
-    for (int i = lane; i < t.full_len; i += 64) {
+    for (int i = l; i < WL; i += 16) {
       const int64_t k = start + i;
-      sh.win[i] = (k >= 0 && k < nd) ? x[k] : 0.0f;
+      win[i] = (i < t.full_len && k >= 0 && k < nd) ? x[k] : 0.0f;
     }
+    float part = 0.0f;
+    for (int i = l; i < W; i += 16) part += win[i];
+    const float neg_mean = -tree16(part) / static_cast<float>(W);
+    for (int i = l; i < t.full_len; i += 16) win[i] += neg_mean;
+    float pe = 0.0f;
+    for (int i = l; i < W; i += 16) pe = __builtin_fmaf(win[i], win[i], pe);
+    const float e1 = tree16(pe);
     wave_sync();
-    float sm = 0.0f;
-    for (int i = lane; i < W; i += 64) sm += sh.win[i];
-    const float neg_mean = -wave_sum_v(sm) / static_cast<float>(W);
-    wave_sync();
-    for (int i = lane; i < t.full_len; i += 64) sh.win[i] += neg_mean;
-    wave_sync();
-    float e = 0.0f;
-    for (int i = lane; i < W; i += 64) e += sh.win[i] * sh.win[i];
-    const float e1 = wave_sum_v(e);
-    // ---- lag correlation.  Work item = (group of 5 consecutive lags, quarter of the window); the
-    // 5 x 5 (lag, sample) blocks reuse 9 window values from registers.  The four quarters of a group
-    // sit in the four lanes of a quad and are added as (q0 + q1) + (q2 + q3). ----------------------
-    for (int pass = 0; pass < passes; ++pass) {
-      const int item = (pass << 6) + lane;
-      const int g = item >> 2, c = item & 3;
-      const int l0 = g * kLagGroup;
+    // ---- lag correlation: 5 x 5 (sample, lag) blocks out of 9 window values in registers ---------
+    float pnorm = 0.0f;
+    for (int g0 = 0; kLagGroup * 16 * g0 < L; ++g0) {
+      const int lb = kLagGroup * (l + 16 * g0);
       float e2[kLagGroup], ip[kLagGroup];
 #pragma unroll
       for (int d = 0; d < kLagGroup; ++d) e2[d] = ip[d] = 0.0f;
-      if (g < groups) {
-        const int i0 = c * chunk_len, i1 = i0 + chunk_len < W ? i0 + chunk_len : W;
-        const float* __restrict__ a = sh.win;
-        const float* __restrict__ cw = sh.win + t.first_lag + l0;
-        int i = i0;
-        for (; i + kLagGroup <= i1; i += kLagGroup) {
-          float av[kLagGroup], cv[2 * kLagGroup - 1], sq[2 * kLagGroup - 1];
+      if (lb < L) {
+        const float* __restrict__ a = win;
+        const float* __restrict__ cw = win + t.first_lag + lb;
+        float c[2 * kLagGroup - 1];
 #pragma unroll
-          for (int u = 0; u < kLagGroup; ++u) av[u] = a[i + u];
+        for (int k = 0; k < kLagGroup - 1; ++k) c[k] = cw[k];
+        int i = 0;
+        for (; i + kLagGroup <= W; i += kLagGroup) {
+          float av[kLagGroup];
 #pragma unroll
-          for (int u = 0; u < 2 * kLagGroup - 1; ++u) cv[u] = cw[i + u];
+          for (int k = 0; k < kLagGroup; ++k) {
+            av[k] = a[i + k];
+            c[kLagGroup - 1 + k] = cw[i + kLagGroup - 1 + k];
+          }
 #pragma unroll
-          for (int u = 0; u < 2 * kLagGroup - 1; ++u) sq[u] = cv[u] * cv[u];
-#pragma unroll
-          for (int u = 0; u < kLagGroup; ++u)
+          for (int k = 0; k < kLagGroup; ++k)
 #pragma unroll
             for (int d = 0; d < kLagGroup; ++d) {
-              e2[d] += sq[u + d];
-              ip[d] += av[u] * cv[u + d];
+              ip[d] = __builtin_fmaf(av[k], c[k + d], ip[d]);
+              e2[d] = __builtin_fmaf(c[k + d], c[k + d], e2[d]);
             }
+#pragma unroll
+          for (int k = 0; k < kLagGroup - 1; ++k) c[k] = c[kLagGroup + k];
         }
-        for (; i < i1; ++i) {  // window quarters that are not a multiple of 5 samples
+        for (; i < W; ++i) {  // windows that are not a multiple of 5 samples
           const float ai = a[i];
 #pragma unroll
           for (int d = 0; d < kLagGroup; ++d) {
             const float vc = cw[i + d];
-            e2[d] += vc * vc;
-            ip[d] += ai * vc;
+            ip[d] = __builtin_fmaf(ai, vc, ip[d]);
+            e2[d] = __builtin_fmaf(vc, vc, e2[d]);
           }
         }
       }
 #pragma unroll
       for (int d = 0; d < kLagGroup; ++d) {
-        e2[d] += dpp_f<0xB1>(e2[d]);
-        ip[d] += dpp_f<0xB1>(ip[d]);
-        e2[d] += dpp_f<0x4E>(e2[d]);
-        ip[d] += dpp_f<0x4E>(ip[d]);
-      }
-      // every lane of the quad holds the totals: lane c finishes lag l0 + c (lane 0 also l0 + 4)
-#pragma unroll
-      for (int d = 0; d < kLagGroup; ++d) {
-        const int l = l0 + d;
-        if (g < groups && l < L && (d & 3) == c) {
+        const int lag = lb + d;
+        if (lag < L) {
           const float norm = e1 * e2[d];
-          const float den = static_cast<float>(sqrt(static_cast<double>(norm + ballast)));
-          sh.nccf[l] = den != 0.0f ? ip[d] / den : 0.0f;
-          sh.norm[l] = norm;
-          if (!rescale) {
-            // the POV feature uses the NCCF without ballast; only the lags around the state chosen by
-            // the traceback will be read back
-            const float den0 = static_cast<float>(sqrt(static_cast<double>(norm + 0.0f)));
-            pov_nccf[frame * L + l] = den0 != 0.0f ? ip[d] / den0 : 0.0f;
-          }
+          const float den = sqrtf(norm + ballast);
+          nccf[lag] = den != 0.0f ? ip[d] / den : 0.0f;
+          // the POV feature uses the NCCF without ballast; only the lags around the state chosen by
+          // the traceback are read back
+          const float den0 = sqrtf(norm);
+          if (valid) pov_nccf[g * L + lag] = den0 != 0.0f ? ip[d] / den0 : 0.0f;
+          pnorm += norm;
         }
       }
     }
+    const float avg_norm_prod = tree16(pnorm) / static_cast<float>(L);  // (RecomputeBacktraces)
+    if (valid && l == 0) anp[g] = avg_norm_prod;
+    for (int i = L + l; i < LN; i += 16) nccf[i] = 0.0f;  // (taps are zero padded)
     wave_sync();
+    // ---- ArbitraryResample: NCCF at the lag of every state -----------------------------------------
+    float* __restrict__ row = nccf_res + g * static_cast<int64_t>(S);
+    for (int s = l; s < S; s += 16) {
+      const float* __restrict__ src = nccf + st_first[s];
+      const float4* __restrict__ wt = reinterpret_cast<const float4*>(taps + s * KT);
+      float v = 0.0f;
+      for (int j = 0; j < KT / 4; ++j) {
+        const float4 wq = wt[j];
+        v = __builtin_fmaf(src[4 * j], wq.x, v);
+        v = __builtin_fmaf(src[4 * j + 1], wq.y, v);
+        v = __builtin_fmaf(src[4 * j + 2], wq.z, v);
+        v = __builtin_fmaf(src[4 * j + 3], wq.w, v);
+      }
+      if (valid) row[s] = v;
+    }
+  }
+}
+
+// ---- 4. Viterbi: one wavefront per utterance ----------------------------------------------------------
+namespace {
+
+struct VitShared {
+  float* fwd;    // [num_states + kFwdPad]
+  float* nxt;    // [num_states]
+  int* bpw;      // [num_states]   backpointers of the current frame
+};
+
+// one forward pass over all frames; returns with sh.fwd = final normalised forward cost
+__device__ void viterbi_forward(const PitchDevTables& t, const float* __restrict__ res, const float* __restrict__ anp,
+                                int64_t T, int64_t T1, bool rescale, float old_b1, float old_b2,
+                                float new_ballast, int16_t* __restrict__ bp, const VitShared& sh,
+                                const float* __restrict__ st_lag, const int lane) {
+  const int S = t.num_states, S4 = (S + 3) & ~3;
+  for (int s = lane; s < S; s += 64) sh.fwd[s] = 0.0f;
+  for (int s = S + lane; s < S + kFwdPad; s += 64) sh.fwd[s] = FLT_MAX;  // scan read-ahead padding
+  const float factor = t.inter_frame_factor;
+  float ahead[kRowRegs];
+#pragma unroll
+  for (int k = 0; k < kRowRegs; ++k) ahead[k] = (S <= 64 * kRowRegs && lane + 64 * k < S && T > 0) ? res[lane + 64 * k] : 0.0f;
+  const int n_super = (S + 127) >> 7;          // states 0, 128, 256, ...
+  const int n_reps = (S + 31) >> 5;            // states 0, 32, 64, ...
+  for (int64_t frame = 0; frame < T; ++frame) {
+    // ---- local cost of every state: 1 - nccf + soft_min_f0 * lag * nccf -> nxt ---------------------
     float scale = 1.0f;
     if (rescale) {
-      float sum = 0.0f;
-      for (int l = 0; l < L; ++l) sum += sh.norm[l];
-      const float avg_norm_prod = sum / static_cast<float>(L);
-      const float old_ms = static_cast<float>(ms);
-      const float old_ballast =
-          static_cast<float>(pow(static_cast<double>(old_ms) * W, 2.0) * static_cast<double>(t.nccf_ballast));
-      scale = powf((old_ballast + avg_norm_prod) / (new_ballast + avg_norm_prod), 0.5f);
+      const float old_ballast = frame < T1 ? old_b1 : old_b2, a = anp[frame];
+      scale = sqrtf((old_ballast + a) / (new_ballast + a));
     }
-    // ---- local cost of every state (NCCF resampled at its lag) -> nxt ------------------------------
-#pragma unroll 2
-    for (int s = lane; s < S; s += 64) {
-      float v = 0.0f;
-      const float* __restrict__ src = sh.nccf + st_first[s];
-      const float4* __restrict__ wt = reinterpret_cast<const float4*>(taps + s * kWaveMaxTaps);
+    const float* __restrict__ row = res + frame * static_cast<int64_t>(S);
+    wave_sync();
+    // (rows are read one frame ahead: the HBM latency of frame t + 1 hides behind the search of frame t)
+    float cur[kRowRegs];
+    if (S <= 64 * kRowRegs) {
 #pragma unroll
-      for (int j = 0; j < kWaveMaxTaps / 4; ++j) {  // weights beyond the state's taps are zero
-        const float4 wq = wt[j];
-        v += src[4 * j] * wq.x;
-        v += src[4 * j + 1] * wq.y;
-        v += src[4 * j + 2] * wq.z;
-        v += src[4 * j + 3] * wq.w;
+      for (int k = 0; k < kRowRegs; ++k) cur[k] = ahead[k];
+      if (frame + 1 < T) {
+#pragma unroll
+        for (int k = 0; k < kRowRegs; ++k)
+          if (lane + 64 * k < S) ahead[k] = row[S + lane + 64 * k];
       }
+    }
+    for (int s = lane, k = 0; s < S; s += 64, ++k) {
+      float v = S <= 64 * kRowRegs ? cur[k < kRowRegs ? k : 0] : row[s];
       if (rescale) v *= scale;
       float local = 1.0f - v;
       local += t.soft_min_f0 * st_lag[s] * v;
       sh.nxt[s] = local;
     }
     // ---- Viterbi step.  cost(i, j) = (j - i)^2 * factor + fwd[j]; its argmin is monotone in i
-    // (Kaldi's own search relies on it).  Level 1: exact argmin of the states 0, 32, 64, ... (4 lanes
-    // per state, strided scan, lowest index wins ties).  Then the strides 16, 8, 4, 2, 1: every new
-    // state scans only between the backpointers of its two already known neighbours. -----------------
-    {
-      const int rep = lane >> 2, sub = lane & 3;
-      const int i_rep = rep << 5;
+    // (Kaldi's own search relies on it).  Level 1: exact argmin of the states 0, 128, 256, ... (a
+    // 16-lane row each, strided scan, lowest index wins ties).  Level 2: the states 32, 64, 96, 160, ...
+    // (4 lanes each) between the backpointers of their two level-1 neighbours.  Then the strides
+    // 16, 8, 4, 2, 1: every new state scans only between the backpointers of its two known
+    // neighbours. -------------------------------------------------------------------------------
+    wave_sync();
+    for (int base = 0; base < n_super; base += 4) {
+      const int r = base + (lane >> 4), sub = lane & 15;
+      const int i_rep = r << 7;
+      float best = FLT_MAX;
+      int best_j = 0x7fffffff;
+      if (r < n_super) {
+        const float fi = static_cast<float>(i_rep);
+#pragma unroll 9
+        for (int j = sub; j < S; j += 16) {
+          const float c = trans_cost(j, fi, factor, sh.fwd[j]);
+          if (c < best) { best = c; best_j = j; }
+        }
+      }
+      quad_argmin(best, best_j);
+      argmin_take(best, best_j, dpp_f<0x124>(best), dpp_i<0x124>(best_j));
+      argmin_take(best, best_j, dpp_f<0x128>(best), dpp_i<0x128>(best_j));
+      if (sub == 0 && r < n_super) {
+        if (best_j >= S) best_j = 0;  // (only if every cost was NaN / inf: no runaway scans below)
+        sh.bpw[i_rep] = best_j;
+        sh.nxt[i_rep] = best + sh.nxt[i_rep];
+      }
+    }
+    wave_sync();
+    for (int base = 0; base < n_reps; base += 16) {
+      // k-th state of this level -> multiple of 32 that is not a multiple of 128
+      const int k = base + (lane >> 2), sub = lane & 3;
+      const int m = k + k / 3 + 1;
+      const int i_rep = m << 5;
       float best = FLT_MAX;
       int best_j = 0x7fffffff;
       if (i_rep < S) {
+        const int below = i_rep & ~127, above = below + 128;
+        const int lo = sh.bpw[below];
+        const int hi = above < S ? sh.bpw[above] : S - 1;
         const float fi = static_cast<float>(i_rep);
-        // (the forward costs are padded with FLT_MAX up to a multiple of 32 states)
-        float fj = static_cast<float>(sub), best_f = 0.0f;
-        for (int j = sub; j < S; j += 32) {
+        // (a step may look beyond `hi`: the argmin over ALL states lies inside the range, so the
+        // extra candidates cannot win; the forward costs are padded with FLT_MAX behind the last state)
+        float fj = static_cast<float>(lo + sub), best_f = fj;
+        for (int j = lo + sub; j <= hi; j += 32) {
           float ff[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) ff[u] = sh.fwd[j + 4 * u];
+          for (int w = 0; w < 8; ++w) ff[w] = sh.fwd[j + 4 * w];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const float d = (fj + static_cast<float>(4 * u)) - fi;
-            const float c = __fadd_rn(__fmul_rn(d * d, factor), ff[u]);
-            if (c < best) { best = c; best_f = fj + static_cast<float>(4 * u); }
+          for (int w = 0; w < 8; ++w) {
+            const float d = (fj + static_cast<float>(4 * w)) - fi;
+            const float c = (d * d) * factor + ff[w];
+            if (c < best) { best = c; best_f = fj + static_cast<float>(4 * w); }
           }
           fj += 32.0f;
         }
         best_j = static_cast<int>(best_f);
       }
       quad_argmin(best, best_j);
-      wave_sync();  // local costs (nxt) written above are read below
       if (sub == 0 && i_rep < S) {
+        if (best_j >= S) best_j = sh.bpw[i_rep & ~127];
         sh.bpw[i_rep] = best_j;
-        sh.nxt[i_rep] = __fadd_rn(best, sh.nxt[i_rep]);
+        sh.nxt[i_rep] = best + sh.nxt[i_rep];
       }
     }
-    for (int h = 16; h >= 1; h >>= 1) {
+    // Gaps whose two level-2 neighbours point at the same state are settled: by monotonicity every state
+    // in between points there too (voiced frames: ONE state attracts the whole lag range, and the five
+    // refinement levels below have nothing left to search).
+    wave_sync();
+    bool any_open = false;
+    for (int s = lane; s < S4; s += 64) {
+      const int below = s & ~31, above = below + 32;
+      const bool inner = s < S && (s & 31) != 0;
+      const int lo = sh.bpw[below < S ? below : 0];
+      const int hi = above < S ? sh.bpw[above] : S - 1;
+      if (inner && lo == hi) {
+        sh.bpw[s] = lo;
+        sh.nxt[s] = trans_cost(lo, static_cast<float>(s), factor, sh.fwd[lo]) + sh.nxt[s];
+      }
+      any_open = any_open || (inner && lo != hi);
+    }
+    const bool refine = __ballot(any_open) != 0;
+    for (int h = refine ? 16 : 0; h >= 1; h >>= 1) {
       wave_sync();
       const int count = (S - h + 2 * h - 1) / (2 * h);  // states h, 3h, 5h, ... < S
       for (int m0 = 0; m0 < count; m0 += 64) {
         const int m = m0 + lane;
-        const bool active = m < count;
-        const int i = h + 2 * h * (active ? m : 0);
+        const int i = h + 2 * h * (m < count ? m : 0);
+        const int g_lo = sh.bpw[i & ~31];
+        const int g_hi = (i & ~31) + 32 < S ? sh.bpw[(i & ~31) + 32] : S - 1;
+        const bool active = m < count && g_lo != g_hi;  // (settled gaps were written above)
+        if (__ballot(active) == 0) continue;
         const int lo = sh.bpw[i - h];
         const int hi = i + h < S ? sh.bpw[i + h] : S - 1;
         const bool is_long = active && hi - lo >= kLongRange;
@@ -730,15 +535,15 @@ __device__ void forward_pass_wave(const PitchDevTables& t, const float* __restri
             src[r] = pending ? __ffsll(static_cast<long long>(pending)) - 1 : -1;
             if (pending) pending &= pending - 1;
           }
-          const int row = lane >> 4, sub = lane & 15;
+          const int row16 = lane >> 4, sub = lane & 15;
           int ri = 0, rlo = 0, rhi = -1;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if (src[r] >= 0) {
               const int a = __builtin_amdgcn_readlane(i, src[r]);
-              const int b = __builtin_amdgcn_readlane(lo, src[r]);
+              const int bb = __builtin_amdgcn_readlane(lo, src[r]);
               const int c = __builtin_amdgcn_readlane(hi, src[r]);
-              if (row == r) { ri = a; rlo = b; rhi = c; }
+              if (row16 == r) { ri = a; rlo = bb; rhi = c; }
             }
           }
           const float fi = static_cast<float>(ri);
@@ -762,7 +567,7 @@ __device__ void forward_pass_wave(const PitchDevTables& t, const float* __restri
         }
         if (active) {
           sh.bpw[i] = best_j;
-          sh.nxt[i] = __fadd_rn(best, sh.nxt[i]);
+          sh.nxt[i] = best + sh.nxt[i];
         }
       }
     }
@@ -772,79 +577,47 @@ __device__ void forward_pass_wave(const PitchDevTables& t, const float* __restri
       lane_min = fminf(lane_min, sh.nxt[s]);
       bp[frame * S + s] = static_cast<int16_t>(sh.bpw[s]);
     }
-    const float m = wave_min_f(lane_min);
-    for (int s = lane; s < S; s += 64) sh.fwd[s] = sh.nxt[s] + (-m);
-    wave_sync();
+    const float mn = wave_min_f(lane_min);
+    for (int s = lane; s < S; s += 64) sh.fwd[s] = sh.nxt[s] + (-mn);
   }
+  wave_sync();
 }
 
 }  // namespace
 
-__global__ __launch_bounds__(kWaveTrackWaves * 64, 4) void pitch_track_wave_kernel(
-    const PitchDevTables t, const PitchBatch b, const float* __restrict__ down,
-    const double* __restrict__ stats, int16_t* __restrict__ backptr, int32_t* __restrict__ states,
-    float* __restrict__ pov_all, float* __restrict__ out) {
+__global__ __launch_bounds__(kVitWaves * 64) void pitch_viterbi_kernel(
+    const PitchDevTables t, const PitchBatch b, const float* __restrict__ nccf_res,
+    const float* __restrict__ anp, const float* __restrict__ ub, int16_t* __restrict__ backptr,
+    int32_t* __restrict__ states, const float* __restrict__ pov_all, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int S = t.num_states, L = t.num_lags, W = t.win_size;
-  // resampler taps of every state, shared by the wavefronts of the workgroup
-  float* taps = reinterpret_cast<float*>(smem);
-  const int S4 = (S + 3) & ~3;
-  int* st_first = reinterpret_cast<int*>(taps + ((S * kWaveMaxTaps + 3) & ~3));
-  float* st_lag = reinterpret_cast<float*>(st_first + S4);
-  for (int i = threadIdx.x; i < S * kWaveMaxTaps; i += blockDim.x) {
-    const int s = i / kWaveMaxTaps, j = i - s * kWaveMaxTaps;
-    taps[i] = (j < t.ar_max_taps && j < t.ar_n[s]) ? t.ar_w[s * t.ar_max_taps + j] : 0.0f;
-  }
-  for (int s = threadIdx.x; s < S; s += blockDim.x) {
-    st_first[s] = t.ar_first[s];
-    st_lag[s] = t.lags[s];
-  }
+  const int S = t.num_states, L = t.num_lags, S4 = (S + 3) & ~3;
+  float* st_lag = reinterpret_cast<float*>(smem);
+  for (int s = threadIdx.x; s < S; s += blockDim.x) st_lag[s] = t.lags[s];
   __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int64_t slot = static_cast<int64_t>(blockIdx.x) * kWaveTrackWaves + wid;
+  const int64_t slot = static_cast<int64_t>(blockIdx.x) * kVitWaves + wid;
   if (slot >= b.n_utts) return;
   const int64_t u = b.order ? b.order[slot] : slot;
   const int64_t f0 = b.frame_offsets[u], T = b.frame_offsets[u + 1] - f0;
   if (T <= 0) return;
   const int64_t T1 = b.frames_phase1[u];
-  const int64_t d0 = b.down_offsets[u], nd = b.down_offsets[u + 1] - d0, nd1 = b.down_phase1[u];
-  const float* __restrict__ x = down + d0;
-  const int per_wave = ((t.full_len + 8 + 3) & ~3) + ((L + kWaveMaxTaps + 3) & ~3) + ((L + 3) & ~3) +
-                       3 * ((S + 3) & ~3) + kFwdPad;
-  WaveShared sh;
-  sh.win = st_lag + S4 + wid * per_wave;
-  sh.nccf = sh.win + ((t.full_len + 8 + 3) & ~3);
-  sh.norm = sh.nccf + ((L + kWaveMaxTaps + 3) & ~3);
-  sh.fwd = sh.norm + ((L + 3) & ~3);
-  sh.nxt = sh.fwd + ((S + 3) & ~3) + kFwdPad;
-  sh.bpw = reinterpret_cast<int*>(sh.nxt + ((S + 3) & ~3));
+  const int per_wave = 3 * S4 + kFwdPad;
+  VitShared sh;
+  sh.fwd = st_lag + S4 + wid * per_wave;
+  sh.nxt = sh.fwd + S4 + kFwdPad;
+  sh.bpw = reinterpret_cast<int*>(sh.nxt + S4);
   int16_t* __restrict__ bp = backptr + f0 * S;
-  float* __restrict__ pov_nccf = pov_all + f0 * L;
+  const float* __restrict__ res = nccf_res + f0 * static_cast<int64_t>(S);
+  const float* __restrict__ pov_nccf = pov_all + f0 * L;
+  const float* __restrict__ o = ub + u * 6;
 
-  const double sq1 = stats[u * 4 + 0], s1 = stats[u * 4 + 1], sq2 = stats[u * 4 + 2],
-               s2 = stats[u * 4 + 3];
-  const double n1 = static_cast<double>(nd1), n2 = static_cast<double>(nd);
-  const double ms1 = nd1 > 0 ? sq1 / n1 - pow(s1 / n1, 2.0) : 0.0;
-  const double ms2 = sq2 / n2 - pow(s2 / n2, 2.0);
-
-  forward_pass_wave(t, x, nd, T, T1, ms1, ms2, false, 0.0f, bp, pov_nccf, sh, taps, st_first, st_lag, lane);
-
-  if (T < t.recompute_frame && T1 > 0) {
-    const double mean = s2 / n2;
-    const float ms_final = static_cast<float>(sq2 / n2 - mean * mean);
-    const float a = static_cast<float>(ms1);
-    const bool approx_equal = (a == ms_final) || (fabsf(a - ms_final) <= 0.01f * (fabsf(a) + fabsf(ms_final)));
-    if (!approx_equal) {
-      const float new_ballast =
-          static_cast<float>(pow(static_cast<double>(ms_final) * W, 2.0) * static_cast<double>(t.nccf_ballast));
-      wave_sync();
-      forward_pass_wave(t, x, nd, T, T1, ms1, ms2, true, new_ballast, bp, pov_nccf, sh, taps, st_first,
-                        st_lag, lane);
-    }
-  }
+  viterbi_forward(t, res, anp + f0, T, T1, false, 0.0f, 0.0f, 0.0f, bp, sh, st_lag, lane);
+  // InputFinished(): RecomputeBacktraces when the utterance is shorter than recompute_frame and some
+  // frame saw a mean-square energy more than 1 % away from the final one (pitch_stats_kernel)
+  if (T < t.recompute_frame && o[5] != 0.0f)
+    viterbi_forward(t, res, anp + f0, T, T1, true, o[2], o[3], o[4], bp, sh, st_lag, lane);
 
   // traceback: best final state (lowest index wins ties), then the chain of backpointers
-  wave_sync();
   __threadfence_block();
   {
     float bv = FLT_MAX;
@@ -871,14 +644,14 @@ __global__ __launch_bounds__(kWaveTrackWaves * 64, 4) void pitch_track_wave_kern
     const float* __restrict__ src = pov_nccf + frame * L + t.ar_first[s];
     const int n = t.ar_n[s];
     float pov = 0.0f;
-    for (int j = 0; j < n; ++j) pov += src[j] * wt[j];
+    for (int j = 0; j < n; ++j) pov = __builtin_fmaf(src[j], wt[j], pov);
     out[(f0 + frame) * 2 + 0] = pov;
     out[(f0 + frame) * 2 + 1] = 1.0f / t.lags[s];
   }
 }
 
-int launch_pitch(const PitchDevTables& t, const PitchBatch& b, float* down, double* stats,
-                 int16_t* backptr, int32_t* states, float* pov_nccf, float* out, hipStream_t stream) {
+int launch_pitch(const PitchDevTables& t, const PitchBatch& b, const PitchScratch& w, float* out,
+                 hipStream_t stream) {
   if (b.total_frames <= 0) return SNF_OK;
   if (t.num_states > 32767) return set_error(SNF_E_RUNTIME, "too many pitch states (delta_pitch too small)");
   if (b.total_down > 0) {
@@ -892,44 +665,53 @@ int launch_pitch(const PitchDevTables& t, const PitchBatch& b, float* down, doub
       hipLaunchKernelGGL(pitch_resample_kernel,
                          dim3(static_cast<unsigned>((b.max_down + threads - 1) / threads),
                               static_cast<unsigned>(nu)),
-                         dim3(threads), 0, stream, t, bs, down);
+                         dim3(threads), 0, stream, t, bs, w.down);
       SNF_HIP_CHECK(hipGetLastError());
     }
   }
   hipLaunchKernelGGL(pitch_stats_kernel, dim3(static_cast<unsigned>(b.n_utts)), dim3(256), 0, stream,
-                     b, down, stats);
+                     t, b, w.down, w.ub);
   SNF_HIP_CHECK(hipGetLastError());
-  const bool wave_path = t.num_states <= 512 && t.ar_max_taps <= kWaveMaxTaps &&
-                         !getenv("SNF_PITCH_BLOCK_KERNEL");
-  if (wave_path) {
-    const int per_wave = ((t.full_len + 8 + 3) & ~3) + ((t.num_lags + kWaveMaxTaps + 3) & ~3) +
-                         ((t.num_lags + 3) & ~3) + 3 * ((t.num_states + 3) & ~3) + kFwdPad;
-    const size_t lds_w = sizeof(float) * (((t.num_states * kWaveMaxTaps + 3) & ~3) +
-                                          2 * ((t.num_states + 3) & ~3) +
-                                          static_cast<size_t>(kWaveTrackWaves) * per_wave);
-    if (lds_w <= 80 * 1024) {
-      if (lds_w > 64 * 1024)
-        SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pitch_track_wave_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          static_cast<int>(lds_w)));
-      const unsigned blocks = static_cast<unsigned>((b.n_utts + kWaveTrackWaves - 1) / kWaveTrackWaves);
-      hipLaunchKernelGGL(pitch_track_wave_kernel, dim3(blocks), dim3(kWaveTrackWaves * 64), lds_w, stream,
-                         t, b, down, stats, backptr, states, pov_nccf, out);
-      SNF_HIP_CHECK(hipGetLastError());
-      return SNF_OK;
-    }
+  static const int trace = getenv("SNF_PITCH_TRACE") ? atoi(getenv("SNF_PITCH_TRACE")) : 0;  // developer knob
+  auto stage_done = [&](const char* name, int index) -> int {
+    if (!trace) return 0;
+    SNF_HIP_CHECK(hipStreamSynchronize(stream));
+    fprintf(stderr, "[snf pitch] %s done\n", name);
+    return trace == index ? 1 : 0;
+  };
+  if (stage_done("resample + stats", 1)) return SNF_OK;
+  const int S = t.num_states, L = t.num_lags, S4 = (S + 3) & ~3, KT = (t.ar_max_taps + 3) & ~3;
+  hipLaunchKernelGGL(pitch_frame_utt_kernel, dim3(static_cast<unsigned>((b.total_frames + 255) / 256)),
+                     dim3(256), 0, stream, b, w.frame_utt);
+  SNF_HIP_CHECK(hipGetLastError());
+  {
+    const int WL = (t.full_len + 16 + 3) & ~3, LN = (L + KT + 3) & ~3;
+    const size_t lds = sizeof(float) * (static_cast<size_t>(S) * KT + S4 +
+                                        static_cast<size_t>(kNccfWaves) * 4 * (WL + LN));
+    if (lds > 160 * 1024) return set_error(SNF_E_RUNTIME, "pitch lag tables do not fit in LDS");
+    if (lds > 64 * 1024)
+      SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pitch_nccf_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    const int64_t n_sets = (b.total_frames + 3) / 4;
+    int64_t blocks = (n_sets + kNccfWaves - 1) / kNccfWaves;
+    if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride: the taps are staged once per workgroup
+    hipLaunchKernelGGL(pitch_nccf_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kNccfWaves * 64), lds,
+                       stream, t, b, w.down, w.ub, w.frame_utt, w.nccf_res, w.pov_nccf, w.anp);
+    SNF_HIP_CHECK(hipGetLastError());
+    if (stage_done("nccf", 2)) return SNF_OK;
   }
-  const int chunks = kTrackThreads / t.num_lags > 0 ? kTrackThreads / t.num_lags : 1;
-  const size_t lds = sizeof(float) * (((t.full_len + 3) & ~3) + 2 * ((t.num_lags + 3) & ~3) +
-                                      2 * ((t.num_states + 3) & ~3) + 16 + 2 * chunks * t.num_lags +
-                                      32);
-  if (lds > 160 * 1024) return set_error(SNF_E_RUNTIME, "pitch state space does not fit in LDS");
-  if (lds > 64 * 1024)
-    SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pitch_track_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-  hipLaunchKernelGGL(pitch_track_kernel, dim3(static_cast<unsigned>(b.n_utts)), dim3(kTrackThreads),
-                     lds, stream, t, b, down, stats, backptr, states, out);
-  SNF_HIP_CHECK(hipGetLastError());
+  {
+    const size_t lds = sizeof(float) * (S4 + static_cast<size_t>(kVitWaves) * (3 * S4 + kFwdPad));
+    if (lds > 160 * 1024) return set_error(SNF_E_RUNTIME, "pitch state space does not fit in LDS");
+    if (lds > 64 * 1024)
+      SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pitch_viterbi_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    const unsigned blocks = static_cast<unsigned>((b.n_utts + kVitWaves - 1) / kVitWaves);
+    hipLaunchKernelGGL(pitch_viterbi_kernel, dim3(blocks), dim3(kVitWaves * 64), lds, stream, t, b,
+                       w.nccf_res, w.anp, w.ub, w.backptr, w.states, w.pov_nccf, out);
+    SNF_HIP_CHECK(hipGetLastError());
+    (void)stage_done("viterbi", 3);
+  }
   return SNF_OK;
 }
 

@@ -456,11 +456,130 @@ __global__ __launch_bounds__(256) void delta_tiled_fixed_kernel(
   }
 }
 
+// The reference's defaults (order 2, window 2) as a flat stream: the [T, D] input and the [T, 3 D] output
+// are both contiguous, so a tile is staged with 16-byte loads, every thread produces FOUR consecutive
+// floats of the flat output (whatever row / order / column they fall on: the divisions by 3 D and D are
+// by compile-time constants) from the clamped neighbours in LDS, and stores them as one dwordx4: loads
+// and stores are fully coalesced 16-byte accesses (the per-(row, column) form above writes 4-byte
+// elements in runs of D).  The utterance of a tile's first row comes from a table built by one thread
+// per tile (a binary search of dependent loads at the head of every workgroup cost more than its
+// arithmetic); rows walk forward from it.  Same products in the same order as the kernels above.
+constexpr int kFlatRows = 256;
+__global__ void delta_tile_utt_kernel(const int64_t* __restrict__ frame_offsets, int64_t n_utts,
+                                      int64_t total_frames, int32_t* __restrict__ tile_utt) {
+  const int64_t tile = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t g = tile * kFlatRows;
+  if (g < total_frames) tile_utt[tile] = static_cast<int32_t>(find_utt(frame_offsets, n_utts, g));
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void delta_flat_o2w2_kernel(
+    const DeltaParams p, const float* __restrict__ in, const int64_t* __restrict__ frame_offsets,
+    const int32_t* __restrict__ tile_utt, const int64_t n_utts, const int64_t total_frames,
+    float* __restrict__ out) {
+  constexpr int kHalo = 4, OD = 3 * D, kTileRows = kFlatRows + 2 * kHalo;
+  constexpr int kTileFloats = (kTileRows * D + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float tile[kTileFloats + 4];
+  __shared__ int row_lo[kFlatRows], row_hi[kFlatRows];
+  const int64_t g0 = static_cast<int64_t>(blockIdx.x) * kFlatRows;
+  const int64_t t0 = g0 - kHalo;
+  const int64_t first = t0 * D, limit = total_frames * D;
+  // the tile starts at float `first` of the input, which is 16-byte aligned only for some tiles: stage
+  // from the aligned float4 at or below it (`skew` floats earlier)
+  const int skew = static_cast<int>(((first % 4) + 4) % 4);
+  const int64_t base = first - skew;
+  for (int i = threadIdx.x; i * 4 < kTileFloats + 4; i += blockDim.x) {
+    const int64_t a = base + 4 * static_cast<int64_t>(i);
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (a >= 0 && a + 3 < limit) {
+      v = *reinterpret_cast<const float4*>(in + a);
+    } else {
+      if (a >= 0 && a < limit) v.x = in[a];
+      if (a + 1 >= 0 && a + 1 < limit) v.y = in[a + 1];
+      if (a + 2 >= 0 && a + 2 < limit) v.z = in[a + 2];
+      if (a + 3 >= 0 && a + 3 < limit) v.w = in[a + 3];
+    }
+    reinterpret_cast<float4*>(tile)[i] = v;
+  }
+  {
+    const int64_t g = g0 + threadIdx.x;
+    if (g < total_frames) {
+      int64_t u = tile_utt[blockIdx.x];
+      while (frame_offsets[u + 1] <= g) ++u;  // (a tile spans few utterances)
+      const int64_t lo = frame_offsets[u] - t0, hi = frame_offsets[u + 1] - 1 - t0;
+      row_lo[threadIdx.x] = lo < 0 ? 0 : static_cast<int>(lo);
+      row_hi[threadIdx.x] = hi > kTileRows - 1 ? kTileRows - 1 : static_cast<int>(hi);
+    }
+  }
+  float sc[15];  // scales of the three orders, concatenated like DeltaParams::scales: 1 + 5 + 9
+#pragma unroll
+  for (int i = 0; i < 15; ++i) sc[i] = p.scales[i];
+  __syncthreads();
+  const int rows_here = static_cast<int>(total_frames - g0 < kFlatRows ? total_frames - g0 : kFlatRows);
+  const int n_out = rows_here * OD;
+  float* __restrict__ obase = out + g0 * OD;   // (g0 * OD * 4 bytes is a multiple of 16: kFlatRows is)
+  const float* __restrict__ tl = tile + skew;
+  for (int e0 = 4 * threadIdx.x; e0 < n_out; e0 += 4 * blockDim.x) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = e0 + k < n_out ? e0 + k : n_out - 1;
+      const int r = e / OD, col = e - r * OD, order = col / D, c = col - order * D;
+      const int lo = row_lo[r], hi = row_hi[r], centre = r + kHalo;
+      float acc = 0.0f;
+      if (order == 0) {
+        acc += sc[0] * tl[centre * D + c];
+      } else if (order == 1) {
+#pragma unroll
+        for (int j = -2; j <= 2; ++j) {
+          int t = centre + j;
+          t = t < lo ? lo : (t > hi ? hi : t);
+          const float s = sc[1 + j + 2];
+          if (s != 0.0f) acc += s * tl[t * D + c];
+        }
+      } else {
+#pragma unroll
+        for (int j = -4; j <= 4; ++j) {
+          int t = centre + j;
+          t = t < lo ? lo : (t > hi ? hi : t);
+          const float s = sc[6 + j + 4];
+          if (s != 0.0f) acc += s * tl[t * D + c];
+        }
+      }
+      v[k] = acc;
+    }
+    if (e0 + 3 < n_out) {
+      *reinterpret_cast<float4*>(obase + e0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      for (int k = 0; k < 4 && e0 + k < n_out; ++k) obase[e0 + k] = v[k];
+    }
+  }
+}
+
 int launch_deltas(const DeltaParams& p, const float* in, int in_cols, const int64_t* frame_offsets,
-                  int64_t n_utts, int64_t total_frames, float* out, hipStream_t stream) {
+                  int64_t n_utts, int64_t total_frames, float* out, int32_t* tile_utt,
+                  hipStream_t stream) {
   const int64_t total = total_frames * in_cols;
   if (total <= 0) return SNF_OK;
   const int halo = p.order * p.window;
+  const bool aligned16 = (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  if (p.order == 2 && p.window == 2 && tile_utt && aligned16 &&
+      (in_cols == 13 || in_cols == 23 || in_cols == 40 || in_cols == 43)) {
+    const unsigned tiles = static_cast<unsigned>((total_frames + kFlatRows - 1) / kFlatRows);
+    hipLaunchKernelGGL(delta_tile_utt_kernel, dim3((tiles + 255) / 256), dim3(256), 0, stream,
+                       frame_offsets, n_utts, total_frames, tile_utt);
+    SNF_HIP_CHECK(hipGetLastError());
+#define SNF_FLAT(D_)                                                                                \
+  hipLaunchKernelGGL((delta_flat_o2w2_kernel<D_>), dim3(tiles), dim3(256), 0, stream, p, in,          \
+                     frame_offsets, tile_utt, n_utts, total_frames, out)
+    if (in_cols == 13) SNF_FLAT(13);
+    else if (in_cols == 23) SNF_FLAT(23);
+    else if (in_cols == 40) SNF_FLAT(40);
+    else SNF_FLAT(43);
+#undef SNF_FLAT
+    SNF_HIP_CHECK(hipGetLastError());
+    return SNF_OK;
+  }
   const size_t lds = 2 * sizeof(int) * kDeltaRows + sizeof(float) * ((p.n_scales + 3) & ~3) +
                      sizeof(float) * static_cast<size_t>(kDeltaRows + 2 * halo) * in_cols;
   const unsigned tiles = static_cast<unsigned>((total_frames + kDeltaRows - 1) / kDeltaRows);

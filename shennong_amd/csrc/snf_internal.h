@@ -146,12 +146,15 @@ int launch_mel_features(const MelParams& p, const BatchArgs& b, float* out, int 
 int launch_rasta(float* mel, const BatchArgs& b, int num_bins, hipStream_t stream);
 int launch_plp_tail(const PlpParams& p, const BatchArgs& b, const float* mel, const double* energy,
                     float* out, hipStream_t stream);
+// `tile_utt`: scratch of ceil(total_frames / 256) int32 (nullptr: per-element kernels only)
 int launch_deltas(const DeltaParams& p, const float* in, int in_cols, const int64_t* frame_offsets,
-                  int64_t n_utts, int64_t total_frames, float* out, hipStream_t stream);
+                  int64_t n_utts, int64_t total_frames, float* out, int32_t* tile_utt,
+                  hipStream_t stream);
 
 
 // ---- register-resident 512-point fast path (kernels_fbank512.hip) ----------------------------------
 constexpr int kFast512MaxBins = 64;    // mel bins: 16 MFMA blocks of 4 bins
+constexpr int kFast512FusedSets = 82;  // fused deltas: frame sets per workgroup (kernels_fbank512.hip)
 struct Fast512Params {
   int win_len, win_shift, remove_dc, snip_edges;
   float preemph, dither;
@@ -164,6 +167,8 @@ struct Fast512Params {
   // group of 4 bins is split into along the FFT bins (partial sums are added through DPP)
   int mm_quads, mm_levels;
   int dd_quads;              // MFCC: DCT-II chain length / 4 (mel bins per K partition / 4)
+  int fused_delta;           // MFCC: rows are [cepstra | delta | delta-delta] (order 2, window 2)
+  const float* delta_scales; // ... composite scales of the three orders, 1 + 5 + 9 floats (device)
   int table_floats;          // total floats of the packed table blob below (warp 1.0)
   int table_stride;          // floats between the blobs of consecutive warp factors (VTLN)
   // one packed blob, copied to LDS at kernel start:
@@ -208,11 +213,21 @@ struct PitchBatch {
   int64_t n_utts, total_frames, total_down;
   int64_t max_down;               // longest downsampled utterance
 };
-// resample -> signal statistics -> fused NCCF + Viterbi per utterance -> traceback + POV output.
-// `backptr` is [total_frames, num_states] int16, `states` [total_frames] int32, `pov_nccf`
-// [total_frames, num_lags] float scratch.
-int launch_pitch(const PitchDevTables& t, const PitchBatch& b, float* down, double* stats,
-                 int16_t* backptr, int32_t* states, float* pov_nccf, float* out, hipStream_t stream);
+// scratch of one pitch batch (all in HBM, owned by the plan)
+struct PitchScratch {
+  float* down;       // [total_down]                  signal resampled to resample_freq
+  float* ub;         // [n_utts][6]                   NCCF ballasts of every utterance (pitch_stats_kernel)
+  float* nccf_res;   // [total_frames][num_states]    NCCF (with ballast) at the lag of every state
+  float* pov_nccf;   // [total_frames][num_lags]      NCCF without ballast at the integer lags
+  float* anp;        // [total_frames]                average norm product (RecomputeBacktraces)
+  int16_t* backptr;  // [total_frames][num_states]
+  int32_t* states;   // [total_frames]                traceback
+  int32_t* frame_utt;  // [total_frames]              utterance of every frame
+};
+// resample -> signal statistics -> frame-parallel NCCF + lag resampling -> Viterbi per utterance ->
+// traceback + POV output
+int launch_pitch(const PitchDevTables& t, const PitchBatch& b, const PitchScratch& w, float* out,
+                 hipStream_t stream);
 
 int launch_vad(const snf_vad_options& o, const float* in, int in_cols, const int64_t* frame_offsets,
                int64_t n_utts, int64_t total_frames, float* thr_scratch, float* out,

@@ -10,10 +10,40 @@ The reference's only parallelism is a joblib thread pool over utterances sharing
     shennong/pipeline.py:580-603 accumulates every utterance of a speaker before applying): the only
     real reduction on the path.  The [n_speakers, 2, dim+1] float64 blocks are all-gathered and summed
     in rank order, so the result does not depend on the collective's internal reduction order.
-``torch.distributed`` (backend "nccl" = RCCL on ROCm, "gloo" on CPU) is plumbing only.
+Transport: every function takes a ``group``.  An ``shennong_amd.comm.RcclComm`` runs the exchange
+steps over RCCL through the C ABI (``snf_comm_*``: device pointers, no framework - what a GPU node
+uses); anything else (None, a torch process group) goes through ``torch.distributed``, which is how the
+multi-process logic is tested on CPU with the gloo backend.
 """
 
 import numpy as np
+
+
+class _TorchTransport:
+    """``torch.distributed`` process group (gloo on CPU, nccl = RCCL on GPU)"""
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.group = group
+        self.rank, self.world_size = dist.get_rank(group), dist.get_world_size(group)
+
+    def all_gather_object(self, obj):
+        import torch.distributed as dist
+        out = [None] * self.world_size
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def gather_features(self, local, dst=0, device=None):
+        return _torch_gather_features(local, dst, self.group, device)
+
+    def allreduce(self, array, op='sum'):
+        assert op == 'sum'
+        return _torch_allreduce_stats(array, self.group, None)
+
+
+def _transport(group):
+    """The object that carries out the exchange steps for `group`"""
+    from shennong_amd.comm import RcclComm
+    return group if isinstance(group, RcclComm) else _TorchTransport(group)
 
 
 def shard_utterances(lengths, world_size):
@@ -42,6 +72,13 @@ def gather_features(local, dst=0, group=None, device=None):
     Names and shapes travel as a small all-gathered object; the matrices travel as ONE contiguous
     float32 buffer per peer, sent point-to-point to `dst`.  Returns the merged dict on `dst`, None
     elsewhere."""
+    transport = _transport(group)
+    if isinstance(transport, _TorchTransport):
+        return _torch_gather_features(local, dst, group, device)
+    return transport.gather_features(local, dst)
+
+
+def _torch_gather_features(local, dst, group, device):
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -84,9 +121,9 @@ def process_all_sharded(processor, utterances, dst=0, group=None, **kwargs):
 
     Every rank passes the same `utterances`; rank `dst` gets the full FeaturesCollection (same keys
     and values as a single-process ``process_all``), the others get None."""
-    import torch.distributed as dist
     from shennong_amd.features import Features, FeaturesCollection
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    transport = _transport(group)
+    rank, world = transport.rank, transport.world_size
     utts = list(utterances)
     signals = [u.load_audio() for u in utts]
     shards = shard_utterances([s.nsamples for s in signals], world)
@@ -117,8 +154,16 @@ def _default_device(group):
 def allreduce_cmvn_stats(stats, group=None, device=None):
     """Sums float64 CMVN statistics blocks [n_speakers, 2, dim + 1] over the ranks.
 
-    One all-gather of the (tiny) blocks, then a rank-ordered host sum: deterministic and identical
-    on every rank."""
+    torch transport: one all-gather of the (tiny) blocks, then a rank-ordered host sum; RCCL transport:
+    one float64 ncclAllReduce on the device.  Identical on every rank."""
+    transport = _transport(group)
+    if isinstance(transport, _TorchTransport):
+        return _torch_allreduce_stats(stats, group, device)
+    stats = np.ascontiguousarray(stats, dtype=np.float64)
+    return transport.allreduce(stats, 'sum').reshape(stats.shape)
+
+
+def _torch_allreduce_stats(stats, group, device):
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -146,17 +191,13 @@ def apply_cmvn_sharded(local_feats, utt2speak=None, norm_vars=True, weights=None
     collection, the reference's ``apply_cmvn(by_collection=True)``).  Every rank gets its own shard
     normalised with the statistics of the complete speakers: local statistics launch ->
     ``allreduce_cmvn_stats`` -> local apply launch.  Returns ``(FeaturesCollection, stats dict)``."""
-    import torch.distributed as dist
     from shennong_amd import _abi, _backend
     from shennong_amd.features import Features, FeaturesCollection
     from shennong_amd.postprocessor.cmvn import CmvnPostProcessor, _fake_stats_for_dims
-    world = dist.get_world_size(group)
     keys = list(local_feats.keys())
     speak = [None if utt2speak is None else utt2speak[k] for k in keys]
-    meta = [None] * world
-    dist.all_gather_object(
-        meta, (sorted(set(speak), key=str), sorted(set(local_feats[k].ndims for k in keys))),
-        group=group)
+    meta = _transport(group).all_gather_object(
+        (sorted(set(speak), key=str), sorted(set(local_feats[k].ndims for k in keys))))
     speakers = sorted(set(s for m in meta for s in m[0]), key=str)
     dims = sorted(set(d for m in meta for d in m[1]))
     if len(dims) != 1:
@@ -197,11 +238,8 @@ def reduce_named_stats(names, stats, group=None):
     Ranks may know different name lists (each holds its own utterances): the union of the names is
     agreed on with one small object all-gather, the blocks are summed with `allreduce_cmvn_stats`
     (rank-ordered, deterministic).  Returns the blocks of THIS rank's `names`, in its order."""
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    gathered = [None] * world
-    dist.all_gather_object(
-        gathered, (list(names), int(stats.shape[-1]) if len(names) else None), group=group)
+    gathered = _transport(group).all_gather_object(
+        (list(names), int(stats.shape[-1]) if len(names) else None))
     widths = sorted(set(w for _, w in gathered if w is not None))
     if not widths:
         return stats
@@ -223,13 +261,13 @@ def extract_features_sharded(configuration, utterances, warps=None, dst=0, group
     they are applied (by-utterance CMVN needs no exchange).  Rank `dst` gets the complete
     FeaturesCollection (point-to-point gather of the matrices, the properties travel as objects), the
     others get None."""
-    import torch.distributed as dist
     from shennong_amd import pipeline
     from shennong_amd.features import Features, FeaturesCollection
     from shennong_amd.logger import get_logger
     from shennong_amd.utterances import Utterances
     log = log or get_logger('pipeline', 'warning')
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    transport = _transport(group)
+    rank, world = transport.rank, transport.world_size
     config = pipeline._init_config(configuration, log=log)
     if warps:
         warps = pipeline._init_warps(warps, config, utterances, log)
@@ -247,9 +285,7 @@ def extract_features_sharded(configuration, utterances, warps=None, dst=0, group
         if hook is not None:  # still take part in the reduction
             hook([], np.zeros((0, 2, 1), dtype=np.float64))
     merged = gather_features({k: v.data for k, v in local.items()}, dst=dst, group=group)
-    meta = [None] * world
-    dist.all_gather_object(
-        meta, {k: (v.times, v.properties) for k, v in local.items()}, group=group)
+    meta = transport.all_gather_object({k: (v.times, v.properties) for k, v in local.items()})
     if merged is None:
         return None
     out = FeaturesCollection()
@@ -268,12 +304,12 @@ def extract_features_streamed_sharded(configuration, utterances, sink, warps=Non
     ``KaldiStreamWriter('feats.<rank>.ark')`` per rank: no features travel between the ranks).  The
     only exchange is the sum of the per-speaker CMVN statistics after the first pass (a few KB,
     `reduce_named_stats`).  Returns the number of utterances this rank wrote."""
-    import torch.distributed as dist
     from shennong_amd import pipeline
     from shennong_amd.logger import get_logger
     from shennong_amd.utterances import Utterances
     log = log or get_logger('pipeline', 'warning')
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    transport = _transport(group)
+    rank, world = transport.rank, transport.world_size
     config = pipeline._init_config(configuration, log=log)
     if warps:
         warps = pipeline._init_warps(warps, config, utterances, log)

@@ -40,3 +40,27 @@ class MfccProcessor(MelFeaturesProcessor):
     @property
     def ndims(self):
         return self.num_ceps
+
+    def process_with_deltas(self, signal, vtln_warp=1.0):
+        """``DeltaPostProcessor().process(self.process(signal, vtln_warp))`` in ONE launch: rows are
+        [cepstra | delta | delta-delta] (order 2, window 2), the cepstra never leave the GPU's local
+        memory between the two stages (reference chain: postprocessor/delta.py:129-131 after
+        processor/mfcc.py:86; BASELINE config 3)"""
+        return self._process_batch_with_deltas([signal], vtln_warp=[vtln_warp])[0]
+
+    def _process_batch_with_deltas(self, signals, vtln_warp=None):
+        from shennong_amd.postprocessor.delta import DeltaPostProcessor
+        from shennong_amd.processor.base import batch_features, check_signal
+        for signal in signals:
+            check_signal(self, signal)
+        warps = [1.0] * len(signals) if vtln_warp is None else list(vtln_warp)
+        opts = self._build_options()
+        opts.append_deltas, opts.delta_order, opts.delta_window = 1, 2, 2
+        datas = self._run(opts, signals, warps)
+        delta = DeltaPostProcessor(order=2, window=2)
+
+        def properties(warp):
+            stage = type('Stage', (), {'properties': self.get_properties(vtln_warp=warp),
+                                       'ndims': self.ndims})
+            return delta.get_properties(stage)
+        return batch_features(datas, self.times, properties, warps)

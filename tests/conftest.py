@@ -68,9 +68,11 @@ def gpu(_gpu_backend):
     return _gpu_backend
 
 
-def assert_close(got, want, rtol=1e-4, atol=1e-5, what=''):
-    """Parity tolerance of the float32 features: 1e-4 relative (BASELINE.json north_star) plus a
-    small absolute term; the measured worst case of every call is appended to the file named by
+def assert_close(got, want, rtol=1e-4, atol=1e-4, what=''):
+    """Parity tolerance of the float32 features: 1e-4 relative (BASELINE.json north_star) plus 1e-4
+    absolute for coefficients that cross zero (an MFCC is a signed sum of 23 log energies of
+    magnitude ~15: float32 round-off of either side reaches 6e-5 there; measured worst cases:
+    profiles/r02_parity_errors.txt).  The measured worst case of every call is appended to the file named by
     SNF_PARITY_LOG (tools/parity_errors.py summarises it; the committed summary is in
     profiles/r02_parity_errors.txt)."""
     got = np.asarray(got)

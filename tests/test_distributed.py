@@ -227,3 +227,38 @@ def test_streamed_sharded_gloo(tmp_path):
         port = s.getsockname()[1]
     mp.spawn(_streamed_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert [open(tmp_path / f'ok{r}').read() for r in range(2)] == ['1', '1']
+
+
+# ---- RCCL transport through the C ABI (needs a GPU; the test box has one: world size 1) ---------------
+@pytest.mark.gpu
+def test_rccl_comm_world_of_one():
+    import numpy as np
+    from shennong_amd import _backend, distributed
+    from shennong_amd.comm import RcclComm
+    if _backend.device_count() < 1:
+        pytest.skip('no HIP device visible')
+    comm = RcclComm(0, 1)
+    assert (comm.rank, comm.world_size) == (0, 1)
+    assert comm.all_gather_object({'a': 1}) == [{'a': 1}]
+    stats = np.arange(24, dtype=np.float64).reshape(4, 2, 3)
+    assert np.array_equal(comm.allreduce(stats, 'sum'), stats)
+    assert np.array_equal(distributed.allreduce_cmvn_stats(stats, group=comm), stats)
+    assert comm.allreduce(np.array([3.5]), 'max')[0] == 3.5
+    comm.barrier()
+    rng = np.random.default_rng(0)
+    local = {'u%d' % i: rng.standard_normal((n, 5)).astype(np.float32) for i, n in enumerate((3, 0, 17))}
+    merged = distributed.gather_features(local, dst=0, group=comm)
+    assert merged.keys() == local.keys()
+    assert all(np.array_equal(merged[k], local[k]) for k in local)
+    assert distributed.gather_features({}, dst=0, group=comm) == {}
+    # device pointers in and out
+    data = rng.standard_normal(1000).astype(np.float32)
+    d_send, d_recv = _backend.DeviceBuffer(data.nbytes), _backend.DeviceBuffer(data.nbytes)
+    d_send.upload(data)
+    comm.gatherv_device(d_send.ptr, data.size, d_recv.ptr, [data.size], 0)
+    back = np.empty_like(data)
+    d_recv.download(back)
+    assert np.array_equal(back, data)
+    with pytest.raises(ValueError):
+        comm.gatherv_device(d_send.ptr, data.size, d_recv.ptr, [data.size], 3)
+    comm.close()

@@ -54,7 +54,7 @@ def test_fbank_options(gpu, audio, wave, opts):
     want = _oracle(proc, wave)
     rtol = 1e-4 if opts.get('use_log_fbank', True) else 2e-4
     assert_close(got.data, want, rtol=rtol,
-                 atol=2e-3 if opts.get('use_log_fbank', True) else 1.0,
+                 atol=1e-4 if opts.get('use_log_fbank', True) else 1.0,
                  what=str(opts))
 
 
@@ -78,7 +78,7 @@ def test_spectrogram(gpu, audio, wave, opts):
     want = _oracle(proc, wave)
     assert got.shape[1] == 257
     # single-bin log power: deep spectral nulls amplify float32 FFT round-off of both sides
-    assert_close(got.data, want, rtol=1e-4, atol=2e-2, what=str(opts))
+    assert_close(got.data, want, rtol=1e-4, atol=2e-3, what=str(opts))  # (spectral nulls)
     assert np.mean(np.abs(got.data - want) < 1e-3) > 0.999
 
 
@@ -91,7 +91,7 @@ def test_plp(gpu, audio, wave, opts):
     proc = PlpProcessor(dither=0, **opts)
     got = proc.process(audio)
     want = _oracle(proc, wave)
-    assert_close(got.data, want, rtol=2e-4, atol=2e-3, what=str(opts))
+    assert_close(got.data, want, rtol=2e-4, atol=1e-4, what=str(opts))
 
 
 @pytest.mark.parametrize('warp', [0.85, 1.0, 1.2])
@@ -152,13 +152,11 @@ def test_delta_batch_edges(gpu):
 
 
 def _pitch_close(got, want):
+    """The tracker implements the oracle's summation orders (oracle/kaldi_oracle.c chain_dot / tree16):
+    every frame - Viterbi state, pitch and POV NCCF - is bit-identical"""
     assert got.shape == want.shape
-    same = got[:, 1] == want[:, 1]
-    # frames where the Viterbi path differs must be rare (float round-off near-ties) and one
-    # lag step (0.5 %) apart at most on average
-    assert same.mean() >= 0.97, same.mean()
-    assert np.max(np.abs(got[:, 1] / want[:, 1] - 1)) < 0.05
-    np.testing.assert_allclose(got[same, 0], want[same, 0], rtol=1e-3, atol=2e-4)
+    np.testing.assert_array_equal(got[:, 1], want[:, 1])
+    np.testing.assert_array_equal(got[:, 0], want[:, 0])
 
 
 @pytest.mark.parametrize('opts', [dict(), dict(frame_shift=0.02),
@@ -573,7 +571,7 @@ def test_short_frames_spectrogram_and_energy(gpu):
     proc = SpectrogramProcessor(sample_rate=8000, dither=0)
     got = proc.process(Audio(wave, 8000))
     assert got.shape[1] == 129
-    assert_close(got.data, _oracle(proc, wave), rtol=1e-4, atol=2e-2)
+    assert_close(got.data, _oracle(proc, wave), rtol=1e-4, atol=2e-3)
     plan = _backend.get_plan(proc._build_options())
     plan.run([wave])
     assert plan.kernel_name(1) == 'mel_features_generic_kernel'
@@ -792,3 +790,43 @@ def test_buffers_from_a_fresh_thread(gpu):
     t.start()
     t.join()
     assert result.get('ok')
+
+
+# ---- MFCC + delta + delta-delta in one launch (BASELINE config 3) ------------------------------------
+@pytest.mark.parametrize('opts', [dict(), dict(use_energy=False, htk_compat=True),
+                                  dict(raw_energy=False), dict(num_ceps=10, num_bins=30)])
+def test_mfcc_with_deltas_equals_the_chain(gpu, audio, opts):
+    proc = MfccProcessor(dither=0, **opts)
+    fused = proc.process_with_deltas(audio)
+    chained = DeltaPostProcessor().process(proc.process(audio))
+    assert fused.shape == chained.shape == (140, 3 * proc.num_ceps)
+    np.testing.assert_array_equal(fused.data, chained.data)
+    assert fused.properties == chained.properties and np.array_equal(fused.times, chained.times)
+    want = orc.deltas(orc.compute(proc._build_options(), audio.data), 2, 2)
+    assert_close(fused.data, want)
+
+
+def test_mfcc_with_deltas_batch(gpu):
+    """ragged batch: utterances of one frame, of several workgroups (> 328 frames: the +-4 frame halo
+    between workgroups is recomputed), one too short for a frame, and per-utterance VTLN warps"""
+    waves = [synth.utterances(50 + i, 1, n)[0] for i, n in enumerate((400, 560, 16000, 90000, 100, 48000, 131072))]
+    warps = [1.0, 0.9, 1.0, 1.1, 1.0, 1.0, 0.95]
+    proc = MfccProcessor(dither=0)
+    audios = [Audio(w, 16000) for w in waves]
+    fused = proc._process_batch_with_deltas(audios, vtln_warp=warps)
+    plain = proc._process_batch(audios, vtln_warp=warps)
+    for f, m in zip(fused, plain):
+        if m.shape[0] == 0:
+            assert f.shape[0] == 0
+            continue
+        np.testing.assert_array_equal(f.data, DeltaPostProcessor().process(m).data)
+    # without warps every utterance is scheduled per workgroup as well
+    for f, m in zip(proc._process_batch_with_deltas(audios), proc._process_batch(audios)):
+        if m.shape[0]:
+            np.testing.assert_array_equal(f.data, DeltaPostProcessor().process(m).data)
+
+
+def test_mfcc_with_deltas_refusals(gpu, audio):
+    proc = MfccProcessor(dither=0, sample_rate=44100)   # frames pad to 2048 samples
+    with pytest.raises(ValueError, match='append_deltas needs frames that pad to 512'):
+        proc.process_with_deltas(Audio(np.zeros(44100, np.int16), 44100))
