@@ -974,7 +974,7 @@ int snf_post_run_batch_device(snf_plan* plan, const float* d_in, int32_t in_cols
   if (own_stream) begin_timing(plan);
   if (plan->kind == SNF_KIND_DELTA) {
     if (in_cols <= 0) return set_error(SNF_E_INVALID, "in_cols must be positive");
-    if ((rc = plan->s_futt.ensure(sizeof(int32_t) * static_cast<size_t>(total_frames / 256 + 2)))) return rc;
+    if ((rc = plan->s_futt.ensure(sizeof(int32_t) * static_cast<size_t>(total_frames / 32 + 2)))) return rc;
     if ((rc = launch_deltas(plan->dp, d_in, in_cols, plan->s_foff.as<int64_t>(), n_utts,
                             total_frames, d_out, plan->s_futt.as<int32_t>(), s)))
       return rc;

@@ -744,8 +744,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
   if (FUSED) {
     // ---- [cepstra | delta | delta-delta] of the workgroup's frames (DeltaPostProcessor order 2, window
     // 2; [KALDI-UPSTREAM] ComputeDeltas): frame indices clamp at the ends of the utterance, the same
-    // products in the same order as delta_flat_o2w2_kernel (kernels_post.hip), four consecutive floats
-    // of the flat output row block per thread and store --------------------------------------------
+    // products in the same order as delta_flat_o2w2_kernel (kernels_post.hip) ------------------------
     __syncthreads();
     const int D = p.num_ceps, OD = 3 * D;
     const int64_t f_first = static_cast<int64_t>(pu_set0) * 4;
@@ -757,39 +756,30 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     float* __restrict__ obase = out + (pu_f0 + f_first) * static_cast<int64_t>(p.out_cols);
     const int last = static_cast<int>(pu_T - 1 - cep_frame0);   // buffer row of the utterance's last frame
     const int first = static_cast<int>(-cep_frame0);            // ... and of its first frame
-    for (int e0 = 4 * threadIdx.x; e0 < n_out; e0 += 4 * blockDim.x) {
-      float v[4];
+    // element (row r, column c): its 9 clamped neighbours are read once for the three orders
+    for (int idx = threadIdx.x; idx < static_cast<int>(rows64) * D; idx += blockDim.x) {
+      const int r = idx / D, c = idx - r * D;
+      const int centre = r + 4;
+      float x[9];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int e = e0 + k < n_out ? e0 + k : n_out - 1;
-        const int r = e / OD, col = e - r * OD, order = col / D, c = col - order * D;
-        const int centre = r + 4;
-        float acc = 0.0f;
-        if (order == 0) {
-          acc += sc[0] * cepbuf[centre * kFusedCols + c];
-        } else if (order == 1) {
-#pragma unroll
-          for (int j = -2; j <= 2; ++j) {
-            int t = centre + j;
-            t = t < first ? first : (t > last ? last : t);
-            const float w = sc[1 + j + 2];
-            if (w != 0.0f) acc += w * cepbuf[t * kFusedCols + c];
-          }
-        } else {
-#pragma unroll
-          for (int j = -4; j <= 4; ++j) {
-            int t = centre + j;
-            t = t < first ? first : (t > last ? last : t);
-            const float w = sc[6 + j + 4];
-            if (w != 0.0f) acc += w * cepbuf[t * kFusedCols + c];
-          }
-        }
-        v[k] = acc;
+      for (int j = 0; j < 9; ++j) {
+        int t = centre + j - 4;
+        t = t < first ? first : (t > last ? last : t);
+        x[j] = cepbuf[t * kFusedCols + c];
       }
-      if (e0 + 3 < n_out) {
-        *reinterpret_cast<f32x4_a4*>(obase + e0) = f32x4_a4{v[0], v[1], v[2], v[3]};
-      } else {
-        for (int k = 0; k < 4 && e0 + k < n_out; ++k) obase[e0 + k] = v[k];
+      float* __restrict__ orow = obase + r * OD + c;
+      int soff = 0;
+#pragma unroll
+      for (int i = 0; i <= 2; ++i) {
+        const int max_off = 2 * i;
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = -max_off; j <= max_off; ++j) {
+          const float w = sc[soff + j + max_off];
+          if (w != 0.0f) acc += w * x[j + 4];
+        }
+        orow[i * D] = acc;
+        soff += 2 * max_off + 1;
       }
     }
   }

@@ -457,18 +457,27 @@ __global__ __launch_bounds__(256) void delta_tiled_fixed_kernel(
 }
 
 // The reference's defaults (order 2, window 2) as a flat stream: the [T, D] input and the [T, 3 D] output
-// are both contiguous, so a tile is staged with 16-byte loads, every thread produces FOUR consecutive
-// floats of the flat output (whatever row / order / column they fall on: the divisions by 3 D and D are
-// by compile-time constants) from the clamped neighbours in LDS, and stores them as one dwordx4: loads
-// and stores are fully coalesced 16-byte accesses (the per-(row, column) form above writes 4-byte
-// elements in runs of D).  The utterance of a tile's first row comes from a table built by one thread
-// per tile (a binary search of dependent loads at the head of every workgroup cost more than its
-// arithmetic); rows walk forward from it.  Same products in the same order as the kernels above.
-constexpr int kFlatRows = 256;
+// are both contiguous.  A tile of rows is staged with 16-byte loads; thread i computes the elements
+// (row, column) i, i + 256, ... for all three orders from ONE read of the 9 clamped neighbours
+// (consecutive lanes -> consecutive columns: conflict-free; the division by D is by a compile-time
+// constant) into an LDS image of the output block, which is then copied out as dwordx4: loads and
+// stores are fully coalesced 16-byte accesses (the per-(row, column) form above writes 4-byte elements in runs of D).  The utterance of a
+// tile's first row comes from a table built by one thread per tile (a binary search of dependent loads
+// at the head of every workgroup costs more than its arithmetic); rows walk forward from it.  Same
+// products in the same order as the kernels above.
+constexpr int kFlatTileBytes = 28 * 1024;  // input tile + output image of one workgroup
+template <int D>
+constexpr int flat_rows() {
+  // rows per tile: a multiple of 4 (16-byte aligned output blocks) that fits the LDS budget
+  int rows = (kFlatTileBytes / 4 - 8 * D - 8) / (4 * D);
+  rows &= ~3;
+  return rows > 256 ? 256 : rows;
+}
 __global__ void delta_tile_utt_kernel(const int64_t* __restrict__ frame_offsets, int64_t n_utts,
-                                      int64_t total_frames, int32_t* __restrict__ tile_utt) {
+                                      int64_t total_frames, int rows_per_tile,
+                                      int32_t* __restrict__ tile_utt) {
   const int64_t tile = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  const int64_t g = tile * kFlatRows;
+  const int64_t g = tile * rows_per_tile;
   if (g < total_frames) tile_utt[tile] = static_cast<int32_t>(find_utt(frame_offsets, n_utts, g));
 }
 
@@ -477,11 +486,13 @@ __global__ __launch_bounds__(256) void delta_flat_o2w2_kernel(
     const DeltaParams p, const float* __restrict__ in, const int64_t* __restrict__ frame_offsets,
     const int32_t* __restrict__ tile_utt, const int64_t n_utts, const int64_t total_frames,
     float* __restrict__ out) {
-  constexpr int kHalo = 4, OD = 3 * D, kTileRows = kFlatRows + 2 * kHalo;
+  constexpr int kRows = flat_rows<D>();
+  constexpr int kHalo = 4, OD = 3 * D, kTileRows = kRows + 2 * kHalo;
   constexpr int kTileFloats = (kTileRows * D + 3) & ~3;
   __shared__ __attribute__((aligned(16))) float tile[kTileFloats + 4];
-  __shared__ int row_lo[kFlatRows], row_hi[kFlatRows];
-  const int64_t g0 = static_cast<int64_t>(blockIdx.x) * kFlatRows;
+  __shared__ __attribute__((aligned(16))) float image[kRows * OD];
+  __shared__ int row_lo[kRows], row_hi[kRows];
+  const int64_t g0 = static_cast<int64_t>(blockIdx.x) * kRows;
   const int64_t t0 = g0 - kHalo;
   const int64_t first = t0 * D, limit = total_frames * D;
   // the tile starts at float `first` of the input, which is 16-byte aligned only for some tiles: stage
@@ -501,57 +512,57 @@ __global__ __launch_bounds__(256) void delta_flat_o2w2_kernel(
     }
     reinterpret_cast<float4*>(tile)[i] = v;
   }
-  {
-    const int64_t g = g0 + threadIdx.x;
+  for (int r = threadIdx.x; r < kRows; r += blockDim.x) {
+    const int64_t g = g0 + r;
     if (g < total_frames) {
       int64_t u = tile_utt[blockIdx.x];
       while (frame_offsets[u + 1] <= g) ++u;  // (a tile spans few utterances)
       const int64_t lo = frame_offsets[u] - t0, hi = frame_offsets[u + 1] - 1 - t0;
-      row_lo[threadIdx.x] = lo < 0 ? 0 : static_cast<int>(lo);
-      row_hi[threadIdx.x] = hi > kTileRows - 1 ? kTileRows - 1 : static_cast<int>(hi);
+      row_lo[r] = lo < 0 ? 0 : static_cast<int>(lo);
+      row_hi[r] = hi > kTileRows - 1 ? kTileRows - 1 : static_cast<int>(hi);
     }
   }
   float sc[15];  // scales of the three orders, concatenated like DeltaParams::scales: 1 + 5 + 9
 #pragma unroll
   for (int i = 0; i < 15; ++i) sc[i] = p.scales[i];
   __syncthreads();
-  const int rows_here = static_cast<int>(total_frames - g0 < kFlatRows ? total_frames - g0 : kFlatRows);
+  const int rows_here = static_cast<int>(total_frames - g0 < kRows ? total_frames - g0 : kRows);
   const int n_out = rows_here * OD;
-  float* __restrict__ obase = out + g0 * OD;   // (g0 * OD * 4 bytes is a multiple of 16: kFlatRows is)
   const float* __restrict__ tl = tile + skew;
-  for (int e0 = 4 * threadIdx.x; e0 < n_out; e0 += 4 * blockDim.x) {
-    float v[4];
+  // element (row r, column c): its 9 clamped neighbours are read ONCE for the three orders (every lane
+  // runs the same taps: no divergence), the three results go to the output image
+  for (int idx = threadIdx.x; idx < rows_here * D; idx += blockDim.x) {
+    const int r = idx / D, c = idx - r * D;
+    const int lo = row_lo[r], hi = row_hi[r], centre = r + kHalo;
+    float x[9];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int e = e0 + k < n_out ? e0 + k : n_out - 1;
-      const int r = e / OD, col = e - r * OD, order = col / D, c = col - order * D;
-      const int lo = row_lo[r], hi = row_hi[r], centre = r + kHalo;
-      float acc = 0.0f;
-      if (order == 0) {
-        acc += sc[0] * tl[centre * D + c];
-      } else if (order == 1) {
-#pragma unroll
-        for (int j = -2; j <= 2; ++j) {
-          int t = centre + j;
-          t = t < lo ? lo : (t > hi ? hi : t);
-          const float s = sc[1 + j + 2];
-          if (s != 0.0f) acc += s * tl[t * D + c];
-        }
-      } else {
-#pragma unroll
-        for (int j = -4; j <= 4; ++j) {
-          int t = centre + j;
-          t = t < lo ? lo : (t > hi ? hi : t);
-          const float s = sc[6 + j + 4];
-          if (s != 0.0f) acc += s * tl[t * D + c];
-        }
-      }
-      v[k] = acc;
+    for (int j = 0; j < 9; ++j) {
+      int t = centre + j - kHalo;
+      t = t < lo ? lo : (t > hi ? hi : t);
+      x[j] = tl[t * D + c];
     }
+    float* __restrict__ orow = image + r * OD + c;
+    int soff = 0;
+#pragma unroll
+    for (int i = 0; i <= 2; ++i) {
+      const int max_off = 2 * i;
+      float acc = 0.0f;
+#pragma unroll
+      for (int j = -max_off; j <= max_off; ++j) {
+        const float w = sc[soff + j + max_off];
+        if (w != 0.0f) acc += w * x[j + kHalo];
+      }
+      orow[i * D] = acc;
+      soff += 2 * max_off + 1;
+    }
+  }
+  __syncthreads();
+  float* __restrict__ obase = out + g0 * OD;   // (g0 * OD * 4 bytes is a multiple of 16: kRows % 4 == 0)
+  for (int e0 = 4 * threadIdx.x; e0 < n_out; e0 += 4 * blockDim.x) {
     if (e0 + 3 < n_out) {
-      *reinterpret_cast<float4*>(obase + e0) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(obase + e0) = *reinterpret_cast<const float4*>(image + e0);
     } else {
-      for (int k = 0; k < 4 && e0 + k < n_out; ++k) obase[e0 + k] = v[k];
+      for (int k = 0; k < 4 && e0 + k < n_out; ++k) obase[e0 + k] = image[e0 + k];
     }
   }
 }
@@ -565,13 +576,15 @@ int launch_deltas(const DeltaParams& p, const float* in, int in_cols, const int6
   const bool aligned16 = (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
   if (p.order == 2 && p.window == 2 && tile_utt && aligned16 &&
       (in_cols == 13 || in_cols == 23 || in_cols == 40 || in_cols == 43)) {
-    const unsigned tiles = static_cast<unsigned>((total_frames + kFlatRows - 1) / kFlatRows);
-    hipLaunchKernelGGL(delta_tile_utt_kernel, dim3((tiles + 255) / 256), dim3(256), 0, stream,
-                       frame_offsets, n_utts, total_frames, tile_utt);
-    SNF_HIP_CHECK(hipGetLastError());
-#define SNF_FLAT(D_)                                                                                \
-  hipLaunchKernelGGL((delta_flat_o2w2_kernel<D_>), dim3(tiles), dim3(256), 0, stream, p, in,          \
-                     frame_offsets, tile_utt, n_utts, total_frames, out)
+#define SNF_FLAT(D_)                                                                                  \
+  do {                                                                                                \
+    constexpr int rows = flat_rows<D_>();                                                             \
+    const unsigned tiles = static_cast<unsigned>((total_frames + rows - 1) / rows);                   \
+    hipLaunchKernelGGL(delta_tile_utt_kernel, dim3((tiles + 255) / 256), dim3(256), 0, stream,        \
+                       frame_offsets, n_utts, total_frames, rows, tile_utt);                          \
+    hipLaunchKernelGGL((delta_flat_o2w2_kernel<D_>), dim3(tiles), dim3(256), 0, stream, p, in,        \
+                       frame_offsets, tile_utt, n_utts, total_frames, out);                           \
+  } while (0)
     if (in_cols == 13) SNF_FLAT(13);
     else if (in_cols == 23) SNF_FLAT(23);
     else if (in_cols == 40) SNF_FLAT(40);

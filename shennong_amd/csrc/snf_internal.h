@@ -146,7 +146,7 @@ int launch_mel_features(const MelParams& p, const BatchArgs& b, float* out, int 
 int launch_rasta(float* mel, const BatchArgs& b, int num_bins, hipStream_t stream);
 int launch_plp_tail(const PlpParams& p, const BatchArgs& b, const float* mel, const double* energy,
                     float* out, hipStream_t stream);
-// `tile_utt`: scratch of ceil(total_frames / 256) int32 (nullptr: per-element kernels only)
+// `tile_utt`: scratch of total_frames / 32 + 2 int32 (nullptr: per-element kernels only)
 int launch_deltas(const DeltaParams& p, const float* in, int in_cols, const int64_t* frame_offsets,
                   int64_t n_utts, int64_t total_frames, float* out, int32_t* tile_utt,
                   hipStream_t stream);

@@ -1,0 +1,112 @@
+"""BASELINE.json configurations 4 and 5 at the scale one GPU of the node sees.
+
+Config 4: PlpProcessor 13 + KaldiPitchProcessor (+ post-processing) on 100 000 utterances of 1-6 s
+sharded over 8 GPUs -> ONE rank's shard of 12 500 ragged utterances (12 h of audio) goes through the
+batched launches; a seeded sample of them is compared with the CPU oracle (pitch: every frame
+bit-identical; PLP: the parity tolerance) and with the same utterance processed alone (bit-identical:
+results do not depend on what else is in the batch).
+
+Config 5: fbank-40 + pitch + delta + CMVN by speaker streamed over a corpus that does not fit in one
+batch -> 10 h of synthetic audio through pipeline.extract_features_streamed in 30-minute batches; every
+utterance arrives exactly once, a sample equals the one-shot pipeline bit for bit.
+"""
+
+import os
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+import pytest
+
+from conftest import assert_close
+from oracle import oracle as orc
+from shennong_amd import Audio, Utterances, pipeline, synth
+from shennong_amd.logger import get_logger
+from shennong_amd.processor import KaldiPitchPostProcessor, KaldiPitchProcessor, PlpProcessor
+
+pytestmark = pytest.mark.gpu
+
+
+def _ragged(args):
+    first, count = args
+    rng = np.random.default_rng(20260927 + first)
+    return [synth.utterances(first + i, 1, int(rng.integers(16000, 96001)))[0] for i in range(count)]
+
+
+def _uniform(args):
+    return synth.utterances(*args)
+
+
+def _pool_map(fn, jobs):
+    workers = max(1, min(16, len(os.sched_getaffinity(0))))
+    if workers == 1:
+        return [fn(j) for j in jobs]
+    with ProcessPoolExecutor(workers) as pool:
+        return list(pool.map(fn, jobs))
+
+
+def test_config4_one_shard(gpu):
+    n = 12500
+    waves = [w for part in _pool_map(_ragged, [(i, min(500, n - i)) for i in range(0, n, 500)]) for w in part]
+    seconds = sum(w.shape[0] for w in waves) / 16000.0
+    assert 11.0 * 3600 < seconds < 13.5 * 3600
+    audios = [Audio(w, 16000, validate=False) for w in waves]
+    plp, pitch, post = PlpProcessor(dither=0), KaldiPitchProcessor(), KaldiPitchPostProcessor(
+        delta_pitch_noise_stddev=0)
+    f_plp = plp._process_batch(audios)
+    f_pitch = pitch._process_batch(audios)
+    f_post = post._process_batch(f_pitch)
+    assert len(f_plp) == len(f_pitch) == len(f_post) == n
+    frames = sum(f.nframes for f in f_pitch)
+    assert frames > 4.0e6
+    for feats, dims in ((f_plp, 13), (f_pitch, 2), (f_post, 3)):
+        assert all(f.ndims == dims for f in feats)
+        assert all(np.isfinite(f.data).all() for f in feats[::97])
+    sample = [int(i) for i in np.random.default_rng(4).choice(n, size=16, replace=False)]
+    sample += [int(np.argmax([w.shape[0] for w in waves])), int(np.argmin([w.shape[0] for w in waves]))]
+    for i in sample:
+        want = orc.pitch(pitch._options, waves[i])
+        np.testing.assert_array_equal(f_pitch[i].data, want, err_msg=f'pitch of utterance {i}')
+        assert_close(f_post[i].data, orc.process_pitch(post._options, want), rtol=1e-4, atol=1e-5,
+                     what=f'pitch post {i}')
+        assert_close(f_plp[i].data, orc.compute(plp._build_options(), waves[i]), rtol=2e-4,
+                     what=f'plp {i}')
+        alone = plp.process(audios[i])
+        np.testing.assert_array_equal(f_plp[i].data, alone.data)
+        np.testing.assert_array_equal(f_pitch[i].data, pitch.process(audios[i]).data)
+
+
+def test_config5_ten_hours_streamed(gpu):
+    n, nsamples, speakers = 12000, 48000, 200      # 10 h of 3 s utterances
+    waves = np.concatenate(_pool_map(_uniform, [(i, 500, nsamples) for i in range(0, n, 500)]))
+    index = Utterances([(f'u{i:05d}', Audio(waves[i], 16000, validate=False), f's{i % speakers:03d}')
+                        for i in range(n)])
+    config = pipeline.get_default_config('filterbank', with_pitch='kaldi', with_cmvn=True, with_delta=True)
+    config['filterbank']['num_bins'] = 40
+    config['filterbank']['dither'] = 0
+    config['pitch']['postprocessing']['delta_pitch_noise_stddev'] = 0
+    config['cmvn']['by_speaker'] = True
+    config['cmvn']['with_vad'] = False
+    quiet = get_logger('test', 'error')
+    seen, kept = [], {}
+    keep = {f'u{i:05d}' for i in range(0, n, 997)}
+
+    def sink(feats):
+        for name, f in feats.items():
+            seen.append(name)
+            assert f.shape == (298, 123) and f.dtype == np.float32   # 40 x 3 + pitch 3
+            if name in keep:
+                kept[name] = f
+    written = pipeline.extract_features_streamed(config, index, sink, max_batch_duration=1800.0, log=quiet)
+    assert written == n and sorted(seen) == sorted(u.name for u in index) and len(set(seen)) == n
+    assert all(np.isfinite(f.data).all() for f in kept.values())
+    # the speakers of the kept utterances, extracted in one shot: the statistics of a speaker come from
+    # the same utterances, so the features must be the same bits
+    wanted = {index.by_name()[k].speaker for k in list(keep)[:3]}
+    subset = Utterances([(u.name, u.load_audio(), u.speaker) for u in index if u.speaker in wanted])
+    whole = pipeline.extract_features(config, subset, log=quiet)
+    checked = 0
+    for name, f in kept.items():
+        if name in whole:
+            assert f == whole[name], name
+            checked += 1
+    assert checked >= 3
