@@ -27,7 +27,7 @@ EXPORTS = [
     'snf_device_name', 'snf_device_synchronize', 'snf_num_frames',
     'snf_first_sample_of_frame', 'snf_window_size', 'snf_window_shift',
     'snf_padded_window_size', 'snf_window_function', 'snf_pitch_num_frames',
-    'snf_plan_create', 'snf_plan_destroy', 'snf_plan_ndims',
+    'snf_plan_create', 'snf_plan_destroy', 'snf_plan_ndims', 'snf_plan_fast_path',
     'snf_plan_num_frames', 'snf_plan_run_batch', 'snf_plan_run_batch_device',
     'snf_post_ndims', 'snf_post_run_batch', 'snf_post_run_batch_device',
     'snf_cmvn_accumulate', 'snf_cmvn_apply', 'snf_cmvn_accumulate_device',
@@ -78,6 +78,7 @@ def lib():
         L.snf_plan_destroy.argtypes = [vp]
         L.snf_plan_destroy.restype = None
         L.snf_plan_ndims.argtypes = [vp]
+        L.snf_plan_fast_path.argtypes = [vp]
         L.snf_plan_num_frames.argtypes = [vp, i64]
         L.snf_plan_num_frames.restype = i64
         L.snf_plan_run_batch.argtypes = [vp, pi16, pi64, i64, pf, pf, pi64]
@@ -207,6 +208,12 @@ class Plan:
         check(lib().snf_plan_create(
             C.byref(self.opts), self.device, C.byref(handle)))
         self.handle = handle
+        if lib().snf_plan_fast_path(handle) == 0:
+            from shennong_amd.logger import get_logger
+            get_logger('backend', 'warning').warning(
+                'this option combination is not covered by the register-resident kernel (frames must '
+                'pad to 512, 256 or 128 samples, <= 64 mel bins, <= 16 cepstra, power spectrum): the '
+                'generic wave-per-frame kernel is used, about 8 times slower per frame')
 
     def __del__(self):
         handle = getattr(self, 'handle', None)

@@ -93,6 +93,9 @@ struct snf_plan {
   DevBuf s_down, s_stats, s_bp, s_doff, s_dp1, s_fp1, s_states, s_setidx, s_edge, s_futt;
   DevBuf s_pres, s_anp;  // pitch: NCCF at the lag of every state [frames, states], norm average [frames]
   bool setidx_valid = false;
+  // calls that draw random numbers (dither, delta-pitch noise) so far: every call gets its own noise
+  // stream (the reference draws from one global rand(): two calls never repeat the same samples)
+  uint64_t noise_calls = 0;
 
   // last uploaded offsets tables (re-validated / re-uploaded only when they change)
   std::vector<int64_t> h_soff, h_foff;
@@ -734,6 +737,19 @@ void snf_plan_destroy(snf_plan* plan) {
 }
 
 int32_t snf_plan_ndims(const snf_plan* plan) { return plan ? plan->ndims : -1; }
+int32_t snf_plan_fast_path(const snf_plan* plan) {
+  if (!plan) return -1;
+  switch (plan->kind) {
+    case SNF_KIND_SPECTROGRAM:
+    case SNF_KIND_FBANK:
+    case SNF_KIND_MFCC:
+    case SNF_KIND_PLP:
+    case SNF_KIND_ENERGY:
+      return plan->fast512 ? 1 : 0;
+    default:
+      return 1;  // (no slower alternative exists for this kind)
+  }
+}
 
 int64_t snf_plan_num_frames(const snf_plan* plan, int64_t n) {
   if (!plan) return -1;
@@ -868,6 +884,10 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
   b.frame_edge = plan->s_edge.as<int32_t>();
   b.frame_utt = plan->setidx_valid ? plan->s_futt.as<int32_t>() : nullptr;
   if (own_stream) begin_timing(plan);
+  if (plan->mp.dither != 0.0f) {
+    const unsigned long long stream_key = plan->o.seed + 0x9E3779B97F4A7C15ull * ++plan->noise_calls;
+    plan->mp.seed = plan->fp.seed = plan->fp_warp.seed = stream_key;
+  }
   if (plan->kind == SNF_KIND_PLP) {
     const int nb = plan->o.mel.num_bins;
     if (use_fast) {
@@ -983,6 +1003,8 @@ int snf_post_run_batch_device(snf_plan* plan, const float* d_in, int32_t in_cols
     if (in_cols != 2)
       return set_error(SNF_E_INVALID, "data shape must be (_, 2), but it is (_, " +
                                           std::to_string(in_cols) + ")");
+    if (plan->ppost.o.delta_pitch_noise_stddev != 0.0f)
+      plan->ppost.seed = plan->o.seed + 0x9E3779B97F4A7C15ull * ++plan->noise_calls;
     if ((rc = launch_pitch_post(plan->ppost, d_in, plan->s_foff.as<int64_t>(), n_utts,
                                 total_frames, d_out, s)))
       return rc;

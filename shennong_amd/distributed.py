@@ -40,6 +40,17 @@ class _TorchTransport:
         return _torch_allreduce_stats(array, self.group, None)
 
 
+def _agree(transport, error):
+    """Collective error check: every rank reports whether its local step failed; if any did, ALL ranks
+    raise (a rank that raised alone would leave the others blocked in the next collective)"""
+    reports = transport.all_gather_object(None if error is None else '%s: %s' % (type(error).__name__, error))
+    failed = [(r, msg) for r, msg in enumerate(reports) if msg is not None]
+    if failed:
+        if error is not None:
+            raise error
+        raise RuntimeError('rank %d failed: %s' % failed[0])
+
+
 def _transport(group):
     """The object that carries out the exchange steps for `group`"""
     from shennong_amd.comm import RcclComm
@@ -276,14 +287,27 @@ def extract_features_sharded(configuration, utterances, warps=None, dst=0, group
     mine = [utts[i] for i in shards[rank]]
     by_speaker = 'cmvn' in config and config['cmvn']['by_speaker']
     hook = (lambda names, stats: reduce_named_stats(names, stats, group=group)) if by_speaker else None
-    if mine:
-        local = pipeline._extract_features(
-            config, Utterances(mine), {u.name: warps[u.name] for u in mine} if warps else None, log,
-            stats_hook=hook)
-    else:
-        local = FeaturesCollection()
-        if hook is not None:  # still take part in the reduction
+    # the statistics hook is a collective: a rank whose local extraction fails BEFORE reaching it would
+    # leave the others waiting, so every rank first validates what it can locally and the ranks agree
+    # on the outcome; the same after the extraction, before the gather
+    error = None
+    try:
+        if not all(u.load_audio().nchannels == 1 for u in mine):  # (what the pipeline refuses first)
+            raise ValueError('all audio files are not mono')
+    except Exception as exc:  # noqa: BLE001
+        error = exc
+    _agree(transport, error)
+    local = FeaturesCollection()
+    try:
+        if mine:
+            local = pipeline._extract_features(
+                config, Utterances(mine), {u.name: warps[u.name] for u in mine} if warps else None, log,
+                stats_hook=hook)
+        elif hook is not None:  # still take part in the reduction
             hook([], np.zeros((0, 2, 1), dtype=np.float64))
+    except Exception as exc:  # noqa: BLE001
+        error = exc
+    _agree(transport, error)
     merged = gather_features({k: v.data for k, v in local.items()}, dst=dst, group=group)
     meta = transport.all_gather_object({k: (v.times, v.properties) for k, v in local.items()})
     if merged is None:

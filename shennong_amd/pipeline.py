@@ -335,7 +335,9 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
     audio (one hour of 16 kHz audio is 115 MB of int16 up and, for 123 columns, 177 MB of float32
     down); each batch goes through the device-resident pipeline and its FeaturesCollection is
     handed to `sink` (a callable, e.g. ``KaldiStreamWriter.write``) and dropped.  The results are
-    those of :func:`extract_features` on the whole corpus, bit for bit: with CMVN by speaker the
+    those of :func:`extract_features` on the whole corpus - bit for bit when no random term is
+    configured (dither 0, delta-pitch noise 0; the noise of a frame depends on the call and on the
+    frame's position in its batch, like the reference's global rand() stream): with CMVN by speaker the
     statistics need every utterance of a speaker before any can be normalised, so a first pass over
     the batches accumulates them (features + VAD only, summed in utterance order like the one-shot
     pipeline does) and the second pass recomputes the features instead of keeping them - on this

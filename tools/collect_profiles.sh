@@ -1,36 +1,41 @@
 #!/bin/bash
 # Collects the artefacts that profiles/ holds for a round (run on the GPU box through gpurun):
-#   bench line, rocprofv3 kernel stats of the same command, HBM traffic counters (separate --pmc passes)
+#   bench line, rocprofv3 kernel stats of the same command, HBM traffic counters and SQ counters (one
+#   --pmc group per run, kernel-trace only), pitch / PLP kernel stats.  Every step is bounded.
 export TMPDIR=/tmp
 root=$(pwd)
 out=$root/gpurun_out/profiles
 mkdir -p $out
-python bench.py > $out/bench_default.json 2> $out/bench_default.err
+timeout -s KILL 500 python bench.py > $out/bench_default.json 2> $out/bench_default.err
 cd /tmp
 rm -rf /tmp/prof_stats
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- \
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- \
   python $root/bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-extra > $out/bench_profiled.json 2> /dev/null
 cp $(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1) $out/bench_fbank40_rocprofv3_kernel_stats.csv
 rm -rf /tmp/prof_pitch
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pitch -- \
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pitch -- \
   python $root/tools/profile_pitch.py 4000 > $out/pitch_plp_run.txt 2> /dev/null
 cp $(find /tmp/prof_pitch -name '*kernel_stats.csv' | head -1) $out/pitch_plp_rocprofv3_kernel_stats.csv
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/prof_$c
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/prof_$c -- \
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA" \
+           "SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES" \
+           "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+           "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+  i=$((i+1)); rm -rf /tmp/prof_pmc_$i
+  timeout -s KILL 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/prof_pmc_$i -- \
     python $root/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-extra > /dev/null 2>&1
-  cp $(find /tmp/prof_$c -name '*counter_collection.csv' | head -1) $out/pmc_$c.csv
+  f=$(find /tmp/prof_pmc_$i -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && cp $f $out/pmc_group_$i.csv
 done
 cd $root
-python - <<'PY'
-import csv, json, collections
-res = {}
-for c in ('FETCH_SIZE', 'WRITE_SIZE'):
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(f'gpurun_out/profiles/pmc_{c}.csv')):
+python - <<'PY' | tee gpurun_out/profiles/pmc_fbank512_summary.txt
+import csv, glob, collections
+acc = collections.defaultdict(list)
+for name in sorted(glob.glob('gpurun_out/profiles/pmc_group_*.csv')):
+    for r in csv.DictReader(open(name)):
         if 'fbank512' in r['Kernel_Name']:
             acc[r['Counter_Name']].append(float(r['Counter_Value']))
-    res[c] = {k: sum(v) / len(v) for k, v in acc.items()}
-print(json.dumps(res))
+for k, v in sorted(acc.items()):
+    print('%-28s %.5e  (n=%d)' % (k, sum(v) / len(v), len(v)))
 PY
-tail -c 600 $out/bench_default.json
+tail -c 400 $out/bench_default.json
