@@ -77,6 +77,9 @@ struct snf_plan {
   DevBuf d_fast_warp_tables, s_blk_utt, s_blk_set0;
   size_t fast_warps_built = 0;   // number of warp ids covered by d_fast_warp_tables
   bool fast_warps_ok = true;     // false: some warp's banks do not fit the fast kernel
+  // register-resident 2048-point path (frames that pad to 2048 or 1024 samples)
+  bool fast2048 = false;
+  DevBuf d_long_tables;
 
   // delta
   DeltaParams dp{};
@@ -318,6 +321,12 @@ int build_mel_plan(snf_plan* plan) {
       plan->h_lifter = lifter_h;
     }
   }
+  if (!plan->fast512 && fbank2048_eligible(p)) {
+    std::vector<float> blob;
+    fbank2048_tables(p, window, &blob);
+    if ((rc = plan->d_long_tables.upload(blob, plan->stream))) return rc;
+    plan->fast2048 = true;
+  }
   return SNF_OK;
 }
 
@@ -345,6 +354,7 @@ int sync_warp_tables(snf_plan* plan) {
   if ((rc = plan->d_mel_first.upload(first, plan->stream))) return rc;
   if ((rc = plan->d_mel_size.upload(size, plan->stream))) return rc;
   if ((rc = plan->d_mel_off.upload(off, plan->stream))) return rc;
+  w.insert(w.end(), 4, 0.0f);  // (the long-frame kernel reads the weights as 16-byte vectors)
   if ((rc = plan->d_mel_w.upload(w, plan->stream))) return rc;
   plan->mp.mel_first = plan->d_mel_first.as<int>();
   plan->mp.mel_size = plan->d_mel_size.as<int>();
@@ -745,7 +755,7 @@ int32_t snf_plan_fast_path(const snf_plan* plan) {
     case SNF_KIND_MFCC:
     case SNF_KIND_PLP:
     case SNF_KIND_ENERGY:
-      return plan->fast512 ? 1 : 0;
+      return (plan->fast512 || plan->fast2048) ? 1 : 0;
     default:
       return 1;  // (no slower alternative exists for this kind)
   }
@@ -834,15 +844,16 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     if ((rc = plan->s_energy.ensure(sizeof(double) * static_cast<size_t>(total_frames)))) return rc;
   }
   bool use_fast = plan->fast512;
+  bool use_long = plan->fast2048;  // (per-utterance VTLN warps included: it reads the plan's bank tables)
   if (use_fast && any_warp) {
     if ((rc = sync_fast_warp_tables(plan))) return rc;
     use_fast = plan->fast_warps_ok;
   }
-  if (use_fast && !plan->mp.snip_edges) {
+  if ((use_fast || use_long) && !plan->mp.snip_edges) {
     // the clamped bulk loads of the centred frames need every utterance to hold one full window
-    for (int64_t u = 0; u < n_utts && use_fast; ++u) {
+    for (int64_t u = 0; u < n_utts && (use_fast || use_long); ++u) {
       const int64_t n = sample_offsets[u + 1] - sample_offsets[u];
-      if (n > 0 && n < plan->mp.win_len) use_fast = false;
+      if (n > 0 && n < plan->mp.win_len) use_fast = use_long = false;
     }
   }
   const bool fused = plan->fp.fused_delta != 0;
@@ -895,6 +906,11 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
                                 plan->s_energy.as<double>(), s)))
         return rc;
       if (own_stream) mark_kernel(plan, "fbank512_kernel");
+    } else if (use_long) {
+      if ((rc = launch_fbank2048(plan->mp, b, plan->d_long_tables.as<float>(), plan->s_mel.as<float>(), nb,
+                                 plan->s_energy.as<double>(), s)))
+        return rc;
+      if (own_stream) mark_kernel(plan, "fbank2048_kernel");
     } else {
       if ((rc = launch_mel_features(plan->mp, b, plan->s_mel.as<float>(), nb,
                                     plan->s_energy.as<double>(), s)))
@@ -914,6 +930,10 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
       if ((rc = launch_fbank512(any_warp ? plan->fp_warp : plan->fp, b, d_out, plan->ndims, nullptr, s)))
         return rc;
       if (own_stream) mark_kernel(plan, "fbank512_kernel");
+    } else if (use_long) {
+      if ((rc = launch_fbank2048(plan->mp, b, plan->d_long_tables.as<float>(), d_out, plan->ndims, nullptr, s)))
+        return rc;
+      if (own_stream) mark_kernel(plan, "fbank2048_kernel");
     } else {
       if ((rc = launch_mel_features(plan->mp, b, d_out, plan->ndims, nullptr, s))) return rc;
       if (own_stream) mark_kernel(plan, "mel_features_generic_kernel");

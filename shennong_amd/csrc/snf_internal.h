@@ -189,6 +189,12 @@ int launch_build_frame_start(const int64_t* d_frame_offsets, const int64_t* d_sa
 int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int out_cols,
                     double* energy_out, hipStream_t stream);
 
+// ---- register-resident 2048-point path (kernels_fbank2048.hip): 44.1 / 48 kHz frames, 32 kHz zero-extended
+bool fbank2048_eligible(const MelParams& mp);
+void fbank2048_tables(const MelParams& mp, const std::vector<float>& window, std::vector<float>* blob);
+int launch_fbank2048(const MelParams& p, const BatchArgs& b, const float* tables, float* out, int out_cols,
+                     double* energy_out, hipStream_t stream);
+
 struct PitchDevTables {
   int first_lag, last_lag, num_lags, num_states, win_size, win_shift, full_len;
   int ar_max_taps, rs_in_unit, rs_out_unit, rs_max_taps;

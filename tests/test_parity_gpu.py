@@ -568,6 +568,58 @@ def test_fast_kernel_short_frames(gpu, cls, sample_rate, opts, snip_edges):
         assert_close(f.data, _oracle(proc, w, wf), rtol=2e-4, what=f'warp {wf} {opts}')
 
 
+@pytest.mark.parametrize('snip_edges', [True, False])
+@pytest.mark.parametrize('cls, sample_rate, opts', [
+    (FilterbankProcessor, 44100, dict(num_bins=40)),          # 1102 samples -> 2048 (reference test rate)
+    (FilterbankProcessor, 44100, dict(num_bins=23, use_energy=True, raw_energy=False)),
+    (FilterbankProcessor, 44100, dict(use_energy=True, htk_compat=True, use_power=False)),
+    (FilterbankProcessor, 44100, dict(remove_dc_offset=False, preemph_coeff=0.0, window_type='hamming')),
+    (MfccProcessor, 44100, dict()),
+    (MfccProcessor, 44100, dict(htk_compat=True, use_energy=False, num_ceps=20, num_bins=40)),
+    (MfccProcessor, 48000, dict(use_energy=False)),           # 1200 samples -> 2048
+    (PlpProcessor, 44100, dict()),
+    (SpectrogramProcessor, 44100, dict()),
+    (SpectrogramProcessor, 32000, dict(raw_energy=False)),    # 800 samples -> 1024: zero-extended
+    (MfccProcessor, 32000, dict()),
+    (FilterbankProcessor, 16000, dict(frame_length=0.064, frame_shift=0.02, num_bins=40)),  # 1024 samples
+    (FilterbankProcessor, 16000, dict(frame_length=0.1, frame_shift=0.03, num_bins=64)),    # 1600 -> 2048
+])
+def test_fast_kernel_long_frames(gpu, cls, sample_rate, opts, snip_edges):
+    """frames that pad to 2048 samples (44.1 / 48 kHz; the reference tests MFCC at 44.1 kHz,
+    test/processor/test_mfcc.py:129-137) and, zero-extended, to 1024 samples (32 kHz) run on the
+    register-resident 2048-point kernel, VTLN warps included"""
+    n = int(0.35 * sample_rate)
+    waves = [synth.utterances(21 + i, 1, n + 1013 * i, sample_rate)[0] for i in range(3)]
+    proc = cls(sample_rate=sample_rate, dither=0, snip_edges=snip_edges, **opts)
+    plan = _backend.get_plan(proc._build_options())
+    linear = opts.get('use_power', True) is False
+    kw = dict(vtln_warp=[1.0, 1.0, 1.0]) if cls is not SpectrogramProcessor else {}
+    feats = proc._process_batch([Audio(w, sample_rate) for w in waves], **kw)
+    assert plan.kernel_name(1) == 'fbank2048_kernel'
+    for w, f in zip(waves, feats):
+        want = _oracle(proc, w)
+        assert f.shape == want.shape
+        assert_close(f.data, want, rtol=2e-4, atol=2e-3 if cls is SpectrogramProcessor else 1e-4,
+                     what=f'{cls.__name__} {sample_rate} {opts}')
+    if cls is SpectrogramProcessor or linear:
+        return
+    warps = [0.9, 1.0, 1.15]
+    feats = proc._process_batch([Audio(w, sample_rate) for w in waves], vtln_warp=warps)
+    assert plan.kernel_name(1) == 'fbank2048_kernel'
+    for w, wf, f in zip(waves, warps, feats):
+        assert_close(f.data, _oracle(proc, w, wf), rtol=2e-4, what=f'warp {wf} {opts}')
+
+
+def test_long_frames_single_utterance_shorter_than_a_window(gpu):
+    """snip_edges = False with an utterance shorter than one window: the generic kernel takes over"""
+    wave = synth.utterances(3, 1, 900, 44100)[0]
+    proc = FilterbankProcessor(sample_rate=44100, dither=0, snip_edges=False)
+    got = proc.process(Audio(wave, 44100))
+    assert_close(got.data, _oracle(proc, wave), rtol=2e-4, what='short utterance')
+    plan = _backend.get_plan(proc._build_options())
+    assert plan.kernel_name(1) == 'mel_features_generic_kernel'
+
+
 def test_short_frames_spectrogram_and_energy(gpu):
     """the spectrogram of a 256-sample frame needs its own 129 bins: generic kernel; the frame
     energy has no spectrum at all: fast kernel"""
