@@ -64,6 +64,9 @@ __device__ __forceinline__ float from_left_lane(float v, int left_lane_bytes) {
 
 }  // namespace
 
+// NJ: element rows a lane can hold inside the window, ceil(win_len / 128): 9 covers 25 ms at 44.1 kHz (and
+// every shorter frame), 10 the same at 48 kHz, 16 any window up to 2048 samples
+template <int NJ>
 __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
     const MelParams p, const BatchArgs b, const float2* __restrict__ gtab, const int bin_step,
     float* __restrict__ out, const int out_cols, double* __restrict__ energy_out) {
@@ -94,17 +97,24 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
 #define SNF_LOAD_FRAME(start_, njl_, lane_off_)                                                        \
   do {                                                                                                 \
     const char* __restrict__ wp_ = reinterpret_cast<const char*>(b.wave + uniform64(start_));          \
-    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                   \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                   \
       if (j < nj_any) {                                                                                \
         const unsigned off_ = j < (njl_) ? (lane_off_) : 0u;                                           \
         raw[j] = *reinterpret_cast<const int_a2*>(wp_ + off_ + 256 * j);                               \
       }                                                                                                \
     }                                                                                                  \
   } while (0)
-  // (no register prefetch of the next frame's samples: a frame is ~10 k clocks of a wave's time, the
-  // load latency a fraction of that, and the other three waves of the SIMD cover it; 16 more live
-  // registers made the allocator spill.  Only the start offset is looked up one frame ahead.)
-  int64_t start_next = g < b.total_frames ? b.frame_start[g] : 0;
+  // The samples of the next frame are requested when the transform of the current one is done (the
+  // epilogue needs few registers) and converted at the top of the next iteration: their latency hides
+  // behind the mel phase without holding 16 registers through the FFT passes.
+  int raw[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) raw[j] = 0;
+  int64_t start_next = 0;
+  if (g < b.total_frames) {
+    SNF_LOAD_FRAME(b.frame_start[g], (L / 2 - lane + 63) >> 6, 4u * lane);
+    start_next = b.frame_start[clamp_frame(g + stride)];
+  }
   for (; g < b.total_frames; g += stride) {
     // lane-derived values of the sample phase are recomputed per frame from an opaque copy of the lane
     // index: hoisted out of the loop they would occupy (and spill) dozens of registers
@@ -127,21 +137,14 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
     float* __restrict__ ps_hi = ps + (576 - kappa);  // P[1024 - kappa - 64 d] = ps_hi[448 - 64 d]
 
     auto in_window = [&](int j) -> bool { return j < njl; };
-    int raw[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) raw[j] = 0;
-    SNF_LOAD_FRAME(start_next, njl, 4u * lane_v);
-    start_next = b.frame_start[clamp_frame(g + stride)];
     const int64_t u = b.frame_utt[g];
     const int edge = p.snip_edges ? 0 : b.frame_edge[g];
-    const int warp_id = b.utt_warp ? b.utt_warp[u] : 0;
+    const int warp_id = b.utt_warp ? __builtin_amdgcn_readfirstlane(b.utt_warp[u]) : 0;
 
     // ---- A: samples -> float, DC removal, pre-emphasis, window ---------------------------------------
-    float4 win4[8];
-    read_quads<8>(t_win, win4);
-    float xe[16], xo[16];
+    float xe[NJ], xo[NJ];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       xe[j] = static_cast<float>(static_cast<short>(raw[j] & 0xffff));
       xo[j] = static_cast<float>(raw[j] >> 16);
     }
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
       }
       wave_lds_sync();
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         if (in_window(j)) {
           const float2 v = base_lane[64 * j];
           xe[j] = v.x;
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
       const unsigned dkey_lo = fmix32(static_cast<unsigned>(k));
       const unsigned dkey_hi = fmix32(static_cast<unsigned>(k >> 32) ^ dkey_lo);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const float2 nz = gauss_pair(dkey_lo, dkey_hi, static_cast<unsigned>(lane_v + 64 * j));
         xe[j] += p.dither * nz.x;
         xo[j] += p.dither * nz.y;
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
     }
     float part = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) part += in_window(j) ? xe[j] + xo[j] : 0.0f;
+    for (int j = 0; j < NJ; ++j) part += in_window(j) ? xe[j] + xo[j] : 0.0f;
     float neg_mean = 0.0f;
     if (p.remove_dc) neg_mean = -wave_sum64(part) / win_len_f;
     float2 z[16];
@@ -191,25 +194,39 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
     if (p.need_raw) {  // raw energy: before pre-emphasis and window
       float e_raw = 0.0f;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const float ae = xe[j] + neg_mean, ao = xo[j] + neg_mean;
         e_raw += in_window(j) ? ae * ae + ao * ao : 0.0f;
       }
       e_lin = wave_sum64(e_raw);
     }
-    float rot_prev = xe[0] + neg_mean;  // lane 0, j = 0: x[-1] := x[0] (Kaldi Preemphasize)
+    // left neighbour x[2n-1] of the even sample of element n: the odd sample of element n-1 = lane L-1
+    // (same j), lane 63 of j-1 for lane 0.  All 16 exchanges are issued before the first one is used.
+    float rot[NJ];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const float ae = xe[j] + neg_mean, ao = xo[j] + neg_mean;
-      // left neighbour x[2n-1]: the odd sample of element n-1 = lane L-1 (same j), lane 63 of j-1 for lane 0
-      const float rot = from_left_lane(ao, left_lane_bytes);
-      const float ap = lane == 0 ? rot_prev : rot;
-      rot_prev = rot;
-      const float2 w = (j & 1) ? make_float2(win4[j >> 1].z, win4[j >> 1].w)
-                               : make_float2(win4[j >> 1].x, win4[j >> 1].y);
-      // (elements outside the window hold finite duplicates: their zero window weights make them 0)
-      z[j] = make_float2((ae - p.preemph * ap) * w.x, (ao - p.preemph * ae) * w.y);
+    for (int j = 0; j < NJ; ++j) rot[j] = from_left_lane(xo[j] + neg_mean, left_lane_bytes);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // (window weights in two halves: 16 live registers instead of 32)
+      if (8 * h < NJ) {
+        float4 win4[4];
+        read_quads<4>(t_win + 8 * h, win4);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const int j = 8 * h + jj;
+          if (j < NJ) {
+            const float ae = xe[j] + neg_mean, ao = xo[j] + neg_mean;
+            // lane 0, j = 0: x[-1] := x[0] (Kaldi Preemphasize)
+            const float ap = lane == 0 ? (j == 0 ? ae : rot[j > 0 ? j - 1 : 0]) : rot[j];
+            const float2 w = (jj & 1) ? make_float2(win4[jj >> 1].z, win4[jj >> 1].w)
+                                      : make_float2(win4[jj >> 1].x, win4[jj >> 1].y);
+            // (elements outside the window hold finite duplicates: their zero window weights make them 0)
+            z[j] = make_float2((ae - p.preemph * ap) * w.x, (ao - p.preemph * ae) * w.y);
+          }
+        }
+      }
     }
+#pragma unroll
+    for (int j = NJ; j < 16; ++j) z[j] = make_float2(0.0f, 0.0f);
     if (p.need_post && !p.need_raw) {
       float e_post = 0.0f;
 #pragma unroll
@@ -304,6 +321,9 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
       wave_lds_sync();
     }
 
+    // next frame: samples (converted at the top of the next iteration), start offset of the one after
+    SNF_LOAD_FRAME(start_next, njl, 4u * lane_v);
+    start_next = b.frame_start[clamp_frame(g + 2 * stride)];
     // ---- F: epilogue (same conventions as mel_features_generic_kernel) -----------------------------------
     float log_energy = 0.0f;
     if (p.kind == SNF_KIND_PLP) {
@@ -344,20 +364,23 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
         float acc = 0.0f;
         for (int i0 = 0; __any(i0 < span); i0 += 16) {
           f32x4_a4 w[4];
+          float pv[16];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int t = t0 + i0 + 4 * i;
             w[i] = *reinterpret_cast<const f32x4_a4*>(wt + ((i0 + 4 * i < span && t < size) ? t : 0));
           }
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int e = 0; e < 16; ++e) {  // all 16 reads in flight before the first use
+            const int t = t0 + i0 + e;
+            pv[e] = ps[(i0 + (e & ~3) < span && t < size) ? (first + t) * bin_step : 0];
+          }
+          lds_wait();
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const int t = t0 + i0 + 4 * i + c;
-              const bool in = i0 + 4 * i < span && t < size;
-              const float pv = ps[in ? (first + t) * bin_step : 0];
-              acc += in ? w[i][c] * pv : 0.0f;
-            }
+          for (int e = 0; e < 16; ++e) {
+            const int t = t0 + i0 + e;
+            acc += (i0 + (e & ~3) < span && t < size) ? w[e >> 2][e & 3] * pv[e] : 0.0f;
+          }
         }
         acc += dpp_row_ror<0xB1>(acc);   // quad_perm [1,0,3,2]
         acc += dpp_row_ror<0x4E>(acc);   // quad_perm [2,3,0,1]
@@ -459,13 +482,21 @@ int launch_fbank2048(const MelParams& p, const BatchArgs& b, const float* tables
                      double* energy_out, hipStream_t stream) {
   if (b.total_frames <= 0) return SNF_OK;
   const int lds = kLongTableBytes + kLongWaves * kLongBufBytes;
-  SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fbank2048_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   int64_t blocks = (b.total_frames + kLongWaves - 1) / kLongWaves;
   if (blocks > 256) blocks = 256;  // one persistent workgroup per CU, grid-stride over the frames
-  hipLaunchKernelGGL(fbank2048_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kLongWaves * 64), lds,
-                     stream, p, b, reinterpret_cast<const float2*>(tables), 2048 / p.padded, out, out_cols,
-                     energy_out);
+  const int rows = (p.win_len + 127) / 128;
+#define SNF_LONG(NJ_)                                                                                      \
+  do {                                                                                                    \
+    SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fbank2048_kernel<NJ_>),              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));                 \
+    hipLaunchKernelGGL(fbank2048_kernel<NJ_>, dim3(static_cast<unsigned>(blocks)), dim3(kLongWaves * 64), \
+                       lds, stream, p, b, reinterpret_cast<const float2*>(tables), 2048 / p.padded, out,  \
+                       out_cols, energy_out);                                                             \
+  } while (0)
+  if (rows <= 9) SNF_LONG(9);
+  else if (rows <= 10) SNF_LONG(10);
+  else SNF_LONG(16);
+#undef SNF_LONG
   SNF_HIP_CHECK(hipGetLastError());
   return SNF_OK;
 }
