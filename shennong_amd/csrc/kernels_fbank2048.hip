@@ -65,8 +65,9 @@ __device__ __forceinline__ float from_left_lane(float v, int left_lane_bytes) {
 }  // namespace
 
 // NJ: element rows a lane can hold inside the window, ceil(win_len / 128): 9 covers 25 ms at 44.1 kHz (and
-// every shorter frame), 10 the same at 48 kHz, 16 any window up to 2048 samples
-template <int NJ>
+// every shorter frame), 10 the same at 48 kHz, 16 any window up to 2048 samples.  KIND: the plan's kind
+// (the epilogue of one kind per instantiation keeps the scalar register file free of the others' flags)
+template <int NJ, int KIND>
 __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
     const MelParams p, const BatchArgs b, const float2* __restrict__ gtab, const int bin_step,
     float* __restrict__ out, const int out_cols, double* __restrict__ energy_out) {
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
   do {                                                                                                 \
     const char* __restrict__ wp_ = reinterpret_cast<const char*>(b.wave + uniform64(start_));          \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                   \
-      if (j < nj_any) {                                                                                \
+      if (NJ < 16 || j < nj_any) {                                                                     \
         const unsigned off_ = j < (njl_) ? (lane_off_) : 0u;                                           \
         raw[j] = *reinterpret_cast<const int_a2*>(wp_ + off_ + 256 * j);                               \
       }                                                                                                \
@@ -111,8 +112,11 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
 #pragma unroll
   for (int j = 0; j < NJ; ++j) raw[j] = 0;
   int64_t start_next = 0;
+  int utt_next = 0, edge_next = 0;   // utterance / edge mark of the frame whose samples are in flight
   if (g < b.total_frames) {
     SNF_LOAD_FRAME(b.frame_start[g], (L / 2 - lane + 63) >> 6, 4u * lane);
+    utt_next = b.frame_utt[g];
+    if (!p.snip_edges) edge_next = b.frame_edge[g];
     start_next = b.frame_start[clamp_frame(g + stride)];
   }
   for (; g < b.total_frames; g += stride) {
@@ -137,9 +141,9 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
     float* __restrict__ ps_hi = ps + (576 - kappa);  // P[1024 - kappa - 64 d] = ps_hi[448 - 64 d]
 
     auto in_window = [&](int j) -> bool { return j < njl; };
-    const int64_t u = b.frame_utt[g];
-    const int edge = p.snip_edges ? 0 : b.frame_edge[g];
-    const int warp_id = b.utt_warp ? __builtin_amdgcn_readfirstlane(b.utt_warp[u]) : 0;
+    const int64_t u = utt_next;
+    const int edge = edge_next;
+    const int warp_v = b.utt_warp ? b.utt_warp[u] : 0;  // (needed by the epilogue only: no wait here)
 
     // ---- A: samples -> float, DC removal, pre-emphasis, window ---------------------------------------
     float xe[NJ], xo[NJ];
@@ -316,17 +320,22 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
     }
     if (lane == 0) ps[512] = p512;
     wave_lds_sync();
-    if (p.kind == SNF_KIND_FBANK && !p.use_power) {  // magnitude spectrum
+    if (KIND == SNF_KIND_FBANK && !p.use_power) {  // magnitude spectrum
       for (int k = lane; k <= M; k += 64) ps[k] = sqrtf(ps[k]);
       wave_lds_sync();
     }
 
     // next frame: samples (converted at the top of the next iteration), start offset of the one after
     SNF_LOAD_FRAME(start_next, njl, 4u * lane_v);
+    {
+      const int64_t gn = clamp_frame(g + stride);
+      utt_next = b.frame_utt[gn];
+      if (!p.snip_edges) edge_next = b.frame_edge[gn];
+    }
     start_next = b.frame_start[clamp_frame(g + 2 * stride)];
     // ---- F: epilogue (same conventions as mel_features_generic_kernel) -----------------------------------
     float log_energy = 0.0f;
-    if (p.kind == SNF_KIND_PLP) {
+    if (KIND == SNF_KIND_PLP) {
       // shennong's PLP floors with float64 eps and takes a double log (reference plp.py:191-193)
       if ((p.need_raw || p.need_post) && lane == 0)
         energy_out[g] = log(fmax(static_cast<double>(e_lin), DBL_EPSILON));
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
       if (p.has_floor && log_energy < p.log_energy_floor) log_energy = p.log_energy_floor;
     }
     float* __restrict__ row = out + g * static_cast<int64_t>(out_cols);
-    if (p.kind == SNF_KIND_SPECTROGRAM) {
+    if (KIND == SNF_KIND_SPECTROGRAM) {
       for (int k = lane; k <= p.half; k += 64) {
         float v = fast_log(floor_eps(ps[k * bin_step]));
         if (k == 0) v = log_energy;
@@ -343,10 +352,11 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
       }
     } else {
       const int nb = p.num_bins;
+      const int warp_id = __builtin_amdgcn_readfirstlane(warp_v);
       const int* __restrict__ mfirst = p.mel_first + warp_id * nb;
       const int* __restrict__ msize = p.mel_size + warp_id * nb;
       const int* __restrict__ moff = p.mel_offset + warp_id * nb;
-      const int mel_col = (p.kind == SNF_KIND_FBANK && p.use_energy && !p.htk_compat) ? 1 : 0;
+      const int mel_col = (KIND == SNF_KIND_FBANK && p.use_energy && !p.htk_compat) ? 1 : 0;
       // teams of 8 lanes per mel bin, 8 bins per round: lane tl of a team owns a contiguous run of `span`
       // taps (a multiple of 4), loads its weights as 16-byte vectors up front (the banks are the plan's
       // ordinary device tables, L1 / L2 resident; the table carries 4 floats of padding) and reads the
@@ -386,9 +396,9 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
         acc += dpp_row_ror<0x4E>(acc);   // quad_perm [2,3,0,1]
         acc += dpp_row_ror<0x141>(acc);  // row_half_mirror: the other quad of the team
         if (active && tl == 0) {
-          if (p.kind == SNF_KIND_FBANK) {
+          if (KIND == SNF_KIND_FBANK) {
             row[mel_col + m] = p.use_log ? fast_log(floor_eps(acc)) : acc;
-          } else if (p.kind == SNF_KIND_MFCC) {
+          } else if (KIND == SNF_KIND_MFCC) {
             melbuf[m] = fast_log(floor_eps(acc));
           } else {  // PLP: linear mel energies, the recipe continues in plp_tail_kernel
             row[m] = acc;
@@ -399,9 +409,9 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
         size = size_n;
         woff = woff_n;
       }
-      if (p.kind == SNF_KIND_FBANK && p.use_energy && lane == 0)
+      if (KIND == SNF_KIND_FBANK && p.use_energy && lane == 0)
         row[p.htk_compat ? nb : 0] = log_energy;
-      if (p.kind == SNF_KIND_MFCC) {
+      if (KIND == SNF_KIND_MFCC) {
         wave_lds_sync();
         // DCT-II: teams of 4 lanes per cepstral coefficient, 16 coefficients per round
         const int ct = lane >> 2, cl = lane & 3;
@@ -410,8 +420,17 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
           const bool ca = c < p.num_ceps;
           const float* __restrict__ dm = p.dct + (ca ? c : 0) * nb;
           float v = 0.0f;
-#pragma unroll 8
-          for (int m = cl; m < nb; m += 4) v += dm[m] * melbuf[m];
+          for (int m0 = 0; m0 < nb; m0 += 32) {  // 8 coefficients per lane in flight
+            float dv[8], mv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int m = m0 + cl + 4 * e;
+              dv[e] = dm[m < nb ? m : 0];
+              mv[e] = melbuf[m < nb ? m : 0];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v += (m0 + cl + 4 * e < nb) ? dv[e] * mv[e] : 0.0f;
+          }
           v += dpp_row_ror<0xB1>(v);
           v += dpp_row_ror<0x4E>(v);
           if (ca && cl == 0) {
@@ -485,17 +504,25 @@ int launch_fbank2048(const MelParams& p, const BatchArgs& b, const float* tables
   int64_t blocks = (b.total_frames + kLongWaves - 1) / kLongWaves;
   if (blocks > 256) blocks = 256;  // one persistent workgroup per CU, grid-stride over the frames
   const int rows = (p.win_len + 127) / 128;
+#define SNF_LONG2(NJ_, KIND_)                                                                              \
+  do {                                                                                                    \
+    SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fbank2048_kernel<NJ_, KIND_>),       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));                 \
+    hipLaunchKernelGGL((fbank2048_kernel<NJ_, KIND_>), dim3(static_cast<unsigned>(blocks)),               \
+                       dim3(kLongWaves * 64), lds, stream, p, b, reinterpret_cast<const float2*>(tables), \
+                       2048 / p.padded, out, out_cols, energy_out);                                       \
+  } while (0)
 #define SNF_LONG(NJ_)                                                                                      \
   do {                                                                                                    \
-    SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fbank2048_kernel<NJ_>),              \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));                 \
-    hipLaunchKernelGGL(fbank2048_kernel<NJ_>, dim3(static_cast<unsigned>(blocks)), dim3(kLongWaves * 64), \
-                       lds, stream, p, b, reinterpret_cast<const float2*>(tables), 2048 / p.padded, out,  \
-                       out_cols, energy_out);                                                             \
+    if (p.kind == SNF_KIND_FBANK) SNF_LONG2(NJ_, SNF_KIND_FBANK);                                         \
+    else if (p.kind == SNF_KIND_MFCC) SNF_LONG2(NJ_, SNF_KIND_MFCC);                                      \
+    else if (p.kind == SNF_KIND_PLP) SNF_LONG2(NJ_, SNF_KIND_PLP);                                        \
+    else SNF_LONG2(NJ_, SNF_KIND_SPECTROGRAM);                                                            \
   } while (0)
   if (rows <= 9) SNF_LONG(9);
   else if (rows <= 10) SNF_LONG(10);
   else SNF_LONG(16);
+#undef SNF_LONG2
 #undef SNF_LONG
   SNF_HIP_CHECK(hipGetLastError());
   return SNF_OK;
