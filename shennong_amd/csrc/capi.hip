@@ -102,6 +102,7 @@ struct snf_plan {
 
   // last uploaded offsets tables (re-validated / re-uploaded only when they change)
   std::vector<int64_t> h_soff, h_foff;
+  int post_table_cols = -1;  // post plans: input width the cached tile records of h_foff were built for
 
   // timing
   hipEvent_t ev[kMaxSlots + 1] = {};
@@ -1008,16 +1009,27 @@ int snf_post_run_batch_device(snf_plan* plan, const float* d_in, int32_t in_cols
   if (total_frames == 0) return SNF_OK;
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : plan->stream;
   const bool own_stream = (stream == nullptr);
-  std::vector<int64_t> foff(frame_offsets, frame_offsets + n_utts + 1);
-  if ((rc = plan->s_foff.upload(foff, s))) return rc;
-  SNF_HIP_CHECK(hipStreamSynchronize(s));
+  // the offsets table (and what the delta kernel derives from it) stays on the device between calls
+  // with the same table: a pipeline runs the same batch layout call after call
+  const bool same_table = plan->post_table_cols == in_cols &&
+                          plan->h_foff.size() == static_cast<size_t>(n_utts) + 1 &&
+                          std::equal(plan->h_foff.begin(), plan->h_foff.end(), frame_offsets);
+  if (!same_table) {
+    plan->h_foff.assign(frame_offsets, frame_offsets + n_utts + 1);
+    plan->post_table_cols = -1;
+    if ((rc = plan->s_foff.upload(plan->h_foff, s))) return rc;
+    SNF_HIP_CHECK(hipStreamSynchronize(s));
+  }
   if (own_stream) begin_timing(plan);
   if (plan->kind == SNF_KIND_DELTA) {
     if (in_cols <= 0) return set_error(SNF_E_INVALID, "in_cols must be positive");
-    if ((rc = plan->s_futt.ensure(sizeof(int32_t) * static_cast<size_t>(total_frames / 32 + 2)))) return rc;
+    if ((rc = plan->s_futt.ensure(4 * sizeof(int64_t) * static_cast<size_t>(total_frames / 32 + 2)))) return rc;
     if ((rc = launch_deltas(plan->dp, d_in, in_cols, plan->s_foff.as<int64_t>(), n_utts,
-                            total_frames, d_out, plan->s_futt.as<int32_t>(), s)))
+                            total_frames, d_out, plan->s_futt.as<int64_t>(), !same_table, s)))
       return rc;
+    // (the tile records are complete before a later call on another stream may use them)
+    if (!same_table && !own_stream) SNF_HIP_CHECK(hipStreamSynchronize(s));
+    plan->post_table_cols = in_cols;
     if (own_stream) mark_kernel(plan, "delta_kernel");
   } else if (plan->kind == SNF_KIND_PITCH_POST) {
     if (in_cols != 2)

@@ -473,18 +473,27 @@ constexpr int flat_rows() {
   rows &= ~3;
   return rows > 256 ? 256 : rows;
 }
+// one 32-byte record per tile: the utterance of its first row and the frame offsets of that utterance and
+// the next two, so that a workgroup learns the utterance boundaries of its rows from ONE load (a chain of
+// dependent loads per row used to be most of a workgroup's life)
 __global__ void delta_tile_utt_kernel(const int64_t* __restrict__ frame_offsets, int64_t n_utts,
                                       int64_t total_frames, int rows_per_tile,
-                                      int32_t* __restrict__ tile_utt) {
+                                      int64_t* __restrict__ tile_info) {
   const int64_t tile = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   const int64_t g = tile * rows_per_tile;
-  if (g < total_frames) tile_utt[tile] = static_cast<int32_t>(find_utt(frame_offsets, n_utts, g));
+  if (g >= total_frames) return;
+  const int64_t u = find_utt(frame_offsets, n_utts, g);
+  int64_t* __restrict__ rec = tile_info + 4 * tile;
+  rec[0] = u;
+  rec[1] = frame_offsets[u];
+  rec[2] = frame_offsets[u + 1];
+  rec[3] = frame_offsets[u + 2 <= n_utts ? u + 2 : n_utts];
 }
 
 template <int D>
 __global__ __launch_bounds__(256) void delta_flat_o2w2_kernel(
     const DeltaParams p, const float* __restrict__ in, const int64_t* __restrict__ frame_offsets,
-    const int32_t* __restrict__ tile_utt, const int64_t n_utts, const int64_t total_frames,
+    const int64_t* __restrict__ tile_info, const int64_t n_utts, const int64_t total_frames,
     float* __restrict__ out) {
   constexpr int kRows = flat_rows<D>();
   constexpr int kHalo = 4, OD = 3 * D, kTileRows = kRows + 2 * kHalo;
@@ -499,39 +508,99 @@ __global__ __launch_bounds__(256) void delta_flat_o2w2_kernel(
   // from the aligned float4 at or below it (`skew` floats earlier)
   const int skew = static_cast<int>(((first % 4) + 4) % 4);
   const int64_t base = first - skew;
-  for (int i = threadIdx.x; i * 4 < kTileFloats + 4; i += blockDim.x) {
+  // the tile is requested first (registers), the utterance bookkeeping below overlaps its latency
+  constexpr int kStage = (kTileFloats / 4 + 1 + 255) / 256;
+  float4 staged[kStage];
+#pragma unroll
+  for (int k = 0; k < kStage; ++k) {
+    const int i = threadIdx.x + 256 * k;
     const int64_t a = base + 4 * static_cast<int64_t>(i);
     float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (a >= 0 && a + 3 < limit) {
-      v = *reinterpret_cast<const float4*>(in + a);
-    } else {
-      if (a >= 0 && a < limit) v.x = in[a];
-      if (a + 1 >= 0 && a + 1 < limit) v.y = in[a + 1];
-      if (a + 2 >= 0 && a + 2 < limit) v.z = in[a + 2];
-      if (a + 3 >= 0 && a + 3 < limit) v.w = in[a + 3];
+    if (i * 4 < kTileFloats + 4) {
+      if (a >= 0 && a + 3 < limit) {
+        v = *reinterpret_cast<const float4*>(in + a);
+      } else {
+        if (a >= 0 && a < limit) v.x = in[a];
+        if (a + 1 >= 0 && a + 1 < limit) v.y = in[a + 1];
+        if (a + 2 >= 0 && a + 2 < limit) v.z = in[a + 2];
+        if (a + 3 >= 0 && a + 3 < limit) v.w = in[a + 3];
+      }
     }
-    reinterpret_cast<float4*>(tile)[i] = v;
+    staged[k] = v;
   }
-  for (int r = threadIdx.x; r < kRows; r += blockDim.x) {
-    const int64_t g = g0 + r;
-    if (g < total_frames) {
-      int64_t u = tile_utt[blockIdx.x];
-      while (frame_offsets[u + 1] <= g) ++u;  // (a tile spans few utterances)
-      const int64_t lo = frame_offsets[u] - t0, hi = frame_offsets[u + 1] - 1 - t0;
-      row_lo[r] = lo < 0 ? 0 : static_cast<int>(lo);
-      row_hi[r] = hi > kTileRows - 1 ? kTileRows - 1 : static_cast<int>(hi);
+  const int rows_here = static_cast<int>(total_frames - g0 < kRows ? total_frames - g0 : kRows);
+  bool interior = rows_here == kRows;
+  {
+    const int64_t* __restrict__ rec = tile_info + 4 * static_cast<int64_t>(blockIdx.x);
+    const int64_t u0 = rec[0], o0 = rec[1], o1 = rec[2], o2 = rec[3];
+    for (int r = threadIdx.x; r < kRows; r += blockDim.x) {
+      const int64_t g = g0 + r;
+      if (g < total_frames) {
+        int64_t lo_f = o0, hi_f = o1;          // [first, end) frames of the row's utterance
+        if (g >= o1) {
+          lo_f = o1;
+          hi_f = o2;
+          if (g >= o2) {                       // more than two boundaries inside the tile (rare)
+            int64_t u = u0 + 2;
+            while (frame_offsets[u + 1] <= g) ++u;
+            lo_f = frame_offsets[u];
+            hi_f = frame_offsets[u + 1];
+          }
+        }
+        const int64_t lo = lo_f - t0, hi = hi_f - 1 - t0;
+        row_lo[r] = lo < 0 ? 0 : static_cast<int>(lo);
+        row_hi[r] = hi > kTileRows - 1 ? kTileRows - 1 : static_cast<int>(hi);
+        interior = interior && lo <= r && hi >= r + 2 * kHalo;
+      }
     }
+  }
+#pragma unroll
+  for (int k = 0; k < kStage; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    if (i * 4 < kTileFloats + 4) reinterpret_cast<float4*>(tile)[i] = staged[k];
   }
   float sc[15];  // scales of the three orders, concatenated like DeltaParams::scales: 1 + 5 + 9
 #pragma unroll
   for (int i = 0; i < 15; ++i) sc[i] = p.scales[i];
-  __syncthreads();
-  const int rows_here = static_cast<int>(total_frames - g0 < kRows ? total_frames - g0 : kRows);
+  // interior tile: every row and its +-4 neighbours lie inside one utterance (3 tiles out of 4 on 3 s
+  // utterances) -> no clamping, and a thread walks down one column of a strip of rows with the 9-row
+  // window in registers: one LDS read per element instead of nine
+  interior = __syncthreads_and(interior);
   const int n_out = rows_here * OD;
   const float* __restrict__ tl = tile + skew;
+  if (interior) {
+    constexpr int kStrips = 256 / D, kStripRows = (kRows + kStrips - 1) / kStrips;
+    const int c = threadIdx.x % D, strip = threadIdx.x / D;
+    if (strip < kStrips) {
+      const int r0 = strip * kStripRows;
+      float v[kStripRows + 2 * kHalo];
+#pragma unroll
+      for (int i = 0; i < kStripRows + 2 * kHalo; ++i)
+        v[i] = r0 + i < kTileRows ? tl[(r0 + i) * D + c] : 0.0f;
+#pragma unroll
+      for (int rr = 0; rr < kStripRows; ++rr) {
+        if (r0 + rr < kRows) {
+          float* __restrict__ orow = image + (r0 + rr) * OD + c;
+          int soff = 0;
+#pragma unroll
+          for (int i = 0; i <= 2; ++i) {
+            const int max_off = 2 * i;
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = -max_off; j <= max_off; ++j) {
+              const float w = sc[soff + j + max_off];
+              if (w != 0.0f) acc += w * v[rr + j + kHalo];
+            }
+            orow[i * D] = acc;
+            soff += 2 * max_off + 1;
+          }
+        }
+      }
+    }
+  }
   // element (row r, column c): its 9 clamped neighbours are read ONCE for the three orders (every lane
   // runs the same taps: no divergence), the three results go to the output image
-  for (int idx = threadIdx.x; idx < rows_here * D; idx += blockDim.x) {
+  for (int idx = threadIdx.x; !interior && idx < rows_here * D; idx += blockDim.x) {
     const int r = idx / D, c = idx - r * D;
     const int lo = row_lo[r], hi = row_hi[r], centre = r + kHalo;
     float x[9];
@@ -568,22 +637,23 @@ __global__ __launch_bounds__(256) void delta_flat_o2w2_kernel(
 }
 
 int launch_deltas(const DeltaParams& p, const float* in, int in_cols, const int64_t* frame_offsets,
-                  int64_t n_utts, int64_t total_frames, float* out, int32_t* tile_utt,
+                  int64_t n_utts, int64_t total_frames, float* out, int64_t* tile_info, bool build_info,
                   hipStream_t stream) {
   const int64_t total = total_frames * in_cols;
   if (total <= 0) return SNF_OK;
   const int halo = p.order * p.window;
   const bool aligned16 = (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-  if (p.order == 2 && p.window == 2 && tile_utt && aligned16 &&
+  if (p.order == 2 && p.window == 2 && tile_info && aligned16 &&
       (in_cols == 13 || in_cols == 23 || in_cols == 40 || in_cols == 43)) {
 #define SNF_FLAT(D_)                                                                                  \
   do {                                                                                                \
     constexpr int rows = flat_rows<D_>();                                                             \
     const unsigned tiles = static_cast<unsigned>((total_frames + rows - 1) / rows);                   \
-    hipLaunchKernelGGL(delta_tile_utt_kernel, dim3((tiles + 255) / 256), dim3(256), 0, stream,        \
-                       frame_offsets, n_utts, total_frames, rows, tile_utt);                          \
+    if (build_info)                                                                                   \
+      hipLaunchKernelGGL(delta_tile_utt_kernel, dim3((tiles + 255) / 256), dim3(256), 0, stream,      \
+                         frame_offsets, n_utts, total_frames, rows, tile_info);                       \
     hipLaunchKernelGGL((delta_flat_o2w2_kernel<D_>), dim3(tiles), dim3(256), 0, stream, p, in,        \
-                       frame_offsets, tile_utt, n_utts, total_frames, out);                           \
+                       frame_offsets, tile_info, n_utts, total_frames, out);                          \
   } while (0)
     if (in_cols == 13) SNF_FLAT(13);
     else if (in_cols == 23) SNF_FLAT(23);

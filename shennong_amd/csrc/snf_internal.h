@@ -146,9 +146,10 @@ int launch_mel_features(const MelParams& p, const BatchArgs& b, float* out, int 
 int launch_rasta(float* mel, const BatchArgs& b, int num_bins, hipStream_t stream);
 int launch_plp_tail(const PlpParams& p, const BatchArgs& b, const float* mel, const double* energy,
                     float* out, hipStream_t stream);
-// `tile_utt`: scratch of total_frames / 32 + 2 int32 (nullptr: per-element kernels only)
+// `tile_info`: scratch of 4 (total_frames / 32 + 2) int64 (nullptr: per-element kernels only), rebuilt
+// from the offsets table when `build_info` is set (the caller keeps it while the table stays the same)
 int launch_deltas(const DeltaParams& p, const float* in, int in_cols, const int64_t* frame_offsets,
-                  int64_t n_utts, int64_t total_frames, float* out, int32_t* tile_utt,
+                  int64_t n_utts, int64_t total_frames, float* out, int64_t* tile_info, bool build_info,
                   hipStream_t stream);
 
 
