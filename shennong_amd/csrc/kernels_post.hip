@@ -465,6 +465,7 @@ __global__ __launch_bounds__(256) void delta_tiled_fixed_kernel(
 // tile's first row comes from a table built by one thread per tile (a binary search of dependent loads
 // at the head of every workgroup costs more than its arithmetic); rows walk forward from it.  Same
 // products in the same order as the kernels above.
+typedef float f4v __attribute__((ext_vector_type(4)));
 constexpr int kFlatTileBytes = 28 * 1024;  // input tile + output image of one workgroup
 template <int D>
 constexpr int flat_rows() {
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(256) void delta_flat_o2w2_kernel(
   float* __restrict__ obase = out + g0 * OD;   // (g0 * OD * 4 bytes is a multiple of 16: kRows % 4 == 0)
   for (int e0 = 4 * threadIdx.x; e0 < n_out; e0 += 4 * blockDim.x) {
     if (e0 + 3 < n_out) {
-      *reinterpret_cast<float4*>(obase + e0) = *reinterpret_cast<const float4*>(image + e0);
+      __builtin_nontemporal_store(*reinterpret_cast<const f4v*>(image + e0), reinterpret_cast<f4v*>(obase + e0));
     } else {
       for (int k = 0; k < 4 && e0 + k < n_out; ++k) obase[e0 + k] = image[e0 + k];
     }
