@@ -508,7 +508,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
         if (mvalid && mm_out >= 0) {
           float* __restrict__ dst = mrow + mel_col + mm_out;
           if (mm_out + 4 <= p.num_bins) {
-            *reinterpret_cast<f32x4_a4*>(dst) = f32x4_a4{mel[0], mel[1], mel[2], mel[3]};
+            // (nontemporal: the rows are written once, 16 bytes per lane, whole 64-byte runs per quad)
+            __builtin_nontemporal_store(f32x4_a4{mel[0], mel[1], mel[2], mel[3]}, reinterpret_cast<f32x4_a4*>(dst));
           } else {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
