@@ -433,12 +433,16 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     float* __restrict__ row = out + g * static_cast<int64_t>(p.out_cols);
     if (KIND == SNF_KIND_SPECTROGRAM) {
       // log power spectrum, 257 bins: lane l stores bins l + 16 i (64-byte segments), bin 0 = energy
+      // (lane l stores bins 4 l + 64 i as 16-byte vectors: 256 contiguous bytes per frame and instruction;
+      // the rows are 1028 bytes, 4-byte aligned; written once -> nontemporal)
       if (valid) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float v = fast_log(fmaxf(0.25f * ptile[l + 16 * i], FLT_EPSILON));
-          if (i == 0 && l == 0) v = log_energy;
-          row[l + 16 * i] = v;
+        for (int i = 0; i < 4; ++i) {
+          const float4 pw = *reinterpret_cast<const float4*>(ptile + 4 * l + 64 * i);
+          f32x4_a4 v = {fast_log(fmaxf(0.25f * pw.x, FLT_EPSILON)), fast_log(fmaxf(0.25f * pw.y, FLT_EPSILON)),
+                        fast_log(fmaxf(0.25f * pw.z, FLT_EPSILON)), fast_log(fmaxf(0.25f * pw.w, FLT_EPSILON))};
+          if (i == 0 && l == 0) v[0] = log_energy;
+          __builtin_nontemporal_store(v, reinterpret_cast<f32x4_a4*>(row + 4 * l + 64 * i));
         }
         if (l == 0) row[256] = fast_log(fmaxf(0.25f * ptile[256], FLT_EPSILON));
       }
