@@ -302,7 +302,8 @@ int build_mel_plan(snf_plan* plan) {
       if (o.cepstral_lifter != 0.0f) make_lifter(o.cepstral_lifter, o.num_ceps, &lifter_h);
     }
     const MelBanksHost no_banks;
-    rc = fast512_build(p, window, plan->banks.empty() ? no_banks : plan->banks[0], dct_h, lifter_h,
+    const bool dual = !want_fused && fast512_dual_eligible(p);
+    rc = fast512_build(p, window, plan->banks.empty() ? no_banks : plan->banks[0], dct_h, lifter_h, dual,
                        &blob, &plan->fp);
     if (rc < 0) return rc;
     if (rc == 0) {  // rc > 0: shape not covered by the fast kernel, keep the generic one
@@ -380,8 +381,9 @@ int sync_fast_warp_tables(snf_plan* plan) {
   Fast512Params fp0{};
   for (size_t w = 0; w < plan->banks.size(); ++w) {
     Fast512Params fp{};
+    // (per-utterance tables: always the 512-point form, also for plans whose flat batches run dual)
     const int rc = fast512_build(plan->mp, plan->h_window, plan->banks[w], plan->h_dct, plan->h_lifter,
-                                 &blobs[w], &fp);
+                                 false, &blobs[w], &fp);
     if (rc < 0) return rc;
     if (rc > 0) {  // this warp's banks need more taps per slot than the kernel unrolls
       plan->fast_warps_ok = false;
@@ -906,7 +908,7 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
       if ((rc = launch_fbank512(any_warp ? plan->fp_warp : plan->fp, b, plan->s_mel.as<float>(), nb,
                                 plan->s_energy.as<double>(), s)))
         return rc;
-      if (own_stream) mark_kernel(plan, "fbank512_kernel");
+      if (own_stream) mark_kernel(plan, (plan->fp.dual && !any_warp) ? "fbank256x2_kernel" : "fbank512_kernel");
     } else if (use_long) {
       if ((rc = launch_fbank2048(plan->mp, b, plan->d_long_tables.as<float>(), plan->s_mel.as<float>(), nb,
                                  plan->s_energy.as<double>(), s)))
@@ -930,7 +932,7 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     if (use_fast) {
       if ((rc = launch_fbank512(any_warp ? plan->fp_warp : plan->fp, b, d_out, plan->ndims, nullptr, s)))
         return rc;
-      if (own_stream) mark_kernel(plan, "fbank512_kernel");
+      if (own_stream) mark_kernel(plan, (plan->fp.dual && !any_warp) ? "fbank256x2_kernel" : "fbank512_kernel");
     } else if (use_long) {
       if ((rc = launch_fbank2048(plan->mp, b, plan->d_long_tables.as<float>(), d_out, plan->ndims, nullptr, s)))
         return rc;

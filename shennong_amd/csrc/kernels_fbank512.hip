@@ -615,6 +615,401 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Frames that pad to 256 samples (8 kHz audio, 10-16 ms windows at 16 kHz): TWO real frames per 16-lane
+// row, packed as one complex signal z[n] = x_a[n] + i x_b[n], n < 256.  The same two register passes as
+// above transform it, and the spectra separate without a twiddle: X_a[k] = (Z[k] + conj Z[256 - k]) / 2,
+// X_b[k] = (Z[k] - conj Z[256 - k]) / 2i.  A wave64 therefore works on 8 frames per iteration instead of
+// the 4 zero-extended ones of the 512-point form (half the transform arithmetic per frame); the mel
+// filterbank (129 bins, the same MFMA block tables, built without the zero-tap spreading) and the DCT
+// run once per sub-frame.  Flat scheduling only: VTLN batches and the spectrogram keep the 512-point form.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kDualSub = 136;  // float offset of sub-frame b inside a row's power tile (129 bins + pad)
+
+template <int NJ, int KIND, int ENERGY, bool DITHER, bool SNIP>
+__global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fast512Params p,
+                                                                     const BatchArgs b,
+                                                                     float* __restrict__ out,
+                                                                     double* __restrict__ energy_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tab = reinterpret_cast<float*>(smem);
+  for (int i = threadIdx.x; i < p.table_floats; i += blockDim.x) tab[i] = p.tables[i];
+  __syncthreads();
+  const float2* __restrict__ t_win = reinterpret_cast<const float2*>(tab + kFastHeaderFloats);
+  const float2* __restrict__ t_tw16 = t_win + 16 * 18;
+  const float4* __restrict__ t_mm_a = reinterpret_cast<const float4*>(tab + p.off_mm_a);
+  const float4* __restrict__ t_dd_a = reinterpret_cast<const float4*>(tab + p.off_dd_a);
+  const float* __restrict__ t_lifter = tab + p.off_lifter;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int l = lane & 15, q = lane >> 4;
+  const int tab_bytes = (p.table_floats * 4 + 255) & ~255;
+  char* wave_base = smem + tab_bytes + (wid * 4 + q) * kFrameTileBytes;
+  float2* tile = reinterpret_cast<float2*>(wave_base);
+  float* ptile = reinterpret_cast<float*>(wave_base) + q * 16;   // sub-frame a at 0, b at kDualSub
+  tile[l * kTileRow + 16] = make_float2(0.0f, 0.0f);  // (padding column: see fbank512_kernel)
+  const int mj = lane & 3;
+  const float* __restrict__ mm_lane = tab + p.off_mm_lane;
+  const int mm_start = reinterpret_cast<const int*>(mm_lane)[lane];
+  const int mm_out = reinterpret_cast<const int*>(mm_lane)[64 + lane];
+  const float mm_f1 = mm_lane[128 + lane], mm_f2 = mm_lane[192 + lane], mm_f3 = mm_lane[256 + lane];
+  float* __restrict__ mtile =
+      reinterpret_cast<float*>(smem + tab_bytes + (wid * 4 + mj) * kFrameTileBytes) + mj * 16;
+
+  const float win_len_f = static_cast<float>(p.win_len), inv_win_len = 1.0f / win_len_f;
+  const int n_waves = blockDim.x >> 6;
+  const int64_t n_sets = (b.total_frames + 7) >> 3;
+  const int64_t set_stride = static_cast<int64_t>(gridDim.x) * n_waves;
+  const int64_t last_frame = b.total_frames - 1;
+  auto start_of = [&](int64_t gi) -> int64_t { return b.frame_start[gi < last_frame ? gi : last_frame]; };
+  auto edge_of = [&](int64_t gi) -> int { return b.frame_edge[gi < last_frame ? gi : last_frame]; };
+  // NJ = 13: the 25 ms / 8 kHz window (200 samples: only element j = 12 can fall outside the window)
+  const bool in_last = l + 16 * (NJ - 1) < p.win_len;
+  auto in_window = [&](int j) -> bool {
+    if (NJ == 13) return j < NJ - 1 || in_last;
+    return l + 16 * j < p.win_len;
+  };
+  // element j of the lane: sample l + 16 j of frame a in the low half, of frame b in the high half
+  auto load_pair = [&](const int16_t* __restrict__ wa, const int16_t* __restrict__ wb, int j) -> int {
+    const bool in = (NJ == 13 && j < NJ - 1) || in_window(j);
+    const unsigned lo = *reinterpret_cast<const unsigned short*>(in ? wa + l + 16 * j : wa);
+    const int hi = *(in ? wb + l + 16 * j : wb);
+    return static_cast<int>(lo | (static_cast<unsigned>(hi) << 16));
+  };
+  int64_t set = static_cast<int64_t>(blockIdx.x) * n_waves + wid;
+  int raw[NJ];
+  int64_t next_a = 0, next_b = 0;
+  int edge_next_a = 0, edge_next_b = 0;
+  if (set < n_sets) {
+    const int64_t ga = set * 8 + 2 * q;
+    const int16_t* __restrict__ wa = b.wave + start_of(ga);
+    const int16_t* __restrict__ wb = b.wave + start_of(ga + 1);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) raw[j] = load_pair(wa, wb, j);
+    next_a = start_of((set + set_stride) * 8 + 2 * q);
+    next_b = start_of((set + set_stride) * 8 + 2 * q + 1);
+    if (!SNIP) {
+      edge_next_a = edge_of(ga);
+      edge_next_b = edge_of(ga + 1);
+    }
+  }
+  float* __restrict__ mrow = out + (set * 8 + 2 * mj) * static_cast<int64_t>(p.out_cols);
+  const int64_t mrow_step = set_stride * 8 * static_cast<int64_t>(p.out_cols);
+  for (; set < n_sets; set += set_stride, mrow += mrow_step) {
+    const int64_t ga = set * 8 + 2 * q;
+    const bool valid_a = ga <= last_frame, valid_b = ga + 1 <= last_frame;
+    const int edge_a = edge_next_a, edge_b = edge_next_b;
+
+    // ---- A: DC removal, pre-emphasis, window (per sub-frame: xe = frame a, xo = frame b) ---------------
+    float4 win4[(NJ + 1) / 2];
+    read_quads<(NJ + 1) / 2>(t_win + l * 18, win4);
+    unsigned dk[4] = {0, 0, 0, 0};
+    if (DITHER) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const unsigned long long k =
+            (static_cast<unsigned long long>(ga + s2) + 1) * 0x9E3779B97F4A7C15ull ^ p.seed;
+        dk[2 * s2] = fmix32(static_cast<unsigned>(k));
+        dk[2 * s2 + 1] = fmix32(static_cast<unsigned>(k >> 32) ^ dk[2 * s2]);
+      }
+    }
+    float xe[NJ], xo[NJ];
+    float part_a = 0.0f, part_b = 0.0f;
+    constexpr bool kIntSum = !DITHER && SNIP;  // (integer sums are exact: see fbank512_kernel)
+    int sum_a = 0, sum_b = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      xe[j] = static_cast<float>(static_cast<short>(raw[j] & 0xffff));
+      xo[j] = static_cast<float>(raw[j] >> 16);
+      if (kIntSum) {
+        const int ta = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, raw[j]), short2v{1, 0}, sum_a, false);
+        const int tb = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, raw[j]), short2v{0, 1}, sum_b, false);
+        sum_a = in_window(j) ? ta : sum_a;
+        sum_b = in_window(j) ? tb : sum_b;
+      }
+    }
+    if (!SNIP && (edge_a | edge_b) != 0) {
+      // [KALDI-UPSTREAM] ExtractWindow, snip_edges = false: reflected samples for the frames that reach
+      // outside their utterance (their prefetched samples came from a clamped window)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int edge = s2 ? edge_b : edge_a;
+        if (edge != 0 && (s2 ? valid_b : valid_a)) {
+          const int64_t u = edge - 1;
+          const int64_t s0 = b.sample_offsets[u], n = b.sample_offsets[u + 1] - s0;
+          const int64_t rel =
+              (ga + s2 - b.frame_offsets[u]) * p.win_shift + p.win_shift / 2 - p.win_len / 2;
+          const int16_t* __restrict__ w0 = b.wave + s0;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            if (in_window(j)) {
+              int64_t k = rel + l + 16 * j;
+              while (k < 0 || k >= n) k = k < 0 ? -k - 1 : 2 * n - 1 - k;
+              const float v = static_cast<float>(w0[k]);
+              if (s2) xo[j] = v; else xe[j] = v;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (DITHER) {  // Kaldi dithers before the DC removal
+        xe[j] += p.dither * gauss_pair(dk[0], dk[1], static_cast<unsigned>(l + 16 * j)).x;
+        xo[j] += p.dither * gauss_pair(dk[2], dk[3], static_cast<unsigned>(l + 16 * j)).x;
+      }
+      if (!kIntSum) {
+        part_a += in_window(j) ? xe[j] : 0.0f;
+        part_b += in_window(j) ? xo[j] : 0.0f;
+      }
+    }
+    if (kIntSum) {
+      part_a = static_cast<float>(sum_a);
+      part_b = static_cast<float>(sum_b);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(xe[j]), "+v"(xo[j]) : : "memory");
+    asm volatile("" : "+v"(part_a), "+v"(part_b) : : "memory");
+    {  // prefetch: samples of the next set, start offsets of the set after it
+      const int16_t* __restrict__ wa = b.wave + next_a;
+      const int16_t* __restrict__ wb = b.wave + next_b;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) raw[j] = load_pair(wa, wb, j);
+      next_a = start_of((set + 2 * set_stride) * 8 + 2 * q);
+      next_b = start_of((set + 2 * set_stride) * 8 + 2 * q + 1);
+      if (!SNIP) {
+        edge_next_a = edge_of((set + set_stride) * 8 + 2 * q);
+        edge_next_b = edge_of((set + set_stride) * 8 + 2 * q + 1);
+      }
+    }
+    float nm_a = 0.0f, nm_b = 0.0f;
+    if (p.remove_dc) {
+      const float sa = row_sum16(part_a), sb = row_sum16(part_b);
+      if (kIntSum) {
+        const float qa = sa * inv_win_len, qb = sb * inv_win_len;
+        nm_a = -__builtin_fmaf(__builtin_fmaf(-qa, win_len_f, sa), inv_win_len, qa);
+        nm_b = -__builtin_fmaf(__builtin_fmaf(-qb, win_len_f, sb), inv_win_len, qb);
+      } else {
+        nm_a = -sa / win_len_f;
+        nm_b = -sb / win_len_f;
+      }
+    }
+    lds_wait();
+    // the left neighbour x[n-1] is element n-1 = lane l-1 (same j), lane 15 of j-1 for lane 0
+    float2 z[16];
+    float er_a = 0.0f, er_b = 0.0f, ep_a = 0.0f, ep_b = 0.0f;
+    float prev_a = xe[0] + nm_a, prev_b = xo[0] + nm_b;  // lane 0, j = 0: x[-1] := x[0]
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j < NJ) {
+        const bool in = in_window(j);
+        const float ae = xe[j] + nm_a, ao = xo[j] + nm_b;
+        const float rot_a = dpp_row_ror<0x121>(ae), rot_b = dpp_row_ror<0x121>(ao);
+        const float pa = l == 0 ? prev_a : rot_a, pb = l == 0 ? prev_b : rot_b;
+        prev_a = rot_a;
+        prev_b = rot_b;
+        const float2 w = (j & 1) ? make_float2(win4[j >> 1].z, win4[j >> 1].w)
+                                 : make_float2(win4[j >> 1].x, win4[j >> 1].y);  // (w[n], w[n]); 0 outside
+        if (ENERGY == 1 && in) {
+          er_a += ae * ae;
+          er_b += ao * ao;
+        }
+        const float ye = (ae - p.preemph * pa) * w.x;
+        const float yo = (ao - p.preemph * pb) * w.y;
+        z[j] = make_float2(ye, yo);
+        if (ENERGY == 2) {
+          ep_a += ye * ye;
+          ep_b += yo * yo;
+        }
+      } else {
+        z[j] = make_float2(0.0f, 0.0f);
+      }
+    }
+    float e_lin_a = 0.0f, e_lin_b = 0.0f;
+    if (ENERGY != 0) {
+      e_lin_a = row_sum16(ENERGY == 1 ? er_a : ep_a);
+      e_lin_b = row_sum16(ENERGY == 1 ? er_b : ep_b);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- B / C: the 256-point complex transform (identical to fbank512_kernel) ------------------------
+    float4 tw4[8];
+    read_quads<8>(t_tw16 + l * 18, tw4);
+    fft16(z);
+    lds_wait();
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2)
+      z[k2] = cmul(z[k2], (k2 & 1) ? make_float2(tw4[k2 >> 1].z, tw4[k2 >> 1].w)
+                                   : make_float2(tw4[k2 >> 1].x, tw4[k2 >> 1].y));
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) tile[k2 * kTileRow + l] = z[k2];
+    wave_lds_sync();
+    read16_b64(tile + l * kTileRow, z);
+    __builtin_amdgcn_sched_barrier(0);
+    fft16(z);
+    __builtin_amdgcn_sched_barrier(0);
+    wave_lds_sync();
+
+    // ---- D: separate the two spectra, power (x4 like fbank512_kernel): bins k = l + 16 k1 <= 128 --------
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) tile[r * 16 + l] = z[r + 8];
+    wave_lds_sync();
+    float2 zpart[8];
+    read8_b64_rev128(tile + (16 - l), zpart);   // zpart[k1] = Z[256 - l - 16 k1]
+    float pa[8], pb[8];
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) {
+      const float2 zk = z[k1], zp = zpart[k1];
+      const float c_re = zk.x + zp.x, c_im = zk.y - zp.y;   // 2 X_a[k]
+      const float d_re = zk.y + zp.y, d_im = zp.x - zk.x;   // 2 X_b[k]
+      pa[k1] = c_re * c_re + c_im * c_im;
+      pb[k1] = d_re * d_re + d_im * d_im;
+    }
+    if (l == 0) {  // k = 0 pairs with itself: X_a[0] = Re Z[0], X_b[0] = Im Z[0]
+      pa[0] = 4.0f * z[0].x * z[0].x;
+      pb[0] = 4.0f * z[0].y * z[0].y;
+    }
+    const float p128_a = 4.0f * z[8].x * z[8].x, p128_b = 4.0f * z[8].y * z[8].y;  // lane 0: Z[128]
+    wave_lds_sync();
+    // ---- E: power tiles ----------------------------------------------------------------------------------
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) {
+      ptile[l + 16 * k1] = pa[k1];
+      ptile[kDualSub + l + 16 * k1] = pb[k1];
+    }
+    if (l == 0) {
+      ptile[128] = p128_a;
+      ptile[kDualSub + 128] = p128_b;
+    }
+    wave_lds_sync();
+
+    // ---- log-energy column ---------------------------------------------------------------------------------
+    float log_e[2] = {0.0f, 0.0f};
+    if (ENERGY != 0) {
+      if (KIND == SNF_KIND_PLP) {
+        if (l == 0) {
+          if (valid_a) energy_out[ga] = log(fmax(static_cast<double>(e_lin_a), DBL_EPSILON));
+          if (valid_b) energy_out[ga + 1] = log(fmax(static_cast<double>(e_lin_b), DBL_EPSILON));
+        }
+      } else {
+        log_e[0] = logf(fmaxf(e_lin_a, FLT_EPSILON));
+        log_e[1] = logf(fmaxf(e_lin_b, FLT_EPSILON));
+        if (p.has_floor) {
+          if (log_e[0] < p.log_energy_floor) log_e[0] = p.log_energy_floor;
+          if (log_e[1] < p.log_energy_floor) log_e[1] = p.log_energy_floor;
+        }
+      }
+    }
+    float* __restrict__ row = out + ga * static_cast<int64_t>(p.out_cols);  // frame a; frame b: + out_cols
+
+    // ---- F: mel filterbank on the matrix pipe, one chain per sub-frame ------------------------------------
+    float mel[2][4];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const float4* __restrict__ bsrc = reinterpret_cast<const float4*>(mtile + kDualSub * s2 + mm_start);
+      const float4* __restrict__ asrc = t_mm_a + lane;
+      f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+      float4 a0 = asrc[0], x0 = bsrc[0];
+      for (int t = 0; t < p.mm_quads; t += 2) {  // (mm_quads is even; the table ends with a row of zeros)
+        const float4 a1 = asrc[(t + 1) * 64], x1 = bsrc[t + 1];
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, x0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, x0.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, x0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, x0.w, acc1, 0, 0, 0);
+        a0 = asrc[(t + 2) * 64];
+        x0 = bsrc[t + 2];
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, x1.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, x1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, x1.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, x1.w, acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mel[s2][i] = acc0[i] + acc1[i];
+      if (p.mm_levels > 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float own = mel[s2][i];
+          fmac_row_shl<4>(mel[s2][i], own, mm_f1);
+          fmac_row_shl<8>(mel[s2][i], own, mm_f2);
+          if (p.mm_levels > 3) fmac_row_shl<12>(mel[s2][i], own, mm_f3);
+        }
+      }
+    }
+    const int64_t mga = set * 8 + 2 * mj;  // MFMA view: lane 4 b + j -> frames 2 j, 2 j + 1 of the set
+    const int mel_col = (KIND == SNF_KIND_FBANK && p.use_energy && !p.htk_compat) ? 1 : 0;
+    if (KIND == SNF_KIND_FBANK || KIND == SNF_KIND_PLP) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        if (KIND == SNF_KIND_FBANK && p.use_log) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) mel[s2][i] = fast_log(floor_eps(mel[s2][i]));
+        }
+        if (mga + s2 <= last_frame && mm_out >= 0) {
+          float* __restrict__ dst = mrow + s2 * p.out_cols + mel_col + mm_out;
+          if (mm_out + 4 <= p.num_bins) {
+            __builtin_nontemporal_store(f32x4_a4{mel[s2][0], mel[s2][1], mel[s2][2], mel[s2][3]},
+                                        reinterpret_cast<f32x4_a4*>(dst));
+          } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+              if (mm_out + i < p.num_bins) dst[i] = mel[s2][i];
+          }
+        }
+        if (KIND == SNF_KIND_FBANK && p.use_energy && l == 0 && (s2 ? valid_b : valid_a))
+          row[s2 * p.out_cols + (p.htk_compat ? p.num_bins : 0)] = log_e[s2];
+      }
+    }
+    if (KIND == SNF_KIND_MFCC) {
+      // log-mel of both sub-frames back to their (now idle) power tiles, then the DCT-II chains
+      wave_lds_sync();
+      if (mm_out >= 0) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+          *reinterpret_cast<float4*>(mtile + kDualSub * s2 + mm_out) =
+              make_float4(fast_log(floor_eps(mel[s2][0])), fast_log(floor_eps(mel[s2][1])),
+                          fast_log(floor_eps(mel[s2][2])), fast_log(floor_eps(mel[s2][3])));
+      }
+      wave_lds_sync();
+      const int kp = (lane >> 2) & 3;
+      const float4 lift = *reinterpret_cast<const float4*>(t_lifter + 4 * q);
+      const float lf[4] = {lift.x, lift.y, lift.z, lift.w};
+      const int cbase = 4 * q;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const float4* __restrict__ dsrc =
+            reinterpret_cast<const float4*>(mtile + kDualSub * s2 + kp * 4 * p.dd_quads);
+        f32x4 c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int t = 0; t < p.dd_quads; ++t) {
+          const float4 a = t_dd_a[t * 64 + lane], x = dsrc[t];
+          c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, x.x, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, x.y, c1, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, x.z, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, x.w, c1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = c0[i] + c1[i];
+          v += dpp_mov<0x104, true>(0.0f, v);
+          v += dpp_mov<0x108, true>(0.0f, v);
+          v *= lf[i];
+          const int c = cbase + i;
+          int oc = c;
+          if (p.htk_compat) {
+            oc = c == 0 ? p.num_ceps - 1 : c - 1;
+            if (c == 0 && !p.use_energy)
+              v = static_cast<float>(static_cast<double>(v) * 1.4142135623730950488016887);
+          }
+          if (mga + s2 <= last_frame && kp == 0 && c < p.num_ceps && !(c == 0 && p.use_energy))
+            mrow[s2 * p.out_cols + oc] = v;
+        }
+        if (p.use_energy && l == 0 && (s2 ? valid_b : valid_a))
+          row[s2 * p.out_cols + (p.htk_compat ? p.num_ceps - 1 : 0)] = log_e[s2];
+      }
+    }
+    wave_lds_sync();  // the tile is reused by the next frame set
+  }
+}
+
 // one thread per frame: sample index (into the concatenated wave) of the frame's first sample.
 // snip_edges = false: frames are centred (start = f shift + shift / 2 - len / 2, [KALDI-UPSTREAM]
 // FirstSampleOfFrame) and may reach outside the utterance; their start is clamped into the utterance
@@ -679,15 +1074,22 @@ bool fast512_eligible(const MelParams& mp, bool any_warp) {
   return true;
 }
 
-// Builds the packed LDS table blob from the plan's host tables (warp 1.0 mel banks).
+bool fast512_dual_eligible(const MelParams& mp) {
+  if (getenv("SNF_DISABLE_DUAL256")) return false;
+  return fast512_eligible(mp, false) && mp.padded == 256 &&
+         (mp.kind == SNF_KIND_FBANK || mp.kind == SNF_KIND_MFCC || mp.kind == SNF_KIND_PLP);
+}
+
+// Builds the packed LDS table blob from the plan's host tables (warp 1.0 mel banks).  `dual`: tables of
+// fbank256x2_kernel (window value per sample instead of per pair, mel taps on the 129 bins themselves).
 int fast512_build(const MelParams& mp, const std::vector<float>& window, const MelBanksHost& mb_in,
-                  const std::vector<float>& dct, const std::vector<float>& lifter,
+                  const std::vector<float>& dct, const std::vector<float>& lifter, bool dual,
                   std::vector<float>* blob, Fast512Params* out) {
   constexpr double kTwoPi = 6.283185307179586476925286766559005;
   // frames shorter than 512 samples: spread the taps of every bin over the bins of the 512-point
   // spectrum of the zero-extended frame (see fast512_eligible)
   MelBanksHost spread;
-  const int bin_stride = 512 / mp.padded;
+  const int bin_stride = dual ? 1 : 512 / mp.padded;
   if (bin_stride > 1 && mb_in.num_bins > 0) {
     spread.num_bins = mb_in.num_bins;
     spread.num_fft_bins = mb_in.num_fft_bins * bin_stride;
@@ -722,12 +1124,19 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
   p.log_energy_floor = mp.log_energy_floor;
   p.num_bins = mp.num_bins;
   p.num_ceps = mp.num_ceps;
+  p.dual = dual ? 1 : 0;
   blob->clear();
   blob->resize(kFastHeaderFloats, 0.0f);  // header, filled in at the end
   // window pairs, lane-major: row l = elements l + 16 j (j < 16), 2 complex of padding
   for (int l = 0; l < 16; ++l)
     for (int j = 0; j < 18; ++j) {
       const int n = l + 16 * j;
+      if (dual) {  // element n of the row = sample n of BOTH sub-frames
+        const float w = j < 16 && n < mp.win_len ? window[n] : 0.0f;
+        blob->push_back(w);
+        blob->push_back(w);
+        continue;
+      }
       blob->push_back(j < 16 && 2 * n < mp.win_len ? window[2 * n] : 0.0f);
       blob->push_back(j < 16 && 2 * n + 1 < mp.win_len ? window[2 * n + 1] : 0.0f);
     }
@@ -943,6 +1352,55 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
     lds = static_cast<size_t>(tab_bytes) + n_waves * 4 * kFrameTileBytes;
   }
   if (lds > 160 * 1024) return set_error(SNF_E_RUNTIME, "fast512: tables do not fit in LDS");
+  const int energy = p.need_raw ? 1 : (p.need_post ? 2 : 0);
+  if (p.dual) {
+    // two frames per 16-lane row (fbank256x2_kernel): flat batches of FBANK / MFCC / PLP plans
+    if (per_utt || fused) return set_error(SNF_E_RUNTIME, "fast512: the dual tables serve flat batches only");
+    const int64_t n_sets8 = (b.total_frames + 7) / 8;
+    int64_t blocks8 = (n_sets8 + n_waves - 1) / n_waves;
+    const int64_t max_blocks8 = 256 * 4 * (kMaxWaves / n_waves);
+    if (blocks8 > max_blocks8) blocks8 = max_blocks8;
+    const dim3 grid8(static_cast<unsigned>(blocks8)), block8(n_waves * 64);
+#define SNF_DUAL5(NJ_, KIND_, EN_, DI_, SN_)                                                         \
+  do {                                                                                              \
+    if (lds > 64 * 1024)                                                                            \
+      SNF_HIP_CHECK(hipFuncSetAttribute(                                                            \
+          reinterpret_cast<const void*>(fbank256x2_kernel<NJ_, KIND_, EN_, DI_, SN_>),              \
+          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                      \
+    hipLaunchKernelGGL((fbank256x2_kernel<NJ_, KIND_, EN_, DI_, SN_>), grid8, block8, lds, stream,  \
+                       q, b, out, energy_out);                                                      \
+  } while (0)
+#define SNF_DUAL3(NJ_, KIND_, EN_)                                                                   \
+  do {                                                                                              \
+    if (p.dither != 0.0f) {                                                                         \
+      if (p.snip_edges) SNF_DUAL5(NJ_, KIND_, EN_, true, true);                                     \
+      else SNF_DUAL5(NJ_, KIND_, EN_, true, false);                                                 \
+    } else {                                                                                        \
+      if (p.snip_edges) SNF_DUAL5(NJ_, KIND_, EN_, false, true);                                    \
+      else SNF_DUAL5(NJ_, KIND_, EN_, false, false);                                                \
+    }                                                                                               \
+  } while (0)
+#define SNF_DUAL(NJ_, KIND_)                                                                         \
+  do {                                                                                              \
+    if (energy == 0) SNF_DUAL3(NJ_, KIND_, 0);                                                      \
+    else if (energy == 1) SNF_DUAL3(NJ_, KIND_, 1);                                                 \
+    else SNF_DUAL3(NJ_, KIND_, 2);                                                                  \
+  } while (0)
+    if ((p.win_len + 15) / 16 == 13) {
+      if (p.kind == SNF_KIND_FBANK) SNF_DUAL(13, SNF_KIND_FBANK);
+      else if (p.kind == SNF_KIND_MFCC) SNF_DUAL(13, SNF_KIND_MFCC);
+      else SNF_DUAL(13, SNF_KIND_PLP);
+    } else {
+      if (p.kind == SNF_KIND_FBANK) SNF_DUAL(16, SNF_KIND_FBANK);
+      else if (p.kind == SNF_KIND_MFCC) SNF_DUAL(16, SNF_KIND_MFCC);
+      else SNF_DUAL(16, SNF_KIND_PLP);
+    }
+#undef SNF_DUAL
+#undef SNF_DUAL3
+#undef SNF_DUAL5
+    SNF_HIP_CHECK(hipGetLastError());
+    return SNF_OK;
+  }
   const int nj = (p.win_len + 31) / 32 == 13 ? 13 : 16;
   const int64_t n_sets = (b.total_frames + 3) / 4;
   int64_t blocks = (n_sets + n_waves - 1) / n_waves;
@@ -984,7 +1442,6 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
     else if (energy == 1) SNF_LAUNCH3(NJ_, KIND_, 1);                                               \
     else SNF_LAUNCH3(NJ_, KIND_, 2);                                                                \
   } while (0)
-  const int energy = p.need_raw ? 1 : (p.need_post ? 2 : 0);
   if (nj == 13) {
     if (p.kind == SNF_KIND_FBANK) SNF_LAUNCH(13, SNF_KIND_FBANK);
     else if (p.kind == SNF_KIND_MFCC) SNF_LAUNCH(13, SNF_KIND_MFCC);

@@ -168,6 +168,7 @@ struct Fast512Params {
   // group of 4 bins is split into along the FFT bins (partial sums are added through DPP)
   int mm_quads, mm_levels;
   int dd_quads;              // MFCC: DCT-II chain length / 4 (mel bins per K partition / 4)
+  int dual;                  // frames pad to 256 samples: two frames per 16-lane row (fbank256x2_kernel)
   int fused_delta;           // MFCC: rows are [cepstra | delta | delta-delta] (order 2, window 2)
   const float* delta_scales; // ... composite scales of the three orders, 1 + 5 + 9 floats (device)
   int table_floats;          // total floats of the packed table blob below (warp 1.0)
@@ -180,8 +181,10 @@ struct Fast512Params {
 };
 
 bool fast512_eligible(const MelParams& mp, bool any_warp);
+// frames that pad to 256 samples: the two-frames-per-row form (flat batches without VTLN warps)
+bool fast512_dual_eligible(const MelParams& mp);
 int fast512_build(const MelParams& mp, const std::vector<float>& window, const MelBanksHost& mb,
-                  const std::vector<float>& dct, const std::vector<float>& lifter,
+                  const std::vector<float>& dct, const std::vector<float>& lifter, bool dual,
                   std::vector<float>* blob, Fast512Params* out);
 int launch_build_frame_start(const int64_t* d_frame_offsets, const int64_t* d_sample_offsets,
                              int64_t n_utts, int64_t total_frames, int win_shift, int win_len,

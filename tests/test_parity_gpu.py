@@ -545,6 +545,10 @@ def test_fast_kernel_vtln(gpu, synth_waves, cls, snip_edges):
     (MfccProcessor, 16000, dict(frame_length=0.01, frame_shift=0.005)),  # 160 samples -> 256
     (FilterbankProcessor, 16000, dict(frame_length=0.008, frame_shift=0.004, num_bins=15)),  # -> 128
     (MfccProcessor, 8000, dict(frame_length=0.016)),          # 128 samples -> 128
+    (FilterbankProcessor, 8000, dict(use_energy=True, htk_compat=True)),
+    (MfccProcessor, 8000, dict(htk_compat=True, use_energy=False, raw_energy=False)),
+    (MfccProcessor, 8000, dict(frame_length=0.03, frame_shift=0.011, remove_dc_offset=False)),  # 240 -> 256
+    (PlpProcessor, 8000, dict(use_energy=False)),
 ])
 def test_fast_kernel_short_frames(gpu, cls, sample_rate, opts, snip_edges):
     """frames that pad to 256 / 128 samples run on the register-resident kernel as the 512-point
@@ -555,12 +559,14 @@ def test_fast_kernel_short_frames(gpu, cls, sample_rate, opts, snip_edges):
     warps = [1.0, 1.0, 1.0]
     feats = proc._process_batch([Audio(w, sample_rate) for w in waves], vtln_warp=warps)
     plan = _backend.get_plan(proc._build_options())
-    assert plan.kernel_name(1) == 'fbank512_kernel'
+    # frames that pad to 256 samples: two frames per 16-lane row (X_a, X_b from one complex transform)
+    padded = 1 << int(np.ceil(np.log2(opts.get('frame_length', 0.025) * sample_rate - 1e-9)))
+    assert plan.kernel_name(1) == ('fbank256x2_kernel' if padded == 256 else 'fbank512_kernel')
     for w, f in zip(waves, feats):
         want = _oracle(proc, w)
         assert f.shape == want.shape
         assert_close(f.data, want, rtol=2e-4, what=f'{cls.__name__} {sample_rate} {opts}')
-    # with VTLN warps (per-utterance tables), same kernel
+    # with VTLN warps (per-utterance tables): the 512-point form of the zero-extended frames
     warps = [0.9, 1.0, 1.15]
     feats = proc._process_batch([Audio(w, sample_rate) for w in waves], vtln_warp=warps)
     assert plan.kernel_name(1) == 'fbank512_kernel'
