@@ -1202,7 +1202,8 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
     if (!pack(trial, nullptr)) break;
     parts = trial;
   }
-  int chain = 32;  // (at least 8 quads: the kernel unrolls that length)
+  int chain = dual ? 16 : 32;  // (at least 8 quads: fbank512_kernel unrolls that length; the dual
+                               // kernel loops over pairs of quads and its filters span half the bins)
   for (int g = 0; g < n_groups; ++g) chain = std::max(chain, per_part(g, parts[g]));
   chain = (chain + 7) & ~7;  // an even number of quads: the kernel issues them in pairs
   p.mm_quads = chain / 4;
