@@ -67,7 +67,7 @@ __device__ __forceinline__ float from_left_lane(float v, int left_lane_bytes) {
 // NJ: element rows a lane can hold inside the window, ceil(win_len / 128): 9 covers 25 ms at 44.1 kHz (and
 // every shorter frame), 10 the same at 48 kHz, 16 any window up to 2048 samples.  KIND: the plan's kind
 // (the epilogue of one kind per instantiation keeps the scalar register file free of the others' flags)
-template <int NJ, int KIND>
+template <int NJ, int KIND, bool DITHER, bool SNIP>
 __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
     const MelParams p, const BatchArgs b, const float2* __restrict__ gtab, const int bin_step,
     float* __restrict__ out, const int out_cols, double* __restrict__ energy_out) {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
   if (g < b.total_frames) {
     SNF_LOAD_FRAME(b.frame_start[g], (L / 2 - lane + 63) >> 6, 4u * lane);
     utt_next = b.frame_utt[g];
-    if (!p.snip_edges) edge_next = b.frame_edge[g];
+    if (!SNIP) edge_next = b.frame_edge[g];
     start_next = b.frame_start[clamp_frame(g + stride)];
   }
   for (; g < b.total_frames; g += stride) {
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
       xe[j] = static_cast<float>(static_cast<short>(raw[j] & 0xffff));
       xo[j] = static_cast<float>(raw[j] >> 16);
     }
-    if (edge != 0) {
+    if (!SNIP && edge != 0) {
       // [KALDI-UPSTREAM] ExtractWindow, snip_edges = false: samples outside the utterance are reflected
       // (-k - 1 below the start, 2 n - 1 - k beyond the end); only the first and last frames of an
       // utterance take this path, their prefetched samples came from a clamped window
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
       lds_wait();
       wave_lds_sync();
     }
-    if (p.dither != 0.0f) {  // Kaldi dithers before the DC removal
+    if (DITHER) {  // Kaldi dithers before the DC removal
       const unsigned long long k = (static_cast<unsigned long long>(g) + 1) * 0x9E3779B97F4A7C15ull ^ p.seed;
       const unsigned dkey_lo = fmix32(static_cast<unsigned>(k));
       const unsigned dkey_hi = fmix32(static_cast<unsigned>(k >> 32) ^ dkey_lo);
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
     {
       const int64_t gn = clamp_frame(g + stride);
       utt_next = b.frame_utt[gn];
-      if (!p.snip_edges) edge_next = b.frame_edge[gn];
+      if (!SNIP) edge_next = b.frame_edge[gn];
     }
     start_next = b.frame_start[clamp_frame(g + 2 * stride)];
     // ---- F: epilogue (same conventions as mel_features_generic_kernel) -----------------------------------
@@ -504,13 +504,23 @@ int launch_fbank2048(const MelParams& p, const BatchArgs& b, const float* tables
   int64_t blocks = (b.total_frames + kLongWaves - 1) / kLongWaves;
   if (blocks > 256) blocks = 256;  // one persistent workgroup per CU, grid-stride over the frames
   const int rows = (p.win_len + 127) / 128;
-#define SNF_LONG2(NJ_, KIND_)                                                                              \
+#define SNF_LONG4(NJ_, KIND_, DI_, SN_)                                                                             \
   do {                                                                                                    \
-    SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fbank2048_kernel<NJ_, KIND_>),       \
+    SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fbank2048_kernel<NJ_, KIND_, DI_, SN_>),       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));                 \
-    hipLaunchKernelGGL((fbank2048_kernel<NJ_, KIND_>), dim3(static_cast<unsigned>(blocks)),               \
+    hipLaunchKernelGGL((fbank2048_kernel<NJ_, KIND_, DI_, SN_>), dim3(static_cast<unsigned>(blocks)),               \
                        dim3(kLongWaves * 64), lds, stream, p, b, reinterpret_cast<const float2*>(tables), \
                        2048 / p.padded, out, out_cols, energy_out);                                       \
+  } while (0)
+#define SNF_LONG3(NJ_, KIND_, DI_)                                                                         \
+  do {                                                                                                    \
+    if (p.snip_edges) SNF_LONG4(NJ_, KIND_, DI_, true);                                                   \
+    else SNF_LONG4(NJ_, KIND_, DI_, false);                                                               \
+  } while (0)
+#define SNF_LONG2(NJ_, KIND_)                                                                              \
+  do {                                                                                                    \
+    if (p.dither != 0.0f) SNF_LONG3(NJ_, KIND_, true);                                                    \
+    else SNF_LONG3(NJ_, KIND_, false);                                                                    \
   } while (0)
 #define SNF_LONG(NJ_)                                                                                      \
   do {                                                                                                    \
@@ -523,6 +533,8 @@ int launch_fbank2048(const MelParams& p, const BatchArgs& b, const float* tables
   else if (rows <= 10) SNF_LONG(10);
   else SNF_LONG(16);
 #undef SNF_LONG2
+#undef SNF_LONG3
+#undef SNF_LONG4
 #undef SNF_LONG
   SNF_HIP_CHECK(hipGetLastError());
   return SNF_OK;
