@@ -357,10 +357,9 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
       const int* __restrict__ msize = p.mel_size + warp_id * nb;
       const int* __restrict__ moff = p.mel_offset + warp_id * nb;
       const int mel_col = (KIND == SNF_KIND_FBANK && p.use_energy && !p.htk_compat) ? 1 : 0;
-      // teams of 8 lanes per mel bin, 8 bins per round: lane tl of a team owns a contiguous run of `span`
-      // taps (a multiple of 4), loads its weights as 16-byte vectors up front (the banks are the plan's
-      // ordinary device tables, L1 / L2 resident; the table carries 4 floats of padding) and reads the
-      // power spectrum from LDS.  The bin indices of the next round are requested a round ahead.
+      // teams of 8 lanes per mel bin, 8 bins per round; the weights come as 16-byte vectors from the plan's
+      // ordinary device tables (L1 / L2 resident; the table carries 4 floats of padding), the power spectrum
+      // from LDS.  The bin indices of the next round are requested a round ahead.
       const int team = lane >> 3, tl = lane & 7;
       bool active = team < nb;
       int first = active ? mfirst[team] : 0, size = active ? msize[team] : 0, woff = active ? moff[team] : 0;
@@ -370,26 +369,30 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
         const int first_n = active_n ? mfirst[mn] : 0, size_n = active_n ? msize[mn] : 0,
                   woff_n = active_n ? moff[mn] : 0;
         const float* __restrict__ wt = p.mel_w + woff;
-        const int span = ((size + 31) >> 5) << 2, t0 = tl * span;
+        // the team reads the filter in slices of 32 taps: lane tl owns taps 32 e + 4 tl + c (c < 4) - the 8
+        // lanes of a team always hit 8 different LDS banks per read, whatever the width of the filter
+        // (a contiguous run per lane collided 4- and 8-fold on the wide filters), and its weights are
+        // one 16-byte load per slice, 128 contiguous bytes per team
+        const int slices = (size + 31) >> 5;
         float acc = 0.0f;
-        for (int i0 = 0; __any(i0 < span); i0 += 16) {
+        for (int e0 = 0; __any(e0 < slices); e0 += 4) {
           f32x4_a4 w[4];
           float pv[16];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const int t = t0 + i0 + 4 * i;
-            w[i] = *reinterpret_cast<const f32x4_a4*>(wt + ((i0 + 4 * i < span && t < size) ? t : 0));
+            const int t = 32 * (e0 + i) + 4 * tl;
+            w[i] = *reinterpret_cast<const f32x4_a4*>(wt + (t < size ? t : 0));
           }
 #pragma unroll
           for (int e = 0; e < 16; ++e) {  // all 16 reads in flight before the first use
-            const int t = t0 + i0 + e;
-            pv[e] = ps[(i0 + (e & ~3) < span && t < size) ? (first + t) * bin_step : 0];
+            const int t = 32 * (e0 + (e >> 2)) + 4 * tl + (e & 3);
+            pv[e] = ps[t < size ? (first + t) * bin_step : 0];
           }
           lds_wait();
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            const int t = t0 + i0 + e;
-            acc += (i0 + (e & ~3) < span && t < size) ? w[e >> 2][e & 3] * pv[e] : 0.0f;
+            const int t = 32 * (e0 + (e >> 2)) + 4 * tl + (e & 3);
+            acc += t < size ? w[e >> 2][e & 3] * pv[e] : 0.0f;
           }
         }
         acc += dpp_row_ror<0xB1>(acc);   // quad_perm [1,0,3,2]
