@@ -64,7 +64,7 @@ struct snf_plan {
   DevBuf d_window, d_tw_fft, d_tw_unpack, d_tw_dft, d_dct, d_lifter, d_idft;
   std::vector<float> warps;  // distinct VTLN warp factors seen so far (index = warp id)
   std::vector<MelBanksHost> banks;
-  DevBuf d_mel_first, d_mel_size, d_mel_off, d_mel_w, d_eql;
+  DevBuf d_mel_first, d_mel_size, d_mel_off, d_mel_w, d_eql, d_mel_w32, d_mel_off32;
   bool warps_dirty = true;
   PlpParams pp{};
   // register-resident fast path for the 512-point configuration
@@ -356,8 +356,24 @@ int sync_warp_tables(snf_plan* plan) {
   if ((rc = plan->d_mel_first.upload(first, plan->stream))) return rc;
   if ((rc = plan->d_mel_size.upload(size, plan->stream))) return rc;
   if ((rc = plan->d_mel_off.upload(off, plan->stream))) return rc;
-  w.insert(w.end(), 4, 0.0f);  // (the long-frame kernel reads the weights as 16-byte vectors)
   if ((rc = plan->d_mel_w.upload(w, plan->stream))) return rc;
+  if (plan->fast2048) {
+    // the long-frame kernel reads a filter in 32-tap slices of 16-byte vectors: a copy of the weights in
+    // which every filter is zero-padded to whole slices, behind one all-zero slice (for the lanes whose
+    // filter has fewer slices than the widest one of their round)
+    std::vector<float> w32(32, 0.0f);
+    std::vector<int> off32;
+    for (const MelBanksHost& mb : plan->banks)
+      for (int b = 0; b < nb; ++b) {
+        off32.push_back(static_cast<int>(w32.size()));
+        w32.insert(w32.end(), mb.w.begin() + mb.offset[b], mb.w.begin() + mb.offset[b] + mb.size[b]);
+        w32.resize((w32.size() + 31) & ~static_cast<size_t>(31), 0.0f);
+      }
+    if ((rc = plan->d_mel_w32.upload(w32, plan->stream))) return rc;
+    if ((rc = plan->d_mel_off32.upload(off32, plan->stream))) return rc;
+    plan->mp.mel_w32 = plan->d_mel_w32.as<float>();
+    plan->mp.mel_off32 = plan->d_mel_off32.as<int>();
+  }
   plan->mp.mel_first = plan->d_mel_first.as<int>();
   plan->mp.mel_size = plan->d_mel_size.as<int>();
   plan->mp.mel_offset = plan->d_mel_off.as<int>();

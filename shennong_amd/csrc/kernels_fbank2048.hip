@@ -25,6 +25,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "snf_internal.h"
@@ -79,6 +80,10 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
   float2* buf = reinterpret_cast<float2*>(smem + kLongTableBytes + wid * kLongBufBytes);
   float* ps = reinterpret_cast<float*>(buf);   // power spectrum [1025] (aliases the buffer)
   float* melbuf = ps + 1032;                    // log-mel energies of the frame (MFCC), <= 128
+  // The mel phase multiplies a few floats beyond the power spectrum by zero weights, and the padding slots
+  // of the transposes (complex index 68 k + 67) are never written: LDS keeps whatever the previous
+  // kernel left there, and 0 * NaN = NaN.  Clear the wave's buffer once.
+  for (int i = lane; i < kLongBufBytes / 8; i += 64) buf[i] = make_float2(0.0f, 0.0f);
   const int L = p.win_len, M = 1024;
   (void)M;
   const float win_len_f = static_cast<float>(L);
@@ -355,45 +360,45 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
       const int warp_id = __builtin_amdgcn_readfirstlane(warp_v);
       const int* __restrict__ mfirst = p.mel_first + warp_id * nb;
       const int* __restrict__ msize = p.mel_size + warp_id * nb;
-      const int* __restrict__ moff = p.mel_offset + warp_id * nb;
       const int mel_col = (KIND == SNF_KIND_FBANK && p.use_energy && !p.htk_compat) ? 1 : 0;
       // teams of 8 lanes per mel bin, 8 bins per round; the weights come as 16-byte vectors from the plan's
       // ordinary device tables (L1 / L2 resident; the table carries 4 floats of padding), the power spectrum
       // from LDS.  The bin indices of the next round are requested a round ahead.
+      const int* __restrict__ moff32 = p.mel_off32 + warp_id * nb;
       const int team = lane >> 3, tl = lane & 7;
       bool active = team < nb;
-      int first = active ? mfirst[team] : 0, size = active ? msize[team] : 0, woff = active ? moff[team] : 0;
+      int first = active ? mfirst[team] : 0, size = active ? msize[team] : 0, woff = active ? moff32[team] : 0;
       for (int m0 = 0; m0 < nb; m0 += 8) {
         const int m = m0 + team, mn = m + 8;
         const bool active_n = mn < nb;
         const int first_n = active_n ? mfirst[mn] : 0, size_n = active_n ? msize[mn] : 0,
-                  woff_n = active_n ? moff[mn] : 0;
-        const float* __restrict__ wt = p.mel_w + woff;
-        // the team reads the filter in slices of 32 taps: lane tl owns taps 32 e + 4 tl + c (c < 4) - the 8
-        // lanes of a team always hit 8 different LDS banks per read, whatever the width of the filter
-        // (a contiguous run per lane collided 4- and 8-fold on the wide filters), and its weights are
-        // one 16-byte load per slice, 128 contiguous bytes per team
+                  woff_n = active_n ? moff32[mn] : 0;
+        // The team reads the filter in slices of 32 taps: lane tl owns taps 32 e + 4 tl + c (c < 4).  The 8
+        // lanes of a team always hit 8 different LDS banks per read, whatever the width of the filter, and
+        // their weights are one 16-byte load per slice, 128 contiguous bytes per team, from a table in which
+        // every filter is zero-padded to whole slices: no per-tap test at all.  A lane whose filter has
+        // fewer slices than the widest of the round multiplies finite buffer contents by the zero slice.
         const int slices = (size + 31) >> 5;
+        const float* __restrict__ wt = p.mel_w32 + woff + 4 * tl;
+        const float* __restrict__ wz = p.mel_w32 + 4 * tl;
         float acc = 0.0f;
-        for (int e0 = 0; __any(e0 < slices); e0 += 4) {
+        auto group = [&](auto step_c, int e0) {
+          constexpr int kStep = decltype(step_c)::value;
           f32x4_a4 w[4];
           float pv[16];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int t = 32 * (e0 + i) + 4 * tl;
-            w[i] = *reinterpret_cast<const f32x4_a4*>(wt + (t < size ? t : 0));
-          }
+          for (int i = 0; i < 4; ++i)
+            w[i] = *reinterpret_cast<const f32x4_a4*>(e0 + i < slices ? wt + 32 * (e0 + i) : wz);
+          const float* __restrict__ pbase = ps + (first + 32 * e0 + 4 * tl) * kStep;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {  // all 16 reads in flight before the first use
-            const int t = 32 * (e0 + (e >> 2)) + 4 * tl + (e & 3);
-            pv[e] = ps[t < size ? (first + t) * bin_step : 0];
-          }
+          for (int e = 0; e < 16; ++e) pv[e] = pbase[(32 * (e >> 2) + (e & 3)) * kStep];
           lds_wait();
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int t = 32 * (e0 + (e >> 2)) + 4 * tl + (e & 3);
-            acc += t < size ? w[e >> 2][e & 3] * pv[e] : 0.0f;
-          }
+          for (int e = 0; e < 16; ++e) acc += w[e >> 2][e & 3] * pv[e];
+        };
+        for (int e0 = 0; __any(e0 < slices); e0 += 4) {
+          if (bin_step == 1) group(std::integral_constant<int, 1>{}, e0);
+          else group(std::integral_constant<int, 2>{}, e0);
         }
         acc += dpp_row_ror<0xB1>(acc);   // quad_perm [1,0,3,2]
         acc += dpp_row_ror<0x4E>(acc);   // quad_perm [2,3,0,1]

@@ -101,6 +101,8 @@ struct MelParams {
   const int* mel_size;       // [n_warps][num_bins]
   const int* mel_offset;     // [n_warps][num_bins] offset into mel_w
   const float* mel_w;
+  const float* mel_w32;      // long-frame kernel: the weights with every filter zero-padded to 32-tap slices
+  const int* mel_off32;      // [n_warps][num_bins] offset into mel_w32 (slice 0 of mel_w32 is all zeros)
   const float* dct;          // [num_ceps][num_bins]
   const float* lifter;       // [num_ceps] or nullptr
 };

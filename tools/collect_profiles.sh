@@ -16,6 +16,20 @@ rm -rf /tmp/prof_pitch
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pitch -- \
   python $root/tools/profile_pitch.py 4000 > $out/pitch_plp_run.txt 2> /dev/null
 cp $(find /tmp/prof_pitch -name '*kernel_stats.csv' | head -1) $out/pitch_plp_rocprofv3_kernel_stats.csv
+rm -rf /tmp/prof_rates
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_rates -- \
+  python $root/tools/profile_rates.py 10 > $out/other_rates_run.txt 2> /dev/null
+cp $(find /tmp/prof_rates -name '*kernel_stats.csv' | head -1) $out/other_rates_rocprofv3_kernel_stats.csv
+# SQ counters of the long-frame and dual kernels (one --pmc group per run)
+j=0
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
+  j=$((j+1)); rm -rf /tmp/prof_pmcr_$j
+  timeout -s KILL 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/prof_pmcr_$j -- \
+    python $root/tools/profile_rates.py 2 > /dev/null 2>&1
+  f=$(find /tmp/prof_pmcr_$j -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && cp $f $out/pmc_rates_group_$j.csv
+done
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA" \
            "SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES" \
@@ -37,5 +51,17 @@ for name in sorted(glob.glob('gpurun_out/profiles/pmc_group_*.csv')):
             acc[r['Counter_Name']].append(float(r['Counter_Value']))
 for k, v in sorted(acc.items()):
     print('%-28s %.5e  (n=%d)' % (k, sum(v) / len(v), len(v)))
+PY
+python - <<'PY' | tee gpurun_out/profiles/pmc_other_rates_summary.txt
+import csv, glob, collections
+acc = collections.defaultdict(list)
+for name in sorted(glob.glob('gpurun_out/profiles/pmc_rates_group_*.csv')):
+    for r in csv.DictReader(open(name)):
+        k = r['Kernel_Name']
+        for tag in ('fbank2048_kernel<9, 1', 'fbank256x2_kernel<13, 1', 'delta_flat_o2w2_kernel<13'):
+            if tag in k:
+                acc[(tag, r['Counter_Name'])].append(float(r['Counter_Value']))
+for (tag, c), v in sorted(acc.items()):
+    print('%-28s %-24s %.5e  (n=%d)' % (tag, c, sum(v) / len(v), len(v)))
 PY
 tail -c 400 $out/bench_default.json
