@@ -211,9 +211,10 @@ class Plan:
         if lib().snf_plan_fast_path(handle) == 0:
             from shennong_amd.logger import get_logger
             get_logger('backend', 'warning').warning(
-                'this option combination is not covered by the register-resident kernel (frames must '
-                'pad to 512, 256 or 128 samples, <= 64 mel bins, <= 16 cepstra, power spectrum): the '
-                'generic wave-per-frame kernel is used, about 8 times slower per frame')
+                'this option combination is not covered by the register-resident kernels (even frames '
+                'that pad to 128 ... 512 samples with <= 64 mel bins, <= 16 cepstra and a power spectrum, '
+                'or to 1024 / 2048 samples with <= 128 mel bins): the generic wave-per-frame kernel is '
+                'used, 5 to 8 times slower per frame')
 
     def __del__(self):
         handle = getattr(self, 'handle', None)
