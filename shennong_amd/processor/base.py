@@ -87,6 +87,10 @@ class FeaturesProcessor(BaseProcessor, metaclass=abc.ABCMeta):
         (ValueError if <= 0) but only sizes the host-side audio loading; the features of all
         utterances are computed by ONE batched launch on the GPU.  Extra `kwargs` must be dicts
         keyed by utterance name and are forwarded to `process`.
+
+        The matrices of the returned collection are row-block VIEWS of one batch-sized array (cutting
+        thousands of copies out of it would dominate the call): keeping a single `Features` alive
+        keeps the whole batch in memory - `Features.copy()` detaches one.
         """
         njobs = get_njobs(njobs, log=self.log)
         for name, value in kwargs.items():

@@ -4,7 +4,17 @@ Same parameters and outputs as reference shennong/processor/energy.py:55-185 (pl
 float64 sum of squares of the Kaldi-processed window, floored, then compressed).  The reference
 returns float64 data computed from float32 windows; this backend returns the same quantity
 rounded once to float32 (what every Kaldi consumer downstream, e.g. the VAD, works in).
+
+Known divergence: the reference hands `signal.data` to Kaldi at its native scale, whereas every
+plan of this backend takes 16-bit samples, so non-int16 audio is first rescaled to the int16 full
+scale (`Audio.astype`, an exact power of two).  For float audio in [-1, 1] the log-energy is therefore
+2 ln(2^15) = 20.79 higher than the reference's (the energy itself 2^30 times), which matters to
+absolute thresholds such as the VAD's; int16 audio - what the pipeline and the reference's own tests
+use - is unaffected.  A warning is logged when it happens.
 """
+
+import numpy as np
+
 
 from shennong_amd import _abi
 from shennong_amd._options import FLAG, Option
@@ -50,6 +60,10 @@ class EnergyProcessor(FramesProcessor):
     def _process_batch(self, signals):
         for signal in signals:
             check_signal(self, signal)
+        if any(signal.dtype != np.int16 for signal in signals):
+            self.log.warning(
+                'energy of non-int16 audio is computed after rescaling to the int16 full scale '
+                '(the reference keeps the native scale: see the module documentation)')
         datas = self._run(self._build_options(), signals)
         # (an utterance without frames comes back as Kaldi's (0, 0) matrix: one column here)
         return batch_features([d if d.shape[0] else d.reshape((0, 1)) for d in datas],
