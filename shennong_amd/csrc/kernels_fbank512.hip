@@ -79,7 +79,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
   const float* __restrict__ gtab = p.tables;
   int h_mm_quads = p.mm_quads, h_mm_levels = p.mm_levels, h_dd_quads = p.dd_quads,
       h_off_mm_a = p.off_mm_a, h_off_mm_lane = p.off_mm_lane, h_off_dd_a = p.off_dd_a,
-      h_off_lifter = p.off_lifter, h_table_floats = p.table_floats;
+      h_off_lifter = p.off_lifter, h_table_floats = p.table_floats, h_off_dd_v = p.off_dd_v,
+      h_dd_groups = p.dd_groups;
   if (PERUTT) {
     pu_u = b.blk_utt[blockIdx.x];
     pu_set0 = b.blk_set0[blockIdx.x];
@@ -97,6 +98,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     h_off_dd_a = hdr[5];
     h_off_lifter = hdr[6];
     h_table_floats = hdr[7];
+    h_off_dd_v = hdr[8];
+    h_dd_groups = hdr[9];
   }
   // ---- stage the tables into LDS (the only workgroup-wide barrier of the kernel) -------------------
   for (int i = threadIdx.x; i < h_table_floats; i += blockDim.x) tab[i] = gtab[i];
@@ -110,6 +113,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
   const float4* __restrict__ t_mm_a = reinterpret_cast<const float4*>(tab + h_off_mm_a);
   const float4* __restrict__ t_dd_a = reinterpret_cast<const float4*>(tab + h_off_dd_a);
   const float* __restrict__ t_lifter = tab + h_off_lifter;
+  const float4* __restrict__ t_dd_v = reinterpret_cast<const float4*>(tab + h_off_dd_v);
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l = lane & 15, q = lane >> 4;
@@ -532,40 +536,72 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
               make_float4(fast_log(floor_eps(mel[0])), fast_log(floor_eps(mel[1])),
                           fast_log(floor_eps(mel[2])), fast_log(floor_eps(mel[3])));
         wave_lds_sync();
-        const int kp = (lane >> 2) & 3;
-        const float4* __restrict__ dsrc = reinterpret_cast<const float4*>(mtile + kp * 4 * h_dd_quads);
-        f32x4 c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int t = 0; t < h_dd_quads; ++t) {
-          const float4 a = t_dd_a[t * 64 + lane], x = dsrc[t];
-          c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, x.x, c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, x.y, c1, 0, 0, 0);
-          c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, x.z, c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, x.w, c1, 0, 0, 0);
-        }
-        const float4 lift = *reinterpret_cast<const float4*>(t_lifter + 4 * q);
-        const float lf[4] = {lift.x, lift.y, lift.z, lift.w};
-        const int cbase = 4 * q;  // first cepstrum of this lane's group (kp = 0 lanes store)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float v = c0[i] + c1[i];
-          v += dpp_mov<0x104, true>(0.0f, v);  // kp 0 + 1, 1 + 2, 2 + 3, 3
-          v += dpp_mov<0x108, true>(0.0f, v);  // kp 0: (0 + 1) + (2 + 3)
-          v *= lf[i];
-          const int c = cbase + i;
-          int oc = c;
+        if (!p.dct_mfma) {
+          // DCT-II + lifter on the vector pipe (the shipped form): lane l of a frame's row owns cepstrum l
+          // (num_ceps <= 16) and walks the log-mel of its frame 4 bins at a time (one broadcast 16-byte
+          // read of the tile + one of the lane-major DCT table per group).  ~40 instructions and no
+          // dependent matrix chain at the end of the set.  Measured a tie with the MFMA chain below on this
+          // kernel (1.17-1.21 against 1.19-1.22 ms), a clear win on fbank256x2_kernel; SNF_DCT_MFMA=1
+          // selects the chain.
+          const float4* __restrict__ dw = t_dd_v + l;
+          const float4* __restrict__ dx = reinterpret_cast<const float4*>(ptile);
+          float v = 0.0f;
+#pragma unroll 2
+          for (int g4 = 0; g4 < h_dd_groups; ++g4) {
+            const float4 w = dw[g4 * 16], x = dx[g4];
+            v += w.x * x.x;
+            v += w.y * x.y;
+            v += w.z * x.z;
+            v += w.w * x.w;
+          }
+          v *= t_lifter[l];
+          if (l == 0 && p.use_energy) v = log_energy;
+          int oc = l;
           if (p.htk_compat) {
-            oc = c == 0 ? p.num_ceps - 1 : c - 1;
-            if (c == 0 && !p.use_energy)
+            oc = l == 0 ? p.num_ceps - 1 : l - 1;
+            if (l == 0 && !p.use_energy)
               v = static_cast<float>(static_cast<double>(v) * 1.4142135623730950488016887);
           }
-          if (mvalid && kp == 0 && c < p.num_ceps && !(c == 0 && p.use_energy)) {
-            if (FUSED) cepbuf[(mgl - cep_frame0) * kFusedCols + oc] = v;
-            else mrow[oc] = v;
+          if (valid && l < p.num_ceps) {
+            if (FUSED) cepbuf[(gl - cep_frame0) * kFusedCols + oc] = v;
+            else row[oc] = v;
           }
-        }
-        if (p.use_energy && valid && l == 0) {
-          if (FUSED) cepbuf[(gl - cep_frame0) * kFusedCols + (p.htk_compat ? p.num_ceps - 1 : 0)] = log_energy;
-          else row[p.htk_compat ? p.num_ceps - 1 : 0] = log_energy;
+        } else {
+          const int kp = (lane >> 2) & 3;
+          const float4* __restrict__ dsrc = reinterpret_cast<const float4*>(mtile + kp * 4 * h_dd_quads);
+          f32x4 c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = {0.0f, 0.0f, 0.0f, 0.0f};
+          for (int t = 0; t < h_dd_quads; ++t) {
+            const float4 a = t_dd_a[t * 64 + lane], x = dsrc[t];
+            c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, x.x, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, x.y, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, x.z, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, x.w, c1, 0, 0, 0);
+          }
+          const float4 lift = *reinterpret_cast<const float4*>(t_lifter + 4 * q);
+          const float lf[4] = {lift.x, lift.y, lift.z, lift.w};
+          const int cbase = 4 * q;  // first cepstrum of this lane's group (kp = 0 lanes store)
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float v = c0[i] + c1[i];
+            v += dpp_mov<0x104, true>(0.0f, v);  // kp 0 + 1, 1 + 2, 2 + 3, 3
+            v += dpp_mov<0x108, true>(0.0f, v);  // kp 0: (0 + 1) + (2 + 3)
+            v *= lf[i];
+            const int c = cbase + i;
+            int oc = c;
+            if (p.htk_compat) {
+              oc = c == 0 ? p.num_ceps - 1 : c - 1;
+              if (c == 0 && !p.use_energy)
+                v = static_cast<float>(static_cast<double>(v) * 1.4142135623730950488016887);
+            }
+            if (mvalid && kp == 0 && c < p.num_ceps && !(c == 0 && p.use_energy)) {
+              if (FUSED) cepbuf[(mgl - cep_frame0) * kFusedCols + oc] = v;
+              else mrow[oc] = v;
+            }
+          }
+          if (p.use_energy && valid && l == 0) {
+            if (FUSED) cepbuf[(gl - cep_frame0) * kFusedCols + (p.htk_compat ? p.num_ceps - 1 : 0)] = log_energy;
+            else row[p.htk_compat ? p.num_ceps - 1 : 0] = log_energy;
+          }
         }
       }
     }
@@ -579,7 +615,6 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     const int D = p.num_ceps, OD = 3 * D;
     const int64_t f_first = static_cast<int64_t>(pu_set0) * 4;
     const int64_t rows64 = pu_T - f_first < 4 * kFusedSets ? pu_T - f_first : 4 * kFusedSets;
-    const int n_out = static_cast<int>(rows64) * OD;
     float sc[15];
 #pragma unroll
     for (int i = 0; i < 15; ++i) sc[i] = p.delta_scales[i];
@@ -638,7 +673,6 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
   const float2* __restrict__ t_win = reinterpret_cast<const float2*>(tab + kFastHeaderFloats);
   const float2* __restrict__ t_tw16 = t_win + 16 * 18;
   const float4* __restrict__ t_mm_a = reinterpret_cast<const float4*>(tab + p.off_mm_a);
-  const float4* __restrict__ t_dd_a = reinterpret_cast<const float4*>(tab + p.off_dd_a);
   const float* __restrict__ t_lifter = tab + p.off_lifter;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l = lane & 15, q = lane >> 4;
@@ -970,40 +1004,30 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
                           fast_log(floor_eps(mel[s2][2])), fast_log(floor_eps(mel[s2][3])));
       }
       wave_lds_sync();
-      const int kp = (lane >> 2) & 3;
-      const float4 lift = *reinterpret_cast<const float4*>(t_lifter + 4 * q);
-      const float lf[4] = {lift.x, lift.y, lift.z, lift.w};
-      const int cbase = 4 * q;
+      // DCT-II + lifter on the vector pipe: lane l of a row owns cepstrum l of the row's two sub-frames
+      const float4* __restrict__ t_dd_v = reinterpret_cast<const float4*>(tab + p.off_dd_v);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const float4* __restrict__ dsrc =
-            reinterpret_cast<const float4*>(mtile + kDualSub * s2 + kp * 4 * p.dd_quads);
-        f32x4 c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int t = 0; t < p.dd_quads; ++t) {
-          const float4 a = t_dd_a[t * 64 + lane], x = dsrc[t];
-          c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, x.x, c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, x.y, c1, 0, 0, 0);
-          c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, x.z, c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, x.w, c1, 0, 0, 0);
+        const float4* __restrict__ dw = t_dd_v + l;
+        const float4* __restrict__ dx = reinterpret_cast<const float4*>(ptile + kDualSub * s2);
+        float v = 0.0f;
+#pragma unroll 2
+        for (int g4 = 0; g4 < p.dd_groups; ++g4) {
+          const float4 w = dw[g4 * 16], x = dx[g4];
+          v += w.x * x.x;
+          v += w.y * x.y;
+          v += w.z * x.z;
+          v += w.w * x.w;
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float v = c0[i] + c1[i];
-          v += dpp_mov<0x104, true>(0.0f, v);
-          v += dpp_mov<0x108, true>(0.0f, v);
-          v *= lf[i];
-          const int c = cbase + i;
-          int oc = c;
-          if (p.htk_compat) {
-            oc = c == 0 ? p.num_ceps - 1 : c - 1;
-            if (c == 0 && !p.use_energy)
-              v = static_cast<float>(static_cast<double>(v) * 1.4142135623730950488016887);
-          }
-          if (mga + s2 <= last_frame && kp == 0 && c < p.num_ceps && !(c == 0 && p.use_energy))
-            mrow[s2 * p.out_cols + oc] = v;
+        v *= t_lifter[l];
+        if (l == 0 && p.use_energy) v = log_e[s2];
+        int oc = l;
+        if (p.htk_compat) {
+          oc = l == 0 ? p.num_ceps - 1 : l - 1;
+          if (l == 0 && !p.use_energy)
+            v = static_cast<float>(static_cast<double>(v) * 1.4142135623730950488016887);
         }
-        if (p.use_energy && l == 0 && (s2 ? valid_b : valid_a))
-          row[s2 * p.out_cols + (p.htk_compat ? p.num_ceps - 1 : 0)] = log_e[s2];
+        if ((s2 ? valid_b : valid_a) && l < p.num_ceps) row[s2 * p.out_cols + oc] = v;
       }
     }
     wave_lds_sync();  // the tile is reused by the next frame set
@@ -1293,9 +1317,17 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
       blob->push_back(bk.group >= 0 && bk.part == 0 && parts[bk.group] > level ? 1.0f : 0.0f);
     }
   // ---- DCT-II as MFMA blocks: block 4 cg + kp = cepstra 4 cg .. 4 cg + 3 x mel bins of partition kp --
+  // The DCT-II of MFCC plans ships on the vector pipe (measured: a tie with the MFMA chain on the
+  // 512-point kernel - 1.17-1.21 against 1.19-1.22 ms -, 19 % faster on the two-frames-per-row kernel,
+  // which only has that form); SNF_DCT_MFMA=1 selects the chain.  Only the table of the selected form
+  // goes into the blob (both would not fit in LDS beside the fused-delta buffer).
+  {
+    const char* knob = getenv("SNF_DCT_MFMA");
+    p.dct_mfma = (!dual && knob && knob[0] == '1') ? 1 : 0;
+  }
   p.dd_quads = 0;
   p.off_dd_a = static_cast<int>(blob->size());
-  if (mp.kind == SNF_KIND_MFCC) {
+  if (mp.kind == SNF_KIND_MFCC && p.dct_mfma) {
     p.dd_quads = ((mp.num_bins + 3) / 4 + 3) / 4;
     const int per = 4 * p.dd_quads;
     for (int t = 0; t < p.dd_quads; ++t)
@@ -1309,6 +1341,20 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
   p.off_lifter = static_cast<int>(blob->size());
   for (int c = 0; c < 16; ++c)
     blob->push_back(c < static_cast<int>(lifter.size()) ? lifter[c] : 1.0f);
+  // DCT-II for the vector pipe, lane-major: group g4 (mel bins 4 g4 .. 4 g4 + 3) x cepstrum l < 16
+  while (blob->size() % 4) blob->push_back(0.0f);
+  p.off_dd_v = static_cast<int>(blob->size());
+  p.dd_groups = 0;
+  if (mp.kind == SNF_KIND_MFCC && !p.dct_mfma) {
+    p.dd_groups = (mp.num_bins + 3) / 4;
+    for (int g4 = 0; g4 < p.dd_groups; ++g4)
+      for (int l = 0; l < 16; ++l)
+        for (int c = 0; c < 4; ++c) {
+          const int m = 4 * g4 + c;
+          blob->push_back(l < mp.num_ceps && m < mp.num_bins ? dct[static_cast<size_t>(l) * mp.num_bins + m]
+                                                             : 0.0f);
+        }
+  }
   p.table_floats = static_cast<int>(blob->size());
   {  // header: what the PERUTT kernel needs to know about THIS warp factor's tables
     int hdr[kFastHeaderFloats] = {};
@@ -1320,6 +1366,8 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
     hdr[5] = p.off_dd_a;
     hdr[6] = p.off_lifter;
     hdr[7] = p.table_floats;
+    hdr[8] = p.off_dd_v;
+    hdr[9] = p.dd_groups;
     std::memcpy(blob->data(), hdr, sizeof(hdr));
   }
   *out = p;

@@ -170,6 +170,8 @@ struct Fast512Params {
   // group of 4 bins is split into along the FFT bins (partial sums are added through DPP)
   int mm_quads, mm_levels;
   int dd_quads;              // MFCC: DCT-II chain length / 4 (mel bins per K partition / 4)
+  int dd_groups;             // MFCC, vector-pipe DCT: groups of 4 mel bins (ceil(num_bins / 4))
+  int dct_mfma;              // MFCC: 1 = DCT-II as the MFMA chain (SNF_DCT_MFMA=1; measured slower), 0 = vector pipe
   int dual;                  // frames pad to 256 samples: two frames per 16-lane row (fbank256x2_kernel)
   int fused_delta;           // MFCC: rows are [cepstra | delta | delta-delta] (order 2, window 2)
   const float* delta_scales; // ... composite scales of the three orders, 1 + 5 + 9 floats (device)
@@ -177,9 +179,10 @@ struct Fast512Params {
   int table_stride;          // floats between the blobs of consecutive warp factors (VTLN)
   // one packed blob, copied to LDS at kernel start:
   //   header[16] | float2 win[16][18] | float2 tw16[16][18] | float2 tw512[16][10] |
-  //   float4 mm_a[mm_quads][64] | mm_lane[5][64] | float4 dd_a[dd_quads][64] | float lifter[16]
+  //   float4 mm_a[mm_quads][64] | mm_lane[5][64] | float4 dd_a[dd_quads][64] | float lifter[16] |
+  //   float4 dd_v[dd_groups][16]
   const float* tables;
-  int off_mm_a, off_mm_lane, off_dd_a, off_lifter;  // float offsets into the blob
+  int off_mm_a, off_mm_lane, off_dd_a, off_lifter, off_dd_v;  // float offsets into the blob
 };
 
 bool fast512_eligible(const MelParams& mp, bool any_warp);
