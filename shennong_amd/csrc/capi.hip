@@ -363,11 +363,18 @@ int sync_warp_tables(snf_plan* plan) {
     // filter has fewer slices than the widest one of their round)
     std::vector<float> w32(32, 0.0f);
     std::vector<int> off32;
+    // ... every filter starts at a multiple of 4 bins (leading zeros) and each group of 4 taps is rotated
+    // by the bin index modulo 4 (= the team of 8 lanes that reads it: kernels_fbank2048.hip)
     for (const MelBanksHost& mb : plan->banks)
       for (int b = 0; b < nb; ++b) {
         off32.push_back(static_cast<int>(w32.size()));
-        w32.insert(w32.end(), mb.w.begin() + mb.offset[b], mb.w.begin() + mb.offset[b] + mb.size[b]);
-        w32.resize((w32.size() + 31) & ~static_cast<size_t>(31), 0.0f);
+        const int lead = mb.first[b] & 3, taps = lead + mb.size[b], rot = b & 3;
+        const size_t base32 = w32.size();
+        w32.resize(base32 + ((taps + 31) & ~31), 0.0f);
+        for (int t = 0; t < ((taps + 3) & ~3); ++t) {
+          const int src = (t & ~3) + (((t & 3) + rot) & 3);  // tap stored at position t of its group
+          if (src >= lead && src < taps) w32[base32 + t] = mb.w[mb.offset[b] + src - lead];
+        }
       }
     if ((rc = plan->d_mel_w32.upload(w32, plan->stream))) return rc;
     if ((rc = plan->d_mel_off32.upload(off32, plan->stream))) return rc;

@@ -84,8 +84,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
   // of the transposes (complex index 68 k + 67) are never written: LDS keeps whatever the previous
   // kernel left there, and 0 * NaN = NaN.  Clear the wave's buffer once.
   for (int i = lane; i < kLongBufBytes / 8; i += 64) buf[i] = make_float2(0.0f, 0.0f);
-  const int L = p.win_len, M = 1024;
-  (void)M;
+  const int L = p.win_len;
   const float win_len_f = static_cast<float>(L);
   const int left_lane_bytes = ((lane + 63) & 63) * 4;
   typedef int __attribute__((aligned(2))) int_a2;
@@ -318,15 +317,29 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
       pm[0] = ny * ny;
     }
     const float p512 = z[8].x * z[8].x + z[8].y * z[8].y;  // self-paired bin 512: lane 0, register 8
+    if (bin_step == 1) {
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
-      ps_lo[64 * d] = pk[d];
-      ps_hi[448 - 64 * d] = pm[d];
+      for (int d = 0; d < 8; ++d) {
+        ps_lo[64 * d] = pk[d];
+        ps_hi[448 - 64 * d] = pm[d];
+      }
+      if (lane == 0) ps[512] = p512;
+    } else {
+      // zero-extended 1024-sample frame: its spectrum is the even bins, kept compactly (bin k at k / 2)
+      if ((kappa & 1) == 0) {
+        float* __restrict__ pe_lo = ps + (kappa >> 1);
+        float* __restrict__ pe_hi = ps + (288 - (kappa >> 1));  // (1024 - kappa - 64 d) / 2 = pe_hi[224 - 32 d]
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          pe_lo[32 * d] = pk[d];
+          pe_hi[224 - 32 * d] = pm[d];
+        }
+      }
+      if (lane == 0) ps[256] = p512;
     }
-    if (lane == 0) ps[512] = p512;
     wave_lds_sync();
     if (KIND == SNF_KIND_FBANK && !p.use_power) {  // magnitude spectrum
-      for (int k = lane; k <= M; k += 64) ps[k] = sqrtf(ps[k]);
+      for (int k = lane; k <= p.half; k += 64) ps[k] = sqrtf(ps[k]);
       wave_lds_sync();
     }
 
@@ -351,7 +364,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
     float* __restrict__ row = out + g * static_cast<int64_t>(out_cols);
     if (KIND == SNF_KIND_SPECTROGRAM) {
       for (int k = lane; k <= p.half; k += 64) {
-        float v = fast_log(floor_eps(ps[k * bin_step]));
+        float v = fast_log(floor_eps(ps[k]));
         if (k == 0) v = log_energy;
         row[k] = v;
       }
@@ -373,32 +386,33 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
         const bool active_n = mn < nb;
         const int first_n = active_n ? mfirst[mn] : 0, size_n = active_n ? msize[mn] : 0,
                   woff_n = active_n ? moff32[mn] : 0;
-        // The team reads the filter in slices of 32 taps: lane tl owns taps 32 e + 4 tl + c (c < 4).  The 8
-        // lanes of a team always hit 8 different LDS banks per read, whatever the width of the filter, and
-        // their weights are one 16-byte load per slice, 128 contiguous bytes per team, from a table in which
-        // every filter is zero-padded to whole slices: no per-tap test at all.  A lane whose filter has
-        // fewer slices than the widest of the round multiplies finite buffer contents by the zero slice.
-        const int slices = (size + 31) >> 5;
+        // The team reads the filter in slices of 32 taps: lane tl owns taps 32 e + 4 tl + c (c < 4), one
+        // 16-byte weight load per slice (128 contiguous bytes per team) from a table in which every filter
+        // starts at a multiple of 4 bins and is zero-padded to whole slices: no per-tap test.  Inside a
+        // group of 4 taps the table is rotated by the team index, and so is the order of the reads: the
+        // four teams of a 32-lane LDS group then sit on the four residues modulo 4 of the banks, the 8
+        // lanes of a team on 8 different banks of their residue - every read is conflict-free.  A lane
+        // whose filter has fewer slices than the widest of the round multiplies finite buffer contents
+        // by the zero slice.
+        const int lead = first & 3, slices = (size + lead + 31) >> 5;
         const float* __restrict__ wt = p.mel_w32 + woff + 4 * tl;
         const float* __restrict__ wz = p.mel_w32 + 4 * tl;
+        const float* __restrict__ pb0 = ps + (first - lead) + 4 * tl;
+        const int rot = team & 3;
+        const float* __restrict__ pb[4] = {pb0 + rot, pb0 + ((rot + 1) & 3), pb0 + ((rot + 2) & 3),
+                                           pb0 + ((rot + 3) & 3)};
         float acc = 0.0f;
-        auto group = [&](auto step_c, int e0) {
-          constexpr int kStep = decltype(step_c)::value;
+        for (int e0 = 0; __any(e0 < slices); e0 += 4) {
           f32x4_a4 w[4];
           float pv[16];
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             w[i] = *reinterpret_cast<const f32x4_a4*>(e0 + i < slices ? wt + 32 * (e0 + i) : wz);
-          const float* __restrict__ pbase = ps + (first + 32 * e0 + 4 * tl) * kStep;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) pv[e] = pbase[(32 * (e >> 2) + (e & 3)) * kStep];
+          for (int e = 0; e < 16; ++e) pv[e] = pb[e & 3][32 * (e0 + (e >> 2))];
           lds_wait();
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc += w[e >> 2][e & 3] * pv[e];
-        };
-        for (int e0 = 0; __any(e0 < slices); e0 += 4) {
-          if (bin_step == 1) group(std::integral_constant<int, 1>{}, e0);
-          else group(std::integral_constant<int, 2>{}, e0);
         }
         acc += dpp_row_ror<0xB1>(acc);   // quad_perm [1,0,3,2]
         acc += dpp_row_ror<0x4E>(acc);   // quad_perm [2,3,0,1]
