@@ -38,9 +38,10 @@ namespace {
 constexpr int kLongWaves = 16;                 // one workgroup per CU: 16 frames in flight
 constexpr int kLongBufBytes = 1088 * 8;        // wave-private LDS: 16 rows x (64 + 4) complex = 64 rows x 17
 // table blob (float2 units): window pairs [64][18] | W1024^(L k1) [64][18] | W2048^(kappa + 64 d) [64][10]
-// | W64^(b c) [4][4][4]; rows padded to 16-byte multiples that ds_read_b128 reads conflict-free
+// | W64^(b c) [4][16 + 2]; rows padded so that ds_read_b128 is conflict-free (the four rows of the last table
+// are broadcast to 16 lanes each: 128-byte rows would put all four on the same banks)
 constexpr int kOffWin = 0, kOffTw1 = 64 * 18, kOffTwU = 2 * 64 * 18, kOffTw2 = 2 * 64 * 18 + 64 * 10;
-constexpr int kLongTableFloat2 = kOffTw2 + 64;
+constexpr int kLongTableFloat2 = kOffTw2 + 4 * 18;
 constexpr int kLongTableBytes = kLongTableFloat2 * 8;
 
 __device__ __forceinline__ float readlane_f(float v, int lane) {
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
     const float2* __restrict__ t_win = tab + kOffWin + lane_v * 18;
     const float2* __restrict__ t_tw1 = tab + kOffTw1 + lane_v * 18;
     const float2* __restrict__ t_twu = tab + kOffTwU + lane_v * 10;
-    const float2* __restrict__ t_tw2 = tab + kOffTw2 + bq * 16;
+    const float2* __restrict__ t_tw2 = tab + kOffTw2 + bq * 18;
     // lane-constant LDS bases (float2 index into the wave's buffer); every access adds a compile-time offset
     const float2* __restrict__ base_lane = buf + lane_v;               // transpose 1 write, exchange write
     float2* __restrict__ base_quad = buf + 68 * kq + bq;             // transpose 1 read, transpose 2 write
@@ -515,7 +516,7 @@ void fbank2048_tables(const MelParams& mp, const std::vector<float>& window, std
     for (int i = 0; i < 4; ++i)
       for (int c = 0; c < 4; ++c) {
         const double a = -kTwoPi * (((bq + 4 * i) * c) % 64) / 64.0;
-        put(kOffTw2 + bq * 16 + i * 4 + c, std::cos(a), std::sin(a));
+        put(kOffTw2 + bq * 18 + i * 4 + c, std::cos(a), std::sin(a));
       }
 }
 
