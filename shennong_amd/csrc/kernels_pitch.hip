@@ -59,25 +59,43 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }  // namespace
 
 // ---- 1. LinearResample ---------------------------------------------------------------------------
-__global__ void pitch_resample_kernel(const PitchDevTables t, const PitchBatch b,
-                                      float* __restrict__ down) {
+// A workgroup computes 256 consecutive output samples of one utterance: the input span they touch
+// (256 x in_unit / out_unit samples + one filter length) is staged into LDS as floats with coalesced
+// loads - zeros outside the utterance: fmaf(w, 0, s) = s exactly, the accumulator never being -0 - and
+// every thread then runs Kaldi's tap loop (one sequential fmaf chain) from LDS.  The per-output gather
+// of 2-byte samples from global memory that this replaces took 0.68 ms per 192 M input samples.
+__global__ __launch_bounds__(256) void pitch_resample_kernel(const PitchDevTables t, const PitchBatch b,
+                                                             float* __restrict__ down) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xs = reinterpret_cast<float*>(smem);
   // blockIdx.y = utterance (no per-thread search), blockIdx.x = 256-sample chunk of its output
   const int64_t u = blockIdx.y;
   const int64_t d0 = b.down_offsets[u], nd = b.down_offsets[u + 1] - d0;
-  const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (k >= nd) return;
+  const int64_t k0 = static_cast<int64_t>(blockIdx.x) * blockDim.x;
+  if (k0 >= nd) return;
   const int64_t s0 = b.sample_offsets[u], n = b.sample_offsets[u + 1] - s0;
   const int16_t* __restrict__ w = b.wave + s0;
+  auto first_of = [&](int64_t k) -> int64_t {
+    const int64_t unit = k / t.rs_out_unit;
+    return t.rs_first[static_cast<int>(k - unit * t.rs_out_unit)] + unit * t.rs_in_unit;
+  };
+  const int64_t k_last = k0 + blockDim.x - 1 < nd - 1 ? k0 + blockDim.x - 1 : nd - 1;
+  const int64_t base = first_of(k0);                        // (first inputs are non-decreasing in k)
+  const int span = static_cast<int>(first_of(k_last) + t.rs_max_taps - base);
+  for (int i = threadIdx.x; i < span; i += blockDim.x) {
+    const int64_t j = base + i;
+    xs[i] = (j >= 0 && j < n) ? static_cast<float>(w[j]) : 0.0f;
+  }
+  __syncthreads();
+  const int64_t k = k0 + threadIdx.x;
+  if (k >= nd) return;
   const int64_t unit = k / t.rs_out_unit;
   const int wrapped = static_cast<int>(k - unit * t.rs_out_unit);
-  const int64_t first_in = t.rs_first[wrapped] + unit * t.rs_in_unit;
+  const float* __restrict__ x = xs + (t.rs_first[wrapped] + unit * t.rs_in_unit - base);
   const float* __restrict__ wt = t.rs_w + wrapped * t.rs_max_taps;
   const int ntaps = t.rs_ntaps[wrapped];
   float s = 0.0f;
-  for (int i = 0; i < ntaps; ++i) {
-    const int64_t j = first_in + i;
-    if (j >= 0 && j < n) s = __builtin_fmaf(wt[i], static_cast<float>(w[j]), s);
-  }
+  for (int i = 0; i < ntaps; ++i) s = __builtin_fmaf(wt[i], x[i], s);
   down[d0 + k] = s;
 }
 
@@ -235,7 +253,9 @@ __device__ __forceinline__ float tree16(float v) {
 constexpr int kLagGroup = 5;   // lags per lane and pass of the correlation
 constexpr int kNccfWaves = 4;  // 16 frames per workgroup
 constexpr int kFwdPad = 36;    // FLT_MAX entries behind the forward costs (unclamped scan steps)
-constexpr int kLongRange = 8;  // candidate ranges at least this long are scanned by a 16-lane row
+constexpr int kLongRange3 = 64;  // level 3 / level 4: candidate ranges at least this long are scanned by a
+constexpr int kLongRange4 = 24;  // 16-lane row instead of one lane
+constexpr int kQueueFloats = 64 * 4;  // long-window queue of a wave: 64 x int4
 constexpr int kVitWaves = 8;   // utterances (= wavefronts) per workgroup of the Viterbi kernel
 constexpr int kRowRegs = 8;    // row values per lane held one frame ahead (up to 512 states)
 
@@ -383,6 +403,7 @@ struct VitShared {
   float* fwd;    // [num_states + kFwdPad]
   float* nxt;    // [num_states]
   int* bpw;      // [num_states]   backpointers of the current frame
+  int4* queue;   // [64]           (state, lo, hi) of the long windows of a pass
 };
 
 // one forward pass over all frames; returns with sh.fwd = final normalised forward cost
@@ -390,7 +411,7 @@ __device__ void viterbi_forward(const PitchDevTables& t, const float* __restrict
                                 int64_t T, int64_t T1, bool rescale, float old_b1, float old_b2,
                                 float new_ballast, int16_t* __restrict__ bp, const VitShared& sh,
                                 const float* __restrict__ st_lag, const int lane) {
-  const int S = t.num_states, S4 = (S + 3) & ~3;
+  const int S = t.num_states;
   for (int s = lane; s < S; s += 64) sh.fwd[s] = 0.0f;
   for (int s = S + lane; s < S + kFwdPad; s += 64) sh.fwd[s] = FLT_MAX;  // scan read-ahead padding
   const float factor = t.inter_frame_factor;
@@ -492,82 +513,67 @@ __device__ void viterbi_forward(const PitchDevTables& t, const float* __restrict
         sh.nxt[i_rep] = best + sh.nxt[i_rep];
       }
     }
-    // Gaps whose two level-2 neighbours point at the same state are settled: by monotonicity every state
-    // in between points there too (voiced frames: ONE state attracts the whole lag range, and the five
-    // refinement levels below have nothing left to search).
-    wave_sync();
-    bool any_open = false;
-    for (int s = lane; s < S4; s += 64) {
-      const int below = s & ~31, above = below + 32;
-      const bool inner = s < S && (s & 31) != 0;
-      const int lo = sh.bpw[below < S ? below : 0];
-      const int hi = above < S ? sh.bpw[above] : S - 1;
-      if (inner && lo == hi) {
-        sh.bpw[s] = lo;
-        sh.nxt[s] = trans_cost(lo, static_cast<float>(s), factor, sh.fwd[lo]) + sh.nxt[s];
-      }
-      any_open = any_open || (inner && lo != hi);
-    }
-    const bool refine = __ballot(any_open) != 0;
-    for (int h = refine ? 16 : 0; h >= 1; h >>= 1) {
+    // Level 3: the states 8, 16, 24, 40, ... (multiples of 8 that are not multiples of 32) between the
+    // backpointers of their two level-2 neighbours; level 4: every other state between the backpointers
+    // of its two neighbours at the multiples of 8.  One lane per state, 64 states per pass, a serial
+    // exact scan of the window (4 candidates in flight); the states whose window is long - a step of the
+    // backpointer function from one attracting state to the next - go to teams of 8 lanes (below).
+    // (Round 2 refined through the strides 16, 8, 4, 2, 1: fewer candidates - 2 350 against 4 000 per
+    // frame - but five levels of setup; measured with the same long-window teams: 9.6 against 8.5 ms.)
+    for (int level = 3; level <= 4; ++level) {
       wave_sync();
-      const int count = (S - h + 2 * h - 1) / (2 * h);  // states h, 3h, 5h, ... < S
-      for (int m0 = 0; m0 < count; m0 += 64) {
-        const int m = m0 + lane;
-        const int i = h + 2 * h * (m < count ? m : 0);
-        const int g_lo = sh.bpw[i & ~31];
-        const int g_hi = (i & ~31) + 32 < S ? sh.bpw[(i & ~31) + 32] : S - 1;
-        const bool active = m < count && g_lo != g_hi;  // (settled gaps were written above)
-        if (__ballot(active) == 0) continue;
-        const int lo = sh.bpw[i - h];
-        const int hi = i + h < S ? sh.bpw[i + h] : S - 1;
-        const bool is_long = active && hi - lo >= kLongRange;
+      const int gap = level == 3 ? 32 : 8;                         // distance of the known neighbours
+      const int count = level == 3 ? ((S + 7) >> 3) - ((S + 31) >> 5) : S - ((S + 7) >> 3);
+      const int long_range = level == 3 ? kLongRange3 : kLongRange4;
+      for (int k0 = 0; k0 < count; k0 += 64) {
+        const int k = k0 + lane < count ? k0 + lane : 0;
+        // k-th state of the level: level 3 -> multiple of 8 that is not a multiple of 32; level 4 -> not
+        // a multiple of 8
+        const int i = level == 3 ? (k + k / 3 + 1) << 3 : k + k / 7 + 1;
+        const bool active = k0 + lane < count;
+        const int below = i & ~(gap - 1), above = below + gap;
+        const int lo = sh.bpw[below];
+        const int hi = above < S ? sh.bpw[above] : S - 1;
+        const bool is_long = active && hi - lo >= long_range;
         float best = FLT_MAX;
         int best_j = lo;
         if (active && !is_long) scan_range(sh.fwd, lo, hi, static_cast<float>(i), factor, best, best_j);
-        // a jump of the backpointer function makes one state of every level scan a long range: those
-        // are searched four at a time, one per 16-lane row (16 candidates per step + a row argmin)
-        unsigned long long pending = __ballot(is_long);
-        while (pending) {
-          int src[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            src[r] = pending ? __ffsll(static_cast<long long>(pending)) - 1 : -1;
-            if (pending) pending &= pending - 1;
-          }
-          const int row16 = lane >> 4, sub = lane & 15;
-          int ri = 0, rlo = 0, rhi = -1;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (src[r] >= 0) {
-              const int a = __builtin_amdgcn_readlane(i, src[r]);
-              const int bb = __builtin_amdgcn_readlane(lo, src[r]);
-              const int c = __builtin_amdgcn_readlane(hi, src[r]);
-              if (row16 == r) { ri = a; rlo = bb; rhi = c; }
-            }
-          }
-          const float fi = static_cast<float>(ri);
-          float cb = FLT_MAX;
-          int cj = 0x7fffffff;
-          for (int j = rlo + sub; j <= rhi; j += 16) {
-            const float c = trans_cost(j, fi, factor, sh.fwd[j]);
-            if (c < cb) { cb = c; cj = j; }
-          }
-          quad_argmin(cb, cj);
-          argmin_take(cb, cj, dpp_f<0x124>(cb), dpp_i<0x124>(cj));
-          argmin_take(cb, cj, dpp_f<0x128>(cb), dpp_i<0x128>(cj));
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (src[r] >= 0) {
-              const float c = lane_f(cb, 16 * r);
-              const int jn = __builtin_amdgcn_readlane(cj, 16 * r);
-              if (lane == src[r]) { best = c; best_j = jn; }
-            }
-          }
-        }
-        if (active) {
+        if (active && !is_long) {
           sh.bpw[i] = best_j;
           sh.nxt[i] = best + sh.nxt[i];
+        }
+        // Long windows (a step of the backpointer function between two attracting states: ~5 states of a
+        // level-3 pass and ~15-45 of the level-4 passes per frame) go through a queue in LDS and are
+        // scanned by teams of 8 lanes, 8 windows per round: 8 candidates per step, a 3-step DPP argmin,
+        // the team's first lane stores.  (Round 2 handed them to 16-lane rows four at a time through
+        // v_readlane broadcasts: ~250 instructions per round; that was most of the tracker's time.)
+        const unsigned long long long_mask = __ballot(is_long);
+        if (long_mask != 0) {
+          if (is_long)
+            sh.queue[__popcll(long_mask & ((1ull << lane) - 1ull))] = make_int4(i, lo, hi, 0);
+          wave_sync();
+          const int n_long = __popcll(long_mask);
+          const int team = lane >> 3, tl = lane & 7;
+          for (int q0 = 0; q0 < n_long; q0 += 8) {
+            const bool on = q0 + team < n_long;
+            const int4 e = sh.queue[on ? q0 + team : 0];
+            const float fi = static_cast<float>(e.x);
+            float cb = FLT_MAX;
+            int cj = 0x7fffffff;
+            if (on) {
+              for (int j = e.y + tl; j <= e.z; j += 8) {
+                const float c = trans_cost(j, fi, factor, sh.fwd[j]);
+                if (c < cb) { cb = c; cj = j; }
+              }
+            }
+            quad_argmin(cb, cj);
+            argmin_take(cb, cj, dpp_f<0x141>(cb), dpp_i<0x141>(cj));  // row_half_mirror: the other quad
+            if (on && tl == 0) {
+              sh.bpw[e.x] = cj;
+              sh.nxt[e.x] = cb + sh.nxt[e.x];
+            }
+          }
+          wave_sync();
         }
       }
     }
@@ -601,21 +607,25 @@ __global__ __launch_bounds__(kVitWaves * 64) void pitch_viterbi_kernel(
   const int64_t f0 = b.frame_offsets[u], T = b.frame_offsets[u + 1] - f0;
   if (T <= 0) return;
   const int64_t T1 = b.frames_phase1[u];
-  const int per_wave = 3 * S4 + kFwdPad;
+  const int per_wave = 3 * S4 + kFwdPad + kQueueFloats;  // (S4 and kFwdPad are multiples of 4: 16-byte queue)
   VitShared sh;
   sh.fwd = st_lag + S4 + wid * per_wave;
   sh.nxt = sh.fwd + S4 + kFwdPad;
   sh.bpw = reinterpret_cast<int*>(sh.nxt + S4);
+  sh.queue = reinterpret_cast<int4*>(sh.bpw + S4);
   int16_t* __restrict__ bp = backptr + f0 * S;
   const float* __restrict__ res = nccf_res + f0 * static_cast<int64_t>(S);
   const float* __restrict__ pov_nccf = pov_all + f0 * L;
   const float* __restrict__ o = ub + u * 6;
 
-  viterbi_forward(t, res, anp + f0, T, T1, false, 0.0f, 0.0f, 0.0f, bp, sh, st_lag, lane);
-  // InputFinished(): RecomputeBacktraces when the utterance is shorter than recompute_frame and some
-  // frame saw a mean-square energy more than 1 % away from the final one (pitch_stats_kernel)
-  if (T < t.recompute_frame && o[5] != 0.0f)
-    viterbi_forward(t, res, anp + f0, T, T1, true, o[2], o[3], o[4], bp, sh, st_lag, lane);
+  // InputFinished(): Kaldi runs RecomputeBacktraces when the utterance is shorter than recompute_frame and
+  // some frame saw a mean-square energy more than 1 % away from the final one (pitch_stats_kernel).  That
+  // pass starts from zero forward costs and overwrites every backpointer: nothing of the first (online)
+  // pass survives it, so an offline batch runs ONE forward pass - the recomputing one when Kaldi would
+  // recompute, the plain one otherwise (round 2 ran both: half of the Viterbi kernel's time).
+  const bool recompute = T < t.recompute_frame && o[5] != 0.0f;
+  viterbi_forward(t, res, anp + f0, T, T1, recompute, recompute ? o[2] : 0.0f, recompute ? o[3] : 0.0f,
+                  recompute ? o[4] : 0.0f, bp, sh, st_lag, lane);
 
   // traceback: best final state (lowest index wins ties), then the chain of backpointers
   __threadfence_block();
@@ -662,10 +672,15 @@ int launch_pitch(const PitchDevTables& t, const PitchBatch& b, const PitchScratc
       bs.sample_offsets = b.sample_offsets + u0;
       bs.down_offsets = b.down_offsets + u0;
       const int64_t nu = b.n_utts - u0 < 65535 ? b.n_utts - u0 : 65535;
+      // LDS: the input span of 256 outputs (ceil(256 in_unit / out_unit) + a unit of slack + one filter)
+      const size_t span_lds = sizeof(float) * (static_cast<size_t>(threads + t.rs_out_unit) * t.rs_in_unit /
+                                                   t.rs_out_unit + t.rs_in_unit + t.rs_max_taps + 8);
+      if (span_lds > 64 * 1024)
+        return set_error(SNF_E_RUNTIME, "pitch resampler: the input span of a workgroup does not fit in LDS");
       hipLaunchKernelGGL(pitch_resample_kernel,
                          dim3(static_cast<unsigned>((b.max_down + threads - 1) / threads),
                               static_cast<unsigned>(nu)),
-                         dim3(threads), 0, stream, t, bs, w.down);
+                         dim3(threads), span_lds, stream, t, bs, w.down);
       SNF_HIP_CHECK(hipGetLastError());
     }
   }
@@ -701,7 +716,7 @@ int launch_pitch(const PitchDevTables& t, const PitchBatch& b, const PitchScratc
     if (stage_done("nccf", 2)) return SNF_OK;
   }
   {
-    const size_t lds = sizeof(float) * (S4 + static_cast<size_t>(kVitWaves) * (3 * S4 + kFwdPad));
+    const size_t lds = sizeof(float) * (S4 + static_cast<size_t>(kVitWaves) * (3 * S4 + kFwdPad + kQueueFloats));
     if (lds > 160 * 1024) return set_error(SNF_E_RUNTIME, "pitch state space does not fit in LDS");
     if (lds > 64 * 1024)
       SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pitch_viterbi_kernel),
