@@ -520,16 +520,17 @@ __device__ void viterbi_forward(const PitchDevTables& t, const float* __restrict
     // backpointer function from one attracting state to the next - go to teams of 8 lanes (below).
     // (Round 2 refined through the strides 16, 8, 4, 2, 1: fewer candidates - 2 350 against 4 000 per
     // frame - but five levels of setup; measured with the same long-window teams: 9.6 against 8.5 ms.)
-    for (int level = 3; level <= 4; ++level) {
+    for (int level = 3; level <= 5; ++level) {
       wave_sync();
-      const int gap = level == 3 ? 32 : 8;                         // distance of the known neighbours
-      const int count = level == 3 ? ((S + 7) >> 3) - ((S + 31) >> 5) : S - ((S + 7) >> 3);
+      // level 3: multiples of 8 that are not multiples of 32, neighbours 32 apart; level 4: the states
+      // 4, 12, 20, ..., neighbours 8 apart; level 5: every other state, neighbours 4 apart
+      const int gap = level == 3 ? 32 : (level == 4 ? 8 : 4);
+      const int count = level == 3 ? ((S + 7) >> 3) - ((S + 31) >> 5)
+                                   : (level == 4 ? (S + 3) >> 3 : S - ((S + 3) >> 2));
       const int long_range = level == 3 ? kLongRange3 : kLongRange4;
       for (int k0 = 0; k0 < count; k0 += 64) {
         const int k = k0 + lane < count ? k0 + lane : 0;
-        // k-th state of the level: level 3 -> multiple of 8 that is not a multiple of 32; level 4 -> not
-        // a multiple of 8
-        const int i = level == 3 ? (k + k / 3 + 1) << 3 : k + k / 7 + 1;
+        const int i = level == 3 ? (k + k / 3 + 1) << 3 : (level == 4 ? 4 + 8 * k : k + k / 3 + 1);
         const bool active = k0 + lane < count;
         const int below = i & ~(gap - 1), above = below + gap;
         const int lo = sh.bpw[below];
