@@ -75,27 +75,40 @@ __global__ __launch_bounds__(256) void pitch_resample_kernel(const PitchDevTable
   if (k0 >= nd) return;
   const int64_t s0 = b.sample_offsets[u], n = b.sample_offsets[u + 1] - s0;
   const int16_t* __restrict__ w = b.wave + s0;
-  auto first_of = [&](int64_t k) -> int64_t {
-    const int64_t unit = k / t.rs_out_unit;
-    return t.rs_first[static_cast<int>(k - unit * t.rs_out_unit)] + unit * t.rs_in_unit;
+  // (32-bit index arithmetic: a 64-bit division costs ~100 instructions, three of them per output was
+  // more than the filter itself; an utterance has fewer than 2^31 samples)
+  const int out_unit = t.rs_out_unit, in_unit = t.rs_in_unit;
+  auto first_of = [&](int k) -> int64_t {
+    const int unit = k / out_unit;
+    return t.rs_first[k - unit * out_unit] + static_cast<int64_t>(unit) * in_unit;
   };
-  const int64_t k_last = k0 + blockDim.x - 1 < nd - 1 ? k0 + blockDim.x - 1 : nd - 1;
-  const int64_t base = first_of(k0);                        // (first inputs are non-decreasing in k)
+  const int k_first = static_cast<int>(k0);
+  const int k_last = k0 + blockDim.x - 1 < nd - 1 ? k_first + static_cast<int>(blockDim.x) - 1
+                                                    : static_cast<int>(nd) - 1;
+  const int64_t base = first_of(k_first);                   // (first inputs are non-decreasing in k)
   const int span = static_cast<int>(first_of(k_last) + t.rs_max_taps - base);
   for (int i = threadIdx.x; i < span; i += blockDim.x) {
     const int64_t j = base + i;
     xs[i] = (j >= 0 && j < n) ? static_cast<float>(w[j]) : 0.0f;
   }
   __syncthreads();
-  const int64_t k = k0 + threadIdx.x;
+  const int k = k_first + static_cast<int>(threadIdx.x);
   if (k >= nd) return;
-  const int64_t unit = k / t.rs_out_unit;
-  const int wrapped = static_cast<int>(k - unit * t.rs_out_unit);
-  const float* __restrict__ x = xs + (t.rs_first[wrapped] + unit * t.rs_in_unit - base);
-  const float* __restrict__ wt = t.rs_w + wrapped * t.rs_max_taps;
-  const int ntaps = t.rs_ntaps[wrapped];
   float s = 0.0f;
-  for (int i = 0; i < ntaps; ++i) s = __builtin_fmaf(wt[i], x[i], s);
+  if (out_unit == 1) {
+    // one filter for every output (integer rate ratios, e.g. 16 kHz -> 4 kHz): uniform weights.  (A
+    // de-interleaved LDS layout that makes the tap reads conflict-free was measured: slower, 0.63 ms
+    // against 0.375 - the strided staging costs more than the conflicts)
+    const float* __restrict__ x = xs + (t.rs_first[0] + static_cast<int64_t>(k) * in_unit - base);
+    const int ntaps = t.rs_ntaps[0];
+    for (int i = 0; i < ntaps; ++i) s = __builtin_fmaf(t.rs_w[i], x[i], s);
+  } else {
+    const int unit = k / out_unit, wrapped = k - unit * out_unit;
+    const float* __restrict__ x = xs + (t.rs_first[wrapped] + static_cast<int64_t>(unit) * in_unit - base);
+    const float* __restrict__ wt = t.rs_w + wrapped * t.rs_max_taps;
+    const int ntaps = t.rs_ntaps[wrapped];
+    for (int i = 0; i < ntaps; ++i) s = __builtin_fmaf(wt[i], x[i], s);
+  }
   down[d0 + k] = s;
 }
 
@@ -665,6 +678,8 @@ int launch_pitch(const PitchDevTables& t, const PitchBatch& b, const PitchScratc
                  hipStream_t stream) {
   if (b.total_frames <= 0) return SNF_OK;
   if (t.num_states > 32767) return set_error(SNF_E_RUNTIME, "too many pitch states (delta_pitch too small)");
+  if (b.max_down > 0x7fffff00)
+    return set_error(SNF_E_RUNTIME, "pitch: an utterance of more than 2^31 resampled samples");
   if (b.total_down > 0) {
     const int threads = 256;
     // grid.y is limited to 65535: utterances are launched in slices
