@@ -575,9 +575,18 @@ __device__ void viterbi_forward(const PitchDevTables& t, const float* __restrict
             float cb = FLT_MAX;
             int cj = 0x7fffffff;
             if (on) {
-              for (int j = e.y + tl; j <= e.z; j += 8) {
-                const float c = trans_cost(j, fi, factor, sh.fwd[j]);
-                if (c < cb) { cb = c; cj = j; }
+              // four candidates of the lane in flight per step; a step may look up to 31 states beyond the
+              // window: the argmin over ALL states lies inside it (monotonicity), so the extra candidates
+              // cannot win, and the forward costs are padded with FLT_MAX behind the last state
+              for (int j = e.y + tl; j <= e.z; j += 32) {
+                float ff[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) ff[w] = sh.fwd[j + 8 * w];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                  const float c = trans_cost(j + 8 * w, fi, factor, ff[w]);
+                  if (c < cb) { cb = c; cj = j + 8 * w; }
+                }
               }
             }
             quad_argmin(cb, cj);
