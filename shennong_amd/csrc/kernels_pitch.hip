@@ -266,8 +266,8 @@ __device__ __forceinline__ float tree16(float v) {
 constexpr int kLagGroup = 5;   // lags per lane and pass of the correlation
 constexpr int kNccfWaves = 4;  // 16 frames per workgroup
 constexpr int kFwdPad = 36;    // FLT_MAX entries behind the forward costs (unclamped scan steps)
-constexpr int kLongRange3 = 64;  // level 3 / level 4: candidate ranges at least this long are scanned by a
-constexpr int kLongRange4 = 24;  // 16-lane row instead of one lane
+constexpr int kLongRange3 = 32;  // level 3 / levels 4-5: windows of at least this many candidates go to the
+constexpr int kLongRange4 = 16;  // 8-lane teams instead of one lane (flat between 8 and 32: measured)
 constexpr int kQueueFloats = 64 * 4;  // long-window queue of a wave: 64 x int4
 constexpr int kVitWaves = 8;   // utterances (= wavefronts) per workgroup of the Viterbi kernel
 constexpr int kRowRegs = 8;    // row values per lane held one frame ahead (up to 512 states)
