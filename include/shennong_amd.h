@@ -224,10 +224,11 @@ int snf_plan_create(const snf_options* opts, int device_id, snf_plan** out);
 void snf_plan_destroy(snf_plan* plan);
 /* output dimension (columns); for DELTA/PITCH_POST/ENERGY see the dedicated entry points */
 int32_t snf_plan_ndims(const snf_plan* plan);
-/* 1 when the plan runs on the register-resident kernel (frames that pad to 512, 256 or 128 samples,
-   up to 64 mel bins and 16 cepstra, power spectrum), 0 when its option combination falls back to the
-   generic wave-per-frame kernel (about 8x slower per frame; e.g. 32-48 kHz audio, magnitude
-   filterbanks): hosts should say so instead of being silently slow. */
+/* 1 when the plan runs on a register-resident kernel (even frames that pad to 512, 256 or 128 samples
+   with up to 64 mel bins, 16 cepstra and a power spectrum: 8 and 16 kHz audio; or to 2048 / 1024 samples
+   with up to 128 mel bins: 32, 44.1 and 48 kHz audio), 0 when its option combination falls back to the
+   generic wave-per-frame kernel (5 to 8x slower per frame; e.g. 4096-sample frames, odd window lengths,
+   magnitude filterbanks on short frames): hosts should say so instead of being silently slow. */
 int32_t snf_plan_fast_path(const snf_plan* plan);
 /* rows produced for an utterance of `num_samples` samples (bit-exact Kaldi NumFrames) */
 int64_t snf_plan_num_frames(const snf_plan* plan, int64_t num_samples);
