@@ -357,9 +357,9 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
     if (KIND == SNF_KIND_PLP) {
       // shennong's PLP floors with float64 eps and takes a double log (reference plp.py:191-193)
       if ((p.need_raw || p.need_post) && lane == 0)
-        energy_out[g] = log(fmax(static_cast<double>(e_lin), DBL_EPSILON));
+        energy_out[g] = static_cast<double>(e_lin);  // (plp_tail_kernel takes the double log)
     } else if (p.need_raw || p.need_post) {
-      log_energy = logf(fmaxf(e_lin, FLT_EPSILON));
+      log_energy = fast_log(floor_eps(e_lin));
       if (p.has_floor && log_energy < p.log_energy_floor) log_energy = p.log_energy_floor;
     }
     float* __restrict__ row = out + g * static_cast<int64_t>(out_cols);

@@ -427,9 +427,9 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     float log_energy = 0.0f;
     if (ENERGY != 0) {
       if (KIND == SNF_KIND_PLP) {
-        if (valid && l == 0) energy_out[g] = log(fmax(static_cast<double>(e_lin), DBL_EPSILON));
+        if (valid && l == 0) energy_out[g] = static_cast<double>(e_lin);  // (plp_tail_kernel takes the double log)
       } else {
-        log_energy = logf(fmaxf(e_lin, FLT_EPSILON));
+        log_energy = fast_log(floor_eps(e_lin));
         if (p.has_floor && log_energy < p.log_energy_floor) log_energy = p.log_energy_floor;
       }
     }
@@ -922,12 +922,12 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
     if (ENERGY != 0) {
       if (KIND == SNF_KIND_PLP) {
         if (l == 0) {
-          if (valid_a) energy_out[ga] = log(fmax(static_cast<double>(e_lin_a), DBL_EPSILON));
-          if (valid_b) energy_out[ga + 1] = log(fmax(static_cast<double>(e_lin_b), DBL_EPSILON));
+          if (valid_a) energy_out[ga] = static_cast<double>(e_lin_a);  // (plp_tail_kernel takes the double log)
+          if (valid_b) energy_out[ga + 1] = static_cast<double>(e_lin_b);  // (plp_tail_kernel takes the double log)
         }
       } else {
-        log_e[0] = logf(fmaxf(e_lin_a, FLT_EPSILON));
-        log_e[1] = logf(fmaxf(e_lin_b, FLT_EPSILON));
+        log_e[0] = fast_log(floor_eps(e_lin_a));
+        log_e[1] = fast_log(floor_eps(e_lin_b));
         if (p.has_floor) {
           if (log_e[0] < p.log_energy_floor) log_e[0] = p.log_energy_floor;
           if (log_e[1] < p.log_energy_floor) log_e[1] = p.log_energy_floor;

@@ -158,7 +158,9 @@ __global__ void plp_tail_kernel(const PlpParams p, const BatchArgs b,
     if (p.lifter) v *= p.lifter[c];
     if (p.cepstral_scale != 1.0f) v *= p.cepstral_scale;
     if (c == 0 && p.use_energy) {
-      double le = energy[g];
+      // shennong's PLP floors with float64 eps and takes a double log (reference plp.py:191-193); the mel
+      // kernels hand over the linear frame energy
+      double le = log(fmax(energy[g], DBL_EPSILON));
       if (floor_it && le < p.log_energy_floor) le = p.log_energy_floor;
       v = static_cast<float>(le);
     }
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(64) void plp_tail_small_kernel(const PlpParams p, c
       if (p.lifter) v *= p.lifter[c];
       if (p.cepstral_scale != 1.0f) v *= p.cepstral_scale;
       if (c == 0 && p.use_energy) {
-        double le = energy[g];
+        double le = log(fmax(energy[g], DBL_EPSILON));  // (linear frame energy from the mel kernel)
         if (p.has_floor && le < p.log_energy_floor) le = p.log_energy_floor;
         v = static_cast<float>(le);
       }

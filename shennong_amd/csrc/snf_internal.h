@@ -142,7 +142,7 @@ struct DeltaParams {
 // ---------------------------------------------------------------------------------------------
 // Fused frame extraction -> window -> FFT -> power -> epilogue.  `out` is [total_frames, out_cols];
 // for kind PLP it receives linear mel energies [total_frames, num_bins] and `energy_out`
-// [total_frames] the log energy column (double).
+// [total_frames] the linear frame energy (double; plp_tail_kernel floors it and takes the double log).
 int launch_mel_features(const MelParams& p, const BatchArgs& b, float* out, int out_cols,
                         double* energy_out, hipStream_t stream);
 int launch_rasta(float* mel, const BatchArgs& b, int num_bins, hipStream_t stream);
