@@ -18,9 +18,10 @@
 //   F  epilogue: mel filterbank by teams of four lanes per bin over the taps (works for per-utterance
 //      VTLN warps: the banks are the plan's ordinary device tables), log / DCT / lifter as in the
 //      generic kernel
-// The index maps were checked lane by lane against numpy.fft (exp/r3/model2048.py in the development
-// tree).  Frames that pad to 1024 samples run as the 2048-point transform of the zero-extended frame:
-// X2048[2 k] = X1024[k], the epilogue reads every second bin.
+// The index maps were checked lane by lane against numpy.fft, and every LDS access against the bank model
+// of MI355X_MICROARCH.md, before the first GPU run (tools/model_fbank2048.py, tests/test_fbank2048_model.py).
+// Frames that pad to 1024 samples run as the 2048-point transform of the zero-extended frame:
+// X2048[2 k] = X1024[k]; their spectrum (the even bins) is kept compactly.
 #include <float.h>
 
 #include <cmath>
