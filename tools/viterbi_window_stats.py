@@ -1,4 +1,4 @@
-"""Developer tool: window statistics of the Viterbi refinement levels of the pitch tracker, from the oracle\x27s
+"""Developer tool: window statistics of the Viterbi refinement levels of the pitch tracker, from the oracle's
 per-frame NCCF rows (candidate evaluations per level, long windows, distinct backpointers per frame):
 python tools/viterbi_window_stats.py synth|noise"""
 import sys, os
