@@ -782,7 +782,7 @@ def test_threaded_callers(gpu, synth_waves):
 
 def test_energy_odd_window(gpu):
     """25 ms at 22.05 kHz without rounding to a power of two is a 551-sample window: fine for the
-    frame energy (no FFT), a Kaldi RealFft error for every spectral kind (found by tools/fuzz_parity.py)"""
+    frame energy (no FFT), a Kaldi RealFft error for every spectral kind (found by tests/tools/fuzz_parity.py)"""
     wave = synth.utterances(9, 1, 22050, 22050)[0]
     for raw in (True, False):
         proc = EnergyProcessor(sample_rate=22050, round_to_power_of_two=False, raw_energy=raw, dither=0)
@@ -795,7 +795,7 @@ def test_energy_odd_window(gpu):
 def test_vtln_option_errors_need_a_frame(gpu, wave):
     """Kaldi builds the mel banks of a warp factor when the first frame asks for them: vtln_low <=
     low_freq is an error for a warped utterance WITH frames, and goes unnoticed for one without
-    (found by tools/fuzz_parity.py)"""
+    (found by tests/tools/fuzz_parity.py)"""
     proc = FilterbankProcessor(num_bins=30, low_freq=100, dither=0)  # vtln_low = 100: bad once warped
     tiny = np.zeros(2, np.int16)
     feats = proc._process_batch([Audio(wave, 16000), Audio(tiny, 16000)], vtln_warp=[1.0, 0.85])

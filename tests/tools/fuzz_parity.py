@@ -8,7 +8,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle as orc  # noqa: E402  (test infrastructure: the checker)
 from shennong_amd import Audio, _backend, synth  # noqa: E402
 from shennong_amd.processor import (  # noqa: E402

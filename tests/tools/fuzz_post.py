@@ -7,7 +7,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle as orc  # noqa: E402  (test infrastructure: the checker)
 from shennong_amd import Audio, Features, _backend, synth  # noqa: E402
 from shennong_amd.postprocessor import (  # noqa: E402

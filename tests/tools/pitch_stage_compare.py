@@ -1,7 +1,7 @@
 """Stage-by-stage comparison of the GPU pitch tracker with the oracle + timing"""
 import os, sys, ctypes as C
 import numpy as np, scipy.io.wavfile
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from shennong_amd import _backend, _abi, synth, Audio
 from shennong_amd.processor import KaldiPitchProcessor

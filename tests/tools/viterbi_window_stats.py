@@ -3,7 +3,7 @@ per-frame NCCF rows (candidate evaluations per level, long windows, distinct bac
 python tools/viterbi_window_stats.py synth|noise"""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle as orc
 from shennong_amd import synth
 from shennong_amd.processor import KaldiPitchProcessor
