@@ -311,6 +311,11 @@ int build_mel_plan(snf_plan* plan) {
       plan->fp.tables = plan->d_fast_tables.as<float>();
       plan->fast512 = true;
       if (plan->kind == SNF_KIND_MFCC && o.append_deltas) {
+        // (the fused form keeps 14 waves' tiles + the cepstra of 336 frames in LDS beside the tables)
+        if (((static_cast<size_t>(plan->fp.table_floats) * 4 + 255) & ~static_cast<size_t>(255)) +
+                14 * 4 * 2176 + sizeof(float) * 4 * (kFast512FusedSets + 2) * 16 > 160 * 1024)
+          return set_error(SNF_E_INVALID, "append_deltas: the mel / DCT tables of this configuration leave no "
+                                          "room for the fused form in LDS; chain a delta plan");
         std::vector<float> scales;
         std::vector<int> dims;
         make_delta_scales(2, 2, &scales, &dims);
@@ -323,6 +328,9 @@ int build_mel_plan(snf_plan* plan) {
       plan->h_lifter = lifter_h;
     }
   }
+  if (want_fused && !plan->fast512)
+    return set_error(SNF_E_INVALID, "append_deltas: this configuration is not covered by the register-resident "
+                                    "512-point kernel (its tables do not fit); chain a delta plan");
   if (!plan->fast512 && fbank2048_eligible(p)) {
     std::vector<float> blob;
     fbank2048_tables(p, window, &blob);

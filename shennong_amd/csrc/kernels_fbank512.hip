@@ -1370,6 +1370,12 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
     hdr[9] = p.dd_groups;
     std::memcpy(blob->data(), hdr, sizeof(hdr));
   }
+  // One 16-wave workgroup needs 16 x 4 frame tiles (139 264 bytes) beside the tables in the 160 KB of a
+  // CU: wide banks (many bins on zero-extended frames, long DCT tables) that leave no room run on the
+  // generic kernel instead of failing at launch (found by tests/tools/fuzz_parity.py).
+  if (((static_cast<size_t>(p.table_floats) * 4 + 255) & ~static_cast<size_t>(255)) +
+          static_cast<size_t>(kMaxWaves) * 4 * kFrameTileBytes > 160 * 1024)
+    return 1;
   *out = p;
   return SNF_OK;
 }

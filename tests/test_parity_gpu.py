@@ -626,6 +626,23 @@ def test_long_frames_single_utterance_shorter_than_a_window(gpu):
     assert plan.kernel_name(1) == 'mel_features_generic_kernel'
 
 
+def test_tables_too_large_for_lds_fall_back(gpu):
+    """banks too wide for the LDS of the register-resident 512-point kernel run on the generic kernel
+    instead of failing at launch (found by tests/tools/fuzz_parity.py: seed 12 case 69, seed 13 case 168)"""
+    waves = [synth.utterances(90 + i, 1, n, 8000)[0] for i, n in enumerate((11120, 6622, 7353, 4236))]
+    proc = FilterbankProcessor(sample_rate=8000, frame_length=0.03, num_bins=64, low_freq=0, dither=0,
+                               window_type='hanning')
+    warps = [0.85, 1.0, 1.1, 0.93]
+    feats = proc._process_batch([Audio(w, 8000) for w in waves], vtln_warp=warps)
+    for w, wf, f in zip(waves, warps, feats):
+        assert_close(f.data, _oracle(proc, w, wf), rtol=2e-4, what=f'wide banks, warp {wf}')
+    wave = synth.utterances(95, 1, 30000, 44100)[0]
+    proc = MfccProcessor(sample_rate=44100, frame_length=0.008, frame_shift=0.0125, num_bins=59, num_ceps=3,
+                         low_freq=100, high_freq=21750, htk_compat=True, use_energy=False, dither=0,
+                         window_type='hanning')
+    assert_close(proc.process(Audio(wave, 44100)).data, _oracle(proc, wave), rtol=2e-4, what='59 bins at 44.1 kHz')
+
+
 def test_short_frames_spectrogram_and_energy(gpu):
     """the spectrogram of a 256-sample frame needs its own 129 bins: generic kernel; the frame
     energy has no spectrum at all: fast kernel"""

@@ -2,7 +2,7 @@
 GPU box): random processor kinds and options, ragged batches with per-utterance VTLN warps, LDS
 poisoned with NaNs before every case.  Prints the failing case (seed + options) and exits non-zero.
 
-    python tools/fuzz_parity.py [n_cases] [seed]"""
+    python tests/tools/fuzz_parity.py [n_cases] [seed]"""
 import os
 import sys
 
@@ -16,7 +16,7 @@ from shennong_amd.processor import (  # noqa: E402
 
 
 def random_case(rng):
-    sample_rate = int(rng.choice([8000, 16000, 16000, 16000, 22050]))
+    sample_rate = int(rng.choice([8000, 8000, 16000, 16000, 16000, 22050, 32000, 44100, 44100, 48000]))
     frame = dict(
         sample_rate=sample_rate, dither=0,
         frame_length=float(rng.choice([0.008, 0.01, 0.016, 0.02, 0.025, 0.025, 0.03, 0.032, 0.05])),
@@ -27,7 +27,7 @@ def random_case(rng):
         round_to_power_of_two=bool(rng.integers(8) > 0))
     kind = str(rng.choice(['fbank', 'fbank', 'mfcc', 'mfcc', 'plp', 'spectrogram', 'energy']))
     nyquist = sample_rate / 2
-    mel = dict(num_bins=int(rng.integers(8, 65)), low_freq=float(rng.choice([0, 20, 100])),
+    mel = dict(num_bins=int(rng.integers(8, 65 if sample_rate < 30000 else 100)), low_freq=float(rng.choice([0, 20, 100])),
                high_freq=float(rng.choice([0, -200, nyquist - 300])))
     if kind == 'fbank':
         proc = FilterbankProcessor(use_energy=bool(rng.integers(2)), raw_energy=bool(rng.integers(2)),
