@@ -99,13 +99,14 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
     return gi < b.total_frames ? gi : b.total_frames - 1;
   };
   // sample loads of one frame: SGPR base + lane offset + immediate 256 j.  Elements no lane needs are
-  // skipped (their registers keep finite stale values, the zero window weights cancel them); a lane
-  // outside the window at the boundary j re-reads lane 0's element.
+  // skipped (their registers keep finite stale values, the zero window weights cancel them: no load ever
+  // reaches beyond the window, i.e. beyond the utterance); a lane outside the window at the boundary j
+  // re-reads lane 0's element.
 #define SNF_LOAD_FRAME(start_, njl_, lane_off_)                                                        \
   do {                                                                                                 \
     const char* __restrict__ wp_ = reinterpret_cast<const char*>(b.wave + uniform64(start_));          \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                   \
-      if (NJ < 16 || j < nj_any) {                                                                     \
+      if (j < nj_any) {                                                                                \
         const unsigned off_ = j < (njl_) ? (lane_off_) : 0u;                                           \
         raw[j] = *reinterpret_cast<const int_a2*>(wp_ + off_ + 256 * j);                               \
       }                                                                                                \
