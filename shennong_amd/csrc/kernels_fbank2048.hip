@@ -6,8 +6,10 @@
 // with the LDS radix-4 FFT of that kernel replaced by register passes:
 //
 //   wave64 = ONE frame; complex packing z[n] = x[2n] + i x[2n+1], n < 1024 = 16 x 16 x 4
-//   A  lane L loads z[L + 64 j], j < 16 (256 contiguous bytes per wave instruction, requested one frame
-//      ahead); DC removal over the wave, pre-emphasis (left neighbour through ds_bpermute), window
+//   A  lane L loads z[L + 64 j], j < 16 (256 contiguous bytes per wave instruction: SGPR base + lane offset
+//      + immediate; the next frame's samples are requested when this frame's transform is done and land
+//      during its mel phase); DC removal over the wave, pre-emphasis (left neighbour through 16
+//      ds_bpermute issued together), window
 //   B  16-point FFT over j in registers, twiddle W1024^(L k1), transpose through the wave's 8.5 KB LDS
 //      buffer (row pitches 68 and 17 complex: every access is bank-conflict free AND a lane-constant base
 //      plus an immediate offset - six address registers serve all ~140 LDS accesses of a frame)
@@ -15,9 +17,11 @@
 //   D  lane (k1, c): 16-point FFT over b -> lane holds Z[k1 + 16 c + 64 d], d < 16
 //   E  real-FFT unpack + power: bins k < 512 pair with 1024 - k, whose spectrum values come from the
 //      partner lane through LDS; power spectrum (1025 bins) to LDS
-//   F  epilogue: mel filterbank by teams of four lanes per bin over the taps (works for per-utterance
-//      VTLN warps: the banks are the plan's ordinary device tables), log / DCT / lifter as in the
-//      generic kernel
+//   F  epilogue: mel filterbank by teams of 8 lanes per bin, 8 bins per round: a lane owns 4 consecutive
+//      taps of every 32-tap slice of the filter (16-byte weight loads from a per-plan table - one per warp
+//      factor for VTLN - in which the filters start at multiples of 4 bins, are zero-padded to whole
+//      slices and rotated by the team index: no per-tap test, conflict-free LDS reads); DCT-II by teams
+//      of 4 lanes per coefficient; log / lifter / energy conventions as in the generic kernel
 // The index maps were checked lane by lane against numpy.fft, and every LDS access against the bank model
 // of MI355X_MICROARCH.md, before the first GPU run (tools/model_fbank2048.py, tests/test_fbank2048_model.py).
 // Frames that pad to 1024 samples run as the 2048-point transform of the zero-extended frame:
