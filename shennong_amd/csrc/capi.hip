@@ -93,9 +93,11 @@ struct snf_plan {
 
   // scratch (host-pointer entry points and intermediates)
   DevBuf s_wave, s_out, s_in, s_soff, s_foff, s_uwarp, s_mel, s_energy;
-  DevBuf s_down, s_stats, s_bp, s_doff, s_dp1, s_fp1, s_states, s_setidx, s_edge, s_futt;
+  DevBuf s_down, s_stats, s_bp, s_doff, s_dp1, s_fp1, s_states, s_setidx, s_edge, s_futt, s_poff, s_pairs;
   DevBuf s_pres, s_anp;  // pitch: NCCF at the lag of every state [frames, states], norm average [frames]
   bool setidx_valid = false;
+  bool pairs_valid = false;   // s_pairs / n_pairs describe the cached offsets tables
+  int64_t n_pairs = 0;
   // calls that draw random numbers (dither, delta-pitch noise) so far: every call gets its own noise
   // stream (the reference draws from one global rand(): two calls never repeat the same samples)
   uint64_t noise_calls = 0;
@@ -862,6 +864,7 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     plan->h_soff.swap(soff);
     plan->h_foff.swap(foff);
     plan->setidx_valid = false;
+    plan->pairs_valid = false;
   }
   if (any_warp && (rc = plan->s_uwarp.upload(warp_ids, s))) return rc;
   BatchArgs b{};
@@ -910,6 +913,25 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     b.blk_utt = plan->s_blk_utt.as<int32_t>();
     b.blk_set0 = plan->s_blk_set0.as<int32_t>();
     b.n_blocks = static_cast<int64_t>(blk_utt.size());
+  } else if (use_fast && plan->fp.dual) {
+    // fbank256x2_kernel: frame pairs formed inside every utterance (PairRec), built once per offsets table
+    if (!plan->pairs_valid) {
+      std::vector<int64_t> poff(static_cast<size_t>(n_utts) + 1, 0);
+      for (int64_t u = 0; u < n_utts; ++u)
+        poff[u + 1] = poff[u] + (frame_offsets[u + 1] - frame_offsets[u] + 1) / 2;
+      plan->n_pairs = poff[n_utts];
+      if ((rc = plan->s_poff.upload(poff, s))) return rc;
+      if ((rc = plan->s_pairs.ensure(sizeof(PairRec) * static_cast<size_t>(plan->n_pairs)))) return rc;
+      if ((rc = launch_build_pair_table(plan->s_foff.as<int64_t>(), plan->s_soff.as<int64_t>(),
+                                        plan->s_poff.as<int64_t>(), n_utts, plan->n_pairs,
+                                        plan->mp.win_shift, plan->mp.win_len, plan->mp.snip_edges,
+                                        plan->s_pairs.as<PairRec>(), s)))
+        return rc;
+      if (!own_stream) SNF_HIP_CHECK(hipStreamSynchronize(s));  // (cached: see below)
+      plan->pairs_valid = true;
+    }
+    b.pair_tab = plan->s_pairs.as<PairRec>();
+    b.n_pairs = plan->n_pairs;
   } else if (!plan->setidx_valid) {
     // frame -> first-sample index, edge marks and utterance index: built once per offsets table,
     // reused by later calls (fast kernel: bulk loads; generic kernel: no per-frame binary search)

@@ -658,6 +658,9 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
 // the 4 zero-extended ones of the 512-point form (half the transform arithmetic per frame); the mel
 // filterbank (129 bins, the same MFMA block tables, built without the zero-tap spreading) and the DCT
 // run once per sub-frame.  Flat scheduling only: VTLN batches and the spectrogram keep the 512-point form.
+// The two real transforms share their roundings (the last bits of X_a depend on x_b), so the pairing is
+// a property of the utterance, not of the batch: frames 2 m and 2 m + 1 of one utterance (PairRec table,
+// built once per offsets table by build_pair_table_kernel); an odd last frame is transformed with itself.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kDualSub = 136;  // float offset of sub-frame b inside a row's power tile (129 bins + pad)
 
@@ -691,11 +694,16 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
 
   const float win_len_f = static_cast<float>(p.win_len), inv_win_len = 1.0f / win_len_f;
   const int n_waves = blockDim.x >> 6;
-  const int64_t n_sets = (b.total_frames + 7) >> 3;
+  const int64_t n_sets = (b.n_pairs + 3) >> 2;
   const int64_t set_stride = static_cast<int64_t>(gridDim.x) * n_waves;
-  const int64_t last_frame = b.total_frames - 1;
-  auto start_of = [&](int64_t gi) -> int64_t { return b.frame_start[gi < last_frame ? gi : last_frame]; };
-  auto edge_of = [&](int64_t gi) -> int { return b.frame_edge[gi < last_frame ? gi : last_frame]; };
+  const int64_t last_pair = b.n_pairs - 1;
+  // a pair record as two 16-byte halves: {start_a, start_b} and {frame_a, utt1, flags}
+  auto starts_of = [&](int64_t pi) -> longlong2 {
+    return reinterpret_cast<const longlong2*>(b.pair_tab + (pi < last_pair ? pi : last_pair))[0];
+  };
+  auto meta_of = [&](int64_t pi) -> int4 {
+    return reinterpret_cast<const int4*>(b.pair_tab + (pi < last_pair ? pi : last_pair))[1];
+  };
   // NJ = 13: the 25 ms / 8 kHz window (200 samples: only element j = 12 can fall outside the window)
   const bool in_last = l + 16 * (NJ - 1) < p.win_len;
   auto in_window = [&](int j) -> bool {
@@ -711,27 +719,22 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
   };
   int64_t set = static_cast<int64_t>(blockIdx.x) * n_waves + wid;
   int raw[NJ];
-  int64_t next_a = 0, next_b = 0;
-  int edge_next_a = 0, edge_next_b = 0;
+  longlong2 next_starts = {0, 0};
+  int4 meta_next = {0, 0, 0, 0};
   if (set < n_sets) {
-    const int64_t ga = set * 8 + 2 * q;
-    const int16_t* __restrict__ wa = b.wave + start_of(ga);
-    const int16_t* __restrict__ wb = b.wave + start_of(ga + 1);
+    const longlong2 st = starts_of(set * 4 + q);
+    const int16_t* __restrict__ wa = b.wave + st.x;
+    const int16_t* __restrict__ wb = b.wave + st.y;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) raw[j] = load_pair(wa, wb, j);
-    next_a = start_of((set + set_stride) * 8 + 2 * q);
-    next_b = start_of((set + set_stride) * 8 + 2 * q + 1);
-    if (!SNIP) {
-      edge_next_a = edge_of(ga);
-      edge_next_b = edge_of(ga + 1);
-    }
+    next_starts = starts_of((set + set_stride) * 4 + q);
+    meta_next = meta_of(set * 4 + q);
   }
-  float* __restrict__ mrow = out + (set * 8 + 2 * mj) * static_cast<int64_t>(p.out_cols);
-  const int64_t mrow_step = set_stride * 8 * static_cast<int64_t>(p.out_cols);
-  for (; set < n_sets; set += set_stride, mrow += mrow_step) {
-    const int64_t ga = set * 8 + 2 * q;
-    const bool valid_a = ga <= last_frame, valid_b = ga + 1 <= last_frame;
-    const int edge_a = edge_next_a, edge_b = edge_next_b;
+  for (; set < n_sets; set += set_stride) {
+    const int4 meta = meta_next, mmeta = meta_of(set * 4 + mj);  // (mmeta: the MFMA view's pair, below)
+    const int64_t ga = static_cast<int64_t>(static_cast<unsigned>(meta.x)) | (static_cast<int64_t>(meta.y) << 32);
+    const bool valid_a = set * 4 + q <= last_pair, valid_b = valid_a && (meta.w & 4) != 0;
+    const int edge_a = (meta.w & 1) ? meta.z : 0, edge_b = (meta.w & 2) ? meta.z : 0;
 
     // ---- A: DC removal, pre-emphasis, window (per sub-frame: xe = frame a, xo = frame b) ---------------
     float4 win4[(NJ + 1) / 2];
@@ -804,16 +807,12 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
     for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(xe[j]), "+v"(xo[j]) : : "memory");
     asm volatile("" : "+v"(part_a), "+v"(part_b) : : "memory");
     {  // prefetch: samples of the next set, start offsets of the set after it
-      const int16_t* __restrict__ wa = b.wave + next_a;
-      const int16_t* __restrict__ wb = b.wave + next_b;
+      const int16_t* __restrict__ wa = b.wave + next_starts.x;
+      const int16_t* __restrict__ wb = b.wave + next_starts.y;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) raw[j] = load_pair(wa, wb, j);
-      next_a = start_of((set + 2 * set_stride) * 8 + 2 * q);
-      next_b = start_of((set + 2 * set_stride) * 8 + 2 * q + 1);
-      if (!SNIP) {
-        edge_next_a = edge_of((set + set_stride) * 8 + 2 * q);
-        edge_next_b = edge_of((set + set_stride) * 8 + 2 * q + 1);
-      }
+      next_starts = starts_of((set + 2 * set_stride) * 4 + q);
+      meta_next = meta_of((set + set_stride) * 4 + q);
     }
     float nm_a = 0.0f, nm_b = 0.0f;
     if (p.remove_dc) {
@@ -969,7 +968,10 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
         }
       }
     }
-    const int64_t mga = set * 8 + 2 * mj;  // MFMA view: lane 4 b + j -> frames 2 j, 2 j + 1 of the set
+    // MFMA view: lane 4 b + j -> pair j of the set
+    const int64_t mga = static_cast<int64_t>(static_cast<unsigned>(mmeta.x)) | (static_cast<int64_t>(mmeta.y) << 32);
+    const bool mvalid[2] = {set * 4 + mj <= last_pair, set * 4 + mj <= last_pair && (mmeta.w & 4) != 0};
+    float* __restrict__ mrow = out + mga * static_cast<int64_t>(p.out_cols);
     const int mel_col = (KIND == SNF_KIND_FBANK && p.use_energy && !p.htk_compat) ? 1 : 0;
     if (KIND == SNF_KIND_FBANK || KIND == SNF_KIND_PLP) {
 #pragma unroll
@@ -978,7 +980,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
 #pragma unroll
           for (int i = 0; i < 4; ++i) mel[s2][i] = fast_log(floor_eps(mel[s2][i]));
         }
-        if (mga + s2 <= last_frame && mm_out >= 0) {
+        if (mvalid[s2] && mm_out >= 0) {
           float* __restrict__ dst = mrow + s2 * p.out_cols + mel_col + mm_out;
           if (mm_out + 4 <= p.num_bins) {
             __builtin_nontemporal_store(f32x4_a4{mel[s2][0], mel[s2][1], mel[s2][2], mel[s2][3]},
@@ -1060,6 +1062,57 @@ __global__ void build_frame_start_kernel(const int64_t* __restrict__ frame_offse
   if (safe + win_len > n) safe = n - win_len;  // n >= win_len is checked by the host
   frame_start[g] = s0 + safe;
   frame_edge[g] = edge ? static_cast<int32_t>(u + 1) : 0;
+}
+
+// one thread per frame pair of fbank256x2_kernel (see PairRec): pair_offsets[u] = pairs of the utterances
+// before u, an utterance of T frames holding (T + 1) / 2 of them.
+__global__ void build_pair_table_kernel(const int64_t* __restrict__ frame_offsets,
+                                        const int64_t* __restrict__ sample_offsets,
+                                        const int64_t* __restrict__ pair_offsets, int64_t n_utts,
+                                        int64_t n_pairs, int win_shift, int win_len, int snip_edges,
+                                        PairRec* __restrict__ pairs) {
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= n_pairs) return;
+  const int64_t u = find_utt(pair_offsets, n_utts, g);
+  const int64_t s0 = sample_offsets[u], n = sample_offsets[u + 1] - s0;
+  const int64_t f0 = frame_offsets[u], n_frames = frame_offsets[u + 1] - f0;
+  const int64_t f = 2 * (g - pair_offsets[u]);
+  const bool has_b = f + 1 < n_frames;
+  PairRec r;
+  r.frame_a = f0 + f;
+  r.utt1 = 0;
+  r.flags = has_b ? 4 : 0;
+  int64_t start[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const int64_t fr = f + (has_b ? s2 : 0);
+    if (snip_edges) {
+      start[s2] = s0 + fr * win_shift;
+    } else {  // (as build_frame_start_kernel)
+      const int64_t rel = fr * win_shift + win_shift / 2 - win_len / 2;
+      int64_t safe = rel < 0 ? 0 : rel;
+      if (safe + win_len > n) safe = n - win_len;
+      start[s2] = s0 + safe;
+      if (rel < 0 || rel + win_len > n) {
+        r.utt1 = static_cast<int32_t>(u + 1);
+        r.flags |= 1 << s2;
+      }
+    }
+  }
+  r.start_a = start[0];
+  r.start_b = start[1];
+  pairs[g] = r;
+}
+
+int launch_build_pair_table(const int64_t* d_frame_offsets, const int64_t* d_sample_offsets,
+                            const int64_t* d_pair_offsets, int64_t n_utts, int64_t n_pairs, int win_shift,
+                            int win_len, int snip_edges, PairRec* d_pairs, hipStream_t stream) {
+  if (n_pairs <= 0) return SNF_OK;
+  hipLaunchKernelGGL(build_pair_table_kernel, dim3(static_cast<unsigned>((n_pairs + 255) / 256)),
+                     dim3(256), 0, stream, d_frame_offsets, d_sample_offsets, d_pair_offsets, n_utts,
+                     n_pairs, win_shift, win_len, snip_edges, d_pairs);
+  SNF_HIP_CHECK(hipGetLastError());
+  return SNF_OK;
 }
 
 int launch_build_frame_start(const int64_t* d_frame_offsets, const int64_t* d_sample_offsets,
@@ -1411,7 +1464,8 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
   if (p.dual) {
     // two frames per 16-lane row (fbank256x2_kernel): flat batches of FBANK / MFCC / PLP plans
     if (per_utt || fused) return set_error(SNF_E_RUNTIME, "fast512: the dual tables serve flat batches only");
-    const int64_t n_sets8 = (b.total_frames + 7) / 8;
+    if (!b.pair_tab || b.n_pairs <= 0) return set_error(SNF_E_RUNTIME, "fast512: no frame pair table");
+    const int64_t n_sets8 = (b.n_pairs + 3) / 4;
     int64_t blocks8 = (n_sets8 + n_waves - 1) / n_waves;
     const int64_t max_blocks8 = 256 * 4 * (kMaxWaves / n_waves);
     if (blocks8 > max_blocks8) blocks8 = max_blocks8;

@@ -107,6 +107,16 @@ struct MelParams {
   const float* lifter;       // [num_ceps] or nullptr
 };
 
+// fbank256x2_kernel: one record per frame pair.  Pairs are formed INSIDE an utterance (frames 2 m and
+// 2 m + 1 counted from the utterance's first frame; an odd last frame is paired with itself), so the
+// features of an utterance do not depend on what else is in the batch.
+struct PairRec {
+  int64_t start_a, start_b;  // first sample of the two frames (clamped into the utterance)
+  int64_t frame_a;           // batch-wide frame index of frame a (frame b, if any, is frame_a + 1)
+  int32_t utt1;              // snip_edges = false: utterance + 1 when either frame reflects at an edge
+  int32_t flags;             // bit 0 / 1: frame a / b reflects; bit 2: frame b exists
+};
+
 struct BatchArgs {
   const int16_t* wave;
   const int64_t* sample_offsets;  // [n_utts+1]
@@ -117,6 +127,8 @@ struct BatchArgs {
   const int32_t* frame_utt;       // [total_frames] utterance of every frame (generic kernel)
   const int32_t* blk_utt;         // [n_blocks] fast path with VTLN warps: utterance of every workgroup
   const int32_t* blk_set0;        // [n_blocks] ... and its first frame set inside that utterance
+  const PairRec* pair_tab;        // [n_pairs] fbank256x2_kernel only
+  int64_t n_pairs;
   int64_t n_blocks;
   int64_t n_utts;
   int64_t total_frames;
@@ -191,6 +203,9 @@ bool fast512_dual_eligible(const MelParams& mp);
 int fast512_build(const MelParams& mp, const std::vector<float>& window, const MelBanksHost& mb,
                   const std::vector<float>& dct, const std::vector<float>& lifter, bool dual,
                   std::vector<float>* blob, Fast512Params* out);
+int launch_build_pair_table(const int64_t* d_frame_offsets, const int64_t* d_sample_offsets,
+                            const int64_t* d_pair_offsets, int64_t n_utts, int64_t n_pairs, int win_shift,
+                            int win_len, int snip_edges, PairRec* d_pairs, hipStream_t stream);
 int launch_build_frame_start(const int64_t* d_frame_offsets, const int64_t* d_sample_offsets,
                              int64_t n_utts, int64_t total_frames, int win_shift, int win_len,
                              int snip_edges, int64_t* d_frame_start, int32_t* d_frame_edge,

@@ -576,6 +576,35 @@ def test_fast_kernel_short_frames(gpu, cls, sample_rate, opts, snip_edges):
 
 @pytest.mark.parametrize('snip_edges', [True, False])
 @pytest.mark.parametrize('cls, sample_rate, opts', [
+    (FilterbankProcessor, 8000, dict()),                      # fbank256x2_kernel: two frames per row
+    (MfccProcessor, 8000, dict()),
+    (PlpProcessor, 8000, dict()),
+    (MfccProcessor, 16000, dict(frame_length=0.016, frame_shift=0.005)),
+    (FilterbankProcessor, 16000, dict()),                     # fbank512_kernel
+    (MfccProcessor, 44100, dict()),                           # fbank2048_kernel
+])
+def test_features_do_not_depend_on_the_batch(gpu, cls, sample_rate, opts, snip_edges):
+    """an utterance's features are the same bits whether it runs alone or inside any batch (the
+    reference processes utterances one by one: shennong/processor/base.py:150-180).  The two-frames-
+    per-row kernel pairs frames inside an utterance for exactly this reason; utterances with odd and
+    even frame counts, and a one-frame utterance, move the pairing of everything behind them."""
+    shift = int(round(opts.get('frame_shift', 0.01) * sample_rate))
+    length = int(round(opts.get('frame_length', 0.025) * sample_rate))
+    lengths = [length + shift * k + r for k, r in [(6, 3), (0, 0), (11, 7), (4, 1), (1, 0), (9, 5)]]
+    waves = [synth.utterances(31 + i, 1, n, sample_rate)[0] for i, n in enumerate(lengths)]
+    proc = cls(sample_rate=sample_rate, dither=0, snip_edges=snip_edges, **opts)
+    audios = [Audio(w, sample_rate) for w in waves]
+    alone = [proc._process_batch([a])[0].data for a in audios]
+    assert len({a.shape[0] % 2 for a in alone}) == 2      # odd and even frame counts both present
+    for order in ([0, 1, 2, 3, 4, 5], [5, 3, 1, 4, 2, 0], [2, 2, 1, 0]):
+        together = proc._process_batch([audios[i] for i in order])
+        for i, f in zip(order, together):
+            assert f.data.shape == alone[i].shape
+            assert np.array_equal(f.data, alone[i]), f'{cls.__name__} {sample_rate}: utterance {i} in {order}'
+
+
+@pytest.mark.parametrize('snip_edges', [True, False])
+@pytest.mark.parametrize('cls, sample_rate, opts', [
     (FilterbankProcessor, 44100, dict(num_bins=40)),          # 1102 samples -> 2048 (reference test rate)
     (FilterbankProcessor, 44100, dict(num_bins=23, use_energy=True, raw_energy=False)),
     (FilterbankProcessor, 44100, dict(use_energy=True, htk_compat=True, use_power=False)),
