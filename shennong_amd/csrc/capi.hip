@@ -88,7 +88,7 @@ struct snf_plan {
   // pitch
   PitchTablesHost pt;
   PitchDevTables pd{};
-  DevBuf d_lags, d_ar_first, d_ar_n, d_ar_w, d_rs_first, d_rs_ntaps, d_rs_w;
+  DevBuf d_lags, d_ar_first, d_ar_n, d_ar_w, d_ar_quad_w, d_ar_quad_base, d_rs_first, d_rs_ntaps, d_rs_w;
   PitchPostParams ppost{};
 
   // scratch (host-pointer entry points and intermediates)
@@ -507,6 +507,41 @@ int build_pitch_plan(snf_plan* plan) {
   if ((rc = plan->d_rs_ntaps.upload(t.resample.ntaps, plan->stream))) return rc;
   if ((rc = plan->d_rs_w.upload(t.resample.weights, plan->stream))) return rc;
   PitchDevTables& d = plan->pd;
+  {
+    // ArbitraryResample as 4 x 4 outer-product steps (see PitchDevTables): quad windows and weights
+    const int S = t.num_states, groups = ((S + 63) / 64 + 1) & ~1;
+    std::vector<int> qbase(static_cast<size_t>(groups) * 16, 0);
+    int kmax = 1;
+    for (int qd = 0; qd < groups * 16; ++qd) {
+      const int s0 = qd * 4;
+      if (s0 >= S) continue;
+      int lo = t.ar_first[s0], hi = lo;
+      for (int s = s0; s < s0 + 4 && s < S; ++s) {
+        lo = std::min(lo, t.ar_first[s]);
+        hi = std::max(hi, t.ar_first[s] + std::max(t.ar_n[s], 0));
+      }
+      qbase[qd] = lo;
+      kmax = std::max(kmax, hi - lo);
+    }
+    const int taps = (kmax + 3) & ~3;
+    std::vector<float> qw(static_cast<size_t>(groups) * taps * 64, 0.0f);
+    for (int g = 0; g < groups; ++g)
+      for (int k = 0; k < taps; ++k)
+        for (int ln = 0; ln < 64; ++ln) {
+          const int s = 64 * g + ln;
+          if (s >= S) continue;
+          const int j = qbase[g * 16 + ln / 4] + k - t.ar_first[s];
+          if (j >= 0 && j < t.ar_n[s])
+            qw[((static_cast<size_t>(g) * (taps / 4) + k / 4) * 64 + ln) * 4 + (k & 3)] =
+                t.ar_w[static_cast<size_t>(s) * t.max_taps + j];
+        }
+    if ((rc = plan->d_ar_quad_w.upload(qw, plan->stream))) return rc;
+    if ((rc = plan->d_ar_quad_base.upload(qbase, plan->stream))) return rc;
+    d.ar_groups = groups;
+    d.ar_quad_taps = taps;
+    d.ar_quad_w = plan->d_ar_quad_w.as<float>();
+    d.ar_quad_base = plan->d_ar_quad_base.as<int>();
+  }
   d.first_lag = t.first_lag;
   d.last_lag = t.last_lag;
   d.num_lags = t.num_lags;

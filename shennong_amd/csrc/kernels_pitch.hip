@@ -33,22 +33,14 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "snf_internal.h"
+#include "device_fft.h"
 
 namespace snf {
 
 namespace {
-
-__device__ __forceinline__ int64_t find_utt(const int64_t* __restrict__ offsets, int64_t n,
-                                            int64_t g) {
-  int64_t lo = 0, hi = n;
-  while (hi - lo > 1) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (offsets[mid] <= g) lo = mid; else hi = mid;
-  }
-  return lo;
-}
 
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -264,13 +256,32 @@ __device__ __forceinline__ float tree16(float v) {
 }
 
 constexpr int kLagGroup = 5;   // lags per lane and pass of the correlation
-constexpr int kNccfWaves = 4;  // 16 frames per workgroup
+constexpr int kNccfWaves = 12;  // 48 frames per workgroup: two workgroups per CU (LDS) = 6 waves per SIMD
 constexpr int kFwdPad = 36;    // FLT_MAX entries behind the forward costs (unclamped scan steps)
 constexpr int kLongRange3 = 32;  // level 3 / levels 4-5: windows of at least this many candidates go to the
 constexpr int kLongRange4 = 16;  // 8-lane teams instead of one lane (flat between 8 and 32: measured)
 constexpr int kQueueFloats = 64 * 4;  // long-window queue of a wave: 64 x int4
 constexpr int kVitWaves = 8;   // utterances (= wavefronts) per workgroup of the Viterbi kernel
-constexpr int kRowRegs = 8;    // row values per lane held one frame ahead (up to 512 states)
+
+// LDS layout of one frame of an NCCF wave: the window (wl floats), then the NCCF at the integer lags.
+// When one pass of the correlation covers every lag (num_lags <= 80: the window is dead by the time the
+// NCCF is written) the NCCF overlays the head of the window.  The frames of a wave sit 16 mod 32 floats
+// apart, so that the two 16-lane rows of a ds_read_b32 lane group (banks = dword address mod 32) never
+// meet in the correlation - lane l of a row reads dword base + 5 l (banks 0, 5, .., 30, 3, .., 28, 1, 6,
+// 11) and that set shifted by 16 is its complement -, and frames 2 and 3 keep their NCCF 8 floats
+// further in, which spreads the four frames of the matrix-pipe resampler over the banks 0, 16, 8, 24.
+struct NccfLayout {
+  int nccf_off;  // floats from the window to the NCCF of frames 0, 1 (frames 2, 3: + 8)
+  int pitch;     // floats between frames
+};
+__host__ __device__ inline NccfLayout nccf_layout(int wl, int ln, int num_lags) {
+  NccfLayout y;
+  const bool overlay = num_lags <= kLagGroup * 16 && ln + 8 <= wl;
+  y.nccf_off = overlay ? 0 : wl;
+  const int n = overlay ? wl : wl + ln + 8;
+  y.pitch = n + ((16 - n % 32) + 32) % 32;
+  return y;
+}
 
 }  // namespace
 
@@ -282,27 +293,31 @@ __global__ void pitch_frame_utt_kernel(const PitchBatch b, int32_t* __restrict__
 }
 
 // ---- 3. NCCF at the integer lags, resampled to the lags of the Viterbi states ------------------------
-__global__ __launch_bounds__(kNccfWaves * 64) void pitch_nccf_kernel(
+__global__ __launch_bounds__(kNccfWaves * 64, 6) void pitch_nccf_kernel(
     const PitchDevTables t, const PitchBatch b, const float* __restrict__ down,
     const float* __restrict__ ub, const int32_t* __restrict__ frame_utt, float* __restrict__ nccf_res,
     float* __restrict__ pov_nccf, float* __restrict__ anp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = t.num_states, L = t.num_lags, W = t.win_size;
-  const int KT = (t.ar_max_taps + 3) & ~3, S4 = (S + 3) & ~3;
-  // sinc taps of every state (zero padded to KT: fmaf(x, 0, v) == v), shared by the workgroup
-  float* taps = reinterpret_cast<float*>(smem);
-  int* st_first = reinterpret_cast<int*>(taps + static_cast<size_t>(S) * KT);
-  for (int i = threadIdx.x; i < S * KT; i += blockDim.x) {
-    const int s = i / KT, j = i - s * KT;
-    taps[i] = (j < t.ar_max_taps && j < t.ar_n[s]) ? t.ar_w[s * t.ar_max_taps + j] : 0.0f;
-  }
-  for (int s = threadIdx.x; s < S; s += blockDim.x) st_first[s] = t.ar_first[s];
+  const int KQ = t.ar_quad_taps >> 2, G = t.ar_groups;
+  // sinc taps of every state quad in matrix-pipe order (PitchDevTables), shared by the workgroup
+  float4* quad_w = reinterpret_cast<float4*>(smem);
+  int* quad_base = reinterpret_cast<int*>(quad_w + static_cast<size_t>(G) * KQ * 64);
+  for (int i = threadIdx.x; i < G * KQ * 64; i += blockDim.x)
+    quad_w[i] = reinterpret_cast<const float4*>(t.ar_quad_w)[i];
+  for (int i = threadIdx.x; i < G * 16; i += blockDim.x) quad_base[i] = t.ar_quad_base[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l = lane & 15, q = lane >> 4;
-  const int WL = (t.full_len + 16 + 3) & ~3, LN = (L + KT + 3) & ~3;
-  float* win = reinterpret_cast<float*>(st_first + S4) + (wid * 4 + q) * (WL + LN);
-  float* nccf = win + WL;
+  const int WL = (t.full_len + 16 + 3) & ~3, LN = (L + t.ar_quad_taps + 3) & ~3;
+  const NccfLayout lay = nccf_layout(WL, LN, L);
+  float* frames0 = reinterpret_cast<float*>(quad_base + G * 16) + wid * 4 * lay.pitch;
+  float* win = frames0 + q * lay.pitch;
+  float* nccf = win + lay.nccf_off + (q >> 1) * 8;
+  // matrix-pipe view of the wave: lane 4 b + j -> state quad b of a group (A operand: state 4 b + j),
+  // frame j of the set (B operand and the four results of the lane)
+  const int mb = lane >> 2, mj = lane & 3;
+  const float* __restrict__ nccf_m = frames0 + mj * lay.pitch + lay.nccf_off + (mj >> 1) * 8;
   const int64_t n_sets = (b.total_frames + 3) >> 2;
   for (int64_t set = static_cast<int64_t>(blockIdx.x) * kNccfWaves + wid; set < n_sets;
        set += static_cast<int64_t>(gridDim.x) * kNccfWaves) {
@@ -341,26 +356,47 @@ __global__ __launch_bounds__(kNccfWaves * 64) void pitch_nccf_kernel(
       if (lb < L) {
         const float* __restrict__ a = win;
         const float* __restrict__ cw = win + t.first_lag + lb;
-        float c[2 * kLagGroup - 1];
+        // blocks of 5 samples x 5 lags out of 9 window values; the 10 LDS values of the next block are
+        // requested before the 50 multiply-adds of the current one (two register sets, A and B; the
+        // reads past the last block land in the window's zero padding and are dropped)
+        float c[kLagGroup - 1];
 #pragma unroll
         for (int k = 0; k < kLagGroup - 1; ++k) c[k] = cw[k];
-        int i = 0;
-        for (; i + kLagGroup <= W; i += kLagGroup) {
-          float av[kLagGroup];
+        float av_a[kLagGroup], cn_a[kLagGroup], av_b[kLagGroup], cn_b[kLagGroup];
+        auto fetch = [&](float (&av)[kLagGroup], float (&cn)[kLagGroup], int at) {
 #pragma unroll
           for (int k = 0; k < kLagGroup; ++k) {
-            av[k] = a[i + k];
-            c[kLagGroup - 1 + k] = cw[i + kLagGroup - 1 + k];
+            av[k] = a[at + k];
+            cn[k] = cw[at + kLagGroup - 1 + k];
           }
+        };
+        auto block = [&](const float (&av)[kLagGroup], const float (&cn)[kLagGroup]) {
+          float cc[2 * kLagGroup - 1];
+#pragma unroll
+          for (int k = 0; k < kLagGroup - 1; ++k) cc[k] = c[k];
+#pragma unroll
+          for (int k = 0; k < kLagGroup; ++k) cc[kLagGroup - 1 + k] = cn[k];
 #pragma unroll
           for (int k = 0; k < kLagGroup; ++k)
 #pragma unroll
             for (int d = 0; d < kLagGroup; ++d) {
-              ip[d] = __builtin_fmaf(av[k], c[k + d], ip[d]);
-              e2[d] = __builtin_fmaf(c[k + d], c[k + d], e2[d]);
+              ip[d] = __builtin_fmaf(av[k], cc[k + d], ip[d]);
+              e2[d] = __builtin_fmaf(cc[k + d], cc[k + d], e2[d]);
             }
 #pragma unroll
-          for (int k = 0; k < kLagGroup - 1; ++k) c[k] = c[kLagGroup + k];
+          for (int k = 0; k < kLagGroup - 1; ++k) c[k] = cc[kLagGroup + k];
+        };
+        fetch(av_a, cn_a, 0);
+        int i = 0;
+        for (; i + 2 * kLagGroup <= W; i += 2 * kLagGroup) {
+          fetch(av_b, cn_b, i + kLagGroup);
+          block(av_a, cn_a);
+          fetch(av_a, cn_a, i + 2 * kLagGroup);
+          block(av_b, cn_b);
+        }
+        if (i + kLagGroup <= W) {
+          block(av_a, cn_a);
+          i += kLagGroup;
         }
         for (; i < W; ++i) {  // windows that are not a multiple of 5 samples
           const float ai = a[i];
@@ -391,20 +427,58 @@ __global__ __launch_bounds__(kNccfWaves * 64) void pitch_nccf_kernel(
     if (valid && l == 0) anp[g] = avg_norm_prod;
     for (int i = L + l; i < LN; i += 16) nccf[i] = 0.0f;  // (taps are zero padded)
     wave_sync();
-    // ---- ArbitraryResample: NCCF at the lag of every state -----------------------------------------
-    float* __restrict__ row = nccf_res + g * static_cast<int64_t>(S);
-    for (int s = l; s < S; s += 16) {
-      const float* __restrict__ src = nccf + st_first[s];
-      const float4* __restrict__ wt = reinterpret_cast<const float4*>(taps + s * KT);
-      float v = 0.0f;
-      for (int j = 0; j < KT / 4; ++j) {
-        const float4 wq = wt[j];
-        v = __builtin_fmaf(src[4 * j], wq.x, v);
-        v = __builtin_fmaf(src[4 * j + 1], wq.y, v);
-        v = __builtin_fmaf(src[4 * j + 2], wq.z, v);
-        v = __builtin_fmaf(src[4 * j + 3], wq.w, v);
-      }
-      if (valid) row[s] = v;
+    // ---- ArbitraryResample: NCCF at the lag of every state, on the matrix pipe.  One
+    // v_mfma_f32_4x4x1_16b_f32 = 16 blocks of (4 states) x (4 frames) += w[state][lag] * nccf[frame][lag]:
+    // a fused multiply-add per element, lags ascending = Kaldi's tap order (zero weights in front of
+    // and behind a state's taps leave its sum unchanged); two groups of 64 states run as independent
+    // chains.  12 steps per group instead of 27 x 12 multiply-adds (+ as many LDS reads) per lane. ------
+    {
+      const int64_t gm = set * 4 + mj;
+      const bool valid_m = gm < b.total_frames;
+      float* __restrict__ row = nccf_res + gm * static_cast<int64_t>(S);
+      // (the usual 12-lag quad window as straight-line code: a loop over a run-time step count makes the
+      // register allocator rotate the two accumulators through v_accvgpr moves every iteration)
+      auto groups = [&](auto kq_const) {
+        constexpr int kKq = decltype(kq_const)::value;
+        const int kq = kKq > 0 ? kKq : KQ;
+        for (int g2 = 0; g2 < G; g2 += 2) {
+          const float* __restrict__ x0 = nccf_m + quad_base[g2 * 16 + mb];
+          const float* __restrict__ x1 = nccf_m + quad_base[g2 * 16 + 16 + mb];
+          const float4* __restrict__ w0 = quad_w + static_cast<size_t>(g2) * kq * 64 + lane;
+          const float4* __restrict__ w1 = w0 + kq * 64;
+          f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int k4 = 0; k4 < kq; ++k4) {
+            const float4 a0 = w0[k4 * 64], a1 = w1[k4 * 64];
+            const float b00 = x0[4 * k4], b01 = x0[4 * k4 + 1], b02 = x0[4 * k4 + 2], b03 = x0[4 * k4 + 3];
+            const float b10 = x1[4 * k4], b11 = x1[4 * k4 + 1], b12 = x1[4 * k4 + 2], b13 = x1[4 * k4 + 3];
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, b00, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, b10, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, b01, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, b11, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, b02, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, b12, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, b03, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, b13, acc1, 0, 0, 0);
+          }
+          if (valid_m) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int s0 = 64 * (g2 + h) + 4 * mb;
+              const f32x4 acc = h ? acc1 : acc0;
+              if (s0 + 4 <= S) {
+                *reinterpret_cast<f32x4_a4*>(row + s0) = f32x4_a4{acc[0], acc[1], acc[2], acc[3]};
+              } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                  if (s0 + i < S) row[s0 + i] = acc[i];
+              }
+            }
+          }
+        }
+      };
+      if (KQ == 3) groups(std::integral_constant<int, 3>{});
+      else groups(std::integral_constant<int, 0>{});
     }
   }
 }
@@ -420,6 +494,9 @@ struct VitShared {
 };
 
 // one forward pass over all frames; returns with sh.fwd = final normalised forward cost
+// NK: 64-state slices of the state space held in registers (7: up to 448 states - the default 417 -,
+// 8: up to 512); 0: any size, rows read from HBM where they are used
+template <int NK>
 __device__ void viterbi_forward(const PitchDevTables& t, const float* __restrict__ res, const float* __restrict__ anp,
                                 int64_t T, int64_t T1, bool rescale, float old_b1, float old_b2,
                                 float new_ballast, int16_t* __restrict__ bp, const VitShared& sh,
@@ -428,9 +505,28 @@ __device__ void viterbi_forward(const PitchDevTables& t, const float* __restrict
   for (int s = lane; s < S; s += 64) sh.fwd[s] = 0.0f;
   for (int s = S + lane; s < S + kFwdPad; s += 64) sh.fwd[s] = FLT_MAX;  // scan read-ahead padding
   const float factor = t.inter_frame_factor;
-  float ahead[kRowRegs];
+  // up to 512 states: the lane's states lane + 64 k live in registers with compile-time indices (a
+  // run-time k puts the array in scratch memory, and the flat load that fetches it back waits for the
+  // row prefetch too: the HBM latency the prefetch is there to hide).  Slots beyond the last state work
+  // on the last state again (same inputs, same stores): the per-frame code has no branch, so the compiler
+  // can count the memory operations in flight and never waits for more than it needs.
+  constexpr bool in_regs = NK > 0;
+  constexpr int kRowRegs = NK > 0 ? NK : 1;
+  float ahead[kRowRegs], soft_lag[kRowRegs];
+  int col[kRowRegs];
 #pragma unroll
-  for (int k = 0; k < kRowRegs; ++k) ahead[k] = (S <= 64 * kRowRegs && lane + 64 * k < S && T > 0) ? res[lane + 64 * k] : 0.0f;
+  for (int k = 0; k < kRowRegs; ++k) {
+    col[k] = lane + 64 * k < S ? lane + 64 * k : S - 1;
+    ahead[k] = (in_regs && T > 0) ? res[col[k]] : 0.0f;
+    soft_lag[k] = t.soft_min_f0 * st_lag[col[k]];
+  }
+  // Loads and stores share one in-order counter (vmcnt), so the wait for the prefetched row would also
+  // wait for every store issued after it.  The backpointers of frame t therefore stay in registers and
+  // are stored at the top of frame t + 1, BEFORE the row of frame t + 2 is requested: the row loads are
+  // always the youngest memory operations when their wait comes, and everything older is a frame old.
+  int bpv[kRowRegs];
+#pragma unroll
+  for (int k = 0; k < kRowRegs; ++k) bpv[k] = 0;
   const int n_super = (S + 127) >> 7;          // states 0, 128, 256, ...
   const int n_reps = (S + 31) >> 5;            // states 0, 32, 64, ...
   for (int64_t frame = 0; frame < T; ++frame) {
@@ -443,22 +539,34 @@ __device__ void viterbi_forward(const PitchDevTables& t, const float* __restrict
     const float* __restrict__ row = res + frame * static_cast<int64_t>(S);
     wave_sync();
     // (rows are read one frame ahead: the HBM latency of frame t + 1 hides behind the search of frame t)
-    float cur[kRowRegs];
-    if (S <= 64 * kRowRegs) {
+    if (in_regs) {
 #pragma unroll
-      for (int k = 0; k < kRowRegs; ++k) cur[k] = ahead[k];
-      if (frame + 1 < T) {
-#pragma unroll
-        for (int k = 0; k < kRowRegs; ++k)
-          if (lane + 64 * k < S) ahead[k] = row[S + lane + 64 * k];
+      for (int k = 0; k < kRowRegs; ++k) {
+        float v = ahead[k];
+        if (rescale) v *= scale;
+        float local = 1.0f - v;
+        local += soft_lag[k] * v;
+        sh.nxt[col[k]] = local;
       }
-    }
-    for (int s = lane, k = 0; s < S; s += 64, ++k) {
-      float v = S <= 64 * kRowRegs ? cur[k < kRowRegs ? k : 0] : row[s];
-      if (rescale) v *= scale;
-      float local = 1.0f - v;
-      local += t.soft_min_f0 * st_lag[s] * v;
-      sh.nxt[s] = local;
+      // the row of frame t + 1, requested now and first used a whole search later.  Unconditional loads
+      // into the registers that just died (clamped column, the last frame reads its own row again): a
+      // load under a branch comes back through a copy, and the copy waits for it right here
+      if (frame > 0) {
+        int16_t* __restrict__ bp_row = bp + (frame - 1) * S;
+#pragma unroll
+        for (int k = 0; k < kRowRegs; ++k) bp_row[col[k]] = static_cast<int16_t>(bpv[k]);
+      }
+      const float* __restrict__ nrow = frame + 1 < T ? row + S : row;
+#pragma unroll
+      for (int k = 0; k < kRowRegs; ++k) ahead[k] = nrow[col[k]];
+    } else {
+      for (int s = lane; s < S; s += 64) {
+        float v = row[s];
+        if (rescale) v *= scale;
+        float local = 1.0f - v;
+        local += t.soft_min_f0 * st_lag[s] * v;
+        sh.nxt[s] = local;
+      }
     }
     // ---- Viterbi step.  cost(i, j) = (j - i)^2 * factor + fwd[j]; its argmin is monotone in i
     // (Kaldi's own search relies on it).  Level 1: exact argmin of the states 0, 128, 256, ... (a
@@ -602,19 +710,37 @@ __device__ void viterbi_forward(const PitchDevTables& t, const float* __restrict
     }
     wave_sync();
     float lane_min = FLT_MAX;
-    for (int s = lane; s < S; s += 64) {
-      lane_min = fminf(lane_min, sh.nxt[s]);
-      bp[frame * S + s] = static_cast<int16_t>(sh.bpw[s]);
+    if (in_regs) {
+      float nx[kRowRegs];
+#pragma unroll
+      for (int k = 0; k < kRowRegs; ++k) {
+        nx[k] = sh.nxt[col[k]];
+        bpv[k] = sh.bpw[col[k]];
+        lane_min = fminf(lane_min, nx[k]);
+      }
+      const float mn = wave_min_f(lane_min);
+#pragma unroll
+      for (int k = 0; k < kRowRegs; ++k) sh.fwd[col[k]] = nx[k] + (-mn);
+    } else {
+      for (int s = lane; s < S; s += 64) {
+        lane_min = fminf(lane_min, sh.nxt[s]);
+        bp[frame * S + s] = static_cast<int16_t>(sh.bpw[s]);
+      }
+      const float mn = wave_min_f(lane_min);
+      for (int s = lane; s < S; s += 64) sh.fwd[s] = sh.nxt[s] + (-mn);
     }
-    const float mn = wave_min_f(lane_min);
-    for (int s = lane; s < S; s += 64) sh.fwd[s] = sh.nxt[s] + (-mn);
+  }
+  if (in_regs && T > 0) {
+    int16_t* __restrict__ bp_row = bp + (T - 1) * S;
+#pragma unroll
+    for (int k = 0; k < kRowRegs; ++k) bp_row[col[k]] = static_cast<int16_t>(bpv[k]);
   }
   wave_sync();
 }
 
 }  // namespace
 
-__global__ __launch_bounds__(kVitWaves * 64) void pitch_viterbi_kernel(
+__global__ __launch_bounds__(kVitWaves * 64, 4) void pitch_viterbi_kernel(
     const PitchDevTables t, const PitchBatch b, const float* __restrict__ nccf_res,
     const float* __restrict__ anp, const float* __restrict__ ub, int16_t* __restrict__ backptr,
     int32_t* __restrict__ states, const float* __restrict__ pov_all, float* __restrict__ out) {
@@ -647,8 +773,10 @@ __global__ __launch_bounds__(kVitWaves * 64) void pitch_viterbi_kernel(
   // pass survives it, so an offline batch runs ONE forward pass - the recomputing one when Kaldi would
   // recompute, the plain one otherwise (round 2 ran both: half of the Viterbi kernel's time).
   const bool recompute = T < t.recompute_frame && o[5] != 0.0f;
-  viterbi_forward(t, res, anp + f0, T, T1, recompute, recompute ? o[2] : 0.0f, recompute ? o[3] : 0.0f,
-                  recompute ? o[4] : 0.0f, bp, sh, st_lag, lane);
+  const float ob1 = recompute ? o[2] : 0.0f, ob2 = recompute ? o[3] : 0.0f, nb = recompute ? o[4] : 0.0f;
+  if (S <= 448) viterbi_forward<7>(t, res, anp + f0, T, T1, recompute, ob1, ob2, nb, bp, sh, st_lag, lane);
+  else if (S <= 512) viterbi_forward<8>(t, res, anp + f0, T, T1, recompute, ob1, ob2, nb, bp, sh, st_lag, lane);
+  else viterbi_forward<0>(t, res, anp + f0, T, T1, recompute, ob1, ob2, nb, bp, sh, st_lag, lane);
 
   // traceback: best final state (lowest index wins ties), then the chain of backpointers
   __threadfence_block();
@@ -720,14 +848,15 @@ int launch_pitch(const PitchDevTables& t, const PitchBatch& b, const PitchScratc
     return trace == index ? 1 : 0;
   };
   if (stage_done("resample + stats", 1)) return SNF_OK;
-  const int S = t.num_states, L = t.num_lags, S4 = (S + 3) & ~3, KT = (t.ar_max_taps + 3) & ~3;
+  const int S = t.num_states, L = t.num_lags, S4 = (S + 3) & ~3;
   hipLaunchKernelGGL(pitch_frame_utt_kernel, dim3(static_cast<unsigned>((b.total_frames + 255) / 256)),
                      dim3(256), 0, stream, b, w.frame_utt);
   SNF_HIP_CHECK(hipGetLastError());
   {
-    const int WL = (t.full_len + 16 + 3) & ~3, LN = (L + KT + 3) & ~3;
-    const size_t lds = sizeof(float) * (static_cast<size_t>(S) * KT + S4 +
-                                        static_cast<size_t>(kNccfWaves) * 4 * (WL + LN));
+    const int WL = (t.full_len + 16 + 3) & ~3, LN = (L + t.ar_quad_taps + 3) & ~3;
+    const size_t lds = sizeof(float) * (static_cast<size_t>(t.ar_groups) * t.ar_quad_taps * 64 +
+                                        t.ar_groups * 16 +
+                                        static_cast<size_t>(kNccfWaves) * 4 * nccf_layout(WL, LN, L).pitch);
     if (lds > 160 * 1024) return set_error(SNF_E_RUNTIME, "pitch lag tables do not fit in LDS");
     if (lds > 64 * 1024)
       SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pitch_nccf_kernel),

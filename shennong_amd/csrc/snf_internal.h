@@ -228,6 +228,12 @@ struct PitchDevTables {
   const int* ar_first;    // [num_states]
   const int* ar_n;        // [num_states]
   const float* ar_w;      // [num_states][ar_max_taps]
+  // the same taps laid out for the matrix pipe (pitch_nccf_kernel): states in groups of 64 = 16 quads;
+  // a quad shares a window of ar_quad_taps lags starting at ar_quad_base (zero weight where a state has
+  // no tap); ar_groups is even (a zero-weight group pads an odd count)
+  int ar_groups, ar_quad_taps;
+  const float* ar_quad_w;   // [ar_groups][ar_quad_taps / 4][64 = quad * 4 + state][4]
+  const int* ar_quad_base;  // [ar_groups][16]
   const int* rs_first;    // [rs_out_unit]
   const int* rs_ntaps;    // [rs_out_unit]
   const float* rs_w;      // [rs_out_unit][rs_max_taps]
