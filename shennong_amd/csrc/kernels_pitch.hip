@@ -223,26 +223,30 @@ __device__ __forceinline__ float trans_cost(int j, float fi, float factor, float
 // are padded with FLT_MAX beyond the last state.
 __device__ __forceinline__ void scan_range(const float* __restrict__ fwd, int lo, int hi, float fi,
                                            float factor, float& best, int& best_j) {
-  float fj = static_cast<float>(lo);
-  {
-    const float d = fj - fi;
-    best = __fadd_rn(__fmul_rn(d * d, factor), fwd[lo]);
-  }
-  float best_f = fj;
+  // The running value is d = j - i (small integers: exact in float, so d equals Kaldi's j - i whichever way
+  // it is reached); per candidate: one add, two multiplies, one add, one compare, one select (the best d)
+  // and one minimum (costs are >= 0 and never NaN: the minimum IS the select of the cost).
+  float d = static_cast<float>(lo) - fi;
+  float b = __fadd_rn(__fmul_rn(d * d, factor), fwd[lo]), bd = d;
   for (int j = lo + 1; j <= hi; j += 4) {
     const float f0 = fwd[j], f1 = fwd[j + 1], f2 = fwd[j + 2], f3 = fwd[j + 3];
-    const float d0 = (fj + 1.0f) - fi, d1 = (fj + 2.0f) - fi, d2 = (fj + 3.0f) - fi, d3 = (fj + 4.0f) - fi;
+    const float d0 = d + 1.0f, d1 = d + 2.0f, d2 = d + 3.0f, d3 = d + 4.0f;
     const float c0 = __fadd_rn(__fmul_rn(d0 * d0, factor), f0);
     const float c1 = __fadd_rn(__fmul_rn(d1 * d1, factor), f1);
     const float c2 = __fadd_rn(__fmul_rn(d2 * d2, factor), f2);
     const float c3 = __fadd_rn(__fmul_rn(d3 * d3, factor), f3);
-    if (c0 < best) { best = c0; best_f = fj + 1.0f; }
-    if (c1 < best) { best = c1; best_f = fj + 2.0f; }
-    if (c2 < best) { best = c2; best_f = fj + 3.0f; }
-    if (c3 < best) { best = c3; best_f = fj + 4.0f; }
-    fj += 4.0f;
+    bd = c0 < b ? d0 : bd;
+    b = fminf(b, c0);
+    bd = c1 < b ? d1 : bd;
+    b = fminf(b, c1);
+    bd = c2 < b ? d2 : bd;
+    b = fminf(b, c2);
+    bd = c3 < b ? d3 : bd;
+    b = fminf(b, c3);
+    d = d3;
   }
-  best_j = static_cast<int>(best_f);
+  best = b;
+  best_j = static_cast<int>(fi + bd);
 }
 
 
@@ -582,11 +586,15 @@ __device__ void viterbi_forward(const PitchDevTables& t, const float* __restrict
       int best_j = 0x7fffffff;
       if (r < n_super) {
         const float fi = static_cast<float>(i_rep);
+        float d = static_cast<float>(sub) - fi, bd = 1.0e9f;
 #pragma unroll 9
         for (int j = sub; j < S; j += 16) {
-          const float c = trans_cost(j, fi, factor, sh.fwd[j]);
-          if (c < best) { best = c; best_j = j; }
+          const float c = __fadd_rn(__fmul_rn(d * d, factor), sh.fwd[j]);
+          bd = c < best ? d : bd;
+          best = fminf(best, c);
+          d += 16.0f;
         }
+        best_j = static_cast<int>(fi + bd);
       }
       quad_argmin(best, best_j);
       argmin_take(best, best_j, dpp_f<0x124>(best), dpp_i<0x124>(best_j));
@@ -612,20 +620,21 @@ __device__ void viterbi_forward(const PitchDevTables& t, const float* __restrict
         const float fi = static_cast<float>(i_rep);
         // (a step may look beyond `hi`: the argmin over ALL states lies inside the range, so the
         // extra candidates cannot win; the forward costs are padded with FLT_MAX behind the last state)
-        float fj = static_cast<float>(lo + sub), best_f = fj;
+        float d = static_cast<float>(lo + sub) - fi, bd = d;
         for (int j = lo + sub; j <= hi; j += 32) {
           float ff[8];
 #pragma unroll
           for (int w = 0; w < 8; ++w) ff[w] = sh.fwd[j + 4 * w];
 #pragma unroll
           for (int w = 0; w < 8; ++w) {
-            const float d = (fj + static_cast<float>(4 * w)) - fi;
-            const float c = (d * d) * factor + ff[w];
-            if (c < best) { best = c; best_f = fj + static_cast<float>(4 * w); }
+            const float dw = d + static_cast<float>(4 * w);
+            const float c = __fadd_rn(__fmul_rn(dw * dw, factor), ff[w]);
+            bd = c < best ? dw : bd;
+            best = fminf(best, c);
           }
-          fj += 32.0f;
+          d += 32.0f;
         }
-        best_j = static_cast<int>(best_f);
+        best_j = static_cast<int>(fi + bd);
       }
       quad_argmin(best, best_j);
       if (sub == 0 && i_rep < S) {
@@ -680,22 +689,27 @@ __device__ void viterbi_forward(const PitchDevTables& t, const float* __restrict
             const bool on = q0 + team < n_long;
             const int4 e = sh.queue[on ? q0 + team : 0];
             const float fi = static_cast<float>(e.x);
-            float cb = FLT_MAX;
+            float cb = FLT_MAX, cd = 1.0e9f;   // best cost, its d = j - i (no candidate: beyond every state)
             int cj = 0x7fffffff;
             if (on) {
               // four candidates of the lane in flight per step; a step may look up to 31 states beyond the
               // window: the argmin over ALL states lies inside it (monotonicity), so the extra candidates
               // cannot win, and the forward costs are padded with FLT_MAX behind the last state
+              float d = static_cast<float>(e.y + tl) - fi;
               for (int j = e.y + tl; j <= e.z; j += 32) {
                 float ff[4];
 #pragma unroll
                 for (int w = 0; w < 4; ++w) ff[w] = sh.fwd[j + 8 * w];
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                  const float c = trans_cost(j + 8 * w, fi, factor, ff[w]);
-                  if (c < cb) { cb = c; cj = j + 8 * w; }
+                  const float dw = d + static_cast<float>(8 * w);
+                  const float c = __fadd_rn(__fmul_rn(dw * dw, factor), ff[w]);
+                  cd = c < cb ? dw : cd;
+                  cb = fminf(cb, c);
                 }
+                d += 32.0f;
               }
+              cj = static_cast<int>(fi + cd);
             }
             quad_argmin(cb, cj);
             argmin_take(cb, cj, dpp_f<0x141>(cb), dpp_i<0x141>(cj));  // row_half_mirror: the other quad
