@@ -264,7 +264,8 @@ constexpr int kNccfWaves = 12;  // 48 frames per workgroup: two workgroups per C
 constexpr int kFwdPad = 36;    // FLT_MAX entries behind the forward costs (unclamped scan steps)
 constexpr int kLongRange3 = 32;  // level 3 / levels 4-5: windows of at least this many candidates go to the
 constexpr int kLongRange4 = 16;  // 8-lane teams instead of one lane (flat between 8 and 32: measured)
-constexpr int kQueueFloats = 64 * 4;  // long-window queue of a wave: 64 x int4
+constexpr int kQueueEntries = 128;                // long-window queue of a wave: int4 (state, lo, hi, -)
+constexpr int kQueueFloats = kQueueEntries * 4;
 constexpr int kVitWaves = 8;   // utterances (= wavefronts) per workgroup of the Viterbi kernel
 
 // LDS layout of one frame of an NCCF wave: the window (wl floats), then the NCCF at the integer lags.
@@ -658,6 +659,7 @@ __device__ void viterbi_forward(const PitchDevTables& t, const float* __restrict
       const int count = level == 3 ? ((S + 7) >> 3) - ((S + 31) >> 5)
                                    : (level == 4 ? (S + 3) >> 3 : S - ((S + 3) >> 2));
       const int long_range = level == 3 ? kLongRange3 : kLongRange4;
+      int n_queued = 0;
       for (int k0 = 0; k0 < count; k0 += 64) {
         const int k = k0 + lane < count ? k0 + lane : 0;
         const int i = level == 3 ? (k + k / 3 + 1) << 3 : (level == 4 ? 4 + 8 * k : k + k / 3 + 1);
@@ -673,20 +675,23 @@ __device__ void viterbi_forward(const PitchDevTables& t, const float* __restrict
           sh.bpw[i] = best_j;
           sh.nxt[i] = best + sh.nxt[i];
         }
-        // Long windows (a step of the backpointer function between two attracting states: ~5 states of a
-        // level-3 pass and ~15-45 of the level-4 passes per frame) go through a queue in LDS and are
-        // scanned by teams of 8 lanes, 8 windows per round: 8 candidates per step, a 3-step DPP argmin,
-        // the team's first lane stores.  (Round 2 handed them to 16-lane rows four at a time through
+        // Long windows (a step of the backpointer function between two attracting states: ~5 states of
+        // level 3 and ~15-45 of levels 4 and 5 per frame) are queued in LDS; the queue is worked off once
+        // per level (nothing in a level reads another state of the level), so that the rounds below run
+        // full: teams of 8 lanes, 8 windows per round, 32 candidates per step, a 3-step DPP argmin, the
+        // team's first lane stores.  (Round 2 handed them to 16-lane rows four at a time through
         // v_readlane broadcasts: ~250 instructions per round; that was most of the tracker's time.)
         const unsigned long long long_mask = __ballot(is_long);
         if (long_mask != 0) {
           if (is_long)
-            sh.queue[__popcll(long_mask & ((1ull << lane) - 1ull))] = make_int4(i, lo, hi, 0);
+            sh.queue[n_queued + __popcll(long_mask & ((1ull << lane) - 1ull))] = make_int4(i, lo, hi, 0);
+          n_queued += __popcll(long_mask);
+        }
+        if (n_queued > kQueueEntries - 64 || (k0 + 64 >= count && n_queued > 0)) {
           wave_sync();
-          const int n_long = __popcll(long_mask);
           const int team = lane >> 3, tl = lane & 7;
-          for (int q0 = 0; q0 < n_long; q0 += 8) {
-            const bool on = q0 + team < n_long;
+          for (int q0 = 0; q0 < n_queued; q0 += 8) {
+            const bool on = q0 + team < n_queued;
             const int4 e = sh.queue[on ? q0 + team : 0];
             const float fi = static_cast<float>(e.x);
             float cb = FLT_MAX, cd = 1.0e9f;   // best cost, its d = j - i (no candidate: beyond every state)
@@ -718,6 +723,7 @@ __device__ void viterbi_forward(const PitchDevTables& t, const float* __restrict
               sh.nxt[e.x] = cb + sh.nxt[e.x];
             }
           }
+          n_queued = 0;
           wave_sync();
         }
       }
