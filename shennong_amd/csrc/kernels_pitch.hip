@@ -263,7 +263,9 @@ constexpr int kLagGroup = 5;   // lags per lane and pass of the correlation
 constexpr int kNccfWaves = 12;  // 48 frames per workgroup: two workgroups per CU (LDS) = 6 waves per SIMD
 constexpr int kFwdPad = 36;    // FLT_MAX entries behind the forward costs (unclamped scan steps)
 constexpr int kLongRange3 = 32;  // level 3 / levels 4-5: windows of at least this many candidates go to the
-constexpr int kLongRange4 = 16;  // 8-lane teams instead of one lane (flat between 8 and 32: measured)
+constexpr int kLongRange4 = 12;  // 8-lane teams instead of one lane (flat between 8 and 32: measured)
+constexpr bool kSplitLevel5 = false;  // refine 4 -> 2 -> 1 instead of 4 -> 1: 27 % fewer candidates, one more level; measured slower (6.41 against 6.22 ms)
+constexpr bool kTracePrefetch = true; // traceback: touch the backpointer rows of a 64-frame chunk first
 constexpr int kQueueEntries = 128;                // long-window queue of a wave: int4 (state, lo, hi, -)
 constexpr int kQueueFloats = kQueueEntries * 4;
 constexpr int kVitWaves = 8;   // utterances (= wavefronts) per workgroup of the Viterbi kernel
@@ -651,18 +653,24 @@ __device__ void viterbi_forward(const PitchDevTables& t, const float* __restrict
     // backpointer function from one attracting state to the next - go to teams of 8 lanes (below).
     // (Round 2 refined through the strides 16, 8, 4, 2, 1: fewer candidates - 2 350 against 4 000 per
     // frame - but five levels of setup; measured with the same long-window teams: 9.6 against 8.5 ms.)
-    for (int level = 3; level <= 5; ++level) {
+    for (int level = 3; level <= (kSplitLevel5 ? 6 : 5); ++level) {
       wave_sync();
       // level 3: multiples of 8 that are not multiples of 32, neighbours 32 apart; level 4: the states
-      // 4, 12, 20, ..., neighbours 8 apart; level 5: every other state, neighbours 4 apart
-      const int gap = level == 3 ? 32 : (level == 4 ? 8 : 4);
+      // 4, 12, 20, ..., neighbours 8 apart; level 5: every other state, neighbours 4 apart (split form:
+      // level 5 the states 2, 6, 10, ..., level 6 the odd states, neighbours 2 apart)
+      const int gap = level == 3 ? 32 : (level == 4 ? 8 : (level == 5 ? 4 : 2));
       const int count = level == 3 ? ((S + 7) >> 3) - ((S + 31) >> 5)
-                                   : (level == 4 ? (S + 3) >> 3 : S - ((S + 3) >> 2));
+                        : level == 4 ? (S + 3) >> 3
+                        : !kSplitLevel5 ? S - ((S + 3) >> 2)
+                        : level == 5 ? (S + 1) >> 2 : S >> 1;
       const int long_range = level == 3 ? kLongRange3 : kLongRange4;
       int n_queued = 0;
       for (int k0 = 0; k0 < count; k0 += 64) {
         const int k = k0 + lane < count ? k0 + lane : 0;
-        const int i = level == 3 ? (k + k / 3 + 1) << 3 : (level == 4 ? 4 + 8 * k : k + k / 3 + 1);
+        const int i = level == 3 ? (k + k / 3 + 1) << 3
+                      : level == 4 ? 4 + 8 * k
+                      : !kSplitLevel5 ? k + k / 3 + 1
+                      : level == 5 ? 2 + 4 * k : 1 + 2 * k;
         const bool active = k0 + lane < count;
         const int below = i & ~(gap - 1), above = below + gap;
         const int lo = sh.bpw[below];
@@ -808,10 +816,39 @@ __global__ __launch_bounds__(kVitWaves * 64, 4) void pitch_viterbi_kernel(
       if (c < bv) { bv = c; best = s; }
     }
     wave_argmin(bv, best);
-    if (lane == 0) {
-      for (int64_t frame = T - 1; frame >= 0; --frame) {
-        states[f0 + frame] = best;
-        best = bp[frame * S + best];
+    if (!kTracePrefetch) {
+      if (lane == 0) {
+        for (int64_t frame = T - 1; frame >= 0; --frame) {
+          states[f0 + frame] = best;
+          best = bp[frame * S + best];
+        }
+      }
+    } else {
+      // 64 frames at a time.  The chain of dependent 2-byte loads is the whole cost (a trip to HBM per
+      // frame), so the wave first touches the rows of the chunk at the columns around the current state -
+      // the path moves a few states per frame, the touched lines hold 64 - and lane 0 then walks through
+      // lines that are already in the cache; the path goes to LDS and is written out 64 frames at once
+      // (a store inside the chain would be waited for together with every load).
+      int* trace = reinterpret_cast<int*>(sh.nxt);
+      for (int64_t hi = T; hi > 0; hi -= 64) {
+        const int n = hi < 64 ? static_cast<int>(hi) : 64;
+        best = __builtin_amdgcn_readfirstlane(best);
+        {
+          int col_t = best + ((lane & 32) ? 24 : -24);
+          col_t = col_t < 0 ? 0 : (col_t > S - 1 ? S - 1 : col_t);
+          const int64_t fa = hi - 1 - (lane & 31), fb = fa - 32;
+          const int16_t va = bp[(fa > 0 ? fa : 0) * S + col_t], vb = bp[(fb > 0 ? fb : 0) * S + col_t];
+          asm volatile("" : : "v"(va), "v"(vb));
+        }
+        if (lane == 0) {
+          for (int k = 0; k < n; ++k) {
+            trace[k] = best;
+            best = bp[(hi - 1 - k) * S + best];
+          }
+        }
+        wave_sync();
+        if (lane < n) states[f0 + hi - 1 - lane] = trace[lane];
+        wave_sync();
       }
     }
   }
