@@ -730,8 +730,21 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
     next_starts = starts_of((set + set_stride) * 4 + q);
     meta_next = meta_of(set * 4 + q);
   }
+  // Loads and stores share one in-order counter (vmcnt): the wait for the prefetched samples at the top of
+  // the loop also covers the output stores issued after them.  Here the prefetch is settled by hand in
+  // front of the iteration's first store (and once before the loop, so that no path into the loop head
+  // carries a pending load): 0.32 against 0.34 ms per 1.19 M frames.  (The same change on fbank512_kernel
+  // measured 5-10 % SLOWER, wherever the settle point was put, and was dropped there.)
+  auto settle_prefetch = [&]() {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(raw[j]));
+    asm volatile("" : "+v"(next_starts.x), "+v"(next_starts.y));
+    asm volatile("" : "+v"(meta_next.x), "+v"(meta_next.y), "+v"(meta_next.z), "+v"(meta_next.w));
+  };
+  settle_prefetch();
   for (; set < n_sets; set += set_stride) {
-    const int4 meta = meta_next, mmeta = meta_of(set * 4 + mj);  // (mmeta: the MFMA view's pair, below)
+    const int4 meta = meta_next;
+    int4 mmeta = meta_of(set * 4 + mj);  // (the MFMA view's pair, below)
     const int64_t ga = static_cast<int64_t>(static_cast<unsigned>(meta.x)) | (static_cast<int64_t>(meta.y) << 32);
     const bool valid_a = set * 4 + q <= last_pair, valid_b = valid_a && (meta.w & 4) != 0;
     const int edge_a = (meta.w & 1) ? meta.z : 0, edge_b = (meta.w & 2) ? meta.z : 0;
@@ -904,6 +917,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
     }
     const float p128_a = 4.0f * z[8].x * z[8].x, p128_b = 4.0f * z[8].y * z[8].y;  // lane 0: Z[128]
     wave_lds_sync();
+    settle_prefetch();
+    asm volatile("" : "+v"(mmeta.x), "+v"(mmeta.y), "+v"(mmeta.w));
     // ---- E: power tiles ----------------------------------------------------------------------------------
 #pragma unroll
     for (int k1 = 0; k1 < 8; ++k1) {
