@@ -20,6 +20,17 @@ rm -rf /tmp/prof_rates
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_rates -- \
   python $root/tools/profile_rates.py 10 > $out/other_rates_run.txt 2> /dev/null
 cp $(find /tmp/prof_rates -name '*kernel_stats.csv' | head -1) $out/other_rates_rocprofv3_kernel_stats.csv
+# SQ counters of the pitch kernels (one --pmc group per run)
+j=0
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+  j=$((j+1)); rm -rf /tmp/prof_pmcp_$j
+  timeout -s KILL 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/prof_pmcp_$j -- \
+    python $root/tools/profile_pitch.py 4000 pitch-only > /dev/null 2>&1
+  f=$(find /tmp/prof_pmcp_$j -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && cp $f $out/pmc_pitch_group_$j.csv
+done
+# SKIP_PMC=1: the counters of the mel kernels are kept from the last collection (kernels unchanged)
+if [ -z "$SKIP_PMC" ]; then
 # SQ counters of the long-frame and dual kernels (one --pmc group per run)
 j=0
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
@@ -41,7 +52,21 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   f=$(find /tmp/prof_pmc_$i -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && cp $f $out/pmc_group_$i.csv
 done
+fi
 cd $root
+python - <<'PY' | tee gpurun_out/profiles/pmc_pitch_summary.txt
+import csv, glob, collections
+acc = collections.defaultdict(list)
+for name in sorted(glob.glob('gpurun_out/profiles/pmc_pitch_group_*.csv')):
+    for r in csv.DictReader(open(name)):
+        k = r['Kernel_Name']
+        for tag in ('pitch_viterbi_kernel', 'pitch_nccf_kernel', 'pitch_resample_kernel'):
+            if tag in k:
+                acc[(tag, r['Counter_Name'])].append(float(r['Counter_Value']))
+for (tag, c), v in sorted(acc.items()):
+    print('%-24s %-24s %.5e per launch (n=%d)' % (tag, c, sum(v) / len(v), len(v)))
+PY
+[ -n "$SKIP_PMC" ] && { tail -c 400 $out/bench_default.json; exit 0; }
 python - <<'PY' | tee gpurun_out/profiles/pmc_fbank512_summary.txt
 import csv, glob, collections
 acc = collections.defaultdict(list)

@@ -6,7 +6,10 @@ from shennong_amd import _backend, synth
 from shennong_amd.processor import KaldiPitchProcessor, PlpProcessor
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 waves = synth.utterances(0, n, 48000)
-for proc in (KaldiPitchProcessor(), PlpProcessor(dither=0), PlpProcessor(dither=0, rasta=True)):
+procs = (KaldiPitchProcessor(), PlpProcessor(dither=0), PlpProcessor(dither=0, rasta=True))
+if len(sys.argv) > 2 and sys.argv[2] == 'pitch-only':   # (counter passes: the pitch kernels only)
+    procs = procs[:1]
+for proc in procs:
     plan = _backend.get_plan(proc._build_options())
     nf = plan.num_frames(48000)
     soff = np.arange(n + 1, dtype=np.int64) * 48000
