@@ -56,52 +56,91 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // loads - zeros outside the utterance: fmaf(w, 0, s) = s exactly, the accumulator never being -0 - and
 // every thread then runs Kaldi's tap loop (one sequential fmaf chain) from LDS.  The per-output gather
 // of 2-byte samples from global memory that this replaces took 0.68 ms per 192 M input samples.
+constexpr int kRsChunks = 4;   // 256-output chunks per workgroup of the resampler
+constexpr int kRsMaxPer = 6;   // staged samples per thread and chunk that travel through registers
+
 __global__ __launch_bounds__(256) void pitch_resample_kernel(const PitchDevTables t, const PitchBatch b,
                                                              float* __restrict__ down) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* xs = reinterpret_cast<float*>(smem);
-  // blockIdx.y = utterance (no per-thread search), blockIdx.x = 256-sample chunk of its output
+  // blockIdx.y = utterance (no per-thread search), blockIdx.x = kRsChunks consecutive 256-sample chunks of
+  // its output.  A workgroup that handles one chunk is a chain of four dependent memory round trips
+  // (offsets, samples, taps, store: 4 us for 250 instructions per wave, 0.375 ms per 192 M samples);
+  // here the offsets are read once and the samples of chunk c + 1 are in flight, in registers, while
+  // chunk c is filtered.
   const int64_t u = blockIdx.y;
   const int64_t d0 = b.down_offsets[u], nd = b.down_offsets[u + 1] - d0;
-  const int64_t k0 = static_cast<int64_t>(blockIdx.x) * blockDim.x;
-  if (k0 >= nd) return;
+  const int64_t k_begin = static_cast<int64_t>(blockIdx.x) * (256 * kRsChunks);
+  if (k_begin >= nd) return;
   const int64_t s0 = b.sample_offsets[u], n = b.sample_offsets[u + 1] - s0;
   const int16_t* __restrict__ w = b.wave + s0;
   // (32-bit index arithmetic: a 64-bit division costs ~100 instructions, three of them per output was
   // more than the filter itself; an utterance has fewer than 2^31 samples)
   const int out_unit = t.rs_out_unit, in_unit = t.rs_in_unit;
+  const int tid = static_cast<int>(threadIdx.x);
   auto first_of = [&](int k) -> int64_t {
     const int unit = k / out_unit;
     return t.rs_first[k - unit * out_unit] + static_cast<int64_t>(unit) * in_unit;
   };
-  const int k_first = static_cast<int>(k0);
-  const int k_last = k0 + blockDim.x - 1 < nd - 1 ? k_first + static_cast<int>(blockDim.x) - 1
-                                                    : static_cast<int>(nd) - 1;
-  const int64_t base = first_of(k_first);                   // (first inputs are non-decreasing in k)
-  const int span = static_cast<int>(first_of(k_last) + t.rs_max_taps - base);
-  for (int i = threadIdx.x; i < span; i += blockDim.x) {
-    const int64_t j = base + i;
-    xs[i] = (j >= 0 && j < n) ? static_cast<float>(w[j]) : 0.0f;
+  // input span of the chunk that starts at output k0: [base, base + span)
+  auto geometry = [&](int64_t k0, int64_t* base, int* span) {
+    const int k_first = static_cast<int>(k0);
+    const int k_last = k0 + 255 < nd - 1 ? k_first + 255 : static_cast<int>(nd) - 1;
+    *base = first_of(k_first);                               // (first inputs are non-decreasing in k)
+    *span = static_cast<int>(first_of(k_last) + t.rs_max_taps - *base);
+  };
+  auto sample = [&](int64_t j) -> float { return (j >= 0 && j < n) ? static_cast<float>(w[j]) : 0.0f; };
+  // samples in flight: raw 16-bit values from clamped (always valid) addresses, no branch and no
+  // conversion until they are staged - a conversion here would wait for every load on the spot
+  auto fetch = [&](int64_t j) -> int {
+    const int64_t jc = j < 0 ? 0 : (j < n ? j : n - 1);
+    return w[jc];
+  };
+  int pre[kRsMaxPer];
+  int64_t base;
+  int span;
+  geometry(k_begin, &base, &span);
+#pragma unroll
+  for (int q = 0; q < kRsMaxPer; ++q) pre[q] = fetch(base + tid + 256 * q);
+  for (int c = 0; c < kRsChunks; ++c) {
+    const int64_t k0 = k_begin + 256 * c;
+    if (k0 >= nd) break;
+    // stage the chunk: zeros outside the utterance (fmaf(w, 0, s) = s exactly, s never being -0)
+#pragma unroll
+    for (int q = 0; q < kRsMaxPer; ++q) {
+      const int64_t j = base + tid + 256 * q;
+      if (tid + 256 * q < span) xs[tid + 256 * q] = (j >= 0 && j < n) ? static_cast<float>(pre[q]) : 0.0f;
+    }
+    for (int i = tid + 256 * kRsMaxPer; i < span; i += 256) xs[i] = sample(base + i);  // (rate ratios above 5)
+    __syncthreads();
+    const int64_t base_cur = base;
+    if (c + 1 < kRsChunks && k0 + 256 < nd) {
+      geometry(k0 + 256, &base, &span);
+#pragma unroll
+      for (int q = 0; q < kRsMaxPer; ++q) pre[q] = fetch(base + tid + 256 * q);
+    }
+    const int k = static_cast<int>(k0) + tid;
+    if (k < nd) {
+      float s = 0.0f;
+      if (out_unit == 1) {
+        // one filter for every output (integer rate ratios, e.g. 16 kHz -> 4 kHz): uniform weights.  (A
+        // de-interleaved LDS layout that makes the tap reads conflict-free was measured: slower, 0.63 ms
+        // against 0.375 - the strided staging costs more than the conflicts)
+        const float* __restrict__ x = xs + (t.rs_first[0] + static_cast<int64_t>(k) * in_unit - base_cur);
+        const int ntaps = t.rs_ntaps[0];
+        for (int i = 0; i < ntaps; ++i) s = __builtin_fmaf(t.rs_w[i], x[i], s);
+      } else {
+        const int unit = k / out_unit, wrapped = k - unit * out_unit;
+        const float* __restrict__ x =
+            xs + (t.rs_first[wrapped] + static_cast<int64_t>(unit) * in_unit - base_cur);
+        const float* __restrict__ wt = t.rs_w + wrapped * t.rs_max_taps;
+        const int ntaps = t.rs_ntaps[wrapped];
+        for (int i = 0; i < ntaps; ++i) s = __builtin_fmaf(wt[i], x[i], s);
+      }
+      down[d0 + k] = s;
+    }
+    __syncthreads();  // (the next chunk overwrites the staged span)
   }
-  __syncthreads();
-  const int k = k_first + static_cast<int>(threadIdx.x);
-  if (k >= nd) return;
-  float s = 0.0f;
-  if (out_unit == 1) {
-    // one filter for every output (integer rate ratios, e.g. 16 kHz -> 4 kHz): uniform weights.  (A
-    // de-interleaved LDS layout that makes the tap reads conflict-free was measured: slower, 0.63 ms
-    // against 0.375 - the strided staging costs more than the conflicts)
-    const float* __restrict__ x = xs + (t.rs_first[0] + static_cast<int64_t>(k) * in_unit - base);
-    const int ntaps = t.rs_ntaps[0];
-    for (int i = 0; i < ntaps; ++i) s = __builtin_fmaf(t.rs_w[i], x[i], s);
-  } else {
-    const int unit = k / out_unit, wrapped = k - unit * out_unit;
-    const float* __restrict__ x = xs + (t.rs_first[wrapped] + static_cast<int64_t>(unit) * in_unit - base);
-    const float* __restrict__ wt = t.rs_w + wrapped * t.rs_max_taps;
-    const int ntaps = t.rs_ntaps[wrapped];
-    for (int i = 0; i < ntaps; ++i) s = __builtin_fmaf(wt[i], x[i], s);
-  }
-  down[d0 + k] = s;
 }
 
 // ---- 2. signal statistics for the NCCF ballast -----------------------------------------------------
@@ -888,7 +927,7 @@ int launch_pitch(const PitchDevTables& t, const PitchBatch& b, const PitchScratc
       if (span_lds > 64 * 1024)
         return set_error(SNF_E_RUNTIME, "pitch resampler: the input span of a workgroup does not fit in LDS");
       hipLaunchKernelGGL(pitch_resample_kernel,
-                         dim3(static_cast<unsigned>((b.max_down + threads - 1) / threads),
+                         dim3(static_cast<unsigned>((b.max_down + threads * kRsChunks - 1) / (threads * kRsChunks)),
                               static_cast<unsigned>(nu)),
                          dim3(threads), span_lds, stream, t, bs, w.down);
       SNF_HIP_CHECK(hipGetLastError());
