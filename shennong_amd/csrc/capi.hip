@@ -931,12 +931,18 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
   const bool fused = plan->fp.fused_delta != 0;
   if (fused && !use_fast)
     return set_error(SNF_E_RUNTIME, "append_deltas: this batch cannot run on the 512-point path");
+  // Two-frames-per-row plans (fbank256x2_kernel) in a batch with VTLN warps: the kernel an utterance runs
+  // on must not depend on its neighbours (the two forms round differently in the last bits), so the
+  // unwarped utterances keep the two-frame kernel and only the warped ones take the zero-extended
+  // 512-point form with their per-warp tables - two launches over disjoint sets of utterances.
+  const bool split_dual = use_fast && plan->fp.dual && any_warp && !fused;
   if (use_fast && (any_warp || fused)) {
     // workgroup -> (utterance, first frame set) list: every workgroup stages the tables of one warp
     // (fused deltas: a workgroup owns a run of frames of one utterance + their delta halo)
     const int kSetsPerBlock = fused ? kFast512FusedSets : 64;  // (kernels_fbank512.hip)
     std::vector<int32_t> blk_utt, blk_set0;
     for (int64_t u = 0; u < n_utts; ++u) {
+      if (split_dual && warp_ids[u] == 0) continue;  // (runs on fbank256x2_kernel: below)
       const int64_t sets = (frame_offsets[u + 1] - frame_offsets[u] + 3) / 4;
       for (int64_t s0 = 0; s0 < sets; s0 += kSetsPerBlock) {
         blk_utt.push_back(static_cast<int32_t>(u));
@@ -948,12 +954,17 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     b.blk_utt = plan->s_blk_utt.as<int32_t>();
     b.blk_set0 = plan->s_blk_set0.as<int32_t>();
     b.n_blocks = static_cast<int64_t>(blk_utt.size());
-  } else if (use_fast && plan->fp.dual) {
+  }
+  BatchArgs b_dual = b;  // the arguments of the two-frame kernel (all utterances, or the unwarped ones)
+  if (use_fast && plan->fp.dual && (!any_warp || split_dual)) {
     // fbank256x2_kernel: frame pairs formed inside every utterance (PairRec), built once per offsets table
+    // (a batch split by warp factor: pairs of the unwarped utterances only, rebuilt on every call)
+    if (split_dual) plan->pairs_valid = false;
     if (!plan->pairs_valid) {
       std::vector<int64_t> poff(static_cast<size_t>(n_utts) + 1, 0);
       for (int64_t u = 0; u < n_utts; ++u)
-        poff[u + 1] = poff[u] + (frame_offsets[u + 1] - frame_offsets[u] + 1) / 2;
+        poff[u + 1] = poff[u] + ((split_dual && warp_ids[u] != 0)
+                                     ? 0 : (frame_offsets[u + 1] - frame_offsets[u] + 1) / 2);
       plan->n_pairs = poff[n_utts];
       if ((rc = plan->s_poff.upload(poff, s))) return rc;
       if ((rc = plan->s_pairs.ensure(sizeof(PairRec) * static_cast<size_t>(plan->n_pairs)))) return rc;
@@ -963,11 +974,15 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
                                         plan->s_pairs.as<PairRec>(), s)))
         return rc;
       if (!own_stream) SNF_HIP_CHECK(hipStreamSynchronize(s));  // (cached: see below)
-      plan->pairs_valid = true;
+      plan->pairs_valid = !split_dual;
     }
-    b.pair_tab = plan->s_pairs.as<PairRec>();
-    b.n_pairs = plan->n_pairs;
-  } else if (!plan->setidx_valid) {
+    b_dual.pair_tab = plan->s_pairs.as<PairRec>();
+    b_dual.n_pairs = plan->n_pairs;
+    b_dual.blk_utt = nullptr;
+    b_dual.blk_set0 = nullptr;
+    b_dual.n_blocks = 0;
+    b_dual.utt_warp = nullptr;
+  } else if (!(use_fast && (any_warp || fused)) && !plan->setidx_valid) {
     // frame -> first-sample index, edge marks and utterance index: built once per offsets table,
     // reused by later calls (fast kernel: bulk loads; generic kernel: no per-frame binary search)
     if ((rc = plan->s_setidx.ensure(sizeof(int64_t) * static_cast<size_t>(total_frames)))) return rc;
@@ -990,13 +1005,24 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     const unsigned long long stream_key = plan->o.seed + 0x9E3779B97F4A7C15ull * ++plan->noise_calls;
     plan->mp.seed = plan->fp.seed = plan->fp_warp.seed = stream_key;
   }
+  // the register-resident 512-point family: one launch, or two over disjoint utterances (split_dual)
+  auto run_fast = [&](float* out, int cols, double* energy) -> int {
+    int rc2;
+    if (plan->fp.dual && (!any_warp || split_dual)) {
+      if (b_dual.n_pairs > 0) {
+        if ((rc2 = launch_fbank512(plan->fp, b_dual, out, cols, energy, s))) return rc2;
+        if (own_stream) mark_kernel(plan, "fbank256x2_kernel");
+      }
+      if (!split_dual || b.n_blocks == 0) return SNF_OK;
+    }
+    if ((rc2 = launch_fbank512(any_warp ? plan->fp_warp : plan->fp, b, out, cols, energy, s))) return rc2;
+    if (own_stream) mark_kernel(plan, "fbank512_kernel");
+    return SNF_OK;
+  };
   if (plan->kind == SNF_KIND_PLP) {
     const int nb = plan->o.mel.num_bins;
     if (use_fast) {
-      if ((rc = launch_fbank512(any_warp ? plan->fp_warp : plan->fp, b, plan->s_mel.as<float>(), nb,
-                                plan->s_energy.as<double>(), s)))
-        return rc;
-      if (own_stream) mark_kernel(plan, (plan->fp.dual && !any_warp) ? "fbank256x2_kernel" : "fbank512_kernel");
+      if ((rc = run_fast(plan->s_mel.as<float>(), nb, plan->s_energy.as<double>()))) return rc;
     } else if (use_long) {
       if ((rc = launch_fbank2048(plan->mp, b, plan->d_long_tables.as<float>(), plan->s_mel.as<float>(), nb,
                                  plan->s_energy.as<double>(), s)))
@@ -1018,9 +1044,7 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     if (own_stream) mark_kernel(plan, "plp_tail_kernel");
   } else {
     if (use_fast) {
-      if ((rc = launch_fbank512(any_warp ? plan->fp_warp : plan->fp, b, d_out, plan->ndims, nullptr, s)))
-        return rc;
-      if (own_stream) mark_kernel(plan, (plan->fp.dual && !any_warp) ? "fbank256x2_kernel" : "fbank512_kernel");
+      if ((rc = run_fast(d_out, plan->ndims, nullptr))) return rc;
     } else if (use_long) {
       if ((rc = launch_fbank2048(plan->mp, b, plan->d_long_tables.as<float>(), d_out, plan->ndims, nullptr, s)))
         return rc;
