@@ -93,7 +93,7 @@ struct snf_plan {
 
   // scratch (host-pointer entry points and intermediates)
   DevBuf s_wave, s_out, s_in, s_soff, s_foff, s_uwarp, s_mel, s_energy;
-  DevBuf s_down, s_stats, s_bp, s_doff, s_dp1, s_fp1, s_states, s_setidx, s_edge, s_futt, s_poff, s_pairs;
+  DevBuf s_down, s_stats, s_bp, s_doff, s_dp1, s_fp1, s_states, s_setidx, s_edge, s_futt, s_poff, s_pairs, s_umask;
   DevBuf s_pres, s_anp;  // pitch: NCCF at the lag of every state [frames, states], norm average [frames]
   bool setidx_valid = false;
   bool pairs_valid = false;   // s_pairs / n_pairs describe the cached offsets tables
@@ -921,15 +921,29 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     if ((rc = sync_fast_warp_tables(plan))) return rc;
     use_fast = plan->fast_warps_ok;
   }
+  // snip_edges = false: the clamped bulk loads of the centred frames need an utterance that holds one full
+  // window.  A shorter utterance ALWAYS runs on the generic kernel, whatever else is in the batch (the
+  // register-resident kernels leave it out, or compute its frames from some window inside the batch and
+  // have them overwritten by the masked generic launch below); a batch shorter than one window holds
+  // nothing but such utterances.
+  std::vector<uint8_t> short_mask;
+  bool any_short = false;
   if ((use_fast || use_long) && !plan->mp.snip_edges) {
-    // the clamped bulk loads of the centred frames need every utterance to hold one full window
-    for (int64_t u = 0; u < n_utts && (use_fast || use_long); ++u) {
-      const int64_t n = sample_offsets[u + 1] - sample_offsets[u];
-      if (n > 0 && n < plan->mp.win_len) use_fast = use_long = false;
+    if (sample_offsets[n_utts] < plan->mp.win_len) {
+      use_fast = use_long = false;
+    } else {
+      short_mask.assign(static_cast<size_t>(n_utts), 0);
+      for (int64_t u = 0; u < n_utts; ++u) {
+        const int64_t n = sample_offsets[u + 1] - sample_offsets[u];
+        if (n > 0 && n < plan->mp.win_len && frame_offsets[u + 1] > frame_offsets[u]) {
+          short_mask[u] = 1;
+          any_short = true;
+        }
+      }
     }
   }
   const bool fused = plan->fp.fused_delta != 0;
-  if (fused && !use_fast)
+  if (fused && (!use_fast || any_short))
     return set_error(SNF_E_RUNTIME, "append_deltas: this batch cannot run on the 512-point path");
   // Two-frames-per-row plans (fbank256x2_kernel) in a batch with VTLN warps: the kernel an utterance runs
   // on must not depend on its neighbours (the two forms round differently in the last bits), so the
@@ -943,6 +957,7 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     std::vector<int32_t> blk_utt, blk_set0;
     for (int64_t u = 0; u < n_utts; ++u) {
       if (split_dual && warp_ids[u] == 0) continue;  // (runs on fbank256x2_kernel: below)
+      if (any_short && short_mask[u]) continue;       // (runs on the generic kernel: below)
       const int64_t sets = (frame_offsets[u + 1] - frame_offsets[u] + 3) / 4;
       for (int64_t s0 = 0; s0 < sets; s0 += kSetsPerBlock) {
         blk_utt.push_back(static_cast<int32_t>(u));
@@ -959,11 +974,11 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
   if (use_fast && plan->fp.dual && (!any_warp || split_dual)) {
     // fbank256x2_kernel: frame pairs formed inside every utterance (PairRec), built once per offsets table
     // (a batch split by warp factor: pairs of the unwarped utterances only, rebuilt on every call)
-    if (split_dual) plan->pairs_valid = false;
+    if (split_dual || any_short) plan->pairs_valid = false;
     if (!plan->pairs_valid) {
       std::vector<int64_t> poff(static_cast<size_t>(n_utts) + 1, 0);
       for (int64_t u = 0; u < n_utts; ++u)
-        poff[u + 1] = poff[u] + ((split_dual && warp_ids[u] != 0)
+        poff[u + 1] = poff[u] + (((split_dual && warp_ids[u] != 0) || (any_short && short_mask[u]))
                                      ? 0 : (frame_offsets[u + 1] - frame_offsets[u] + 1) / 2);
       plan->n_pairs = poff[n_utts];
       if ((rc = plan->s_poff.upload(poff, s))) return rc;
@@ -974,7 +989,7 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
                                         plan->s_pairs.as<PairRec>(), s)))
         return rc;
       if (!own_stream) SNF_HIP_CHECK(hipStreamSynchronize(s));  // (cached: see below)
-      plan->pairs_valid = !split_dual;
+      plan->pairs_valid = !split_dual && !any_short;
     }
     b_dual.pair_tab = plan->s_pairs.as<PairRec>();
     b_dual.n_pairs = plan->n_pairs;
@@ -989,7 +1004,7 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     if ((rc = plan->s_edge.ensure(sizeof(int32_t) * static_cast<size_t>(total_frames)))) return rc;
     if ((rc = plan->s_futt.ensure(sizeof(int32_t) * static_cast<size_t>(total_frames)))) return rc;
     if ((rc = launch_build_frame_start(plan->s_foff.as<int64_t>(), plan->s_soff.as<int64_t>(), n_utts,
-                                       total_frames, plan->mp.win_shift, plan->mp.win_len,
+                                       total_frames, sample_offsets[n_utts], plan->mp.win_shift, plan->mp.win_len,
                                        plan->mp.snip_edges, plan->s_setidx.as<int64_t>(),
                                        plan->s_edge.as<int32_t>(), plan->s_futt.as<int32_t>(), s)))
       return rc;
@@ -1013,10 +1028,22 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
         if ((rc2 = launch_fbank512(plan->fp, b_dual, out, cols, energy, s))) return rc2;
         if (own_stream) mark_kernel(plan, "fbank256x2_kernel");
       }
-      if (!split_dual || b.n_blocks == 0) return SNF_OK;
+      if (!split_dual) return SNF_OK;
     }
+    if (b.blk_utt != nullptr && b.n_blocks == 0) return SNF_OK;  // (no utterance left for this form)
     if ((rc2 = launch_fbank512(any_warp ? plan->fp_warp : plan->fp, b, out, cols, energy, s))) return rc2;
     if (own_stream) mark_kernel(plan, "fbank512_kernel");
+    return SNF_OK;
+  };
+  // utterances shorter than a window (snip_edges = false), after the register-resident kernels
+  auto run_short = [&](float* out, int cols, double* energy) -> int {
+    if (!any_short || !(use_fast || use_long)) return SNF_OK;
+    int rc2;
+    if ((rc2 = plan->s_umask.upload(short_mask, s))) return rc2;
+    BatchArgs bm = b;
+    bm.utt_mask = plan->s_umask.as<uint8_t>();
+    if ((rc2 = launch_mel_features(plan->mp, bm, out, cols, energy, s))) return rc2;
+    if (own_stream) mark_kernel(plan, "mel_features_generic_kernel");
     return SNF_OK;
   };
   if (plan->kind == SNF_KIND_PLP) {
@@ -1034,6 +1061,7 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
         return rc;
       if (own_stream) mark_kernel(plan, "mel_features_generic_kernel");
     }
+    if ((rc = run_short(plan->s_mel.as<float>(), nb, plan->s_energy.as<double>()))) return rc;
     if (plan->o.rasta) {
       if ((rc = launch_rasta(plan->s_mel.as<float>(), b, nb, s))) return rc;
       if (own_stream) mark_kernel(plan, "rasta_kernel");
@@ -1053,6 +1081,7 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
       if ((rc = launch_mel_features(plan->mp, b, d_out, plan->ndims, nullptr, s))) return rc;
       if (own_stream) mark_kernel(plan, "mel_features_generic_kernel");
     }
+    if ((rc = run_short(d_out, plan->ndims, nullptr))) return rc;
   }
   if (own_stream) SNF_HIP_CHECK(hipStreamSynchronize(s));
   return SNF_OK;

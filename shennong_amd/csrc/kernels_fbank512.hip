@@ -1057,8 +1057,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
 // for the bulk loads and frame_edge marks them for the reflecting reload.
 __global__ void build_frame_start_kernel(const int64_t* __restrict__ frame_offsets,
                                          const int64_t* __restrict__ sample_offsets, int64_t n_utts,
-                                         int64_t total_frames, int win_shift, int win_len,
-                                         int snip_edges, int64_t* __restrict__ frame_start,
+                                         int64_t total_frames, int64_t total_samples, int win_shift,
+                                         int win_len, int snip_edges, int64_t* __restrict__ frame_start,
                                          int32_t* __restrict__ frame_edge,
                                          int32_t* __restrict__ frame_utt) {
   const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -1074,8 +1074,12 @@ __global__ void build_frame_start_kernel(const int64_t* __restrict__ frame_offse
   const int64_t rel = f * win_shift + win_shift / 2 - win_len / 2;
   const bool edge = rel < 0 || rel + win_len > n;
   int64_t safe = rel < 0 ? 0 : rel;
-  if (safe + win_len > n) safe = n - win_len;  // n >= win_len is checked by the host
-  frame_start[g] = s0 + safe;
+  if (safe + win_len > n) safe = n - win_len;
+  // an utterance shorter than a window (its frames are recomputed by the generic kernel afterwards, the
+  // host sees to that): any window inside the batch will do
+  int64_t abs_start = s0 + safe;
+  if (abs_start + win_len > total_samples) abs_start = total_samples - win_len;
+  frame_start[g] = abs_start < 0 ? 0 : abs_start;
   frame_edge[g] = edge ? static_cast<int32_t>(u + 1) : 0;
 }
 
@@ -1131,14 +1135,14 @@ int launch_build_pair_table(const int64_t* d_frame_offsets, const int64_t* d_sam
 }
 
 int launch_build_frame_start(const int64_t* d_frame_offsets, const int64_t* d_sample_offsets,
-                             int64_t n_utts, int64_t total_frames, int win_shift, int win_len,
-                             int snip_edges, int64_t* d_frame_start, int32_t* d_frame_edge,
+                             int64_t n_utts, int64_t total_frames, int64_t total_samples, int win_shift,
+                             int win_len, int snip_edges, int64_t* d_frame_start, int32_t* d_frame_edge,
                              int32_t* d_frame_utt, hipStream_t stream) {
   if (total_frames <= 0) return SNF_OK;
   hipLaunchKernelGGL(build_frame_start_kernel,
                      dim3(static_cast<unsigned>((total_frames + 255) / 256)), dim3(256), 0, stream,
-                     d_frame_offsets, d_sample_offsets, n_utts, total_frames, win_shift, win_len,
-                     snip_edges, d_frame_start, d_frame_edge, d_frame_utt);
+                     d_frame_offsets, d_sample_offsets, n_utts, total_frames, total_samples, win_shift,
+                     win_len, snip_edges, d_frame_start, d_frame_edge, d_frame_utt);
   SNF_HIP_CHECK(hipGetLastError());
   return SNF_OK;
 }

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(kWaves * 64, 8) void mel_features_generic_kernel(
     // (frame -> utterance table when the host built one: the binary search is a chain of ~14
     // dependent loads per frame)
     const int64_t u = b.frame_utt ? b.frame_utt[g] : find_utt(b.frame_offsets, b.n_utts, g);
+    if (b.utt_mask && !b.utt_mask[u]) continue;  // (a wave-uniform choice: one frame per wave)
     const int64_t f = g - b.frame_offsets[u];
     const int64_t s0 = b.sample_offsets[u];
     const int64_t n = b.sample_offsets[u + 1] - s0;

@@ -127,6 +127,7 @@ struct BatchArgs {
   const int32_t* frame_utt;       // [total_frames] utterance of every frame (generic kernel)
   const int32_t* blk_utt;         // [n_blocks] fast path with VTLN warps: utterance of every workgroup
   const int32_t* blk_set0;        // [n_blocks] ... and its first frame set inside that utterance
+  const uint8_t* utt_mask;        // [n_utts] generic kernel: when set, only the utterances marked 1 are computed
   const PairRec* pair_tab;        // [n_pairs] fbank256x2_kernel only
   int64_t n_pairs;
   int64_t n_blocks;
@@ -207,8 +208,8 @@ int launch_build_pair_table(const int64_t* d_frame_offsets, const int64_t* d_sam
                             const int64_t* d_pair_offsets, int64_t n_utts, int64_t n_pairs, int win_shift,
                             int win_len, int snip_edges, PairRec* d_pairs, hipStream_t stream);
 int launch_build_frame_start(const int64_t* d_frame_offsets, const int64_t* d_sample_offsets,
-                             int64_t n_utts, int64_t total_frames, int win_shift, int win_len,
-                             int snip_edges, int64_t* d_frame_start, int32_t* d_frame_edge,
+                             int64_t n_utts, int64_t total_frames, int64_t total_samples, int win_shift,
+                             int win_len, int snip_edges, int64_t* d_frame_start, int32_t* d_frame_edge,
                              int32_t* d_frame_utt, hipStream_t stream);
 int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int out_cols,
                     double* energy_out, hipStream_t stream);

@@ -509,10 +509,11 @@ def test_fast_kernel_centred_frames(gpu, synth_waves, cls):
         want = _oracle(proc, w)
         assert f.shape == want.shape
         assert_close(f.data, want, rtol=2e-4, what=cls.__name__)
-    # an utterance shorter than one window cannot take the clamped bulk loads: generic kernel
+    # an utterance shorter than one window cannot take the clamped bulk loads: it runs on the generic
+    # kernel (a second, masked launch), the other utterance stays where it always runs
     short = [waves[0], np.asarray(waves[1][:300])]
     feats = proc._process_batch([Audio(w, 16000) for w in short])
-    assert plan.kernel_name(1) == 'mel_features_generic_kernel'
+    assert (plan.kernel_name(1), plan.kernel_name(2)) == ('fbank512_kernel', 'mel_features_generic_kernel')
     for w, f in zip(short, feats):
         assert_close(f.data, _oracle(proc, w), rtol=2e-4, what='short')
 
@@ -595,12 +596,16 @@ def test_features_do_not_depend_on_the_batch(gpu, cls, sample_rate, opts, snip_e
     shift = int(round(opts.get('frame_shift', 0.01) * sample_rate))
     length = int(round(opts.get('frame_length', 0.025) * sample_rate))
     lengths = [length + shift * k + r for k, r in [(6, 3), (0, 0), (11, 7), (4, 1), (1, 0), (9, 5)]]
+    # shorter than one window: no frame with snip_edges, reflected frames (generic kernel, alone or not)
+    # without
+    lengths.append(length - shift // 2 - 3)
     waves = [synth.utterances(31 + i, 1, n, sample_rate)[0] for i, n in enumerate(lengths)]
     proc = cls(sample_rate=sample_rate, dither=0, snip_edges=snip_edges, **opts)
     audios = [Audio(w, sample_rate) for w in waves]
     alone = [proc._process_batch([a])[0].data for a in audios]
-    assert len({a.shape[0] % 2 for a in alone}) == 2      # odd and even frame counts both present
-    for order in ([0, 1, 2, 3, 4, 5], [5, 3, 1, 4, 2, 0], [2, 2, 1, 0]):
+    assert len({a.shape[0] % 2 for a in alone[:6]}) == 2      # odd and even frame counts both present
+    assert alone[6].shape[0] == (0 if snip_edges else (lengths[6] + shift // 2) // shift)
+    for order in ([0, 1, 2, 3, 4, 5], [5, 3, 1, 4, 2, 0], [2, 2, 1, 0], [6, 0, 3], [4, 6], [6, 6]):
         together = proc._process_batch([audios[i] for i in order])
         for i, f in zip(order, together):
             assert f.data.shape == alone[i].shape
