@@ -241,6 +241,12 @@ int64_t snf_plan_num_frames(const snf_plan* plan, int64_t num_samples);
  *   out             concatenated row-major float32 [frame_offsets[n_utts], ndims]
  *   frame_offsets   n_utts+1 row offsets; frame_offsets[u+1]-frame_offsets[u] must equal
  *                   snf_plan_num_frames(plan, samples of u)
+ * The rows of an utterance are the same bits whatever else is in the batch (the reference processes one
+ * utterance at a time: shennong/processor/base.py:150-180): the kernel an utterance runs on depends on the
+ * plan, on its own warp factor and on its own length only - a batch may therefore take more than one
+ * launch (unwarped / warped utterances of a two-frames-per-row plan; utterances shorter than one window
+ * with snip_edges = 0 go to the generic kernel).  Exception: dither != 0 (a random stream keyed by the
+ * frame's position in the batch).
  * Host-pointer variant: stages through device memory owned by the plan (H2D, kernels, D2H).
  */
 int snf_plan_run_batch(snf_plan* plan, const int16_t* wave, const int64_t* sample_offsets,
