@@ -24,6 +24,12 @@ from shennong_amd import _backend
 _PORT_OFFSET = 1017   # rendezvous port = MASTER_PORT + this (MASTER_PORT itself belongs to the launcher)
 
 
+def rendezvous_port(master_port):
+    """Port of this module's own rendezvous: next to the launcher's, inside the valid range"""
+    port = master_port + _PORT_OFFSET
+    return port if port <= 65535 else master_port - _PORT_OFFSET
+
+
 def _send_msg(sock, payload):
     sock.sendall(struct.pack('<Q', len(payload)) + payload)
 
@@ -92,7 +98,7 @@ class RcclComm:
         return cls(rank, int(os.environ.get('WORLD_SIZE', '1')),
                    device=local if device is None else device,
                    addr=os.environ.get('MASTER_ADDR', '127.0.0.1'),
-                   port=int(os.environ.get('MASTER_PORT', '29500')) + _PORT_OFFSET)
+                   port=rendezvous_port(int(os.environ.get('MASTER_PORT', '29500'))))
 
     def close(self):
         if self._handle:

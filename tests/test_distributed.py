@@ -229,6 +229,15 @@ def test_streamed_sharded_gloo(tmp_path):
     assert [open(tmp_path / f'ok{r}').read() for r in range(2)] == ['1', '1']
 
 
+def test_rendezvous_port_next_to_the_launchers():
+    """the transport's own rendezvous never takes MASTER_PORT (the launcher's store lives there) and
+    stays inside the valid port range"""
+    from shennong_amd.comm import rendezvous_port
+    for master in (1024, 29500, 64518, 64519, 65535):
+        port = rendezvous_port(master)
+        assert port != master and 0 < port <= 65535
+
+
 # ---- RCCL transport through the C ABI (needs a GPU; the test box has one: world size 1) ---------------
 @pytest.mark.gpu
 def test_rccl_comm_world_of_one():
