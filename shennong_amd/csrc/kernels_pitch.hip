@@ -7,14 +7,16 @@
 // offline single-chunk call the reference makes (frames_per_chunk = 0).
 //
 // Four launches per batch:
-//   1. pitch_resample_kernel  one thread per downsampled sample: 16 kHz -> 4 kHz windowed-sinc FIR
+//   1. pitch_resample_kernel  one thread per downsampled sample: 16 kHz -> 4 kHz windowed-sinc FIR (a
+//                             workgroup filters 4 chunks of 256 samples, the next chunk's input in flight)
 //   2. pitch_stats_kernel     one workgroup per utterance: signal sum / sum of squares, from which
 //                             one thread derives the NCCF ballasts of the utterance
 //   3. pitch_nccf_kernel      FRAME-parallel (nothing in it depends on the previous frame): wave64 =
 //                             4 frames x 16 lanes; lane l correlates the lags 5 l .. 5 l + 4 against
 //                             the frame's window in LDS (5 x 5 register blocks), NCCF with and
-//                             without ballast, then the 16 lanes resample the NCCF to the log-spaced
-//                             lags of the Viterbi states (sinc taps in LDS) -> [frames, states] in HBM
+//                             without ballast, then the NCCF is resampled to the log-spaced lags of the
+//                             Viterbi states on the matrix pipe (v_mfma_f32_4x4x1: 4 states x 4 frames
+//                             per block, one exact fused multiply-add per tap) -> [frames, states] in HBM
 //   4. pitch_viterbi_kernel   the only sequential part: one wavefront per utterance walks the frames,
 //                             local cost from the row of 3, exact argmin of the transition cost with
 //                             the monotone divide-and-conquer search, backpointers to HBM, traceback.
@@ -23,7 +25,9 @@
 // on the library build; the CPU oracle (oracle/kaldi_oracle.c, chain_dot / tree16) fixes ONE order and
 // these kernels implement exactly that order, so the tracker agrees with the oracle bit for bit and the
 // Viterbi paths are identical (a one-ulp difference in a cost flips near-ties in unvoiced regions):
-//   - FIR taps, lag correlations, sinc resampling: s = fmaf(a[i], b[i], s), i ascending, from 0;
+//   - FIR taps, lag correlations, sinc resampling: s = fmaf(a[i], b[i], s), i ascending, from 0 (the
+//     matrix-pipe form of the sinc resampling is the same chain: K = 1 per instruction, lags ascending,
+//     zero weights outside a state's taps);
 //   - frame mean / frame energy / norm average: lane l of 16 sums its elements l, l + 16, ...
 //     ascending, the 16 partial sums are added as a balanced tree of neighbours (DPP quad_perm xor 1,
 //     xor 2, row_half_mirror, row_mirror: every lane ends with the same bits);
