@@ -169,6 +169,23 @@ def test_pitch(gpu, audio, wave, opts):
     _pitch_close(got.data, want)
 
 
+@pytest.mark.parametrize('opts', [
+    dict(min_f0=40),                   # 461 states (the 8-slice register form), 95 lags: two correlation
+                                       # passes, NCCF beside the window instead of over it
+    dict(delta_pitch=0.004),           # 521 states: the rows are read where they are used (no register form)
+    dict(upsample_filter_width=7),     # 14 sinc taps per state: 16-lag quad windows (run-time step count)
+    dict(min_f0=70, max_f0=300, delta_pitch=0.01, lowpass_cutoff=800, resample_freq=3200),
+])
+def test_pitch_option_paths(gpu, synth_waves, opts):
+    """option sets that leave the instantiations the default configuration runs on (kernels_pitch.hip:
+    viterbi_forward<7> / <8> / <0>, the overlaid NCCF, the straight-line 12-lag resampling)"""
+    proc = KaldiPitchProcessor(**opts)
+    waves = list(synth_waves)[:3]
+    outs = proc._process_batch([Audio(w, 16000) for w in waves])
+    for w, o in zip(waves, outs):
+        _pitch_close(o.data, orc.pitch(proc._options, w))
+
+
 def test_pitch_batch(gpu, synth_waves):
     proc = KaldiPitchProcessor()
     outs = proc._process_batch([Audio(w, 16000) for w in synth_waves])
