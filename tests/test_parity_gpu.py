@@ -647,6 +647,28 @@ def test_features_do_not_depend_on_the_warps_of_the_batch(gpu, cls, sample_rate)
             assert np.array_equal(f.data, alone[i]), f'{cls.__name__} {sample_rate}: utterance {i} in {order}'
 
 
+@pytest.mark.parametrize('cls, sample_rate', [(MfccProcessor, 8000), (FilterbankProcessor, 16000),
+                                              (PlpProcessor, 8000), (FilterbankProcessor, 44100)])
+def test_every_route_in_one_batch(gpu, cls, sample_rate):
+    """snip_edges = False, VTLN warps and utterances shorter than a window together: warped / unwarped /
+    sub-window utterances each take their own kernel inside one call (capi.hip: split_dual, run_short),
+    also when one of the groups is empty; every utterance agrees with the oracle and with itself alone"""
+    win = int(round(0.025 * sample_rate))
+    n = int(0.3 * sample_rate)
+    waves = [synth.utterances(71 + i, 1, m, sample_rate)[0]
+             for i, m in enumerate((win - 9, n, n + 57, win - 40, n + 131))]
+    warps = [0.9, 1.0, 1.1, 1.0, 1.0]
+    proc = cls(sample_rate=sample_rate, dither=0, snip_edges=False)
+    audios = [Audio(w, sample_rate) for w in waves]
+    alone = [proc._process_batch([a], vtln_warp=[wf])[0].data for a, wf in zip(audios, warps)]
+    for order in ([0, 1, 2, 3, 4], [0, 3], [0, 2], [3, 1], [0, 3, 0]):
+        together = proc._process_batch([audios[i] for i in order], vtln_warp=[warps[i] for i in order])
+        for i, f in zip(order, together):
+            assert np.array_equal(f.data, alone[i]), f'{cls.__name__} {sample_rate}: utterance {i} in {order}'
+    for w, wf, f in zip(waves, warps, alone):
+        assert_close(f, _oracle(proc, w, wf), rtol=2e-4, what=f'{cls.__name__} {sample_rate} warp {wf}')
+
+
 @pytest.mark.parametrize('snip_edges', [True, False])
 @pytest.mark.parametrize('cls, sample_rate, opts', [
     (FilterbankProcessor, 44100, dict(num_bins=40)),          # 1102 samples -> 2048 (reference test rate)
