@@ -1298,10 +1298,14 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
     if (!pack(trial, nullptr)) break;
     parts = trial;
   }
-  int chain = dual ? 16 : 32;  // (at least 8 quads: fbank512_kernel unrolls that length; the dual
-                               // kernel loops over pairs of quads and its filters span half the bins)
+  // The chain is as long as the longest part (a multiple of 4 bins = whole quads): 28 for 40 bins and 24
+  // for 23 bins at 16 kHz (round 3; it used to be padded to 32).  fbank512b_kernel issues an odd quad on its
+  // own; fbank512_kernel issues quads in pairs and runs the row of zeros behind the table as the eighth
+  // (same sums, four idle instructions on the per-utterance / dithered paths); the two-frames-per-row
+  // kernel keeps an even count.
+  int chain = 16;
   for (int g = 0; g < n_groups; ++g) chain = std::max(chain, per_part(g, parts[g]));
-  chain = (chain + 7) & ~7;  // an even number of quads: the kernel issues them in pairs
+  chain = dual ? ((chain + 7) & ~7) : ((chain + 3) & ~3);
   p.mm_quads = chain / 4;
   p.mm_levels = 1;
   for (int g = 0; g < n_groups; ++g) p.mm_levels = std::max(p.mm_levels, parts[g]);
@@ -1360,7 +1364,7 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
   }
   while (blob->size() % 4) blob->push_back(0.0f);  // 16-byte alignment of the float4 tables
   p.off_mm_a = static_cast<int>(blob->size());
-  for (int t = 0; t < p.mm_quads + 1; ++t)  // (+ the row of zeros the last look-ahead read lands on)
+  for (int t = 0; t < p.mm_quads + 2; ++t)  // (+ two rows of zeros: the look-ahead reads of the pair loops)
     for (int lane = 0; lane < 64; ++lane)
       for (int c = 0; c < 4; ++c) {
         const Block& bk = blocks[lane >> 2];
@@ -1455,6 +1459,7 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
 int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int out_cols,
                     double* energy_out, hipStream_t stream) {
   if (b.total_frames <= 0) return SNF_OK;
+  if (fbank512b_eligible(p, b)) return launch_fbank512b(p, b, out, out_cols, energy_out, stream);
   Fast512Params q = p;
   q.out_cols = out_cols;
   const bool per_utt = b.blk_utt != nullptr;

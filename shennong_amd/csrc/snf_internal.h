@@ -213,6 +213,10 @@ int launch_build_frame_start(const int64_t* d_frame_offsets, const int64_t* d_sa
                              int32_t* d_frame_utt, hipStream_t stream);
 int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int out_cols,
                     double* energy_out, hipStream_t stream);
+// the occupancy-first form of the same kernel (kernels_fbank512b.hip): flat, undithered, snip_edges batches
+bool fbank512b_eligible(const Fast512Params& p, const BatchArgs& b);
+int launch_fbank512b(const Fast512Params& p, const BatchArgs& b, float* out, int out_cols,
+                     double* energy_out, hipStream_t stream);
 
 // ---- register-resident 2048-point path (kernels_fbank2048.hip): 44.1 / 48 kHz frames, 32 kHz zero-extended
 bool fbank2048_eligible(const MelParams& mp);
