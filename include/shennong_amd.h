@@ -180,11 +180,12 @@ typedef struct snf_options {
   /* DeltaFeaturesOptions */
   int32_t delta_order;  /* 2 */
   int32_t delta_window; /* 2 */
-  /* mfcc only: non-zero appends the deltas of order `delta_order` / window `delta_window` to every
-     row in the same launch, [cepstra | delta | delta-delta] = what DeltaPostProcessor().process(
-     MfccProcessor().process(audio)) returns (reference postprocessor/delta.py:129-131 chained after
-     processor/mfcc.py:86), without the [T, num_ceps] round trip through HBM.  Order 2 / window 2 on
-     the 512-point path only; anything else is refused at plan creation. */
+  /* mfcc only: non-zero appends the deltas of order 2 / window 2 to every row in the same call,
+     [cepstra | delta | delta-delta] = what DeltaPostProcessor().process(MfccProcessor().process(audio))
+     returns (reference postprocessor/delta.py:129-131 chained after processor/mfcc.py:86): the plan runs
+     the MFCC kernel into a scratch in HBM and the delta kernel on it (any MFCC configuration).  The
+     one-launch form of round 2 (512-point path only, slower) is selected by SNF_FUSED_DELTA=1 in the
+     environment of snf_plan_create.  Other orders / windows are refused at plan creation. */
   int32_t append_deltas;
   snf_pitch_options pitch;
   snf_pitch_post_options pitch_post;

@@ -81,9 +81,15 @@ struct snf_plan {
   bool fast2048 = false;
   DevBuf d_long_tables;
 
-  // delta
+  // delta (post-processor plans, and MFCC plans with append_deltas)
   DeltaParams dp{};
   DevBuf d_scales, d_dims;
+  // append_deltas: true = the MFCC kernel writes [T, num_ceps] to a scratch and the delta kernel forms the
+  // rows (two launches: 1.17 + 0.11 ms per 2.98 M frames); false = fbank512_kernel's fused mode (one
+  // launch, 1.46 ms: it loses to the chain; SNF_FUSED_DELTA=1 selects it)
+  bool chain_deltas = false;
+  DevBuf s_cep, s_tile;
+  bool tile_valid = false;  // s_tile describes the cached frame offsets table
 
   // pitch
   PitchTablesHost pt;
@@ -293,7 +299,21 @@ int build_mel_plan(snf_plan* plan) {
     }
   }
   p.ndims = plan->ndims;
-  const bool want_fused = plan->kind == SNF_KIND_MFCC && o.append_deltas;
+  if (plan->kind == SNF_KIND_MFCC && o.append_deltas) {
+    const char* knob = getenv("SNF_FUSED_DELTA");
+    plan->chain_deltas = !(knob && knob[0] == '1');
+    std::vector<float> scales;
+    std::vector<int> dims;
+    make_delta_scales(2, 2, &scales, &dims);
+    if ((rc = plan->d_scales.upload(scales, plan->stream))) return rc;
+    if ((rc = plan->d_dims.upload(dims, plan->stream))) return rc;
+    plan->dp.order = 2;
+    plan->dp.window = 2;
+    plan->dp.n_scales = static_cast<int>(scales.size());
+    plan->dp.scales = plan->d_scales.as<float>();
+    plan->dp.dims = plan->d_dims.as<int>();
+  }
+  const bool want_fused = plan->kind == SNF_KIND_MFCC && o.append_deltas && !plan->chain_deltas;
   if (want_fused && (!fast512_eligible(p, false) || o.num_ceps > 16))
     return set_error(SNF_E_INVALID, "append_deltas needs frames that pad to 512 samples (the register-"
                                     "resident path); chain a delta plan for this configuration");
@@ -312,16 +332,12 @@ int build_mel_plan(snf_plan* plan) {
       if ((rc = plan->d_fast_tables.upload(blob, plan->stream))) return rc;
       plan->fp.tables = plan->d_fast_tables.as<float>();
       plan->fast512 = true;
-      if (plan->kind == SNF_KIND_MFCC && o.append_deltas) {
+      if (want_fused) {
         // (the fused form keeps 14 waves' tiles + the cepstra of 336 frames in LDS beside the tables)
         if (((static_cast<size_t>(plan->fp.table_floats) * 4 + 255) & ~static_cast<size_t>(255)) +
                 14 * 4 * 2176 + sizeof(float) * 4 * (kFast512FusedSets + 2) * 16 > 160 * 1024)
           return set_error(SNF_E_INVALID, "append_deltas: the mel / DCT tables of this configuration leave no "
                                           "room for the fused form in LDS; chain a delta plan");
-        std::vector<float> scales;
-        std::vector<int> dims;
-        make_delta_scales(2, 2, &scales, &dims);
-        if ((rc = plan->d_scales.upload(scales, plan->stream))) return rc;
         plan->fp.fused_delta = 1;
         plan->fp.delta_scales = plan->d_scales.as<float>();
       }
@@ -900,6 +916,7 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     plan->h_foff.swap(foff);
     plan->setidx_valid = false;
     plan->pairs_valid = false;
+    plan->tile_valid = false;
   }
   if (any_warp && (rc = plan->s_uwarp.upload(warp_ids, s))) return rc;
   BatchArgs b{};
@@ -1071,17 +1088,35 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
       return rc;
     if (own_stream) mark_kernel(plan, "plp_tail_kernel");
   } else {
+    // append_deltas as two launches: the cepstra go to a scratch, the delta kernel forms the rows
+    float* feat_out = d_out;
+    int feat_cols = plan->ndims;
+    if (plan->chain_deltas) {
+      feat_cols = plan->o.num_ceps;
+      if ((rc = plan->s_cep.ensure(sizeof(float) * static_cast<size_t>(total_frames) * feat_cols))) return rc;
+      feat_out = plan->s_cep.as<float>();
+    }
     if (use_fast) {
-      if ((rc = run_fast(d_out, plan->ndims, nullptr))) return rc;
+      if ((rc = run_fast(feat_out, feat_cols, nullptr))) return rc;
     } else if (use_long) {
-      if ((rc = launch_fbank2048(plan->mp, b, plan->d_long_tables.as<float>(), d_out, plan->ndims, nullptr, s)))
+      if ((rc = launch_fbank2048(plan->mp, b, plan->d_long_tables.as<float>(), feat_out, feat_cols, nullptr, s)))
         return rc;
       if (own_stream) mark_kernel(plan, "fbank2048_kernel");
     } else {
-      if ((rc = launch_mel_features(plan->mp, b, d_out, plan->ndims, nullptr, s))) return rc;
+      if ((rc = launch_mel_features(plan->mp, b, feat_out, feat_cols, nullptr, s))) return rc;
       if (own_stream) mark_kernel(plan, "mel_features_generic_kernel");
     }
-    if ((rc = run_short(d_out, plan->ndims, nullptr))) return rc;
+    if ((rc = run_short(feat_out, feat_cols, nullptr))) return rc;
+    if (plan->chain_deltas) {
+      if ((rc = plan->s_tile.ensure(4 * sizeof(int64_t) * static_cast<size_t>(total_frames / 32 + 2)))) return rc;
+      if ((rc = launch_deltas(plan->dp, feat_out, feat_cols, plan->s_foff.as<int64_t>(), n_utts, total_frames,
+                              d_out, plan->s_tile.as<int64_t>(), !plan->tile_valid, s)))
+        return rc;
+      // (the tile records are cached: complete before a later call on another stream may use them)
+      if (!plan->tile_valid && !own_stream) SNF_HIP_CHECK(hipStreamSynchronize(s));
+      plan->tile_valid = true;
+      if (own_stream) mark_kernel(plan, "delta_kernel");
+    }
   }
   if (own_stream) SNF_HIP_CHECK(hipStreamSynchronize(s));
   return SNF_OK;

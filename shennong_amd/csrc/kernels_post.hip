@@ -646,8 +646,11 @@ int launch_deltas(const DeltaParams& p, const float* in, int in_cols, const int6
   if (total <= 0) return SNF_OK;
   const int halo = p.order * p.window;
   const bool aligned16 = (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-  if (p.order == 2 && p.window == 2 && tile_info && aligned16 &&
+  if (p.order == 2 && p.window == 2 && tile_info &&
       (in_cols == 13 || in_cols == 23 || in_cols == 40 || in_cols == 43)) {
+    // The tile records are rebuilt whenever the caller asks (`build_info`: its offsets table changed), on
+    // whichever path this call then takes: the caller remembers the table, not the path, and a later call
+    // with 16-byte aligned pointers must not find records of an older table.
 #define SNF_FLAT(D_)                                                                                  \
   do {                                                                                                \
     constexpr int rows = flat_rows<D_>();                                                             \
@@ -655,8 +658,9 @@ int launch_deltas(const DeltaParams& p, const float* in, int in_cols, const int6
     if (build_info)                                                                                   \
       hipLaunchKernelGGL(delta_tile_utt_kernel, dim3((tiles + 255) / 256), dim3(256), 0, stream,      \
                          frame_offsets, n_utts, total_frames, rows, tile_info);                       \
-    hipLaunchKernelGGL((delta_flat_o2w2_kernel<D_>), dim3(tiles), dim3(256), 0, stream, p, in,        \
-                       frame_offsets, tile_info, n_utts, total_frames, out);                          \
+    if (aligned16)                                                                                    \
+      hipLaunchKernelGGL((delta_flat_o2w2_kernel<D_>), dim3(tiles), dim3(256), 0, stream, p, in,      \
+                         frame_offsets, tile_info, n_utts, total_frames, out);                        \
   } while (0)
     if (in_cols == 13) SNF_FLAT(13);
     else if (in_cols == 23) SNF_FLAT(23);
@@ -664,7 +668,7 @@ int launch_deltas(const DeltaParams& p, const float* in, int in_cols, const int6
     else SNF_FLAT(43);
 #undef SNF_FLAT
     SNF_HIP_CHECK(hipGetLastError());
-    return SNF_OK;
+    if (aligned16) return SNF_OK;
   }
   const size_t lds = 2 * sizeof(int) * kDeltaRows + sizeof(float) * ((p.n_scales + 3) & ~3) +
                      sizeof(float) * static_cast<size_t>(kDeltaRows + 2 * halo) * in_cols;

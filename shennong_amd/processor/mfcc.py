@@ -42,10 +42,11 @@ class MfccProcessor(MelFeaturesProcessor):
         return self.num_ceps
 
     def process_with_deltas(self, signal, vtln_warp=1.0):
-        """``DeltaPostProcessor().process(self.process(signal, vtln_warp))`` in ONE launch: rows are
-        [cepstra | delta | delta-delta] (order 2, window 2), the cepstra never leave the GPU's local
-        memory between the two stages (reference chain: postprocessor/delta.py:129-131 after
-        processor/mfcc.py:86; BASELINE config 3)"""
+        """``DeltaPostProcessor().process(self.process(signal, vtln_warp))`` through ONE plan and one
+        call: rows are [cepstra | delta | delta-delta] (order 2, window 2); the cepstra stay in HBM
+        between the MFCC kernel and the delta kernel (two launches: the one-launch form of round 2
+        measured 13 % slower and is kept behind SNF_FUSED_DELTA=1; reference chain:
+        postprocessor/delta.py:129-131 after processor/mfcc.py:86; BASELINE config 3)"""
         return self._process_batch_with_deltas([signal], vtln_warp=[vtln_warp])[0]
 
     def _process_batch_with_deltas(self, signals, vtln_warp=None):

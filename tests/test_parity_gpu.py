@@ -966,7 +966,7 @@ def test_buffers_from_a_fresh_thread(gpu):
     assert result.get('ok')
 
 
-# ---- MFCC + delta + delta-delta in one launch (BASELINE config 3) ------------------------------------
+# ---- MFCC + delta + delta-delta through one plan (BASELINE config 3) ---------------------------------
 @pytest.mark.parametrize('opts', [dict(), dict(use_energy=False, htk_compat=True),
                                   dict(raw_energy=False), dict(num_ceps=10, num_bins=30)])
 def test_mfcc_with_deltas_equals_the_chain(gpu, audio, opts):
@@ -1000,7 +1000,27 @@ def test_mfcc_with_deltas_batch(gpu):
             np.testing.assert_array_equal(f.data, DeltaPostProcessor().process(m).data)
 
 
-def test_mfcc_with_deltas_refusals(gpu, audio):
-    proc = MfccProcessor(dither=0, sample_rate=44100)   # frames pad to 2048 samples
-    with pytest.raises(ValueError, match='append_deltas needs frames that pad to 512'):
-        proc.process_with_deltas(Audio(np.zeros(44100, np.int16), 44100))
+def test_mfcc_with_deltas_other_rates(gpu):
+    """two launches (the shipped form of append_deltas) cover every MFCC configuration, e.g. frames that pad
+    to 2048 samples"""
+    proc = MfccProcessor(dither=0, sample_rate=44100)
+    audio44 = Audio(synth.utterances(7, 1, 44100)[0], 44100)
+    np.testing.assert_array_equal(proc.process_with_deltas(audio44).data,
+                                  DeltaPostProcessor().process(proc.process(audio44)).data)
+
+
+def test_mfcc_with_deltas_fused_form(gpu, audio, monkeypatch):
+    """SNF_FUSED_DELTA=1 selects the one-launch form of round 2 (slower than the two launches, kept for the
+    A/B in bench.py): same rows, and its refusals"""
+    from shennong_amd import _backend
+    monkeypatch.setenv('SNF_FUSED_DELTA', '1')
+    _backend.clear_plans()
+    try:
+        proc = MfccProcessor(dither=0)
+        np.testing.assert_array_equal(proc.process_with_deltas(audio).data,
+                                      DeltaPostProcessor().process(proc.process(audio)).data)
+        proc44 = MfccProcessor(dither=0, sample_rate=44100)   # frames pad to 2048 samples
+        with pytest.raises(ValueError, match='append_deltas needs frames that pad to 512'):
+            proc44.process_with_deltas(Audio(np.zeros(44100, np.int16), 44100))
+    finally:
+        _backend.clear_plans()
