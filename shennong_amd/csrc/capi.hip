@@ -1048,8 +1048,9 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
       if (!split_dual) return SNF_OK;
     }
     if (b.blk_utt != nullptr && b.n_blocks == 0) return SNF_OK;  // (no utterance left for this form)
-    if ((rc2 = launch_fbank512(any_warp ? plan->fp_warp : plan->fp, b, out, cols, energy, s))) return rc2;
-    if (own_stream) mark_kernel(plan, "fbank512_kernel");
+    const Fast512Params& fpx = any_warp ? plan->fp_warp : plan->fp;
+    if ((rc2 = launch_fbank512(fpx, b, out, cols, energy, s))) return rc2;
+    if (own_stream) mark_kernel(plan, fbank512b_eligible(fpx, b) ? "fbank512b_kernel" : "fbank512_kernel");
     return SNF_OK;
   };
   // utterances shorter than a window (snip_edges = false), after the register-resident kernels

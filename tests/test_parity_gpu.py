@@ -509,7 +509,7 @@ def test_fast_kernel_window_lengths(gpu, audio, wave, cls, frame_length):
     assert_close(got.data, want, what=f'{cls.__name__} {frame_length}')
     plan = _backend.get_plan(proc._build_options())
     plan.run([np.asarray(wave, np.int16)])
-    assert plan.kernel_name(1) == 'fbank512_kernel'
+    assert plan.kernel_name(1) == 'fbank512b_kernel'   # (flat batch, snip_edges, no dither)
 
 
 @pytest.mark.parametrize('cls', [FilterbankProcessor, MfccProcessor, PlpProcessor,
@@ -579,7 +579,8 @@ def test_fast_kernel_short_frames(gpu, cls, sample_rate, opts, snip_edges):
     plan = _backend.get_plan(proc._build_options())
     # frames that pad to 256 samples: two frames per 16-lane row (X_a, X_b from one complex transform)
     padded = 1 << int(np.ceil(np.log2(opts.get('frame_length', 0.025) * sample_rate - 1e-9)))
-    assert plan.kernel_name(1) == ('fbank256x2_kernel' if padded == 256 else 'fbank512_kernel')
+    flat = 'fbank512b_kernel' if snip_edges else 'fbank512_kernel'
+    assert plan.kernel_name(1) == ('fbank256x2_kernel' if padded == 256 else flat)
     for w, f in zip(waves, feats):
         want = _oracle(proc, w)
         assert f.shape == want.shape
@@ -800,8 +801,50 @@ def test_more_than_2g_output_elements(gpu):
             got.ctypes.data_as(C.c_void_p), C.c_void_p(d_delta.ptr + u * nfr * 39 * 4), got.nbytes))
         alone = dplan.run_post([mplan.run([block[u % 100]])[0]])[0]
         assert np.array_equal(got, alone), u
-    for buf in (d_wave, d_mfcc, d_delta):
+    for buf in (d_mfcc, d_delta):
         buf.free()
+    # fbank-40 (fbank512b_kernel: the rows of a set leave through a buffer descriptor rebuilt per set): more
+    # than 2^32 BYTES of output need 3.2 x the utterances - the wave buffer is reused as utterance u % 28200
+    fproc = FilterbankProcessor(num_bins=40, dither=0)
+    fplan = _backend.get_plan(fproc._build_options())
+    d_out = _backend.DeviceBuffer(n_utts * nfr * 40 * 4)
+    fplan.run_device(d_wave.ptr, soff, foff, d_out.ptr)
+    assert fplan.kernel_name(1) == 'fbank512b_kernel' and n_utts * nfr * 40 * 4 > 2**30
+    for u in (0, n_utts // 2, n_utts - 1):
+        got = np.empty((nfr, 40), dtype=np.float32)
+        _backend.check(_backend.lib().snf_memcpy_d2h(
+            got.ctypes.data_as(C.c_void_p), C.c_void_p(d_out.ptr + u * nfr * 160), got.nbytes))
+        assert np.array_equal(got, fplan.run([block[u % 100]])[0]), u
+    d_out.free()
+    d_wave.free()
+
+
+def test_more_than_4g_output_bytes_flat_kernel(gpu):
+    """fbank-40 rows past byte 2^32 of the output (91 000 utterances, 4.3 GB of rows, 8.7 GB of samples): the
+    flat kernel addresses every set through its own 64-bit base"""
+    import ctypes as C
+    block = synth.utterances(78, 100, 48000)
+    n_utts, nsamp, nfr = 91000, 48000, 298
+    assert n_utts * nfr * 160 > 2**32
+    plan = _backend.get_plan(FilterbankProcessor(num_bins=40, dither=0)._build_options())
+    soff = np.arange(n_utts + 1, dtype=np.int64) * nsamp
+    foff = np.arange(n_utts + 1, dtype=np.int64) * nfr
+    d_wave = _backend.DeviceBuffer(n_utts * nsamp * 2)
+    flat = np.ascontiguousarray(block.reshape(-1))
+    for k in range(n_utts // 100):
+        _backend.check(_backend.lib().snf_memcpy_h2d(
+            C.c_void_p(d_wave.ptr + k * flat.nbytes), flat.ctypes.data_as(C.c_void_p), flat.nbytes))
+    d_out = _backend.DeviceBuffer(n_utts * nfr * 160)
+    plan.run_device(d_wave.ptr, soff, foff, d_out.ptr)
+    assert plan.kernel_name(1) == 'fbank512b_kernel'
+    boundary = 2**32 // (nfr * 160)
+    for u in (0, boundary - 1, boundary, boundary + 1, n_utts - 1):
+        got = np.empty((nfr, 40), dtype=np.float32)
+        _backend.check(_backend.lib().snf_memcpy_d2h(
+            got.ctypes.data_as(C.c_void_p), C.c_void_p(d_out.ptr + u * nfr * 160), got.nbytes))
+        assert np.array_equal(got, plan.run([block[u % 100]])[0]), u
+    d_wave.free()
+    d_out.free()
 
 
 def test_long_utterance(gpu):
