@@ -220,7 +220,10 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     read_quads<(NJ + 1) / 2>(t_win + l * 18, win4);
     unsigned dkey_lo = 0, dkey_hi = 0;
     if (DITHER) {
-      const unsigned long long k = (static_cast<unsigned long long>(g) + 1) * 0x9E3779B97F4A7C15ull ^ p.seed;
+      // (keyed by the frame's place in its utterance, not in the batch: snf_internal.h)
+      const int64_t du = PERUTT ? pu_u : static_cast<int64_t>(b.frame_utt[g < b.total_frames ? g : last_frame]);
+      const unsigned long long k =
+          wave_noise_id(b.wave, b.sample_offsets, du, PERUTT ? gl : g - b.frame_offsets[du]) ^ p.seed;
       dkey_lo = fmix32(static_cast<unsigned>(k));
       dkey_hi = fmix32(static_cast<unsigned>(k >> 32) ^ dkey_lo);
     }
@@ -754,10 +757,12 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
     read_quads<(NJ + 1) / 2>(t_win + l * 18, win4);
     unsigned dk[4] = {0, 0, 0, 0};
     if (DITHER) {
+      // (keyed by the frames' places in their utterance - PairRec.utt1 - not in the batch: snf_internal.h)
+      const int64_t du = meta.z > 0 ? meta.z - 1 : 0;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const unsigned long long k =
-            (static_cast<unsigned long long>(ga + s2) + 1) * 0x9E3779B97F4A7C15ull ^ p.seed;
+            wave_noise_id(b.wave, b.sample_offsets, du, ga + s2 - b.frame_offsets[du]) ^ p.seed;
         dk[2 * s2] = fmix32(static_cast<unsigned>(k));
         dk[2 * s2 + 1] = fmix32(static_cast<unsigned>(k >> 32) ^ dk[2 * s2]);
       }
@@ -1099,7 +1104,7 @@ __global__ void build_pair_table_kernel(const int64_t* __restrict__ frame_offset
   const bool has_b = f + 1 < n_frames;
   PairRec r;
   r.frame_a = f0 + f;
-  r.utt1 = 0;
+  r.utt1 = static_cast<int32_t>(u + 1);  // (always: the dither stream is keyed per utterance; `flags` marks edges)
   r.flags = has_b ? 4 : 0;
   int64_t start[2];
 #pragma unroll
@@ -1112,10 +1117,7 @@ __global__ void build_pair_table_kernel(const int64_t* __restrict__ frame_offset
       int64_t safe = rel < 0 ? 0 : rel;
       if (safe + win_len > n) safe = n - win_len;
       start[s2] = s0 + safe;
-      if (rel < 0 || rel + win_len > n) {
-        r.utt1 = static_cast<int32_t>(u + 1);
-        r.flags |= 1 << s2;
-      }
+      if (rel < 0 || rel + win_len > n) r.flags |= 1 << s2;
     }
   }
   r.start_a = start[0];

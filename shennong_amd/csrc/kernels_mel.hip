@@ -118,13 +118,14 @@ __global__ __launch_bounds__(kWaves * 64, 8) void mel_features_generic_kernel(
                               : f * p.win_shift + p.win_shift / 2 - p.win_len / 2;
     const int16_t* __restrict__ w = b.wave + s0;
 
+    const uint64_t noise_id = p.dither != 0.0f ? wave_noise_id(b.wave, b.sample_offsets, u, f) : 0;
     // ---- ExtractWindow: copy L samples, reflecting at the utterance edges ------------------------
     float part = 0.0f;
     for (int i = lane; i < L; i += 64) {
       int64_t k = start + i;
       while (k < 0 || k >= n) k = k < 0 ? -k - 1 : 2 * n - 1 - k;
       float v = static_cast<float>(w[k]);
-      if (p.dither != 0.0f) v += p.dither * gauss(p.seed, static_cast<uint64_t>(g), i);
+      if (p.dither != 0.0f) v += p.dither * gauss(p.seed, noise_id, i);
       xs[i] = v;
       part += v;
     }

@@ -761,7 +761,8 @@ __global__ void pitch_post_kernel(const PitchPostParams p, const float* __restri
     }
     float noise = 0.0f;
     if (o.delta_pitch_noise_stddev != 0.0f)
-      noise = gauss(p.seed, static_cast<uint64_t>(g)) * o.delta_pitch_noise_stddev;
+      noise = gauss(p.seed, frame_noise_id(g - f0, f1 - f0, __float_as_uint(in[f0 * 2 + 1]))) *
+              o.delta_pitch_noise_stddev;  // (keyed per utterance, not per batch row: snf_internal.h)
     row[idx++] = (acc + noise) * o.delta_pitch_scale;
   }
   if (o.add_raw_log_pitch) row[idx++] = log_pitch;
@@ -833,7 +834,8 @@ __global__ __launch_bounds__(kPostRows) void pitch_post_tiled_kernel(
     }
     float noise = 0.0f;
     if (o.delta_pitch_noise_stddev != 0.0f)
-      noise = gauss(p.seed, static_cast<uint64_t>(g)) * o.delta_pitch_noise_stddev;
+      noise = gauss(p.seed, frame_noise_id(g - f0, f1 - f0, __float_as_uint(in[f0 * 2 + 1]))) *
+              o.delta_pitch_noise_stddev;  // (keyed per utterance, not per batch row: snf_internal.h)
     row[idx++] = (acc + noise) * o.delta_pitch_scale;
   }
   if (o.add_raw_log_pitch) row[idx++] = log_pitch;

@@ -113,7 +113,7 @@ struct MelParams {
 struct PairRec {
   int64_t start_a, start_b;  // first sample of the two frames (clamped into the utterance)
   int64_t frame_a;           // batch-wide frame index of frame a (frame b, if any, is frame_a + 1)
-  int32_t utt1;              // snip_edges = false: utterance + 1 when either frame reflects at an edge
+  int32_t utt1;              // utterance + 1
   int32_t flags;             // bit 0 / 1: frame a / b reflects; bit 2: frame b exists
 };
 
@@ -134,6 +134,30 @@ struct BatchArgs {
   int64_t n_utts;
   int64_t total_frames;
 };
+
+// The noise stream of a frame (dither, delta-pitch noise) is keyed by what the frame IS, not by where it
+// sits in the batch: its index inside its utterance, the utterance's length and the bits of its first
+// element (two samples / the first pitch value).  An utterance therefore draws the same noise alone and in
+// any batch of the same call count (the per-call stream key is in `seed`), and the utterances of a batch draw
+// different noise.  The reference draws from C rand(): no stream is "the" Kaldi one.
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint64_t frame_noise_id(int64_t local_frame, int64_t utt_len, uint32_t first_bits) {
+  uint64_t x = static_cast<uint64_t>(local_frame) * 0x9E3779B97F4A7C15ull +
+               static_cast<uint64_t>(utt_len) * 0xC2B2AE3D27D4EB4Full + first_bits;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+// ... of the frame `local_frame` of utterance `u` of a waveform batch
+__device__ __forceinline__ uint64_t wave_noise_id(const int16_t* __restrict__ wave,
+                                                  const int64_t* __restrict__ sample_offsets, int64_t u,
+                                                  int64_t local_frame) {
+  const int64_t s0 = sample_offsets[u], n = sample_offsets[u + 1] - s0;
+  uint32_t first = n > 0 ? static_cast<uint16_t>(wave[s0]) : 0u;
+  if (n > 1) first |= static_cast<uint32_t>(static_cast<uint16_t>(wave[s0 + 1])) << 16;
+  return frame_noise_id(local_frame, n, first);
+}
+#endif
 
 struct PlpParams {
   int num_bins, lpc_order, num_ceps, use_energy, htk_compat, has_floor, rasta;

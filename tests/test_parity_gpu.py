@@ -630,6 +630,67 @@ def test_features_do_not_depend_on_the_batch(gpu, cls, sample_rate, opts, snip_e
             assert np.array_equal(f.data, alone[i]), f'{cls.__name__} {sample_rate}: utterance {i} in {order}'
 
 
+@pytest.mark.parametrize('snip_edges', [True, False])
+@pytest.mark.parametrize('cls, sample_rate, opts', [
+    (FilterbankProcessor, 8000, dict()),                      # fbank256x2_kernel
+    (FilterbankProcessor, 16000, dict()),                     # fbank512_kernel (dither keeps the round-2 form)
+    (MfccProcessor, 44100, dict()),                           # fbank2048_kernel
+    (FilterbankProcessor, 16000, dict(frame_length=0.019, frame_shift=0.007, use_power=False)),  # generic
+])
+def test_default_dither_does_not_depend_on_the_batch(gpu, cls, sample_rate, opts, snip_edges):
+    """dither = 1.0 is the reference's DEFAULT (processor/base.py:122): the noise stream of a frame is keyed
+    by its index inside its utterance, the utterance's length and first samples and the call count of the
+    plan - not by its row in the batch -, so the default configuration too returns the same bits for an
+    utterance alone and in any batch (same call count: a fresh plan per call here), and different
+    utterances / different calls draw different noise"""
+    shift = int(round(opts.get('frame_shift', 0.01) * sample_rate))
+    length = int(round(opts.get('frame_length', 0.025) * sample_rate))
+    lengths = [length + shift * k + r for k, r in [(6, 3), (0, 0), (11, 7), (4, 1), (6, 3)]]
+    waves = [synth.utterances(41 + i, 1, n, sample_rate)[0] for i, n in enumerate(lengths)]
+    proc = cls(sample_rate=sample_rate, snip_edges=snip_edges, **opts)
+    assert proc.dither == 1.0
+    audios = [Audio(w, sample_rate) for w in waves]
+
+    def fresh(batch):
+        _backend.clear_plans()  # a new plan: its first call, the same noise stream key
+        return [f.data for f in proc._process_batch(batch)]
+    alone = [fresh([a])[0] for a in audios]
+    for order in ([0, 1, 2, 3, 4], [4, 2, 0], [3, 3, 1]):
+        for i, data in zip(order, fresh([audios[i] for i in order])):
+            assert np.array_equal(data, alone[i]), f'{cls.__name__} {sample_rate}: utterance {i} in {order}'
+    # the noise is there (dither 0 gives other bits), utterances of equal length draw different noise, and a
+    # second call on the same plan draws a new stream
+    quiet = cls(sample_rate=sample_rate, snip_edges=snip_edges, dither=0, **opts)._process_batch(audios)
+    assert not np.array_equal(quiet[0].data, alone[0])
+    assert not np.array_equal(alone[0] - quiet[0].data, alone[4] - quiet[4].data)
+    _backend.clear_plans()
+    first = proc._process_batch([audios[0]])[0].data
+    again = proc._process_batch([audios[0]])[0].data
+    assert np.array_equal(first, alone[0]) and not np.array_equal(again, first)
+    _backend.clear_plans()
+
+
+def test_delta_pitch_noise_does_not_depend_on_the_batch(gpu):
+    """the same for the random term of KaldiPitchPostProcessor's delta-pitch column (default stddev 0.005)"""
+    rng = np.random.default_rng(5)
+    feats = []
+    for n in (30, 1, 57, 30):
+        data = np.stack([rng.uniform(-1, 1, n), rng.uniform(60, 300, n)], axis=1).astype(np.float32)
+        feats.append(Features(data, np.arange(n) * 0.01, properties={'pitch': {}}, validate=False))
+    post = KaldiPitchPostProcessor()
+    assert post.delta_pitch_noise_stddev > 0
+    plan_opts = post._build_options()
+
+    def fresh(batch):
+        _backend.clear_plans()
+        return _backend.get_plan(plan_opts).run_post([f.data for f in batch])
+    alone = [fresh([f])[0] for f in feats]
+    for order in ([0, 1, 2, 3], [3, 2], [1, 0, 0]):
+        for i, data in zip(order, fresh([feats[i] for i in order])):
+            assert np.array_equal(data, alone[i]), (i, order)
+    _backend.clear_plans()
+
+
 @pytest.mark.parametrize('cls, sample_rate', [(MfccProcessor, 8000), (PlpProcessor, 8000),
                                               (FilterbankProcessor, 16000), (MfccProcessor, 44100)])
 def test_features_do_not_depend_on_the_warps_of_the_batch(gpu, cls, sample_rate):
