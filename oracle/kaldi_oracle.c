@@ -1190,10 +1190,19 @@ static int pitch_impl(const snf_pitch_options* o, const int16_t* wave16, int64_t
     float mn = fwd[0];
     for (int s = 1; s < S; s++) if (fwd[s] < mn) mn = fwd[s];
     for (int s = 0; s < S; s++) fwd[s] += -mn;
-    /* RecomputeBacktraces at frame recompute_frame-1 sees only identical stats -> no-op */
   }
-  /* InputFinished(): RecomputeBacktraces when the utterance is shorter than recompute_frame */
-  if (T < o->recompute_frame) {
+  /* [KALDI-UPSTREAM] pitch-functions.cc runs RecomputeBacktraces (a) inside AcceptWaveform when frame
+   * recompute_frame - 1 has just been processed, over the frames 0 .. recompute_frame - 1, and (b) in
+   * InputFinished() when the utterance has fewer frames than that, over all of them.  In the offline
+   * call the first AcceptWaveform covers the T1 frames available before the resampler is flushed (all
+   * with the statistics ms1) and the flush adds the last T - T1 (2 or 3) frames with ms2:
+   *   T1 >= recompute_frame: (a) compares ms1 with ms1 -> nothing to do;
+   *   T  <  recompute_frame: (b) with the final ms2;
+   *   T1 <  recompute_frame <= T (utterances of 500 - 502 pitch frames): (a) fires in the SECOND call,
+   *     with ms2, over frames 0 .. 499 of which T1 carry ms1; the forward costs restart from zero and
+   *     frames 500 .. T - 1 follow with their own (ms2) NCCF.  Frames >= T1 rescale by exactly 1, so this
+   *     is the same computation as (b) - round 3; it used to be left out on both sides. */
+  if (T < o->recompute_frame || T1 < o->recompute_frame) {
     float mean_square = (float)ms2;
     int must = 0;
     for (int64_t t = 0; t < T; t++) {

@@ -843,7 +843,9 @@ __global__ __launch_bounds__(kVitWaves * 64, 4) void pitch_viterbi_kernel(
   // pass starts from zero forward costs and overwrites every backpointer: nothing of the first (online)
   // pass survives it, so an offline batch runs ONE forward pass - the recomputing one when Kaldi would
   // recompute, the plain one otherwise (round 2 ran both: half of the Viterbi kernel's time).
-  const bool recompute = T < t.recompute_frame && o[5] != 0.0f;
+  // (... or when frame recompute_frame - 1 falls into the frames the flush adds: T1 < recompute_frame <= T,
+  // utterances of 500 - 502 frames; frames >= T1 rescale by exactly 1, so it is the same pass)
+  const bool recompute = (T < t.recompute_frame || T1 < t.recompute_frame) && o[5] != 0.0f;
   const float ob1 = recompute ? o[2] : 0.0f, ob2 = recompute ? o[3] : 0.0f, nb = recompute ? o[4] : 0.0f;
   if (S <= 448) viterbi_forward<7>(t, res, anp + f0, T, T1, recompute, ob1, ob2, nb, bp, sh, st_lag, lane);
   else if (S <= 512) viterbi_forward<8>(t, res, anp + f0, T, T1, recompute, ob1, ob2, nb, bp, sh, st_lag, lane);

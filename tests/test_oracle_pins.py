@@ -265,6 +265,39 @@ def test_pitch_structure(wave):
     assert np.all((raw[:, 1] >= 50) & (raw[:, 1] <= 400)) and np.all(np.abs(raw[:, 0]) <= 1.01)
 
 
+def _click_utterance(n, seed=3):
+    """a quiet utterance that ends in a loud click: the two samples the resampler emits at the flush change
+    the mean square of the whole signal by far more than 1 %"""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)
+    w = (rng.normal(0, 12, n) + 40 * np.sin(2 * np.pi * 140 * t / 16000)).astype(np.int16)
+    w[-24:] = (20000 * np.sin(2 * np.pi * 300 * np.arange(24) / 16000 + 0.5)).astype(np.int16)
+    return w
+
+
+@pytest.mark.parametrize('nsamples, nframes', [(80240, 500), (80400, 501), (80560, 502), (80720, 503)])
+def test_pitch_recompute_backtraces_corner(nsamples, nframes):
+    """[KALDI-UPSTREAM] pitch-functions.cc: RecomputeBacktraces runs when frame recompute_frame - 1 (499) has
+    been processed.  In the offline call the first AcceptWaveform covers the frames available before the flush
+    (T1 = T - 3) and InputFinished adds the rest, so for utterances of 500 - 502 frames frame 499 arrives in
+    the SECOND call, with the final signal statistics: frames 0 .. T1 - 1 are rescaled exactly as
+    InputFinished rescales a shorter utterance.  From 503 frames on frame 499 arrives in the first call and
+    nothing is recomputed."""
+    wave = _click_utterance(nsamples)
+    po = _abi.default_pitch_options()
+    assert po.recompute_frame == 500 and orc.pitch_num_frames(po, nsamples) == nframes
+    default = orc.pitch(po, wave)
+    po.recompute_frame = 100000   # every utterance is "short": InputFinished recomputes all frames
+    all_frames = orc.pitch(po, wave)
+    po.recompute_frame = 1        # frame 0 arrives in the first call: never recomputed
+    never = orc.pitch(po, wave)
+    assert not np.array_equal(all_frames, never)      # the click matters
+    if nframes <= 502:
+        np.testing.assert_array_equal(default, all_frames)
+    else:
+        np.testing.assert_array_equal(default, never)
+
+
 def test_pitch_tracks_a_tone():
     """A 5-harmonic 150 Hz tone in light noise must be tracked within one lag step"""
     from shennong_amd import synth

@@ -186,6 +186,20 @@ def test_pitch_option_paths(gpu, synth_waves, opts):
         _pitch_close(o.data, orc.pitch(proc._options, w))
 
 
+def test_pitch_recompute_backtraces_corner(gpu):
+    """utterances of 500 - 503 pitch frames whose last samples move the mean square (the T1 < 500 <= T corner
+    of Kaldi's RecomputeBacktraces, tests/test_oracle_pins.py): every frame equals the oracle, in one batch
+    and for the settings of recompute_frame that force / forbid the second pass"""
+    from test_oracle_pins import _click_utterance
+    waves = [_click_utterance(n) for n in (80240, 80400, 80560, 80720, 40000)]
+    for rf in (500, 100000, 1):
+        opts = KaldiPitchProcessor()._build_options()
+        opts.pitch.recompute_frame = rf
+        outs = _backend.get_plan(opts).run(waves)
+        for w, o in zip(waves, outs):
+            _pitch_close(o, orc.pitch(opts.pitch, w))
+
+
 def test_pitch_batch(gpu, synth_waves):
     proc = KaldiPitchProcessor()
     outs = proc._process_batch([Audio(w, 16000) for w in synth_waves])
