@@ -129,3 +129,143 @@ def features(wave, kind='fbank', sample_rate=16000, frame_shift=0.01, frame_leng
     if use_energy is None or use_energy:
         out[:, 0] = log_energy
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Kaldi pitch tracker in float64 (round 3).  An independent restatement of [KALDI-UPSTREAM] pitch-functions.cc
+# / resample.cc - LinearResample, ComputeCorrelation / ComputeNccf with the ballast, ArbitraryResample to the
+# log-spaced lags, and the Viterbi recursion as a FULL search over all previous states - with every sum in
+# double and numpy's own summation orders.  oracle/kaldi_oracle.c fixes float32 summation orders that a GPU
+# wavefront reproduces bit for bit (chain_dot / tree16), so "GPU == oracle" says nothing about how far those
+# orders sit from the exact arithmetic: this restatement does (tests/test_oracle_pins.py reports
+# max |oracle - f64| of the NCCF and the fraction of frames whose Viterbi state differs).
+# Reached by the reference at shennong/processor/pitch_kaldi.py:296-299.
+# ---------------------------------------------------------------------------------------------------------
+def _filter_func(t, cutoff, num_zeros):
+    """resample.cc FilterFunc: Hann-windowed sinc, t in seconds"""
+    t = np.asarray(t, dtype=np.float64)
+    window = np.where(np.abs(t) < num_zeros / (2.0 * cutoff),
+                      0.5 * (1 + np.cos(2 * np.pi * cutoff / num_zeros * t)), 0.0)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        filt = np.where(t != 0, np.sin(2 * np.pi * cutoff * t) / (np.pi * t), 2.0 * cutoff)
+    return filt * window
+
+
+def linear_resample(wave, rate_in=16000, rate_out=4000, cutoff=1000.0, num_zeros=1, flush=True):
+    """LinearResample of the whole signal (samples outside it are zero); returns the output samples"""
+    from math import gcd
+    wave = np.asarray(wave, dtype=np.float64)
+    n = wave.shape[0]
+    base = gcd(rate_in, rate_out)
+    in_unit, out_unit = rate_in // base, rate_out // base
+    tick = rate_in // base * rate_out
+    interval = n * (tick // rate_in)
+    if not flush:
+        interval -= int(np.floor(num_zeros / (2.0 * cutoff) * tick))
+    if interval <= 0:
+        return np.zeros(0)
+    per_out = tick // rate_out
+    last = interval // per_out
+    if last * per_out == interval:
+        last -= 1
+    n_out = last + 1
+    width = num_zeros / (2.0 * cutoff)
+    out = np.zeros(n_out)
+    k = np.arange(n_out)
+    for i in range(out_unit):
+        t_out = i / rate_out
+        lo = int(np.ceil((t_out - width) * rate_in))
+        hi = int(np.floor((t_out + width) * rate_in))
+        taps = np.arange(lo, hi + 1)
+        w = _filter_func(taps / rate_in - t_out, cutoff, num_zeros) / rate_in
+        sel = k[k % out_unit == i]
+        idx = (sel // out_unit)[:, None] * in_unit + taps[None, :]
+        ok = (idx >= 0) & (idx < n)
+        out[sel] = (np.where(ok, wave[np.clip(idx, 0, n - 1)], 0.0) * w[None, :]).sum(axis=1)
+    return out
+
+
+def pitch(wave, samp_freq=16000, frame_shift_ms=10.0, frame_length_ms=25.0, min_f0=50.0, max_f0=400.0,
+          soft_min_f0=10.0, penalty_factor=0.1, lowpass_cutoff=1000.0, resample_freq=4000,
+          delta_pitch=0.005, nccf_ballast=7000.0, lowpass_filter_width=1, upsample_filter_width=5,
+          recompute_frame=500):
+    """-> dict(out [T, 2] (POV NCCF, pitch), nccf [T, S] (resampled, with ballast), states [T], lags [S])
+    snip_edges = True, the offline single-chunk call (frames before / after the resampler flush see the
+    signal statistics of their phase; RecomputeBacktraces as in kaldi_oracle.c)."""
+    samp_freq, resample_freq = int(samp_freq), int(resample_freq)
+    down1 = linear_resample(wave, samp_freq, resample_freq, lowpass_cutoff, lowpass_filter_width, flush=False)
+    down = linear_resample(wave, samp_freq, resample_freq, lowpass_cutoff, lowpass_filter_width, flush=True)
+    n1, n2 = down1.shape[0], down.shape[0]
+    outer_min = 1.0 / max_f0 - upsample_filter_width / (2.0 * resample_freq)
+    outer_max = 1.0 / min_f0 + upsample_filter_width / (2.0 * resample_freq)
+    first_lag, last_lag = int(np.ceil(resample_freq * outer_min)), int(np.floor(resample_freq * outer_max))
+    L = last_lag + 1 - first_lag
+    W = int(resample_freq * frame_length_ms / 1000.0)
+    shift = int(resample_freq * frame_shift_ms / 1000.0)
+    full = W + last_lag
+    T1 = 0 if n1 < full else (n1 - full) // shift + 1
+    T = 0 if n2 < W else (n2 - W) // shift + 1
+    T1 = min(T1, T)
+    # SelectLags runs in BaseFloat in Kaldi; the float32 lags are part of the algorithm's definition
+    lags = []
+    lag = np.float32(1.0 / max_f0)
+    while lag <= np.float32(1.0 / min_f0):
+        lags.append(float(lag))
+        lag = np.float32(float(lag) * (1.0 + delta_pitch))
+    lags = np.array(lags)
+    S = lags.shape[0]
+    if T <= 0:
+        return dict(out=np.zeros((0, 2)), nccf=np.zeros((0, S)), states=np.zeros(0, int), lags=lags)
+    ms1 = (down[:n1] ** 2).sum() / n1 - (down[:n1].sum() / n1) ** 2 if n1 > 0 else 0.0
+    ms2 = (down ** 2).sum() / n2 - (down.sum() / n2) ** 2
+    # ArbitraryResample: weights of the (<= 2 * width + 1) integer lags around every log-spaced lag
+    up_cut = 0.5 * resample_freq
+    fw = upsample_filter_width / (2.0 * up_cut)
+    tq = lags - first_lag / resample_freq
+    ar = np.zeros((S, L))
+    for s in range(S):
+        lo = max(int(np.ceil(resample_freq * (tq[s] - fw))), 0)
+        hi = min(int(np.floor(resample_freq * (tq[s] + fw))), L - 1)
+        j = np.arange(lo, hi + 1)
+        ar[s, j] = _filter_func(tq[s] - j / resample_freq, up_cut, upsample_filter_width) / resample_freq
+    padded = np.concatenate([down, np.zeros(full + shift)])
+    frames = padded[np.arange(T)[:, None] * shift + np.arange(full)[None, :]]
+    frames = frames - frames[:, :W].mean(axis=1, keepdims=True)
+    e1 = (frames[:, :W] ** 2).sum(axis=1)
+    inner = np.zeros((T, L))
+    norm = np.zeros((T, L))
+    for li, lg in enumerate(range(first_lag, last_lag + 1)):
+        seg = frames[:, lg:lg + W]
+        inner[:, li] = (frames[:, :W] * seg).sum(axis=1)
+        norm[:, li] = e1 * (seg ** 2).sum(axis=1)
+    ms = np.where(np.arange(T) < T1, ms1, ms2)
+    ballast = (ms * W) ** 2 * nccf_ballast
+    den = np.sqrt(norm + ballast[:, None])
+    nccf_pitch = np.where(den != 0, inner / np.where(den != 0, den, 1.0), 0.0)
+    den0 = np.sqrt(norm)
+    nccf_pov = np.where(den0 != 0, inner / np.where(den0 != 0, den0, 1.0), 0.0)
+    res = nccf_pitch @ ar.T
+    res_pov = nccf_pov @ ar.T
+    differ = T1 > 0 and not abs(ms1 - ms2) <= 0.01 * (abs(ms1) + abs(ms2))
+    if (T < recompute_frame or T1 < recompute_frame) and differ:
+        anp = norm.sum(axis=1) / L
+        new_b = (ms2 * W) ** 2 * nccf_ballast
+        res = res * np.sqrt((ballast + anp) / (new_b + anp))[:, None]
+    # Viterbi: full search (Kaldi's bounded two-sweep search finds the same argmin; ties -> lowest index)
+    iff = np.log(1.0 + delta_pitch) ** 2 * penalty_factor
+    trans = (np.arange(S)[None, :] - np.arange(S)[:, None]) ** 2 * iff   # [i (this), j (previous)]
+    fwd = np.zeros(S)
+    bp = np.zeros((T, S), dtype=np.int64)
+    for t in range(T):
+        cost = trans + fwd[None, :]
+        bp[t] = cost.argmin(axis=1)
+        fwd = cost[np.arange(S), bp[t]] + (1.0 - res[t] + soft_min_f0 * lags * res[t])
+        fwd -= fwd.min()
+    states = np.zeros(T, dtype=np.int64)
+    best = int(fwd.argmin())
+    out = np.zeros((T, 2))
+    for t in range(T - 1, -1, -1):
+        states[t] = best
+        out[t] = (res_pov[t, best], 1.0 / lags[best])
+        best = bp[t, best]
+    return dict(out=out, nccf=res, states=states, lags=lags)

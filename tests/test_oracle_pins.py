@@ -12,6 +12,7 @@ import pytest
 
 from conftest import GOLDEN
 from oracle import oracle as orc, spec_f64
+from shennong_amd import synth
 from shennong_amd import _abi
 
 
@@ -296,6 +297,42 @@ def test_pitch_recompute_backtraces_corner(nsamples, nframes):
         np.testing.assert_array_equal(default, all_frames)
     else:
         np.testing.assert_array_equal(default, never)
+
+
+def pitch_oracle_vs_f64(waves):
+    """(max |resampled NCCF oracle - float64|, frames whose Viterbi state differs, frames, largest state
+    distance) of the C oracle against oracle/spec_f64.pitch over `waves`"""
+    po = _abi.default_pitch_options()
+    worst, differ, total, step = 0.0, 0, 0, 0
+    for w in waves:
+        ref = spec_f64.pitch(w)
+        out, _, res, _, states = orc.pitch_debug(po, w)
+        worst = max(worst, float(np.abs(res - ref['nccf']).max()))
+        differ += int((states != ref['states']).sum())
+        step = max(step, int(np.abs(states - ref['states']).max()))
+        total += states.shape[0]
+        same = states == ref['states']
+        # where the path is the same the outputs are the same quantities in two precisions
+        np.testing.assert_allclose(out[same, 1], ref['out'][same, 1], rtol=1e-6)
+        np.testing.assert_allclose(out[same, 0], ref['out'][same, 0], atol=2e-5)
+    return worst, differ, total, step
+
+
+def test_pitch_against_float64_restatement(wave):
+    """THE parity statement of the pitch tracker (the GPU tracker equals the C oracle bit for bit because the
+    oracle fixes summation orders a wavefront reproduces - that equality says nothing about the distance to
+    the exact arithmetic; this test does).  oracle/spec_f64.pitch restates LinearResample, the NCCF with
+    ballast, ArbitraryResample and a FULL-search Viterbi in float64.  Measured (profiles/r03_pitch_f64.txt):
+    test.wav 2.9e-7 / 0 of 140 frames; 50 synthetic 2 s utterances 9.0e-8 / 5 of 9 900 frames, each one state
+    (0.5 % of the pitch value) off where two paths tie within float32 round-off."""
+    worst, differ, total, step = pitch_oracle_vs_f64([wave])
+    assert worst < 1e-6 and differ == 0 and total == 140
+    waves = [synth.utterances(900 + i, 1, 32000)[0] for i in range(50)]
+    worst, differ, total, step = pitch_oracle_vs_f64(waves)
+    assert total == 9900
+    assert worst < 5e-7, worst                 # measured 9.0e-8
+    assert differ <= total // 200, differ      # measured 5 (0.05 %); bound 0.5 %
+    assert step <= 2, step                     # measured 1
 
 
 def test_pitch_tracks_a_tone():
