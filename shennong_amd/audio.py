@@ -5,8 +5,9 @@ samples (one column per channel) and a sample rate; the sample type is one of in
 or float64 and each type has a full scale (2**15, 2**30 and 1.0): ``astype`` rescales between them
 (audio.py:469-518), the processors ask for int16.  WAV files are read with scipy (audio.py:179-320;
 the reference falls back to pydub / ffmpeg and to sox for flac, mp3, ...: neither exists offline,
-those formats raise a ValueError that says so).  Writing and resampling audio are not on the
-features path and are not provided.
+those formats raise a ValueError that says so).  `save` writes WAV files and `resample` is the
+reference's scipy backend (Fourier-domain resampling; its sox backend needs the external binary) -
+neither is on the features path, both are what the reference's callers use (pipeline_manager.py:240).
 """
 
 import collections
@@ -83,6 +84,45 @@ class Audio:
         sample_rate, data = _read_wav(filename, 'cannot scan audio file', mmap=True)
         return _Metadata(1 if data.ndim == 1 else data.shape[1], sample_rate, data.shape[0],
                          data.shape[0] / sample_rate)
+
+    def save(self, filename):
+        """Writes the signal to the WAV file `filename` (reference audio.py:288-320; the other
+        containers it writes through pydub / ffmpeg are refused here)
+
+        Raises ValueError if the file exists, has no extension or is not ``.wav``."""
+        filename = str(filename)
+        if os.path.isfile(filename):
+            raise ValueError(f'{filename}: file already exists')
+        if '.' not in os.path.basename(filename):
+            raise ValueError(f'{filename}: cannot write audio file without extension')
+        if not filename.lower().endswith('.wav'):
+            raise ValueError(f'{filename}: only WAV files can be written here (the reference encodes other '
+                             f'formats with pydub/ffmpeg)')
+        try:
+            scipy.io.wavfile.write(filename, self.sample_rate, self.data)
+        except (ValueError, OSError) as err:
+            raise ValueError(f'{filename}: cannot write file, {err}') from None
+
+    def resample(self, sample_rate, backend='scipy'):
+        """The signal resampled to `sample_rate`, in its own sample type (reference audio.py:358-424).
+        `backend` 'scipy' is scipy.signal.resample (Fourier method: exact for band-limited signals, slow
+        for long ones); 'sox' - the reference's default - needs the sox binary and is refused here."""
+        if backend not in ('sox', 'scipy'):
+            raise ValueError(f'backend must be sox or scipy, it is {backend}')
+        if backend == 'sox':
+            raise ValueError('the sox backend needs the sox binary, which is not available here: '
+                             'use backend="scipy"')
+        if not isinstance(sample_rate, (int, np.integer)) or sample_rate <= 0:
+            raise ValueError(f'resampling at {sample_rate} failed!')
+        if sample_rate == self.sample_rate:
+            return self
+        import scipy.signal
+        nsamples = int(self.nsamples * sample_rate / self.sample_rate)
+        data = scipy.signal.resample(self.data, nsamples)
+        if np.issubdtype(self.dtype, np.integer):
+            lo, hi = _FORMATS[self.dtype][1:]
+            data = np.clip(np.rint(data), lo, hi)  # (overshoot of the sinc interpolation near full scale)
+        return Audio(data.astype(self.dtype), int(sample_rate), validate=False)
 
     # ---- views and conversions --------------------------------------------------------------------
     def channel(self, index):

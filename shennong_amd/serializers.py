@@ -1,12 +1,14 @@
-"""Features files: numpy ``.npz`` and Kaldi ``.ark`` (+ ``.scp``), nothing else.
+"""Features files: numpy ``.npz``, Kaldi ``.ark`` (+ ``.scp``), matlab ``.mat``, pickle ``.pkl`` and a
+directory of ``.csv`` files - the formats of reference shennong/serializers.py that need no package
+missing here (h5features is not installed and says so), with the reference's file layouts, so files stay
+interchangeable with it, and its entry points (`supported_extensions`, `supported_serializers`,
+`get_serializer(cls, filename, log, serializer)` -> an object with `save` / `load`).
 
 At GPU rates the writer decides the wall time of a corpus run (the reference reports 2:30 to write
-38 h of MFCC as npz, features_collection.py:19-26), so the only formats kept are the two the hot path
-needs: one self-contained ``.npz`` per collection, and the Kaldi binary archive, which can be
-appended to batch by batch (`KaldiStreamWriter`) while ``pipeline.extract_features_streamed`` runs.
-Both layouts are the reference's own (reference serializers.py:224-247 and :392-505), so files stay
-interchangeable with it; the matlab / pickle / csv / h5features / json layouts of the reference are
-out of scope here.
+38 h of MFCC as npz, features_collection.py:19-26): the two formats on the hot path are one
+self-contained ``.npz`` per collection and the Kaldi binary archive, which can be appended to batch by
+batch (`KaldiStreamWriter`) while ``pipeline.extract_features_streamed`` runs; mat / pickle / csv are
+plain host-side writers for interchange.
 
 Kaldi table entry ([KALDI-UPSTREAM] util/kaldi-holder-inl.h, matrix/kaldi-matrix.cc Write):
 ``<key> \\0B`` + ``DM `` (double) or ``FM `` (float) + ``\\4<int32 rows>\\4<int32 cols>`` + row-major
@@ -18,6 +20,7 @@ the ``{"__ndarray__": ..., "dtype": ..., "shape": ...}`` encoding the reference'
 import copy
 import json
 import os
+import pickle
 import struct
 
 import numpy as np
@@ -25,66 +28,225 @@ import numpy as np
 from shennong_amd.features import Features
 
 
-# ---- the two formats ---------------------------------------------------------------------------------
-def _format_of(filename, serializer):
-    """'numpy' or 'kaldi', from the explicit name or the file extension"""
-    by_extension = {'.npz': 'numpy', '.ark': 'kaldi'}
-    if serializer is not None:
-        if serializer not in by_extension.values():
+# ---- one (writer, reader) pair per format ---------------------------------------------------------------
+def _write_numpy(features, filename, with_properties, compress=True):
+    entries = {name: f._to_dict(with_properties=with_properties) for name, f in features.items()}
+    write = np.savez_compressed if compress is True else np.savez
+    with open(filename, 'wb') as stream:
+        write(stream, features=entries, allow_pickle=True)
+
+
+def _read_numpy(cls, filename):
+    with open(filename, 'rb') as stream:
+        stored = np.load(stream, allow_pickle=True)['features'].item()
+    return cls((name, Features._from_dict(entry, validate=False)) for name, entry in stored.items())
+
+
+def _write_kaldi(features, filename, with_properties, scp=False, double=True):
+    with KaldiStreamWriter(filename, scp=scp, with_properties=with_properties, double=double) as writer:
+        writer.write(features)
+
+
+def _read_kaldi(cls, filename):
+    return cls(_read_kaldi_collection(filename))
+
+
+def _write_matlab(features, filename, with_properties, compress=True):
+    """one struct per item with the fields data / times (/ properties), reference serializers.py:250-264"""
+    import scipy.io
+    scipy.io.savemat(filename, {name: f._to_dict(with_properties=with_properties)
+                                for name, f in features.items()},
+                     long_field_names=True, appendmat=False, do_compression=compress)
+
+
+def _read_matlab(cls, filename):
+    import scipy.io
+    # the shapes of data / times from an unsqueezed read (a one-frame item is a [1, D] matrix, not a vector),
+    # the properties from a simplified one (nested dicts instead of struct arrays)
+    shaped = scipy.io.loadmat(filename, appendmat=False, mat_dtype=True)
+    stored = scipy.io.loadmat(filename, appendmat=False, mat_dtype=True, simplify_cells=True)
+
+    def plain(value):
+        # matlab keeps no lists and no scalars: cell arrays and 0-d / 1 x n arrays come back in their place
+        if isinstance(value, dict):
+            return {k: plain(v) for k, v in value.items()}
+        if isinstance(value, (list, tuple)):
+            return [plain(v) for v in value]
+        if isinstance(value, np.ndarray):
+            if value.dtype == object:
+                return [plain(v) for v in value.tolist()]
+            return value.item() if value.ndim == 0 else value
+        return value
+    out = cls()
+    for name, entry in stored.items():
+        if name.startswith('__'):
+            continue
+        properties = plain(entry.get('properties', {})) or {}
+        stages = properties.get('pipeline')
+        if stages is not None:
+            # a list of ONE stage collapses into that stage, and its [first, last] columns into an array
+            stages = stages if isinstance(stages, list) else [stages]
+            properties['pipeline'] = [
+                {k: (np.asarray(v).astype(int).tolist() if k == 'columns' else v) for k, v in st.items()}
+                for st in stages]
+        data, times = shaped[name]['data'][0, 0], shaped[name]['times'][0, 0]
+        if times.shape == (1, data.shape[0]) and times.shape != (data.shape[0], 2):
+            times = times[0]  # (a vector of T start times was written as a 1 x T row)
+        out[name] = Features(data, times, properties, validate=False)
+    return out
+
+
+def _write_pickle(features, filename, with_properties):
+    if not with_properties:
+        features = type(features)((name, Features(f.data, f.times, validate=False))
+                                  for name, f in features.items())
+    with open(filename, 'wb') as stream:
+        pickle.dump(features, stream)
+
+
+def _read_pickle(cls, filename):
+    with open(filename, 'rb') as stream:
+        return pickle.load(stream)
+
+
+def _write_csv(features, dirname, with_properties):
+    """a directory with `<item>.csv` ([times | data], the dtypes and the width in a header line) and
+    `<item>.json` (properties), reference serializers.py:508-547"""
+    os.makedirs(dirname)
+    for name, feat in features.items():
+        times = feat.times.reshape(feat.nframes, -1)
+        np.savetxt(os.path.join(dirname, name + '.csv'), np.hstack((times, feat.data)), comments='# ',
+                   header=f'data_dtype = {feat.dtype}, times_dtype = {feat.times.dtype}, '
+                          f'features_ndims = {feat.ndims}')
+        if with_properties and feat.properties:
+            with open(os.path.join(dirname, name + '.json'), 'wt', encoding='utf-8') as stream:
+                stream.write(json.dumps(feat.properties, indent=4, cls=_ArrayEncoder))
+
+
+def _read_csv(cls, dirname):
+    out = cls()
+    for entry in sorted(os.listdir(dirname)):
+        if not entry.endswith('.csv'):
+            continue
+        path = os.path.join(dirname, entry)
+        with open(path, 'r', encoding='utf-8') as stream:
+            header = stream.readline().strip()
+        try:
+            fields = dict(part.split(' = ') for part in header.lstrip('# ').split(', '))
+            data_dtype, times_dtype = np.dtype(fields['data_dtype']), np.dtype(fields['times_dtype'])
+            ndims = int(fields['features_ndims'])
+        except (KeyError, ValueError, TypeError):
+            raise ValueError(f'failed to parse header from {path}') from None
+        table = np.atleast_2d(np.loadtxt(path))
+        times = table[:, :table.shape[1] - ndims].astype(times_dtype)
+        properties = {}
+        sidecar = path[:-4] + '.json'
+        if os.path.isfile(sidecar):
+            with open(sidecar, 'r', encoding='utf-8') as stream:
+                properties = json.loads(stream.read(), object_hook=_decode_arrays)
+        out[entry[:-4]] = Features(table[:, table.shape[1] - ndims:].astype(data_dtype),
+                                   times[:, 0] if times.shape[1] == 1 else times, properties, validate=False)
+    return out
+
+
+def _no_h5features(*args, **kwargs):
+    raise ValueError('the h5features format needs the h5features package, which is not installed here; '
+                     'use .npz, .ark, .mat, .pkl or a csv directory')
+
+
+# name -> (extension, writer, reader); '' = a directory
+_FORMATS = {
+    'numpy': ('.npz', _write_numpy, _read_numpy),
+    'matlab': ('.mat', _write_matlab, _read_matlab),
+    'pickle': ('.pkl', _write_pickle, _read_pickle),
+    'h5features': ('.h5f', _no_h5features, _no_h5features),
+    'kaldi': ('.ark', _write_kaldi, _read_kaldi),
+    'csv': ('', _write_csv, _read_csv),
+}
+
+
+class FeaturesSerializer:
+    """One features file in one format: `save(features, with_properties=True, **kwargs)` and `load()`
+    (reference serializers.py:112-221; `compress` for numpy / matlab, `scp` / `double` for kaldi)"""
+    def __init__(self, cls, filename, log, name):
+        self._cls, self._filename, self._log, self.name = cls, str(filename), log, name
+        _, self._write, self._read = _FORMATS[name]
+
+    filename = property(lambda self: self._filename, doc='The file (csv: the directory) read or written')
+
+    def save(self, features, with_properties=True, **kwargs):
+        if type(features).__name__ != 'FeaturesCollection':
             raise ValueError(
-                f'invalid serializer {serializer}, must be in {list(by_extension.values())}')
-        return serializer
-    ext = os.path.splitext(str(filename))[1]
-    if ext not in by_extension:
-        raise ValueError(f'invalid extension {ext}, must be in {list(by_extension)}')
-    return by_extension[ext]
+                f'features must be FeaturesCollection but are {type(features).__name__}')
+        if os.path.exists(self.filename) if self.name == 'csv' else os.path.isfile(self.filename):
+            raise IOError(f'file already exists: {self.filename}')
+        if not features.is_valid():
+            raise ValueError('features are not valid')
+        if self._log:
+            self._log.info('writing %s', self.filename)
+        self._write(features, self.filename, with_properties, **kwargs)
+
+    def load(self, **kwargs):
+        if self.name == 'csv':
+            if not os.path.isdir(self.filename):
+                raise IOError(f'directory not found: {self.filename}')
+        else:
+            for test, problem in ((os.path.isfile, 'found'), (lambda f: os.access(f, os.R_OK), 'readable')):
+                if not test(self.filename):
+                    raise IOError(f'file not {problem}: {self.filename}')
+        if self._log:
+            self._log.info('loading %s', self.filename)
+        features = self._read(self._cls, self.filename, **kwargs)
+        if not features.is_valid():  # pragma: nocover
+            raise ValueError(f'features not valid in "{self.filename}"')
+        return features
+
+
+def supported_serializers():
+    """format name -> a factory ``(cls, filename, log) -> FeaturesSerializer``"""
+    def factory(name):
+        return lambda cls, filename, log=None: FeaturesSerializer(cls, filename, log, name)
+    return {name: factory(name) for name in _FORMATS}
+
+
+def supported_extensions():
+    """file extension ('' = a directory of csv files) -> the same factories"""
+    by_name = supported_serializers()
+    return {ext: by_name[name] for name, (ext, _, _) in _FORMATS.items()}
+
+
+def get_serializer(cls, filename, log=None, serializer=None):
+    """The serializer of `filename`, from its extension or from the format name `serializer`"""
+    if cls.__name__ != 'FeaturesCollection':
+        raise ValueError('The `cls` parameter must be shennong.features.FeaturesCollection')
+    if serializer is None:
+        ext = os.path.splitext(str(filename))[1]
+        try:
+            return supported_extensions()[ext](cls, filename, log)
+        except KeyError:
+            raise ValueError(
+                f'invalid extension {ext}, must be in {list(supported_extensions())}') from None
+    try:
+        return supported_serializers()[serializer](cls, filename, log)
+    except KeyError:
+        raise ValueError(
+            f'invalid serializer {serializer}, must be in {list(supported_serializers())}') from None
 
 
 def save(features, filename, serializer=None, with_properties=True, log=None, **kwargs):
-    """Writes a FeaturesCollection; IOError if the file exists, ValueError if the collection is not
-    valid.  `compress` (numpy, default True), `scp` / `double` (kaldi)."""
-    filename = str(filename)
-    fmt = _format_of(filename, serializer)
-    if type(features).__name__ != 'FeaturesCollection':
-        raise ValueError(
-            f'features must be FeaturesCollection but are {type(features).__name__}')
-    if os.path.isfile(filename):
-        raise IOError(f'file already exists: {filename}')
-    if not features.is_valid():
-        raise ValueError('features are not valid')
-    if log:
-        log.info('writing %s', filename)
-    if fmt == 'numpy':
-        entries = {name: f._to_dict(with_properties=with_properties) for name, f in features.items()}
-        write = np.savez_compressed if kwargs.get('compress', True) is True else np.savez
-        with open(filename, 'wb') as stream:
-            write(stream, features=entries, allow_pickle=True)
-    else:
-        with KaldiStreamWriter(filename, scp=kwargs.get('scp', False),
-                               with_properties=with_properties,
-                               double=kwargs.get('double', True)) as writer:
-            writer.write(features)
+    """Writes a FeaturesCollection; IOError if the file exists, ValueError if the collection is not valid"""
+    cls = type(features) if type(features).__name__ == 'FeaturesCollection' else _collection_class()
+    get_serializer(cls, filename, log, serializer).save(features, with_properties=with_properties, **kwargs)
 
 
 def load(cls, filename, serializer=None, log=None):
     """Reads a collection back as `cls` (FeaturesCollection)"""
-    filename = str(filename)
-    fmt = _format_of(filename, serializer)
-    for test, problem in ((os.path.isfile, 'found'), (lambda f: os.access(f, os.R_OK), 'readable')):
-        if not test(filename):
-            raise IOError(f'file not {problem}: {filename}')
-    if log:
-        log.info('loading %s', filename)
-    if fmt == 'numpy':
-        with open(filename, 'rb') as stream:
-            stored = np.load(stream, allow_pickle=True)['features'].item()
-        features = cls((name, Features._from_dict(entry, validate=False))
-                       for name, entry in stored.items())
-    else:
-        features = cls(_read_kaldi_collection(filename))
-    if not features.is_valid():  # pragma: nocover
-        raise ValueError(f'features not valid in "{filename}"')
-    return features
+    return get_serializer(cls, filename, log, serializer).load()
+
+
+def _collection_class():
+    from shennong_amd.features import FeaturesCollection
+    return FeaturesCollection
 
 
 # ---- properties JSON -----------------------------------------------------------------------------------

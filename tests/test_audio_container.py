@@ -146,3 +146,42 @@ def test_segments_tile_the_signal(audio, parts):
 def test_bad_segments(audio, segments, message):
     with pytest.raises(ValueError, match=message):
         audio.segment(segments)
+
+
+# ---- writing and resampling (reference test/test_audio.py:69-112, :264-290) ----------------------------
+def test_save_and_reload(tmpdir, audio):
+    target = str(tmpdir.join('copy.wav'))
+    audio.save(target)
+    assert Audio.load(target) == audio
+    for path, message in ((target, 'file already exists'), (str(tmpdir.join('noext')), 'without extension'),
+                          (str(tmpdir.join('x.flac')), 'only WAV files')):
+        with pytest.raises(ValueError, match=message):
+            audio.save(path)
+
+
+@pytest.mark.parametrize('fs', [4000, 8000, 16000, 32000, 44100])
+def test_resample(audio, fs):
+    again = audio.resample(fs)
+    assert (again.nchannels, again.sample_rate, again.dtype) == (audio.nchannels, fs, audio.dtype)
+    assert abs(again.nsamples - int(audio.nsamples * fs / audio.sample_rate)) <= 1
+    assert again.data.mean() == pytest.approx(audio.data.mean(), abs=0.25)
+    if fs >= audio.sample_rate:
+        # band-limited round trip: up and back down returns the signal (to the rounding of int16)
+        back = again.resample(audio.sample_rate)
+        assert abs(back.nsamples - audio.nsamples) <= 1   # (int() of a non-integer ratio loses a sample)
+        if back.nsamples == audio.nsamples:
+            assert np.abs(back.data.astype(np.int64) - audio.data.astype(np.int64)).max() <= 2
+    # a tone keeps its frequency: the spectral peak of 440 Hz stays at 440 Hz
+    t = np.arange(16000) / 16000.0
+    tone = Audio((8000 * np.sin(2 * np.pi * 440 * t)).astype(np.int16), 16000).resample(fs)
+    spectrum = np.abs(np.fft.rfft(tone.data.astype(np.float64)))
+    assert abs(np.argmax(spectrum) * fs / tone.nsamples - 440.0) <= 1.0
+
+
+def test_resample_refusals(audio):
+    with pytest.raises(ValueError, match='backend must be sox or scipy, it is a_bad_one'):
+        audio.resample(5, backend='a_bad_one')
+    with pytest.raises(ValueError, match='resampling at 0 failed'):
+        audio.resample(0)
+    with pytest.raises(ValueError, match='sox binary'):
+        audio.resample(8000, backend='sox')

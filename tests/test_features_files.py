@@ -1,5 +1,6 @@
-"""Features files: numpy .npz and Kaldi .ark, one-shot and streamed.  Host-only:
-the features are a fixed random matrix shaped like the MFCCs of test.wav, no device call."""
+"""Features files: numpy .npz and Kaldi .ark, one-shot and streamed, and the matlab /
+pickle / csv interchange formats of the reference (reference test/test_serializers.py).  Host-only: the
+features are a fixed random matrix shaped like the MFCCs of test.wav, no device call."""
 
 import os
 
@@ -10,7 +11,8 @@ from shennong_amd import Features, FeaturesCollection
 from shennong_amd import serializers
 from shennong_amd.processor import MfccProcessor
 
-FORMATS = [('numpy', 'feats.npz'), ('kaldi', 'feats.ark')]
+FORMATS = [('numpy', 'feats.npz'), ('kaldi', 'feats.ark'), ('matlab', 'feats.mat'), ('pickle', 'feats.pkl'),
+           ('csv', 'feats')]
 
 
 @pytest.fixture(scope='module')
@@ -28,7 +30,7 @@ def mfcc_col(mfcc):
 def test_format_lookup(tmp_path, mfcc_col):
     for args, message in (
             (('foo.spam', None), 'invalid extension .spam'),
-            (('foo.h5f', None), 'invalid extension .h5f'),
+            (('foo.h5f', None), 'h5features package, which is not installed'),
             (('foo.npz', 'spam'), 'invalid serializer spam'),
             (('foo.file', 'kaldi'), 'the file extension must be ".ark", it is ".file"')):
         with pytest.raises(ValueError, match=message):
@@ -56,12 +58,40 @@ def test_round_trip(tmp_path, mfcc_col, fmt, name, with_properties):
 
 @pytest.mark.parametrize('fmt, name', FORMATS)
 def test_bad_files(tmp_path, mfcc_col, fmt, name):
-    with pytest.raises(IOError, match='file not found'):
+    with pytest.raises(IOError, match='directory not found' if fmt == 'csv' else 'file not found'):
         FeaturesCollection.load(str(tmp_path / name))
     invalid = FeaturesCollection(mfcc=Features(
         np.full((2, 2), np.nan, dtype=np.float32), np.arange(2, dtype=np.float64), validate=False))
     with pytest.raises(ValueError, match='features are not valid'):
         invalid.save(str(tmp_path / name))
+
+
+def test_reference_entry_points(tmp_path, mfcc_col):
+    """supported_extensions / supported_serializers / get_serializer of reference serializers.py:20-109"""
+    assert list(serializers.supported_extensions()) == ['.npz', '.mat', '.pkl', '.h5f', '.ark', '']
+    assert list(serializers.supported_serializers()) == ['numpy', 'matlab', 'pickle', 'h5features', 'kaldi', 'csv']
+    with pytest.raises(ValueError, match='must be shennong.features.FeaturesCollection'):
+        serializers.get_serializer(Features, 'x.npz', None)
+    writer = serializers.get_serializer(FeaturesCollection, str(tmp_path / 'x.pkl'), None)
+    assert writer.filename == str(tmp_path / 'x.pkl')
+    writer.save(mfcc_col)
+    assert serializers.get_serializer(FeaturesCollection, writer.filename, None, 'pickle').load() == mfcc_col
+
+
+def test_shapes_survive_matlab_and_csv(tmp_path):
+    """one-frame items, one-column items, 1-D and 2-D times: matlab squeezes vectors, csv is a flat table"""
+    rng = np.random.default_rng(1)
+    col = FeaturesCollection(
+        one_frame=Features(rng.standard_normal((1, 3)).astype(np.float32), np.array([[0, 0.025]])),
+        one_column=Features(rng.standard_normal((2, 1)), np.array([0.0, 0.01])),
+        square=Features(rng.standard_normal((2, 2)), np.array([[0.0, 0.025], [0.01, 0.035]]),
+                        properties={'pipeline': [{'name': 'mfcc', 'columns': [0, 1]}], 'mfcc': {'warp': 1.0}}))
+    for name in ('shapes.mat', 'shapes'):
+        col.save(str(tmp_path / name))
+        back = FeaturesCollection.load(str(tmp_path / name))
+        assert back == col
+        for key in col:
+            assert back[key].shape == col[key].shape and back[key].times.shape == col[key].times.shape
 
 
 def test_kaldi_sidecars(tmp_path, mfcc_col):
