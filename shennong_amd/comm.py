@@ -2,7 +2,8 @@
 
 One process per GPU.  The data path (feature blocks, CMVN statistics) goes over RCCL / xGMI with
 device pointers; what little host metadata the ranks need to agree on (names and shapes of the blocks,
-the RCCL unique id) travels over plain TCP sockets to rank 0, opened from the rendezvous variables a
+the RCCL unique id) travels over TCP sockets to rank 0 - every frame authenticated with the job's token
+(`_job_key`), size-capped, and parsed as plain data only (`_DataUnpickler`) - opened from the variables a
 launcher such as ``torch.distributed.run`` exports (``RANK``, ``WORLD_SIZE``, ``LOCAL_RANK``,
 ``MASTER_ADDR``, ``MASTER_PORT``) - the launcher is only a process spawner here, torch is never
 imported.
@@ -11,6 +12,9 @@ An ``RcclComm`` can be passed wherever ``shennong_amd.distributed`` takes a ``gr
 """
 
 import ctypes as C
+import hashlib
+import hmac
+import io
 import os
 import pickle
 import socket
@@ -21,20 +25,41 @@ import numpy as np
 
 from shennong_amd import _backend
 
-_PORT_OFFSET = 1017   # rendezvous port = MASTER_PORT + this (MASTER_PORT itself belongs to the launcher)
+_PORT_OFFSET = 1017   # default rendezvous port = MASTER_PORT + this (MASTER_PORT itself belongs to the launcher)
+_MAGIC = b'SNFC'
+_HELLO = struct.Struct('<4sI')
 
 
 def rendezvous_port(master_port):
-    """Port of this module's own rendezvous: next to the launcher's, inside the valid range"""
+    """Port of this module's own rendezvous: ``SNF_COMM_PORT`` when set, else next to the launcher's,
+    inside the valid range"""
+    if os.environ.get('SNF_COMM_PORT'):
+        return int(os.environ['SNF_COMM_PORT'])
     port = master_port + _PORT_OFFSET
     return port if port <= 65535 else master_port - _PORT_OFFSET
 
 
-def _send_msg(sock, payload):
-    sock.sendall(struct.pack('<Q', len(payload)) + payload)
+def _job_key():
+    """Key of the message authentication codes: every frame on the rendezvous sockets carries an
+    HMAC-SHA256 over its length and payload, so only processes that hold the job's token are accepted
+    as peers and nothing they did not send is ever parsed.  The token is ``SNF_COMM_TOKEN`` (export the
+    same random string to every rank) or, failing that, the launcher's ``TORCHELASTIC_RUN_ID``; with
+    neither the key is a constant and the socket must not be reachable by anyone else (the default
+    address is the loopback interface)."""
+    token = os.environ.get('SNF_COMM_TOKEN') or os.environ.get('TORCHELASTIC_RUN_ID', '')
+    return hashlib.sha256(b'shennong_amd.comm/1:' + token.encode('utf-8')).digest()
 
 
-def _recv_msg(sock):
+def _max_message():
+    return int(os.environ.get('SNF_COMM_MAX_MSG', str(4 << 30)))   # bytes; a bogus length never allocates more
+
+
+def _send_msg(sock, payload, key):
+    head = struct.pack('<Q', len(payload))
+    sock.sendall(head + hmac.new(key, head + payload, hashlib.sha256).digest() + payload)
+
+
+def _recv_msg(sock, key, limit=None):
     def read(n):
         chunks = []
         while n:
@@ -44,8 +69,38 @@ def _recv_msg(sock):
             chunks.append(chunk)
             n -= len(chunk)
         return b''.join(chunks)
-    (size,) = struct.unpack('<Q', read(8))
-    return read(size)
+    head = read(8)
+    (size,) = struct.unpack('<Q', head)
+    if size > (limit if limit is not None else _max_message()):
+        raise ConnectionError('rendezvous message of %d bytes exceeds the limit' % size)
+    mac, payload = read(32), read(size)
+    if not hmac.compare_digest(mac, hmac.new(key, head + payload, hashlib.sha256).digest()):
+        raise ConnectionError('rendezvous message failed authentication (SNF_COMM_TOKEN differs?)')
+    return payload
+
+
+class _DataUnpickler(pickle.Unpickler):
+    """Unpickles plain data only - builtin containers and scalars, numpy arrays and scalars - whatever the
+    peer sent: the metadata the ranks exchange (names, shapes, times, properties) needs nothing else, and a
+    pickle that names any other global is refused instead of executed."""
+    _ALLOWED = {
+        ('builtins', 'set'), ('builtins', 'frozenset'), ('builtins', 'slice'), ('builtins', 'range'),
+        ('builtins', 'complex'), ('builtins', 'bytearray'), ('collections', 'OrderedDict'),
+        ('numpy', 'ndarray'), ('numpy', 'dtype'),
+        ('numpy.core.multiarray', '_reconstruct'), ('numpy.core.multiarray', 'scalar'),
+        ('numpy._core.multiarray', '_reconstruct'), ('numpy._core.multiarray', 'scalar'),
+        ('numpy.core.numeric', '_frombuffer'), ('numpy._core.numeric', '_frombuffer'),
+    }
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED or (module == 'numpy.dtypes' and name.endswith('DType')):
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError('rendezvous payload names %s.%s: only plain data is accepted'
+                                     % (module, name))
+
+
+def _loads(payload):
+    return _DataUnpickler(io.BytesIO(payload)).load()
 
 
 class RcclComm:
@@ -54,6 +109,7 @@ class RcclComm:
         self.rank, self.world_size = int(rank), int(world_size)
         self.device = _backend.get_device() if device is None else int(device)
         self._peers = {}     # rank 0: rank -> socket; others: {0: socket}
+        self._key = _job_key()
         self._handle = C.c_void_p()
         lib = _backend.lib()
         ident = (C.c_char * 128)()
@@ -65,14 +121,26 @@ class RcclComm:
                 server.bind((addr, port))
                 server.listen(self.world_size)
                 server.settimeout(timeout)
+                deadline = time.time() + timeout
                 while len(self._peers) < self.world_size - 1:
+                    if time.time() > deadline:
+                        raise TimeoutError('rendezvous: %d of %d peers arrived'
+                                           % (len(self._peers), self.world_size - 1))
                     conn, _ = server.accept()
                     conn.settimeout(timeout)
-                    peer = pickle.loads(_recv_msg(conn))
+                    # a fixed-format, authenticated hello: anything else (a port scanner, a process of
+                    # another job, a second claim on a rank) is dropped and does not take a slot
+                    try:
+                        magic, peer = _HELLO.unpack(_recv_msg(conn, self._key, limit=_HELLO.size))
+                        if magic != _MAGIC or not 0 < peer < self.world_size or peer in self._peers:
+                            raise ConnectionError('bad hello')
+                    except (ConnectionError, struct.error, OSError):
+                        conn.close()
+                        continue
                     self._peers[peer] = conn
                 server.close()
                 for conn in self._peers.values():
-                    _send_msg(conn, bytes(ident))
+                    _send_msg(conn, bytes(ident), self._key)
         else:
             deadline = time.time() + timeout
             while True:
@@ -84,8 +152,8 @@ class RcclComm:
                         raise
                     time.sleep(0.05)
             conn.settimeout(timeout)
-            _send_msg(conn, pickle.dumps(self.rank))
-            C.memmove(ident, _recv_msg(conn), 128)
+            _send_msg(conn, _HELLO.pack(_MAGIC, self.rank), self._key)
+            C.memmove(ident, _recv_msg(conn, self._key, limit=128), 128)
             self._peers[0] = conn
         _backend.check(lib.snf_comm_init(ident, self.world_size, self.rank, self.device,
                                          C.byref(self._handle)))
@@ -122,13 +190,13 @@ class RcclComm:
         if self.rank == 0:
             objs = [obj] + [None] * (self.world_size - 1)
             for peer, conn in self._peers.items():
-                objs[peer] = pickle.loads(_recv_msg(conn))
+                objs[peer] = _loads(_recv_msg(conn, self._key))
             payload = pickle.dumps(objs)
             for conn in self._peers.values():
-                _send_msg(conn, payload)
+                _send_msg(conn, payload, self._key)
             return objs
-        _send_msg(self._peers[0], pickle.dumps(obj))
-        return pickle.loads(_recv_msg(self._peers[0]))
+        _send_msg(self._peers[0], pickle.dumps(obj), self._key)
+        return _loads(_recv_msg(self._peers[0], self._key))
 
     # ---- device data over RCCL -------------------------------------------------------------------------
     def gatherv_device(self, d_send, send_count, d_recv, recv_counts, root=0):

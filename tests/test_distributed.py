@@ -238,6 +238,48 @@ def test_rendezvous_port_next_to_the_launchers():
         assert port != master and 0 < port <= 65535
 
 
+def test_rendezvous_port_override(monkeypatch):
+    from shennong_amd.comm import rendezvous_port
+    monkeypatch.setenv('SNF_COMM_PORT', '40123')
+    assert rendezvous_port(29500) == 40123
+
+
+def test_rendezvous_frames_are_authenticated_capped_and_plain_data(monkeypatch):
+    """what crosses the rendezvous sockets: an HMAC over every frame (only holders of the job token are
+    peers), a size cap checked before anything is allocated, and an unpickler that accepts plain data only"""
+    import pickle
+    import numpy as np
+    from shennong_amd import comm
+    monkeypatch.setenv('SNF_COMM_TOKEN', 'job-a')
+    key_a = comm._job_key()
+    monkeypatch.setenv('SNF_COMM_TOKEN', 'job-b')
+    key_b = comm._job_key()
+    assert key_a != key_b
+    meta = [(['u0', 'u1'], [(3, 13), (0, 13)]), None, 'ValueError: x',
+            {'u0': (np.arange(3) * 0.01, {'pipeline': [{'name': 'mfcc', 'columns': [0, 12]}], 'warp': np.float32(1)})}]
+    left, right = socket.socketpair()
+    try:
+        comm._send_msg(left, pickle.dumps(meta), key_a)
+        back = comm._loads(comm._recv_msg(right, key_a))
+        assert back[:3] == meta[:3] and np.array_equal(back[3]['u0'][0], meta[3]['u0'][0])
+        assert back[3]['u0'][1] == meta[3]['u0'][1]
+        comm._send_msg(left, b'hello', key_b)                      # another job's token
+        with pytest.raises(ConnectionError, match='failed authentication'):
+            comm._recv_msg(right, key_a)
+        comm._send_msg(left, b'x' * 64, key_a)                     # longer than the reader allows
+        with pytest.raises(ConnectionError, match='exceeds the limit'):
+            comm._recv_msg(right, key_a, limit=16)
+    finally:
+        left.close()
+        right.close()
+
+    class Payload:
+        def __reduce__(self):
+            return (os.getenv, ('HOME',))
+    with pytest.raises(pickle.UnpicklingError, match='only plain data'):
+        comm._loads(pickle.dumps(Payload()))
+
+
 # ---- RCCL transport through the C ABI (needs a GPU; the test box has one: world size 1) ---------------
 @pytest.mark.gpu
 def test_rccl_comm_world_of_one():
