@@ -11,10 +11,16 @@ The reference's only parallelism is a joblib thread pool over utterances sharing
     real reduction on the path.  The [n_speakers, 2, dim+1] float64 blocks are all-gathered and summed
     in rank order, so the result does not depend on the collective's internal reduction order.
 Transport: every function takes a ``group``.  An ``shennong_amd.comm.RcclComm`` runs the exchange
-steps over RCCL through the C ABI (``snf_comm_*``: device pointers, no framework - what a GPU node
-uses); anything else (None, a torch process group) goes through ``torch.distributed``, which is how the
+steps over RCCL through the C ABI (``snf_comm_*``: device pointers, no framework).  ``group=None`` is
+that transport too whenever the process was started by a launcher (``WORLD_SIZE`` in the environment) on
+a machine with a GPU: one ``RcclComm.from_env()`` per process, created on first use.  A
+``torch.distributed`` process group is used only when the caller passes one (or has initialised
+``torch.distributed`` in a process without launcher variables / without a GPU): that is how the
 multi-process logic is tested on CPU with the gloo backend.
 """
+
+import os
+
 
 import numpy as np
 
@@ -42,19 +48,60 @@ class _TorchTransport:
 
 def _agree(transport, error):
     """Collective error check: every rank reports whether its local step failed; if any did, ALL ranks
-    raise (a rank that raised alone would leave the others blocked in the next collective)"""
-    reports = transport.all_gather_object(None if error is None else '%s: %s' % (type(error).__name__, error))
-    failed = [(r, msg) for r, msg in enumerate(reports) if msg is not None]
+    raise (a rank that raised alone would leave the others blocked in the next collective).  Payloads are
+    tagged: a rank that failed BEFORE the statistics exchange meets its peers' ('stats', ...) gather with
+    its ('status', ...) - the peers raise there (`reduce_named_stats`) and come back here, so this rank
+    reports once more to meet them."""
+    payload = ('status', None if error is None else '%s: %s' % (type(error).__name__, error))
+    reports = transport.all_gather_object(payload)
+    if any(rep[0] == 'stats' for rep in reports):
+        reports = transport.all_gather_object(payload)
+    failed = [(r, rep[1]) for r, rep in enumerate(reports) if rep[0] == 'status' and rep[1] is not None]
     if failed:
         if error is not None:
             raise error
         raise RuntimeError('rank %d failed: %s' % failed[0])
 
 
+class _SingleTransport:
+    """One process, no launcher: every exchange step is the identity"""
+    rank, world_size = 0, 1
+
+    def all_gather_object(self, obj):
+        return [obj]
+
+    def gather_features(self, local, dst=0):
+        return dict(local)
+
+    def allreduce(self, array, op='sum'):
+        return np.array(array, dtype=np.float64, copy=True)
+
+
+_ENV_COMM = None
+
+
 def _transport(group):
-    """The object that carries out the exchange steps for `group`"""
+    """The object that carries out the exchange steps for `group` (see the module docstring)"""
+    global _ENV_COMM
     from shennong_amd.comm import RcclComm
-    return group if isinstance(group, RcclComm) else _TorchTransport(group)
+    if isinstance(group, (RcclComm, _SingleTransport, _TorchTransport)):
+        return group
+    if group is not None:
+        return _TorchTransport(group)      # an explicitly passed torch process group
+    if _ENV_COMM is not None:
+        return _ENV_COMM
+    from shennong_amd import _backend
+    launched = int(os.environ.get('WORLD_SIZE', '0')) > 0 and 'RANK' in os.environ
+    if launched and _backend.device_count() > 0:
+        _ENV_COMM = RcclComm.from_env()
+        return _ENV_COMM
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return _TorchTransport(None)   # (CPU tests: the caller initialised gloo itself)
+    except ImportError:  # pragma: nocover
+        pass
+    return _SingleTransport()
 
 
 def shard_utterances(lengths, world_size):
@@ -85,7 +132,7 @@ def gather_features(local, dst=0, group=None, device=None):
     elsewhere."""
     transport = _transport(group)
     if isinstance(transport, _TorchTransport):
-        return _torch_gather_features(local, dst, group, device)
+        return _torch_gather_features(local, dst, transport.group, device)
     return transport.gather_features(local, dst)
 
 
@@ -130,29 +177,78 @@ def _torch_gather_features(local, dst, group, device):
 def process_all_sharded(processor, utterances, dst=0, group=None, **kwargs):
     """``processor.process_all`` over the utterances owned by this rank, then the gather.
 
-    Every rank passes the same `utterances`; rank `dst` gets the full FeaturesCollection (same keys
-    and values as a single-process ``process_all``), the others get None."""
-    from shennong_amd.features import Features, FeaturesCollection
+    Every rank passes the same `utterances`; the shards are balanced by the durations the utterance index
+    already holds and every rank decodes ONLY its own shard.  Over RCCL the feature rows never visit the
+    host on the way: the kernel's output buffer is handed to ``snf_comm_gatherv`` as it is and the root
+    makes one download of everything.  Rank `dst` gets the full FeaturesCollection (same keys and values
+    as a single-process ``process_all``), the others get None."""
+    from shennong_amd.comm import RcclComm
+    from shennong_amd.features import FeaturesCollection
     transport = _transport(group)
     rank, world = transport.rank, transport.world_size
     utts = list(utterances)
-    signals = [u.load_audio() for u in utts]
-    shards = shard_utterances([s.nsamples for s in signals], world)
+    shards = shard_utterances([u.duration for u in utts], world)
     mine = shards[rank]
+    signals = [utts[i].load_audio() for i in mine]
     per_utt = {k: [v[utts[i].name] for i in mine] for k, v in kwargs.items()}
-    feats = processor._process_batch([signals[i] for i in mine], **per_utt) if mine else []
-    local = {utts[i].name: f.data for i, f in zip(mine, feats)}
-    merged = gather_features(local, dst=dst, group=group)
+    if isinstance(transport, RcclComm) and set(kwargs) <= {'vtln_warp'} and hasattr(processor, '_build_options'):
+        merged = _gather_device_resident(processor, [utts[i].name for i in mine], signals,
+                                         per_utt.get('vtln_warp'), transport, dst)
+    else:
+        feats = processor._process_batch(signals, **per_utt) if mine else []
+        merged = gather_features({utts[i].name: f.data for i, f in zip(mine, feats)}, dst=dst, group=transport)
     if merged is None:
         return None
-    out = FeaturesCollection()
-    for i, u in enumerate(utts):
-        data = merged[u.name]
-        extra = {k: v[u.name] for k, v in kwargs.items()}
-        out[u.name] = Features(
-            data, processor.times(data.shape[0]),
-            properties=processor.get_properties(**extra), validate=False)
-    return out
+    feats = processor._wrap_batch([merged[u.name] for u in utts],
+                                  **{k: [v[u.name] for u in utts] for k, v in kwargs.items()})
+    return FeaturesCollection((u.name, f) for u, f in zip(utts, feats))
+
+
+def _gather_device_resident(processor, names, signals, warps, comm, dst):
+    """This rank's shard through ``plan.run_device`` and the rows straight from that buffer to the root:
+    ``{name: float32 [nframes, ndims]}`` of all ranks on `dst`, None elsewhere"""
+    from shennong_amd import _backend
+    from shennong_amd.processor.base import check_signal
+    for signal in signals:
+        check_signal(processor, signal)
+    plan = _backend.get_plan(processor._build_options())
+    ndims = plan.ndims
+    waves = [np.ascontiguousarray(s.astype(np.int16).data) for s in signals]
+    soff = np.zeros(len(waves) + 1, dtype=np.int64)
+    np.cumsum([w.shape[0] for w in waves], out=soff[1:])
+    nframes = [int(plan.num_frames(w.shape[0])) for w in waves]
+    foff = np.zeros(len(waves) + 1, dtype=np.int64)
+    np.cumsum(nframes, out=foff[1:])
+    meta = comm.all_gather_object((list(names), nframes))
+    counts = [sum(nf) * ndims for _, nf in meta]
+    d_wave = _backend.DeviceBuffer(max(int(soff[-1]) * 2, 16), device=comm.device)
+    d_out = _backend.DeviceBuffer(max(int(foff[-1]) * ndims * 4, 16), device=comm.device)
+    d_all = None
+    try:
+        if soff[-1] > 0:
+            d_wave.upload(np.concatenate(waves))
+        if foff[-1] > 0:
+            plan.run_device(d_wave.ptr, soff, foff, d_out.ptr, vtln_warps=warps)
+        if comm.rank == dst:
+            d_all = _backend.DeviceBuffer(max(4 * sum(counts), 16), device=comm.device)
+        comm.gatherv_device(d_out.ptr, int(foff[-1]) * ndims, d_all.ptr if d_all else None, counts, dst)
+        if comm.rank != dst:
+            return None
+        host = np.empty(sum(counts), dtype=np.float32)
+        if host.size:
+            d_all.download(host)
+    finally:
+        for buf in (d_wave, d_out, d_all):
+            if buf is not None:
+                buf.free()
+    if not np.isfinite(host).all():
+        raise ValueError('features are not valid (non-finite values)')
+    merged, pos = {}, 0
+    for names_r, nframes_r in meta:
+        for name, nf in zip(names_r, nframes_r):
+            merged[name] = host[pos:pos + nf * ndims].reshape(nf, ndims).copy()
+            pos += nf * ndims
+    return merged
 
 
 def _default_device(group):
@@ -169,7 +265,7 @@ def allreduce_cmvn_stats(stats, group=None, device=None):
     one float64 ncclAllReduce on the device.  Identical on every rank."""
     transport = _transport(group)
     if isinstance(transport, _TorchTransport):
-        return _torch_allreduce_stats(stats, group, device)
+        return _torch_allreduce_stats(stats, transport.group, device)
     stats = np.ascontiguousarray(stats, dtype=np.float64)
     return transport.allreduce(stats, 'sum').reshape(stats.shape)
 
@@ -250,7 +346,12 @@ def reduce_named_stats(names, stats, group=None):
     agreed on with one small object all-gather, the blocks are summed with `allreduce_cmvn_stats`
     (rank-ordered, deterministic).  Returns the blocks of THIS rank's `names`, in its order."""
     gathered = _transport(group).all_gather_object(
-        (list(names), int(stats.shape[-1]) if len(names) else None))
+        ('stats', list(names), int(stats.shape[-1]) if len(names) else None))
+    # a peer that failed before it got here is in `_agree`: everybody stops (and meets it there again)
+    for rep in gathered:
+        if rep[0] != 'stats':
+            raise RuntimeError('another rank failed before the statistics exchange: %s' % (rep[1],))
+    gathered = [rep[1:] for rep in gathered]
     widths = sorted(set(w for _, w in gathered if w is not None))
     if not widths:
         return stats

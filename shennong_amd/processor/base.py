@@ -80,6 +80,12 @@ class FeaturesProcessor(BaseProcessor, metaclass=abc.ABCMeta):
         return [self.process(s, **{k: v[i] for k, v in kwargs.items()})
                 for i, s in enumerate(signals)]
 
+    def _wrap_batch(self, datas, **kwargs):
+        """The Features of matrices this processor computed (the tail of `_process_batch`; the sharded driver
+        builds the root's collection from gathered rows with it): `kwargs` hold one value per matrix"""
+        keys = [tuple(sorted((k, v[i]) for k, v in kwargs.items())) for i in range(len(datas))]
+        return batch_features(datas, self.times, lambda key: self.get_properties(**dict(key)), keys)
+
     def process_all(self, utterances, njobs=None, **kwargs):
         """Returns features processed from several input `utterances`
 
@@ -195,6 +201,9 @@ class MelFeaturesProcessor(FramesProcessor):
         for signal in signals:
             check_signal(self, signal)
         warps = [1.0] * len(signals) if vtln_warp is None else list(vtln_warp)
-        datas = self._run(self._build_options(), signals, warps)
+        return self._wrap_batch(self._run(self._build_options(), signals, warps), vtln_warp=warps)
+
+    def _wrap_batch(self, datas, vtln_warp=None):
+        warps = [1.0] * len(datas) if vtln_warp is None else list(vtln_warp)
         return batch_features(
             datas, self.times, lambda w: self.get_properties(vtln_warp=w), warps)
