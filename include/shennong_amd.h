@@ -311,6 +311,13 @@ int snf_concat_columns_device(int device_id, const float* d_a, int32_t cols_a,
                               const int64_t* offsets_b, int64_t n_utts, float* d_out,
                               const int64_t* offsets_out);
 
+/*
+ * Number of NaN / +-Inf among n floats of a device-resident block (16-byte aligned): the data part of
+ * reference shennong/features.py:170-215 `Features.is_valid` ("data contains non-finite numbers"), run on
+ * the whole batch before its only device -> host copy.
+ */
+int snf_count_nonfinite_device(int device_id, const float* d_data, uint64_t n, uint64_t* count);
+
 /* ---- device memory + timing (so hosts without torch can keep data resident in HBM) ---------- */
 int snf_malloc(void** dptr, uint64_t bytes);
 int snf_free(void* dptr);

@@ -1500,6 +1500,26 @@ int snf_concat_columns_device(int device_id, const float* d_a, int32_t cols_a,
   return rc;
 }
 
+int snf_count_nonfinite_device(int device_id, const float* d_data, uint64_t n, uint64_t* count) {
+  if (!count) return set_error(SNF_E_INVALID, "null count");
+  *count = 0;
+  if (n == 0) return SNF_OK;
+  if (!d_data) return set_error(SNF_E_INVALID, "null buffer");
+  if (reinterpret_cast<uintptr_t>(d_data) & 15) return set_error(SNF_E_INVALID, "buffer is not 16-byte aligned");
+  SNF_HIP_CHECK(hipSetDevice(device_id));
+  unsigned long long* d_count;
+  SNF_HIP_CHECK(hipMalloc(&d_count, sizeof(unsigned long long)));
+  int rc = SNF_OK;
+  unsigned long long host = 0;
+  if (hipMemset(d_count, 0, sizeof(unsigned long long)) != hipSuccess) rc = set_error(SNF_E_HIP, "memset failed");
+  if (!rc) rc = launch_count_nonfinite(d_data, n, d_count, nullptr);
+  if (!rc && hipMemcpy(&host, d_count, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess)
+    rc = set_error(SNF_E_HIP, "non-finite count kernel failed");
+  (void)hipFree(d_count);
+  *count = host;
+  return rc;
+}
+
 int snf_malloc(void** dptr, uint64_t bytes) {
   SNF_HIP_CHECK(hipMalloc(dptr, bytes));
   return SNF_OK;

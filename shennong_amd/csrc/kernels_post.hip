@@ -1146,4 +1146,36 @@ int launch_concat_columns(const float* a, int cols_a, const int64_t* d_off_a, co
   return SNF_OK;
 }
 
+// Features.validate's data check (reference features.py:170-215 `is_valid`: "data contains non-finite
+// numbers") for a block that is still in HBM: the number of NaN / +-Inf among n floats.  An exponent
+// field of all ones is the test; 16-byte loads over the aligned body, one atomic per workgroup.
+__global__ void __launch_bounds__(256) count_nonfinite_kernel(const float* __restrict__ x, uint64_t n,
+                                                              unsigned long long* __restrict__ count) {
+  const uint64_t n4 = n >> 2;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4* x4 = reinterpret_cast<const u32x4*>(x);
+  unsigned bad = 0;
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const u32x4 v = __builtin_nontemporal_load(x4 + i);
+    bad += ((v.x & 0x7F800000u) == 0x7F800000u) + ((v.y & 0x7F800000u) == 0x7F800000u) +
+           ((v.z & 0x7F800000u) == 0x7F800000u) + ((v.w & 0x7F800000u) == 0x7F800000u);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const unsigned v = __float_as_uint(x[(n4 << 2) + threadIdx.x]);
+    bad += (v & 0x7F800000u) == 0x7F800000u;
+  }
+  if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) return;  // (the usual case: nothing to add)
+  atomicAdd(count, static_cast<unsigned long long>(bad));
+}
+
+int launch_count_nonfinite(const float* x, uint64_t n, unsigned long long* d_count, hipStream_t stream) {
+  if (n == 0) return SNF_OK;
+  const uint64_t want = (n / 4 + 255) / 256;
+  const unsigned blocks = static_cast<unsigned>(want < 1 ? 1 : (want > 256 * 16 ? 256 * 16 : want));
+  hipLaunchKernelGGL(count_nonfinite_kernel, dim3(blocks), dim3(256), 0, stream, x, n, d_count);
+  SNF_HIP_CHECK(hipGetLastError());
+  return SNF_OK;
+}
+
 }  // namespace snf

@@ -305,6 +305,7 @@ int launch_cmvn_apply(const float* in, int in_cols, const int64_t* frame_offsets
 int launch_concat_columns(const float* a, int cols_a, const int64_t* d_off_a, const float* b, int cols_b,
                           const int64_t* d_off_b, int64_t n_utts, float* out, const int64_t* d_off_out,
                           int64_t total_rows, hipStream_t stream);
+int launch_count_nonfinite(const float* x, uint64_t n, unsigned long long* d_count, hipStream_t stream);
 int launch_sliding_cmvn(const snf_sliding_cmvn_options& o, const float* in, int in_cols,
                         const int64_t* frame_offsets, int64_t n_utts, float* out,
                         hipStream_t stream);

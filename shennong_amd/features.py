@@ -48,12 +48,39 @@ class Features:
     def __init__(self, data, times, properties=None, validate=True):
         self._data, self._times = data, times
         self._properties = {} if properties is None else properties
+        self._shared = None
         if validate is True:
             self.validate()
 
+    @classmethod
+    def _of_batch(cls, data, times, properties, extra=None):
+        """One utterance of a batched launch: `times` and `properties` are objects SHARED by every
+        utterance of the batch with the same frame count / the same history (plus this utterance's own
+        `extra` entries).  The private copies every Features owns (reference features.py:62-168: both are
+        plain attributes a caller may edit) are made when `times` / `properties` are first read - a corpus
+        run that writes the matrices and never looks at them pays nothing per utterance."""
+        self = cls.__new__(cls)
+        self._data, self._times, self._properties = data, None, None
+        self._shared = (times, properties, extra)
+        return self
+
     data = property(lambda self: self._data, doc='The features matrix [nframes, ndims]')
-    times = property(lambda self: self._times, doc='The times of the rows, [nframes, 2] or [nframes]')
-    properties = property(lambda self: self._properties, doc='How the features were made')
+
+    @property
+    def times(self):
+        """The times of the rows, [nframes, 2] or [nframes]"""
+        if self._times is None:
+            self._times = self._shared[0].copy()
+        return self._times
+
+    @property
+    def properties(self):
+        """How the features were made"""
+        if self._properties is None:
+            self._properties = copy_properties(self._shared[1])
+            if self._shared[2]:
+                self._properties.update(copy_properties(self._shared[2]))
+        return self._properties
     dtype = property(lambda self: self.data.dtype)
     shape = property(lambda self: self.data.shape)
     nframes = property(lambda self: self.shape[0])

@@ -14,6 +14,7 @@ configuration entry; precomputed `warps` are supported), CREPE pitch, bottleneck
 """
 
 import os
+import threading
 
 import numpy as np
 import yaml
@@ -326,8 +327,33 @@ def _batches(utterances, max_duration):
         yield batch
 
 
+def _in_flight(batches, work, depth):
+    """``work(b, batch)`` for every batch, results in order, at most `depth` batches started and not yet
+    handed over.  With `depth` > 1 the batches run on threads: the staging copy, the transfers and the
+    launches of one (all outside the interpreter lock) overlap the per-utterance bookkeeping of another."""
+    if depth <= 1:
+        for b, batch in enumerate(batches):
+            yield work(b, batch)
+        return
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    pending = deque()
+    with ThreadPoolExecutor(max_workers=depth) as pool:
+        try:
+            for b, batch in enumerate(batches):
+                pending.append(pool.submit(work, b, batch))
+                if len(pending) >= depth:
+                    yield pending.popleft().result()
+            while pending:
+                yield pending.popleft().result()
+        finally:
+            for future in pending:
+                future.cancel()
+
+
 def extract_features_streamed(configuration, utterances, sink, warps=None,
                               max_batch_duration=3600.0, njobs=1, stats_reduce=None,
+                              resident_bytes=16 << 30,
                               log=get_logger('pipeline', 'warning')):
     """:func:`extract_features` for a corpus that must not sit in memory at once (BASELINE config 5)
 
@@ -341,14 +367,19 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
     statistics need every utterance of a speaker before any can be normalised, so a first pass over
     the batches accumulates them (features + VAD only, summed in utterance order like the one-shot
     pipeline does) and the second pass recomputes the features instead of keeping them - on this
-    hardware the features are cheaper to recompute than to store.
+    hardware the features are cheaper to recompute than to store.  What the first pass does keep is the
+    uploaded int16 audio, in HBM, up to `resident_bytes` (96 kB per 3 s utterance; 0 = keep nothing): the
+    second pass of those batches starts from the device buffers - no file is read twice, nothing crosses
+    the host link twice.  `njobs` (the reference's number of parallel jobs, pipeline.py:340-377) is the
+    number of batches in flight: each runs on its own thread, `sink` is always called from the caller's
+    thread and in corpus order.
 
     `stats_reduce(names, stats) -> stats` sums the speakers' statistics across processes when the
     corpus is sharded (see shennong_amd.distributed.extract_features_streamed_sharded).
 
     Returns the number of utterances written."""
     from shennong_amd.utterances import Utterances
-    get_njobs(njobs, log=log)
+    depth = min(get_njobs(njobs, log=log), 8)
     config = _init_config(configuration, log=log)
     if not max_batch_duration > 0:
         raise ValueError('max_batch_duration must be strictly positive')
@@ -365,31 +396,42 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
         return {u.name: warps[u.name] for u in batch} if warps else None
 
     hook = None
-    if by_speaker:
-        total = {}
-        for batch in _batches(utts, max_batch_duration):
-            speakers, per_utt = _extract_features(
-                config, Utterances(batch), sub(batch), log, stats_only=True)
-            for speaker, stats in zip(speakers, per_utt):
-                if speaker in total:
-                    total[speaker] += stats
-                else:
-                    total[speaker] = stats.copy()
-        if stats_reduce is not None:
-            names = list(total)
-            reduced = stats_reduce(names, np.stack([total[k] for k in names]) if names
-                                   else np.zeros((0, 2, 1), dtype=np.float64))
-            total = dict(zip(names, reduced))
+    resident = _ResidentWaves(resident_bytes) if by_speaker and resident_bytes > 0 else None
+    try:
+        if by_speaker:
+            total = {}
 
-        def hook(names, _partial):
-            return np.stack([total[k] for k in names])
+            def first_pass(b, batch):
+                return _extract_features(config, Utterances(batch), sub(batch), log, stats_only=True,
+                                         resident=resident, batch_id=b)
 
-    count = 0
-    for batch in _batches(utts, max_batch_duration):
-        features = _extract_features(config, Utterances(batch), sub(batch), log, stats_hook=hook)
-        sink(features)
-        count += len(features)
-    return count
+            for speakers, per_utt in _in_flight(_batches(utts, max_batch_duration), first_pass, depth):
+                for speaker, stats in zip(speakers, per_utt):
+                    if speaker in total:
+                        total[speaker] += stats
+                    else:
+                        total[speaker] = stats.copy()
+            if stats_reduce is not None:
+                names = list(total)
+                reduced = stats_reduce(names, np.stack([total[k] for k in names]) if names
+                                       else np.zeros((0, 2, 1), dtype=np.float64))
+                total = dict(zip(names, reduced))
+
+            def hook(names, _partial):
+                return np.stack([total[k] for k in names])
+
+        def second_pass(b, batch):
+            return _extract_features(config, Utterances(batch), sub(batch), log, stats_hook=hook,
+                                     resident=resident, batch_id=b)
+
+        count = 0
+        for features in _in_flight(_batches(utts, max_batch_duration), second_pass, depth):
+            sink(features)
+            count += len(features)
+        return count
+    finally:
+        if resident is not None:
+            resident.clear()
 
 
 class _Meta:
@@ -397,24 +439,67 @@ class _Meta:
     The properties of a stage are the same for every utterance that went through the same processors
     with the same per-utterance arguments (warp factor, CMVN group): `key` names that history and
     `cache` holds one properties dictionary per history, copied once per utterance at the end."""
+    __slots__ = ('properties', 'ndims', 'nframes', 'times', 'key', '_derived')
+
     def __init__(self, properties, ndims, nframes, times, key=None):
         self.properties = properties
         self.ndims = ndims
         self.nframes = nframes
         self.times = times
         self.key = key
+        self._derived = {}
 
     def derive(self, cache, tag, make_properties, ndims=None, nframes=None, times=None):
+        """The _Meta after one more stage.  Utterances with the same history and frame count share one
+        _Meta object, so the second utterance to take the same step finds the result here."""
+        memo = (tag, ndims, nframes, id(times))
+        found = self._derived.get(memo)
+        if found is not None:
+            return found
         key = (self.key, tag)
         if key not in cache:
             cache[key] = make_properties(self)
-        return _Meta(cache[key], self.ndims if ndims is None else ndims,
-                     self.nframes if nframes is None else nframes,
-                     self.times if times is None else times, key)
+        found = self._derived[memo] = _Meta(
+            cache[key], self.ndims if ndims is None else ndims,
+            self.nframes if nframes is None else nframes,
+            self.times if times is None else times, key)
+        return found
+
+
+class _ResidentWaves:
+    """Uploaded waveforms kept in HBM between the two passes of :func:`extract_features_streamed`
+    (96 kB per 3 s utterance: 16 GiB hold 140 hours of 16 kHz audio), so that the second pass neither reads
+    the audio files nor crosses the host link again.  Batches that do not fit the budget are re-uploaded."""
+    def __init__(self, budget):
+        self.budget = int(budget)
+        self.held = 0
+        self._items = {}
+        self._lock = threading.Lock()  # (the batches in flight run on threads)
+
+    def offer(self, key, d_wave, soff):
+        with self._lock:
+            if self.held + d_wave.nbytes > self.budget:
+                return False
+            self._items[key] = (d_wave, soff)
+            self.held += d_wave.nbytes
+            return True
+
+    def take(self, key):
+        with self._lock:
+            item = self._items.pop(key, None)
+            if item is not None:
+                self.held -= item[0].nbytes
+            return item
+
+    def clear(self):
+        for d_wave, _ in self._items.values():
+            d_wave.free()
+        self._items.clear()
+        self.held = 0
 
 
 def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=None,
-                      stats_only=False):
+                      stats_only=False, resident=None, batch_id=None):
     """The whole pipeline with the intermediate features resident in HBM: the waveforms go up once,
     every stage is one batched launch on device buffers (features, energy -> VAD, CMVN statistics and
     apply, delta, pitch and its post-processing, column concatenation), the final matrices come down
@@ -422,7 +507,8 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
 
     `stats_only` (first pass of :func:`extract_features_streamed`): stop after the CMVN accumulation
     and return ``(group name of every utterance, per-utterance statistics [n, 2, dim + 1])``; the
-    pitch stage, which the statistics do not depend on, is skipped."""
+    pitch stage, which the statistics do not depend on, is skipped.  `resident` (a _ResidentWaves) keeps
+    the uploaded waveforms of batch `batch_id` in HBM after that pass and hands them to the next one."""
     features_name = [k for k in config.keys() if k in valid_features()][0]
     with_cmvn = 'cmvn' in config
     if with_cmvn and config['cmvn']['by_speaker'] and not utterances.has_speakers():
@@ -457,7 +543,6 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             ', '.join(str(s) + 'Hz' for s in samplerates))
 
     from shennong_amd.processor.base import check_signal
-    audios = [u.load_audio() for u in utts]
     DB = _backend.DeviceBuffer
     frame_length = frame_shift = None
     cache = {}          # properties per processing history (see _Meta)
@@ -477,23 +562,29 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
         proc.sample_rate = rate
         if frame_length is None:
             frame_length, frame_shift = proc.frame_length, proc.frame_shift
-        for i in idx:
-            check_signal(proc, audios[i])
-        waves = [audios[i].astype(np.int16).data for i in idx]
-        soff = offsets([w.shape[0] for w in waves])
-        wave, token = _backend.stage_rows(waves, np.int16)  # (page-locked staging: full link rate)
-        d_wave = DB(max(wave.nbytes, 16))
-        try:
-            d_wave.upload(wave)
-        finally:
-            del wave
-            _backend.STAGING.release(token)
+        held = resident.take((batch_id, rate)) if resident is not None else None
+        if held is not None:
+            d_wave, soff = held
+        else:
+            waves = []
+            for i in idx:
+                audio = utts[i].load_audio()
+                check_signal(proc, audio)
+                waves.append(audio.astype(np.int16).data)
+            soff = offsets([w.shape[0] for w in waves])
+            d_wave = _backend.upload_rows(waves, np.int16)  # (page-locked staging: full link rate)
+            del waves
+        lengths = np.diff(soff)
+
+        def frame_offsets(a_plan):
+            frames_of = {x: a_plan.num_frames(x) for x in np.unique(lengths).tolist()}
+            return offsets([frames_of[x] for x in lengths.tolist()])
         st = {'idx': idx, 'soff': soff, 'd_wave': d_wave}
 
         opts = proc._build_options()
         plan = _backend.get_plan(opts)
         dim = plan.ndims
-        foff = offsets([plan.num_frames(w.shape[0]) for w in waves])
+        foff = frame_offsets(plan)
         d_feat = DB(max(int(foff[-1]) * dim * 4, 16))
         vt = wlist = None
         if warps and features_name != 'spectrogram':
@@ -502,17 +593,19 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
         log.debug('extract %s on %d utterances at %d Hz', features_name, len(idx), rate)
         plan.run_device(d_wave.ptr, soff, foff, d_feat.ptr, vtln_warps=vt)
         st.update(foff=foff, dim=dim, d_feat=d_feat)
-        for k, i in enumerate(idx):
-            t = int(foff[k + 1] - foff[k])
-            extra = {'vtln_warp': wlist[k] if wlist is not None else 1.0} \
-                if features_name != 'spectrogram' else {}
-            key = (features_name, rate, extra.get('vtln_warp'))
-            if key not in cache:
-                cache[key] = proc.get_properties(**extra)
-            tkey = ('times', features_name, rate, t)
-            if tkey not in cache:
-                cache[tkey] = proc.times(t)
-            meta[i] = _Meta(cache[key], dim, t, cache[tkey], key)
+        step = {}
+        for k, (i, t) in enumerate(zip(idx, np.diff(foff).tolist())):
+            warp = None if features_name == 'spectrogram' else wlist[k] if wlist is not None else 1.0
+            found = step.get((warp, t))
+            if found is None:
+                key = (features_name, rate, warp)
+                if key not in cache:
+                    cache[key] = proc.get_properties(**({} if warp is None else {'vtln_warp': warp}))
+                tkey = ('times', features_name, rate, t)
+                if tkey not in cache:
+                    cache[tkey] = proc.times(t)
+                found = step[(warp, t)] = _Meta(cache[key], dim, t, cache[tkey], key)
+            meta[i] = found
 
         if with_cmvn and config['cmvn']['with_vad']:
             energy = _processor_class('energy')()
@@ -520,7 +613,7 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             energy.frame_shift = frame_shift
             energy.sample_rate = rate
             eplan = _backend.get_plan(energy._build_options())
-            efoff = offsets([eplan.num_frames(w.shape[0]) for w in waves])
+            efoff = frame_offsets(eplan)
             if not np.array_equal(efoff, foff):
                 raise ValueError('energy and features differ in number of frames')
             d_energy = DB(max(int(foff[-1]) * 4, 16))
@@ -541,7 +634,7 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             pproc = _processor_class('kaldi_pitch')(**params)
             post = _processor_class('kaldi_pitch_post')(**config['pitch']['postprocessing'])
             pplan = _backend.get_plan(pproc._build_options())
-            pfoff = offsets([pplan.num_frames(w.shape[0]) for w in waves])
+            pfoff = frame_offsets(pplan)
             d_raw = DB(max(int(pfoff[-1]) * 2 * 4, 16))
             pplan.run_device(d_wave.ptr, soff, pfoff, d_raw.ptr)
             qplan = _backend.get_plan(post._build_options())
@@ -550,17 +643,21 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             qplan.run_post_device(d_raw.ptr, 2, pfoff, d_pitch.ptr)
             d_raw.free()
             st.update(pfoff=pfoff, pdim=pdim, d_pitch=d_pitch)
-            for k, i in enumerate(idx):
-                t = int(pfoff[k + 1] - pfoff[k])
-                key = ('pitch', rate)
-                if key not in cache:
-                    cache[key] = pproc.get_properties()
-                tkey = ('times', 'pitch', rate, t)
-                if tkey not in cache:
-                    cache[tkey] = pproc.times(t)
-                raw_meta = _Meta(cache[key], 2, t, cache[tkey], key)
-                pmeta[i] = raw_meta.derive(cache, 'post', post.get_properties, ndims=pdim)
-        d_wave.free()
+            step = {}
+            for i, t in zip(idx, np.diff(pfoff).tolist()):
+                found = step.get(t)
+                if found is None:
+                    key = ('pitch', rate)
+                    if key not in cache:
+                        cache[key] = pproc.get_properties()
+                    tkey = ('times', 'pitch', rate, t)
+                    if tkey not in cache:
+                        cache[tkey] = pproc.times(t)
+                    found = step[t] = _Meta(cache[key], 2, t, cache[tkey], key).derive(
+                        cache, 'post', post.get_properties, ndims=pdim)
+                pmeta[i] = found
+        if not (stats_only and resident is not None and resident.offer((batch_id, rate), d_wave, soff)):
+            d_wave.free()
         groups_state.append(st)
 
     # ---- CMVN: statistics of every utterance in one launch per sample rate, summed per speaker (or
@@ -610,11 +707,14 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
                 groups=group_of[st['idx']], norm_vars=True)
             st['d_feat'].free()
             st['d_feat'] = d_out
-        for i in range(n):
-            g = int(group_of[i])
-            meta[i] = meta[i].derive(
-                cache, ('cmvn', g),
-                lambda m, g=g: CmvnPostProcessor(dim, stats=stats[g]).get_properties(m))
+        step = {}  # (the utterances of a group that share a _Meta take this step once)
+        for i, g in enumerate(group_of.tolist()):
+            m = step.get((meta[i], g))
+            if m is None:
+                m = step[(meta[i], g)] = meta[i].derive(
+                    cache, ('cmvn', g),
+                    lambda m, g=g: CmvnPostProcessor(dim, stats=stats[g]).get_properties(m))
+            meta[i] = m
 
     # ---- delta ----------------------------------------------------------------------------------------
     if 'delta' in config:
@@ -626,8 +726,12 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             dplan.run_post_device(st['d_feat'].ptr, st['dim'], st['foff'], d_out.ptr)
             st['d_feat'].free()
             st['d_feat'], st['dim'] = d_out, odim
+            step = {}
             for i in st['idx']:
-                meta[i] = meta[i].derive(cache, 'delta', delta.get_properties, ndims=odim)
+                m = step.get(meta[i])
+                if m is None:
+                    m = step[meta[i]] = meta[i].derive(cache, 'delta', delta.get_properties, ndims=odim)
+                meta[i] = m
 
     # ---- pitch columns (the number of frames can differ by a few because of the downsampling in the
     # pitch tracker: same tolerance as Kaldi's paste-feats), then the only device -> host copy -----------
@@ -636,21 +740,21 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
     for st in groups_state:
         idx = st['idx']
         if 'd_pitch' in st:
-            rows = []
-            for k, i in enumerate(idx):
-                ckey = ('rows', meta[i].nframes, pmeta[i].nframes, id(meta[i].times), id(pmeta[i].times))
-                if ckey not in cache:  # (same frame counts and times: same trimming, checked once)
-                    cache[ckey] = Features._concatenate_meta(
+            rows, step = [], {}
+            for i in idx:
+                hit = step.get((meta[i], pmeta[i]))
+                if hit is None:  # (same frame counts, times and histories: trimmed and merged once)
+                    r, times = Features._concatenate_meta(
                         meta[i].nframes, meta[i].ndims, meta[i].times, {},
                         pmeta[i].nframes, pmeta[i].times, {}, tolerance, log)[:2]
-                r, times = cache[ckey]
-                rows.append(r)
-                meta[i] = meta[i].derive(
-                    cache, ('concat', pmeta[i].key),
-                    lambda m, o=pmeta[i]: Features._concatenate_meta(
-                        1, m.ndims, m.times[:1], m.properties, 1, m.times[:1], o.properties,
-                        tolerance, log)[2],
-                    ndims=meta[i].ndims + pmeta[i].ndims, nframes=r, times=times)
+                    hit = step[(meta[i], pmeta[i])] = (r, meta[i].derive(
+                        cache, ('concat', pmeta[i].key),
+                        lambda m, o=pmeta[i]: Features._concatenate_meta(
+                            1, m.ndims, m.times[:1], m.properties, 1, m.times[:1], o.properties,
+                            tolerance, log)[2],
+                        ndims=meta[i].ndims + pmeta[i].ndims, nframes=r, times=times))
+                rows.append(hit[0])
+                meta[i] = hit[1]
             ooff = offsets(rows)
             odim = st['dim'] + st['pdim']
             d_out = DB(max(int(ooff[-1]) * odim * 4, 16))
@@ -660,27 +764,28 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             st['d_feat'].free()
             st['d_pitch'].free()
             st['d_feat'], st['dim'], st['foff'] = d_out, odim, ooff
-        host = np.empty((int(st['foff'][-1]), st['dim']), dtype=np.float32)
+        host = _backend.result_array((int(st['foff'][-1]), st['dim']), np.float32)
         if host.size:
+            # (Features.validate's data check, once for the batch and before it leaves HBM)
+            _backend.check_finite_device(st['d_feat'].ptr, host.size)
             st['d_feat'].download(host)
-            _backend._check_finite(host)  # (Features.validate's data check, once for the batch)
         st['d_feat'].free()
+        cuts = st['foff'].tolist()
         for k, i in enumerate(idx):
-            results[i] = host[st['foff'][k]:st['foff'][k + 1]]  # views of the one downloaded array
+            results[i] = host[cuts[k]:cuts[k + 1]]  # views of the one downloaded array
+    of_batch = Features._of_batch
     for i, utt in enumerate(utts):
-        props = copy_properties(meta[i].properties)
-        if utt.speaker:
-            props['speaker'] = utt.speaker
-        props['audio'] = {
-            'file': (os.path.abspath(utt.audio_file)
-                     if isinstance(utt.audio_file, str) else None),
-            'sample_rate': meta_of[i].sample_rate}
+        # what is this utterance's own; the processors' part of the properties and the times are shared by
+        # every utterance with the same history / frame count and copied when first read (Features._of_batch)
+        audio = {'file': (os.path.abspath(utt.audio_file) if isinstance(utt.audio_file, str) else None),
+                 'sample_rate': meta_of[i].sample_rate}
         if utt.tstart is not None:
-            props['audio']['tstart'] = utt.tstart
-            props['audio']['tstop'] = utt.tstop
-        props['audio']['duration'] = utt.duration
+            audio['tstart'] = utt.tstart
+            audio['tstop'] = utt.tstop
+        audio['duration'] = utt.duration
+        extra = {'audio': audio, 'speaker': utt.speaker} if utt.speaker else {'audio': audio}
         # (times are generated, hence sorted; the data were checked above: no per-utterance validate)
-        out[utt.name] = Features(results[i], meta[i].times.copy(), properties=props, validate=False)
+        out[utt.name] = of_batch(results[i], meta[i].times, meta[i].properties, extra)
     return out
 
 

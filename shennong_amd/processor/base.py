@@ -45,8 +45,7 @@ def batch_features(datas, times_of, properties_of, keys=None):
             times_cache[nframes] = times_of(nframes)
         if key not in props_cache:
             props_cache[key] = properties_of(key)
-        out.append(Features(data, times_cache[nframes].copy(),
-                            properties=copy_properties(props_cache[key]), validate=False))
+        out.append(Features._of_batch(data, times_cache[nframes], props_cache[key]))
     return out
 
 

@@ -90,6 +90,32 @@ def test_features_validate_and_copy(mfcc):
     assert mfcc.copy(subsample=2).shape == (70, 13)
 
 
+def test_features_of_a_batch_own_their_times_and_properties():
+    """the utterances of one launch are built on SHARED times / properties objects; what each Features
+    hands out is its own copy (made when first read), equal to what the eager constructor holds"""
+    times = np.arange(8, dtype=np.float64).reshape(4, 2)
+    shared = {'mfcc': {'num_ceps': 13, 'table': np.arange(3.0)}, 'pipeline': [{'name': 'mfcc', 'columns': [0, 1]}]}
+    data = np.ones((8, 2), dtype=np.float32)
+    a = Features._of_batch(data[:4], times, shared, {'speaker': 'anna', 'audio': {'file': None, 'duration': 1.0}})
+    b = Features._of_batch(data[4:], times, shared, None)
+    eager = Features(data[:4], times.copy(), properties=dict(
+        shared, speaker='anna', audio={'file': None, 'duration': 1.0}))
+    assert a == eager and a.is_valid() and a.nframes == 4 and a.ndims == 2
+    assert b.properties.keys() == shared.keys() and 'speaker' not in shared
+    assert a.times is not times and a.times is a.times and a.properties is a.properties
+    a.times[0, 0] = 99.0
+    a.properties['mfcc']['num_ceps'] = 7
+    a.properties['mfcc']['table'][0] = -1.0
+    a.properties['pipeline'][0]['columns'][0] = 5
+    a.properties['audio']['duration'] = 2.0
+    assert times[0, 0] == 0.0 and b.times[0, 0] == 0.0
+    assert shared['mfcc']['num_ceps'] == 13 and b.properties['mfcc']['num_ceps'] == 13
+    assert shared['mfcc']['table'][0] == 0.0 and b.properties['pipeline'][0]['columns'] == [0, 1]
+    c = a.copy()
+    assert c == a and c.properties is not a.properties and a != eager
+    assert Features._from_dict(b._to_dict()) == b
+
+
 def test_features_concatenate(mfcc, capsys):
     both = mfcc.concatenate(mfcc)
     assert both.nframes == mfcc.nframes and both.ndims == 2 * mfcc.ndims

@@ -191,7 +191,7 @@ def _streamed_worker(rank, world, port, tmpdir):
     index = Utterances([(f'u{i}', wav, f's{i % 3}', 0.1 * (i % 4), 0.1 * (i % 4) + 0.3 + 0.1 * (i % 5))
                         for i in range(1, 10)])
 
-    def fake(config, utterances, warps, log, tolerance=2, stats_hook=None, stats_only=False):
+    def fake(config, utterances, warps, log, tolerance=2, stats_hook=None, stats_only=False, **_resident):
         # stand-in for the device pipeline (no GPU on the CPU ranks): the "statistics" of utterance
         # u<i> are i, the "features" of an utterance are its speaker's global statistics
         utts = list(utterances)

@@ -405,7 +405,7 @@ def test_streamed_driver_logic(monkeypatch):
     index = _segments_index()
     calls = []
 
-    def fake(config, utterances, warps, log, tolerance=2, stats_hook=None, stats_only=False):
+    def fake(config, utterances, warps, log, tolerance=2, stats_hook=None, stats_only=False, **_resident):
         utts = list(utterances)
         per_utt = np.stack([np.full((2, 3), float(int(u.name[1]))) for u in utts])
         if stats_only:
@@ -448,6 +448,39 @@ def test_streamed_driver_logic(monkeypatch):
     assert all(k == 'apply' for k, _ in calls)
 
 
+@pytest.mark.parametrize('depth', [1, 2, 3, 8])
+def test_batches_in_flight(depth):
+    """results in order whatever the completion order, never more than `depth` batches started and not
+    handed over, the first failure reaches the caller"""
+    import threading
+    import time
+    lock = threading.Lock()
+    state = {'running': 0, 'peak': 0, 'started': 0}
+
+    def work(b, batch):
+        with lock:
+            state['running'] += 1
+            state['started'] += 1
+            state['peak'] = max(state['peak'], state['running'])
+        time.sleep(0.002 * ((7 * b) % 5))
+        with lock:
+            state['running'] -= 1
+        if batch == 'bad':
+            raise ValueError('batch %d' % b)
+        return b, batch
+
+    batches = ['b%d' % i for i in range(11)]
+    handed = []
+    for b, batch in pipeline._in_flight(iter(batches), work, depth):
+        assert state['started'] - len(handed) <= depth
+        handed.append((b, batch))
+    assert handed == list(enumerate(batches))
+    assert state['peak'] <= depth and (depth == 1 or state['peak'] > 1)
+    assert list(pipeline._in_flight(iter([]), work, depth)) == []
+    with pytest.raises(ValueError, match='batch 2'):
+        list(pipeline._in_flight(iter(['a', 'b', 'bad', 'c', 'bad']), work, depth))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('by_speaker', [True, False, None])
 def test_pipeline_streamed(gpu, tmp_path, by_speaker):
@@ -482,6 +515,70 @@ def test_pipeline_streamed(gpu, tmp_path, by_speaker):
     for suffix in ('.ark', '.times.ark'):
         assert open(str(tmp_path / 'corpus') + suffix, 'rb').read() == \
             open(str(tmp_path / 'oneshot') + suffix, 'rb').read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('njobs', [1, 3])
+@pytest.mark.parametrize('resident_bytes', [0, 40000, 16 << 30])
+def test_pipeline_streamed_resident_waves(gpu, resident_bytes, njobs):
+    """the audio uploaded by the statistics pass stays in HBM for the second pass (all of it, the first
+    batches only, none of it): same features as the one-shot pipeline, nothing left allocated"""
+    index = _segments_index()
+    config = pipeline.get_default_config('mfcc', with_cmvn=True, with_delta=True, with_pitch='kaldi')
+    config['mfcc']['dither'] = 0
+    config['pitch']['postprocessing']['delta_pitch_noise_stddev'] = 0
+    config['cmvn']['with_vad'] = False
+    whole = pipeline.extract_features(config, index)
+    kept = []
+    offer = pipeline._ResidentWaves.offer
+
+    def spy(self, key, d_wave, soff):
+        ok = offer(self, key, d_wave, soff)
+        kept.append((key, ok, self.held))
+        return ok
+
+    got = {}
+    pipeline._ResidentWaves.offer = spy
+    try:
+        n = pipeline.extract_features_streamed(config, index, got.update, max_batch_duration=1.5,
+                                               resident_bytes=resident_bytes, njobs=njobs)
+    finally:
+        pipeline._ResidentWaves.offer = offer
+    assert n == 6 and list(got) == list(whole.keys())
+    for k in whole:
+        assert got[k] == whole[k], k
+    if resident_bytes == 0:
+        assert not kept
+    else:
+        assert len(kept) >= 3 and any(ok for _, ok, _ in kept)
+        assert all(held <= resident_bytes for _, _, held in kept)
+        assert all(ok for _, ok, _ in kept) == (resident_bytes > 40000)
+
+
+@pytest.mark.gpu
+def test_non_finite_features_are_refused_on_the_device(gpu):
+    """Features.validate's data check runs on the batch while it is still in HBM"""
+    from shennong_amd import _backend
+    x = np.zeros(100003, dtype=np.float32)
+    buf = _backend.DeviceBuffer(x.nbytes)
+    try:
+        buf.upload(x)
+        _backend.check_finite_device(buf.ptr, x.size)
+        for where, value in ((0, np.nan), (57, np.inf), (100002, -np.inf), (100000, np.nan)):
+            y = x.copy()
+            y[where] = value
+            buf.upload(y)
+            with pytest.raises(ValueError, match='non-finite'):
+                _backend.check_finite_device(buf.ptr, x.size)
+            if where < 64:  # (a clean part of the same buffer)
+                _backend.check_finite_device(buf.ptr + 4 * 64, 1000)
+        y = x.copy()
+        y[::7] = np.float32(3.4e38)
+        y[1::7] = np.float32(-1e-45)
+        buf.upload(y)
+        _backend.check_finite_device(buf.ptr, x.size)
+    finally:
+        buf.free()
 
 
 def test_copy_properties():
