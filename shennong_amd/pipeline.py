@@ -425,9 +425,16 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
                                      resident=resident, batch_id=b)
 
         count = 0
-        for features in _in_flight(_batches(utts, max_batch_duration), second_pass, depth):
+        batches = _in_flight(_batches(utts, max_batch_duration), second_pass, depth)
+        while True:
+            # (nothing of batch k is referenced here while batch k + 1 is made: its page-locked result block
+            # is back in the pool by then, see _backend.result_array)
+            features = next(batches, None)
+            if features is None:
+                break
             sink(features)
             count += len(features)
+            del features
         return count
     finally:
         if resident is not None:

@@ -72,10 +72,11 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for name in sorted(glob.glob('gpurun_out/profiles/pmc_group_*.csv')):
     for r in csv.DictReader(open(name)):
-        if 'fbank512' in r['Kernel_Name']:
-            acc[r['Counter_Name']].append(float(r['Counter_Value']))
-for k, v in sorted(acc.items()):
-    print('%-28s %.5e  (n=%d)' % (k, sum(v) / len(v), len(v)))
+        for tag in ('fbank512b_kernel<13, 1,', 'fbank512b_kernel<13, 2,'):   # fbank-40, MFCC-13
+            if tag in r['Kernel_Name']:
+                acc[(tag, r['Counter_Name'])].append(float(r['Counter_Value']))
+for (tag, k), v in sorted(acc.items()):
+    print('%-26s %-28s %.5e  (n=%d)' % (tag, k, sum(v) / len(v), len(v)))
 PY
 python - <<'PY' | tee gpurun_out/profiles/pmc_other_rates_summary.txt
 import csv, glob, collections

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """profiles/hbm_traffic.json from the separate rocprofv3 --pmc passes of tools/collect_profiles.sh:
-python tools/make_hbm_traffic.py profiles/r02_pmc  (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU of fbank512_kernel)"""
+python tools/make_hbm_traffic.py profiles/r03_pmc  (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU of the fbank-40 instantiation
+of fbank512b_kernel; the MFCC-13 instantiation of the same run is reported beside it)"""
 import collections
 import csv
 import glob
@@ -9,17 +10,21 @@ import os
 import sys
 
 src = sys.argv[1]
-acc = collections.defaultdict(list)
+FBANK, MFCC = 'fbank512b_kernel<13, 1,', 'fbank512b_kernel<13, 2,'   # <NJ, KIND (1 fbank, 2 mfcc), ..>
+acc, acc_mfcc = collections.defaultdict(list), collections.defaultdict(list)
 for name in sorted(glob.glob(os.path.join(src, 'pmc_group_*.csv'))):
     for r in csv.DictReader(open(name)):
-        if 'fbank512_kernel' in r['Kernel_Name']:
+        if FBANK in r['Kernel_Name']:
             acc[r['Counter_Name']].append(float(r['Counter_Value']))
+        if MFCC in r['Kernel_Name']:
+            acc_mfcc[r['Counter_Name']].append(float(r['Counter_Value']))
 mean = {k: sum(v) / len(v) for k, v in acc.items()}
+mean_mfcc = {k: sum(v) / len(v) for k, v in acc_mfcc.items()}
 fetch_kib, write_kib = mean['FETCH_SIZE'], mean['WRITE_SIZE']
 frames = 10000 * 298
 out = {
     '_comment': (
-        'HBM traffic of fbank512_kernel<13,1,0,false,true,0> per launch (10 000 x 3 s utterances, fbank-40), '
+        'HBM traffic of fbank512b_kernel<13, 1, 0, true> per launch (10 000 x 3 s utterances, fbank-40), '
         'from two separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) with --kernel-trace only '
         '(tools/collect_profiles.sh), corrected as MI355X_MICROARCH.md prescribes: counters are in KiB; on '
         'gfx950 FETCH_SIZE reports 1/2 of the bytes of a coalesced streaming read (TCC_EA0_RDREQ x 64 B for '
@@ -33,6 +38,13 @@ out = {
     'write_bytes': int(round(write_kib * 1024)),
     'traffic_bytes_per_launch': int(round(2 * fetch_kib * 1024 + write_kib * 1024)),
     'algorithmic_bytes_per_launch': frames * 480,
+    'mfcc13': {
+        '_comment': 'fbank512b_kernel<13, 2, 1, true> (MFCC-13 with raw energy) in the same runs: 372 B/frame algorithmic',
+        'FETCH_SIZE_KiB': mean_mfcc.get('FETCH_SIZE'), 'WRITE_SIZE_KiB': mean_mfcc.get('WRITE_SIZE'),
+        'traffic_bytes_per_launch': (int(round(2 * mean_mfcc['FETCH_SIZE'] * 1024 + mean_mfcc['WRITE_SIZE'] * 1024))
+                                     if 'FETCH_SIZE' in mean_mfcc and 'WRITE_SIZE' in mean_mfcc else None),
+        'algorithmic_bytes_per_launch': frames * 372,
+        'valu_wave_instrs_per_launch': mean_mfcc.get('SQ_INSTS_VALU')},
     'valu': {
         '_comment': (
             'SQ_INSTS_VALU per launch of the same workload (separate --pmc pass) against the f32 VALU issue '
