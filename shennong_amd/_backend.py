@@ -664,6 +664,9 @@ class _DevicePool:
     8 GiB of the 288 GB); a buffer is reused for a request of at least half its size."""
     def __init__(self):
         self.limit = int(os.environ.get('SNF_DEVICE_POOL_BYTES', 8 << 30))
+        # tests: a reused buffer is filled with NaN bit patterns before it is handed out, so that a kernel
+        # that relies on what a fresh allocation happens to contain shows up
+        self.poison = bool(int(os.environ.get('SNF_DEVICE_POOL_POISON', '0')))
         self._free = {}  # device -> list of (capacity, pointer)
         self._bytes = 0
         self._lock = threading.Lock()
@@ -714,6 +717,8 @@ class DeviceBuffer:
                 DEVICE_POOL.clear()  # (out of memory with buffers parked in the pool: give them back first)
                 check(lib().snf_malloc(C.byref(ptr), want))
             block = (want, ptr.value)
+        elif DEVICE_POOL.poison:
+            check(lib().snf_memset(C.c_void_p(block[1]), 0xFF, block[0]))
         self._capacity, self.ptr = block
         self.nbytes = int(nbytes)
 

@@ -63,8 +63,11 @@ def gpu(_gpu_backend):
     """Skips when no device is visible; on the GPU box a missing library is an error.  Every GPU
     test starts from LDS filled with NaN bit patterns: LDS is not cleared between kernels, and a
     kernel that multiplies a word it never wrote by a zero weight is correct only as long as the
-    previous tenant of that CU left something finite there (this bit the last mel bin once)."""
+    previous tenant of that CU left something finite there (this bit the last mel bin once).  The same
+    goes for HBM now that freed device buffers are pooled and reused."""
     _gpu_backend.check(_gpu_backend.lib().snf_debug_fill_lds(0xFFFFFFFF))
+    # (and every device buffer that comes back from the pool is handed out full of NaN bit patterns)
+    _gpu_backend.DEVICE_POOL.poison = True
     return _gpu_backend
 
 
