@@ -658,6 +658,37 @@ def _check_finite(out):
         raise ValueError('data contains non-finite numbers (nan of infinity)')
 
 
+_STREAMS = threading.local()
+
+
+def _copy_stream(device):
+    """One non-blocking HIP stream per (thread, device) for asynchronous copies"""
+    streams = getattr(_STREAMS, 'by_device', None)
+    if streams is None:
+        streams = _STREAMS.by_device = {}
+    if device not in streams:
+        handle = C.c_void_p()
+        check(lib().snf_stream_create(C.byref(handle)))
+        streams[device] = handle.value
+    return streams[device]
+
+
+_SIDE_POOL = None
+
+
+def side_pool():
+    """Two worker threads for launches that do not depend on what the calling thread does next (the pitch
+    tracker beside the features -> CMVN -> delta chain of the pipeline): every entry point releases the
+    interpreter lock, every plan has its own stream"""
+    global _SIDE_POOL
+    if _SIDE_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        with _LOCK:
+            if _SIDE_POOL is None:
+                _SIDE_POOL = ThreadPoolExecutor(max_workers=2, thread_name_prefix='snf-side')
+    return _SIDE_POOL
+
+
 class _DevicePool:
     """Freed device buffers kept for the next batch (hipMalloc / hipFree synchronise the device and cost
     0.1-0.4 ms each; a pipeline call makes twenty of them).  Bounded by SNF_DEVICE_POOL_BYTES (default
@@ -735,6 +766,16 @@ class DeviceBuffer:
             array.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
             array.nbytes))
         return array
+
+    def download_async(self, array):
+        """Starts the copy into `array` on this thread's copy stream and returns a callable that waits for
+        it: the caller does its host-side bookkeeping in between (the copy only overlaps when `array` is
+        page-locked, :func:`result_array`; into plain memory it is done when this returns)"""
+        bind_device(self.device)
+        stream = _copy_stream(self.device)
+        check(lib().snf_memcpy_d2h_async(array.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
+                                         array.nbytes, C.c_void_p(stream)))
+        return lambda: check(lib().snf_stream_synchronize(C.c_void_p(stream)))
 
     def free(self):
         if self.ptr:

@@ -588,6 +588,53 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             return offsets([frames_of[x] for x in lengths.tolist()])
         st = {'idx': idx, 'soff': soff, 'd_wave': d_wave}
 
+        if 'pitch' in config and not stats_only:
+            params = {k: v for k, v in config['pitch'].items()
+                      if k not in ('processor', 'postprocessing')}
+            params['sample_rate'] = rate
+            params['frame_shift'] = frame_shift
+            params['frame_length'] = frame_length
+            pproc = _processor_class('kaldi_pitch')(**params)
+            post = _processor_class('kaldi_pitch_post')(**config['pitch']['postprocessing'])
+            pplan = _backend.get_plan(pproc._build_options())
+            pfoff = frame_offsets(pplan)
+            qplan = _backend.get_plan(post._build_options())
+            pdim = qplan.post_ndims(2)
+
+            def track(d_wave=d_wave, soff=soff, pfoff=pfoff, pplan=pplan, qplan=qplan, pdim=pdim):
+                # the tracker needs nothing but the audio: it runs on a side thread (its own stream) while
+                # this one takes the audio through the features, VAD, CMVN and delta, and is waited for where
+                # the columns are joined (the audio buffer is released there, after its last reader)
+                d_raw = d_pitch = None
+                try:
+                    d_raw = DB(max(int(pfoff[-1]) * 2 * 4, 16))
+                    pplan.run_device(d_wave.ptr, soff, pfoff, d_raw.ptr)
+                    d_pitch = DB(max(int(pfoff[-1]) * pdim * 4, 16))
+                    qplan.run_post_device(d_raw.ptr, 2, pfoff, d_pitch.ptr)
+                    return d_pitch
+                except BaseException:
+                    if d_pitch is not None:
+                        d_pitch.free()
+                    raise
+                finally:
+                    if d_raw is not None:
+                        d_raw.free()
+
+            st.update(pfoff=pfoff, pdim=pdim, pitch_job=_backend.side_pool().submit(track))
+            step = {}
+            for i, t in zip(idx, np.diff(pfoff).tolist()):
+                found = step.get(t)
+                if found is None:
+                    key = ('pitch', rate)
+                    if key not in cache:
+                        cache[key] = pproc.get_properties()
+                    tkey = ('times', 'pitch', rate, t)
+                    if tkey not in cache:
+                        cache[tkey] = pproc.times(t)
+                    found = step[t] = _Meta(cache[key], 2, t, cache[tkey], key).derive(
+                        cache, 'post', post.get_properties, ndims=pdim)
+                pmeta[i] = found
+
         opts = proc._build_options()
         plan = _backend.get_plan(opts)
         dim = plan.ndims
@@ -632,38 +679,9 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             d_energy.free()
             st['d_vad'] = d_vad
 
-        if 'pitch' in config and not stats_only:
-            params = {k: v for k, v in config['pitch'].items()
-                      if k not in ('processor', 'postprocessing')}
-            params['sample_rate'] = rate
-            params['frame_shift'] = frame_shift
-            params['frame_length'] = frame_length
-            pproc = _processor_class('kaldi_pitch')(**params)
-            post = _processor_class('kaldi_pitch_post')(**config['pitch']['postprocessing'])
-            pplan = _backend.get_plan(pproc._build_options())
-            pfoff = frame_offsets(pplan)
-            d_raw = DB(max(int(pfoff[-1]) * 2 * 4, 16))
-            pplan.run_device(d_wave.ptr, soff, pfoff, d_raw.ptr)
-            qplan = _backend.get_plan(post._build_options())
-            pdim = qplan.post_ndims(2)
-            d_pitch = DB(max(int(pfoff[-1]) * pdim * 4, 16))
-            qplan.run_post_device(d_raw.ptr, 2, pfoff, d_pitch.ptr)
-            d_raw.free()
-            st.update(pfoff=pfoff, pdim=pdim, d_pitch=d_pitch)
-            step = {}
-            for i, t in zip(idx, np.diff(pfoff).tolist()):
-                found = step.get(t)
-                if found is None:
-                    key = ('pitch', rate)
-                    if key not in cache:
-                        cache[key] = pproc.get_properties()
-                    tkey = ('times', 'pitch', rate, t)
-                    if tkey not in cache:
-                        cache[tkey] = pproc.times(t)
-                    found = step[t] = _Meta(cache[key], 2, t, cache[tkey], key).derive(
-                        cache, 'post', post.get_properties, ndims=pdim)
-                pmeta[i] = found
-        if not (stats_only and resident is not None and resident.offer((batch_id, rate), d_wave, soff)):
+        if 'pitch_job' in st:
+            pass  # (the tracker still reads the audio: released where it is waited for)
+        elif not (stats_only and resident is not None and resident.offer((batch_id, rate), d_wave, soff)):
             d_wave.free()
         groups_state.append(st)
 
@@ -744,9 +762,14 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
     # pitch tracker: same tolerance as Kaldi's paste-feats), then the only device -> host copy -----------
     out = FeaturesCollection()
     results = [None] * n
+    pending = []
     for st in groups_state:
         idx = st['idx']
-        if 'd_pitch' in st:
+        if 'pitch_job' in st:
+            try:
+                st['d_pitch'] = st.pop('pitch_job').result()
+            finally:
+                st['d_wave'].free()
             rows, step = [], {}
             for i in idx:
                 hit = step.get((meta[i], pmeta[i]))
@@ -773,10 +796,13 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             st['d_feat'], st['dim'], st['foff'] = d_out, odim, ooff
         host = _backend.result_array((int(st['foff'][-1]), st['dim']), np.float32)
         if host.size:
-            # (Features.validate's data check, once for the batch and before it leaves HBM)
+            # (Features.validate's data check, once for the batch and before it leaves HBM; the copy then
+            # runs while the per-utterance objects below are made - they only need to know WHERE their rows
+            # will be)
             _backend.check_finite_device(st['d_feat'].ptr, host.size)
-            st['d_feat'].download(host)
-        st['d_feat'].free()
+            pending.append((st['d_feat'].download_async(host), st['d_feat']))
+        else:
+            st['d_feat'].free()
         cuts = st['foff'].tolist()
         for k, i in enumerate(idx):
             results[i] = host[cuts[k]:cuts[k + 1]]  # views of the one downloaded array
@@ -793,6 +819,9 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
         extra = {'audio': audio, 'speaker': utt.speaker} if utt.speaker else {'audio': audio}
         # (times are generated, hence sorted; the data were checked above: no per-utterance validate)
         out[utt.name] = of_batch(results[i], meta[i].times, meta[i].properties, extra)
+    for wait, d_feat in pending:
+        wait()
+        d_feat.free()
     return out
 
 
