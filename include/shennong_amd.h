@@ -323,7 +323,7 @@ int snf_malloc(void** dptr, uint64_t bytes);
 int snf_free(void* dptr);
 int snf_memcpy_h2d(void* dst, const void* src, uint64_t bytes);
 int snf_memcpy_d2h(void* dst, const void* src, uint64_t bytes);
-int snf_memset(void* dst, int value, uint64_t bytes);
+int snf_memset(void* dst, int value, uint64_t bytes);  /* complete when it returns (the plans use their own streams) */
 /* Streams and stream-ordered copies for callers that overlap the transfers of one batch with the
    kernels of another (the *_device entry points take the stream; page-locked host memory from
    snf_host_malloc is required for the copies to be asynchronous). */

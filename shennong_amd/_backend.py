@@ -749,7 +749,7 @@ class DeviceBuffer:
                 check(lib().snf_malloc(C.byref(ptr), want))
             block = (want, ptr.value)
         elif DEVICE_POOL.poison:
-            check(lib().snf_memset(C.c_void_p(block[1]), 0xFF, block[0]))
+            check(lib().snf_memset(C.c_void_p(block[1]), 0xFF, block[0]))  # (complete when it returns)
         self._capacity, self.ptr = block
         self.nbytes = int(nbytes)
 

@@ -1560,7 +1560,11 @@ int snf_memcpy_d2h_async(void* dst, const void* src, uint64_t bytes, void* strea
   return SNF_OK;
 }
 int snf_memset(void* dst, int value, uint64_t bytes) {
+  // hipMemset on device memory returns before the fill has run, and the plans' streams are non-blocking:
+  // they do not wait for the null stream.  A caller that fills a buffer and then hands it to a plan expects
+  // the fill to be over (found by the pipeline fuzzer: the fill landed on top of a kernel's output).
   SNF_HIP_CHECK(hipMemset(dst, value, bytes));
+  SNF_HIP_CHECK(hipStreamSynchronize(nullptr));
   return SNF_OK;
 }
 namespace {

@@ -49,16 +49,26 @@ def main():
                f'delta={with_delta} pitch={with_pitch} n={n} rates={rates} warps={warps}')
         cfg = pipeline._init_config(config, log=log)
         per_utt = pipeline._init_warps(warps, cfg, index, log) if warps else None
-        a = pipeline._extract_features(cfg, index, per_utt, log)
-        b = pipeline._extract_features_by_stage(cfg, index, per_utt, log)
+        try:
+            a = pipeline._extract_features(cfg, index, per_utt, log)
+            b = pipeline._extract_features_by_stage(cfg, index, per_utt, log)
+        except Exception:
+            print('FAIL (exception)', tag, [(it[0], it[1].nsamples, it[1].sample_rate, it[2]) for it in items])
+            raise
         if list(a.keys()) != list(b.keys()) or any(not a[k] == b[k] for k in a):
             bad = [k for k in a if not a[k] == b[k]]
             print('FAIL resident != by stage', tag, bad,
                   [float(np.abs(a[k].data - b[k].data).max()) for k in bad if a[k].shape == b[k].shape])
             return 1
         got = FeaturesCollection()
-        pipeline.extract_features_streamed(config, index, got.update, warps=warps,
-                                           max_batch_duration=float(rng.uniform(0.3, 3.0)), log=log)
+        batch_s = float(rng.uniform(0.3, 3.0))
+        try:
+            pipeline.extract_features_streamed(config, index, got.update, warps=warps,
+                                               max_batch_duration=batch_s, log=log)
+        except Exception:
+            print('FAIL (exception, streamed)', tag, batch_s,
+                  [(it[0], it[1].nsamples, it[1].sample_rate, it[2]) for it in items])
+            raise
         if list(got.keys()) != list(a.keys()) or any(not got[k] == a[k] for k in a):
             print('FAIL streamed != one shot', tag, [k for k in a if not got[k] == a[k]])
             return 1
