@@ -312,6 +312,17 @@ int snf_concat_columns_device(int device_id, const float* d_a, int32_t cols_a,
                               const int64_t* offsets_out);
 
 /*
+ * Random terms (dither, reference processor/base.py:122; delta-pitch noise, pitch_kaldi.py:321-327).  A
+ * draw is keyed by (options seed, noise call, the frame's index inside its utterance, the utterance's
+ * length and first samples): never by the frame's position in the batch.  The noise call is the plan's own
+ * count of calls that draw - every call a new stream, like the reference's global rand() - unless the
+ * calling thread names it for its NEXT such call with snf_set_noise_call(call != 0): a caller that must see
+ * the same noise for the same utterance in two passes over a corpus (streamed CMVN by speaker: statistics
+ * pass, then apply pass) names the same call in both.
+ */
+int snf_set_noise_call(uint64_t call);
+
+/*
  * Number of NaN / +-Inf among n floats of a device-resident block (16-byte aligned): the data part of
  * reference shennong/features.py:170-215 `Features.is_valid` ("data contains non-finite numbers"), run on
  * the whole batch before its only device -> host copy.

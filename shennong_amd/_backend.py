@@ -31,7 +31,7 @@ EXPORTS = [
     'snf_plan_num_frames', 'snf_plan_run_batch', 'snf_plan_run_batch_device',
     'snf_post_ndims', 'snf_post_run_batch', 'snf_post_run_batch_device',
     'snf_cmvn_accumulate', 'snf_cmvn_apply', 'snf_cmvn_accumulate_device',
-    'snf_cmvn_apply_device', 'snf_concat_columns_device', 'snf_count_nonfinite_device',
+    'snf_cmvn_apply_device', 'snf_concat_columns_device', 'snf_count_nonfinite_device', 'snf_set_noise_call',
     'snf_malloc', 'snf_free', 'snf_memcpy_h2d', 'snf_memcpy_d2h', 'snf_memset',
     'snf_host_malloc', 'snf_host_free', 'snf_debug_fill_lds', 'snf_debug_pitch_scratch',
     'snf_stream_create', 'snf_stream_destroy', 'snf_stream_synchronize', 'snf_memcpy_h2d_async',
@@ -99,6 +99,7 @@ def lib():
         L.snf_concat_columns_device.argtypes = [
             i32, vp, i32, pi64, vp, i32, pi64, i64, vp, pi64]
         L.snf_count_nonfinite_device.argtypes = [i32, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.snf_set_noise_call.argtypes = [C.c_uint64]
         L.snf_malloc.argtypes = [C.POINTER(vp), C.c_uint64]
         L.snf_free.argtypes = [vp]
         L.snf_memcpy_h2d.argtypes = [vp, vp, C.c_uint64]
@@ -409,11 +410,15 @@ class Plan:
             stats.shape[0], int(bool(norm_vars)), int(bool(reverse)), C.c_void_p(d_out)))
 
     # -- device-resident variants (benchmark / pipelines that keep data in HBM) --
-    def run_device(self, d_wave, soff, foff, d_out, vtln_warps=None, stream=None):
+    def run_device(self, d_wave, soff, foff, d_out, vtln_warps=None, stream=None, noise_call=None):
+        """`noise_call`: the noise stream of this call when the plan dithers (see snf_set_noise_call);
+        None = the plan's own call count, a new stream per call"""
         n = soff.shape[0] - 1
         warp = None
         if vtln_warps is not None:
             warp = np.ascontiguousarray(vtln_warps, dtype=np.float32)
+        if noise_call:
+            lib().snf_set_noise_call(int(noise_call))  # (thread-local, used up by the call below)
         check(lib().snf_plan_run_batch_device(
             self.handle, C.c_void_p(d_wave),
             soff.ctypes.data_as(C.POINTER(C.c_int64)), n,
@@ -422,8 +427,10 @@ class Plan:
             C.c_void_p(d_out), foff.ctypes.data_as(C.POINTER(C.c_int64)),
             C.c_void_p(stream) if stream else None))
 
-    def run_post_device(self, d_in, in_cols, foff, d_out, stream=None):
+    def run_post_device(self, d_in, in_cols, foff, d_out, stream=None, noise_call=None):
         n = foff.shape[0] - 1
+        if noise_call:
+            lib().snf_set_noise_call(int(noise_call))
         check(lib().snf_post_run_batch_device(
             self.handle, C.c_void_p(d_in), in_cols,
             foff.ctypes.data_as(C.POINTER(C.c_int64)), n, C.c_void_p(d_out),

@@ -712,6 +712,23 @@ extern "C" {
 const char* snf_version(void) { return "shennong_amd 0.1 (gfx950)"; }
 const char* snf_last_error(void) { return last_error(); }
 
+namespace {
+// noise stream of the next call of THIS thread that draws random numbers (0: the plan's own call count)
+thread_local uint64_t t_noise_call = 0;
+// every run entry point takes it first thing: a name given to a call that draws nothing is not left behind
+// for the thread's next call
+uint64_t take_noise_call() {
+  const uint64_t pinned = t_noise_call;
+  t_noise_call = 0;
+  return pinned;
+}
+}  // namespace
+
+int snf_set_noise_call(uint64_t call) {
+  t_noise_call = call;
+  return SNF_OK;
+}
+
 int snf_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -867,6 +884,7 @@ int64_t snf_plan_num_frames(const snf_plan* plan, int64_t n) {
 int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64_t* sample_offsets,
                               int64_t n_utts, const float* vtln_warp, float* d_out,
                               const int64_t* frame_offsets, void* stream) {
+  const uint64_t named_call = take_noise_call();
   if (!plan) return set_error(SNF_E_INVALID, "null plan");
   std::lock_guard<std::mutex> lock(plan->mu);
   int rc = guard_device(plan);
@@ -1034,7 +1052,7 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
   b.frame_utt = plan->setidx_valid ? plan->s_futt.as<int32_t>() : nullptr;
   if (own_stream) begin_timing(plan);
   if (plan->mp.dither != 0.0f) {
-    const unsigned long long stream_key = plan->o.seed + 0x9E3779B97F4A7C15ull * ++plan->noise_calls;
+    const unsigned long long stream_key = plan->o.seed + 0x9E3779B97F4A7C15ull * (named_call ? named_call : ++plan->noise_calls);
     plan->mp.seed = plan->fp.seed = plan->fp_warp.seed = stream_key;
   }
   // the register-resident 512-point family: one launch, or two over disjoint utterances (split_dual)
@@ -1174,6 +1192,7 @@ int32_t snf_post_ndims(const snf_plan* plan, int32_t in_cols) {
 int snf_post_run_batch_device(snf_plan* plan, const float* d_in, int32_t in_cols,
                               const int64_t* frame_offsets, int64_t n_utts, float* d_out,
                               void* stream) {
+  const uint64_t named_call = take_noise_call();
   if (!plan) return set_error(SNF_E_INVALID, "null plan");
   if (n_utts <= 0) return n_utts == 0 ? SNF_OK : set_error(SNF_E_INVALID, "n_utts < 0");
   if (!frame_offsets) return set_error(SNF_E_INVALID, "null offsets table");
@@ -1215,7 +1234,7 @@ int snf_post_run_batch_device(snf_plan* plan, const float* d_in, int32_t in_cols
       return set_error(SNF_E_INVALID, "data shape must be (_, 2), but it is (_, " +
                                           std::to_string(in_cols) + ")");
     if (plan->ppost.o.delta_pitch_noise_stddev != 0.0f)
-      plan->ppost.seed = plan->o.seed + 0x9E3779B97F4A7C15ull * ++plan->noise_calls;
+      plan->ppost.seed = plan->o.seed + 0x9E3779B97F4A7C15ull * (named_call ? named_call : ++plan->noise_calls);
     if ((rc = launch_pitch_post(plan->ppost, d_in, plan->s_foff.as<int64_t>(), n_utts,
                                 total_frames, d_out, s)))
       return rc;

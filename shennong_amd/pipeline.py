@@ -441,6 +441,13 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
             resident.clear()
 
 
+# The device-resident pipeline draws its random terms (dither, delta-pitch noise) from ONE named noise call
+# (snf_set_noise_call): the features of an utterance are a function of the configuration and the utterance
+# alone - the same in the statistics pass and the apply pass of the streamed pipeline, in any batch split,
+# in every run (the reference, whose dither comes from Kaldi's global rand(), has none of these).
+_NOISE_CALL = 1
+
+
 class _Meta:
     """What the post-processors' `get_properties` need to know about features that live in HBM.
     The properties of a stage are the same for every utterance that went through the same processors
@@ -610,7 +617,7 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
                     d_raw = DB(max(int(pfoff[-1]) * 2 * 4, 16))
                     pplan.run_device(d_wave.ptr, soff, pfoff, d_raw.ptr)
                     d_pitch = DB(max(int(pfoff[-1]) * pdim * 4, 16))
-                    qplan.run_post_device(d_raw.ptr, 2, pfoff, d_pitch.ptr)
+                    qplan.run_post_device(d_raw.ptr, 2, pfoff, d_pitch.ptr, noise_call=_NOISE_CALL)
                     return d_pitch
                 except BaseException:
                     if d_pitch is not None:
@@ -645,7 +652,7 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             wlist = [warps[utts[i].name] for i in idx]
             vt = np.asarray(wlist, dtype=np.float32)
         log.debug('extract %s on %d utterances at %d Hz', features_name, len(idx), rate)
-        plan.run_device(d_wave.ptr, soff, foff, d_feat.ptr, vtln_warps=vt)
+        plan.run_device(d_wave.ptr, soff, foff, d_feat.ptr, vtln_warps=vt, noise_call=_NOISE_CALL)
         st.update(foff=foff, dim=dim, d_feat=d_feat)
         step = {}
         for k, (i, t) in enumerate(zip(idx, np.diff(foff).tolist())):
@@ -671,7 +678,7 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             if not np.array_equal(efoff, foff):
                 raise ValueError('energy and features differ in number of frames')
             d_energy = DB(max(int(foff[-1]) * 4, 16))
-            eplan.run_device(d_wave.ptr, soff, foff, d_energy.ptr)
+            eplan.run_device(d_wave.ptr, soff, foff, d_energy.ptr, noise_call=_NOISE_CALL)
             vad = _processor_class('vad')(**config['cmvn']['vad'])
             d_vad = DB(max(int(foff[-1]) * 4, 16))
             _backend.get_plan(vad._build_options()).run_post_device(

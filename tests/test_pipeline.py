@@ -556,6 +556,41 @@ def test_pipeline_streamed_resident_waves(gpu, resident_bytes, njobs):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('features', ['mfcc', 'filterbank'])
+def test_pipeline_random_terms_are_a_function_of_the_utterance(gpu, features):
+    """the reference's DEFAULT configuration dithers (processor/base.py:122), its VAD energy too, and the
+    pitch post-processing adds noise to the delta-pitch column: the pipeline draws all of them from one named
+    noise call keyed per utterance, so the statistics pass and the apply pass of the streamed pipeline see
+    the same features - streamed == one-shot bit for bit with every random term ON, whatever the batch
+    split, and two runs agree"""
+    index = _segments_index()
+    config = pipeline.get_default_config(features, with_cmvn=True, with_delta=True, with_pitch='kaldi')
+    assert config[features]['dither'] == 1.0 and config['cmvn']['with_vad'] is True
+    assert config['pitch']['postprocessing']['delta_pitch_noise_stddev'] > 0
+    config['cmvn']['by_speaker'] = True
+    whole = pipeline.extract_features(config, index)
+    again = pipeline.extract_features(config, index)
+    quiet = pipeline.get_default_config(features, with_cmvn=True, with_delta=True, with_pitch='kaldi')
+    quiet[features]['dither'] = 0
+    quiet['cmvn']['by_speaker'] = True
+    silent = pipeline.extract_features(quiet, index)
+    for k in whole:
+        assert whole[k] == again[k], k
+        assert not np.array_equal(whole[k].data, silent[k].data), k   # (the noise is there)
+    for batch_s in (0.7, 1.5, 100.0):
+        got = {}
+        pipeline.extract_features_streamed(config, index, got.update, max_batch_duration=batch_s)
+        assert list(got) == list(whole.keys())
+        for k in whole:
+            assert got[k] == whole[k], (k, batch_s)
+    # a processor called directly keeps the reference's behaviour: a new stream per call
+    from shennong_amd.processor import MfccProcessor
+    audio = index['u1'].load_audio()
+    proc = MfccProcessor(sample_rate=audio.sample_rate)
+    assert not np.array_equal(proc.process(audio).data, proc.process(audio).data)
+
+
+@pytest.mark.gpu
 def test_non_finite_features_are_refused_on_the_device(gpu):
     """Features.validate's data check runs on the batch while it is still in HBM"""
     from shennong_amd import _backend
