@@ -541,6 +541,7 @@ class _ResultBlock:
     matrices are numpy views of it (``np.asarray(block)``: numpy keeps the block as their base); the
     buffer goes back to the pool when the last of them is gone."""
     _LIMIT = 4 << 30   # page-locked result memory handed out and not yet returned, at most
+    _FRESH = 1 << 30   # ... below which a result may page-lock a new buffer (see result_array)
     _held = 0
     _lock = threading.Lock()
 
@@ -564,17 +565,18 @@ class _ResultBlock:
 
 def result_array(shape, dtype):
     """Uninitialised host array for the one device -> host copy of a batch: pooled page-locked memory
-    (no page faults, no munmap per batch, twice the link rate of pageable memory).  A new page-locked
-    buffer is only made while no earlier result block is alive - the steady state of a corpus run that
-    writes every batch and drops it; a caller that keeps its results gets plain numpy memory for the next
-    ones (page-locking is slower than the page faults it saves unless the buffer is used again), and at
-    most `_ResultBlock._LIMIT` bytes are ever handed out."""
+    (no page faults, no munmap per batch, twice the link rate of pageable memory).  Page-locking fresh memory
+    costs ~0.25 ms/MB - more than the page faults it saves unless the buffer is used again -, so a NEW buffer
+    is only made while the result blocks that are alive stay under `_ResultBlock._FRESH` bytes: the steady
+    state of a corpus run that writes every batch and drops it reuses one or two blocks for ever, a caller
+    that keeps all its results gets plain numpy memory once that much is pinned (pooled blocks that fit are
+    still used, up to `_ResultBlock._LIMIT` alive)."""
     nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
     with _ResultBlock._lock:
         held = _ResultBlock._held
     if held + nbytes > _ResultBlock._LIMIT or nbytes < _Staging._MIN_BYTES:
         return np.empty(shape, dtype=dtype)
-    array, token = STAGING.array(shape, dtype, allocate=held == 0)
+    array, token = STAGING.array(shape, dtype, allocate=held + nbytes <= _ResultBlock._FRESH)
     if token is None:
         return array
     block = _ResultBlock(shape, dtype, token, token[1])

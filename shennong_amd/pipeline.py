@@ -580,10 +580,12 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
         if held is not None:
             d_wave, soff = held
         else:
-            waves = []
+            waves, checked = [], set()
             for i in idx:
                 audio = utts[i].load_audio()
-                check_signal(proc, audio)
+                if (audio.nchannels, audio.sample_rate) not in checked:  # (one check per kind of signal)
+                    check_signal(proc, audio)
+                    checked.add((audio.nchannels, audio.sample_rate))
                 waves.append(audio.astype(np.int16).data)
             soff = offsets([w.shape[0] for w in waves])
             d_wave = _backend.upload_rows(waves, np.int16)  # (page-locked staging: full link rate)
