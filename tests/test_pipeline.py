@@ -591,6 +591,52 @@ def test_pipeline_random_terms_are_a_function_of_the_utterance(gpu, features):
 
 
 @pytest.mark.gpu
+def test_result_blocks_and_pooled_buffers(gpu):
+    """the host array of a batch is a pooled page-locked block: views keep it alive, the last one gives it
+    back, a new block is only page-locked while few result bytes are alive; device buffers are pooled"""
+    import gc
+    from shennong_amd import _backend
+    block_cls = _backend._ResultBlock
+    gc.collect()
+    held0 = block_cls._held
+    a = _backend.result_array((300000, 4), np.float32)         # 4.8 MB: page-locked
+    assert isinstance(a.base, block_cls) and block_cls._held > held0
+    a[...] = 7.0
+    rows = a[10:20]
+    address = a.ctypes.data
+    del a
+    gc.collect()
+    assert block_cls._held > held0 and float(rows.sum()) == 7.0 * 40   # a view keeps the block
+    del rows
+    gc.collect()
+    assert block_cls._held == held0
+    b = _backend.result_array((300000, 4), np.float32)          # the block came back to the pool
+    assert b.ctypes.data == address
+    small = _backend.result_array((10, 4), np.float32)          # not worth a pinned buffer
+    assert not isinstance(small.base, block_cls)
+    fresh, block_cls._FRESH = block_cls._FRESH, 1 << 20
+    try:
+        c = _backend.result_array((400000, 4), np.float32)      # no pooled block fits, none may be made
+        assert not isinstance(c.base, block_cls)
+    finally:
+        block_cls._FRESH = fresh
+    del b
+    # device buffers: a freed buffer is handed out again for a request of similar size
+    d = _backend.DeviceBuffer(3 << 20)
+    ptr = d.ptr
+    d.free()
+    e = _backend.DeviceBuffer((3 << 20) - 4096)
+    assert e.ptr == ptr and e.nbytes == (3 << 20) - 4096
+    e.free()
+    rows = [np.full(50000 + 7 * k, k, dtype=np.int16) for k in range(120)]   # 12 MB: the threaded path
+    buf = _backend.upload_rows(rows, np.int16)
+    back = np.empty(sum(r.shape[0] for r in rows), dtype=np.int16)
+    buf.download(back)
+    buf.free()
+    assert np.array_equal(back, np.concatenate(rows))
+
+
+@pytest.mark.gpu
 def test_non_finite_features_are_refused_on_the_device(gpu):
     """Features.validate's data check runs on the batch while it is still in HBM"""
     from shennong_amd import _backend

@@ -12,6 +12,8 @@ rm -rf /tmp/prof_stats
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- \
   python $root/bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-extra > $out/bench_profiled.json 2> /dev/null
 cp $(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1) $out/bench_fbank40_rocprofv3_kernel_stats.csv
+# the same trace restricted to the 20 timed launches of each kernel (settle and warm-up launches dropped)
+python $root/tools/timed_launch_stats.py $(find /tmp/prof_stats -name '*kernel_trace.csv' | head -1) 20 > $out/bench_fbank40_timed_launches_stats.csv
 rm -rf /tmp/prof_pitch
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pitch -- \
   python $root/tools/profile_pitch.py 4000 > $out/pitch_plp_run.txt 2> /dev/null
