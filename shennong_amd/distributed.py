@@ -221,12 +221,11 @@ def _gather_device_resident(processor, names, signals, warps, comm, dst):
     np.cumsum(nframes, out=foff[1:])
     meta = comm.all_gather_object((list(names), nframes))
     counts = [sum(nf) * ndims for _, nf in meta]
-    d_wave = _backend.DeviceBuffer(max(int(soff[-1]) * 2, 16), device=comm.device)
-    d_out = _backend.DeviceBuffer(max(int(foff[-1]) * ndims * 4, 16), device=comm.device)
-    d_all = None
+    d_wave = d_out = d_all = None
     try:
-        if soff[-1] > 0:
-            d_wave.upload(np.concatenate(waves))
+        # (threaded gather + copy through page-locked staging, like the single-process pipeline)
+        d_wave = _backend.upload_rows(waves, np.int16, device=comm.device) if waves else None
+        d_out = _backend.DeviceBuffer(max(int(foff[-1]) * ndims * 4, 16), device=comm.device)
         if foff[-1] > 0:
             plan.run_device(d_wave.ptr, soff, foff, d_out.ptr, vtln_warps=warps)
         if comm.rank == dst:
@@ -234,19 +233,22 @@ def _gather_device_resident(processor, names, signals, warps, comm, dst):
         comm.gatherv_device(d_out.ptr, int(foff[-1]) * ndims, d_all.ptr if d_all else None, counts, dst)
         if comm.rank != dst:
             return None
-        host = np.empty(sum(counts), dtype=np.float32)
+        # Features.validate's data check on the gathered block while it is in HBM, then ONE copy to the host
+        host = _backend.result_array((sum(counts),), np.float32)
         if host.size:
+            try:
+                _backend.check_finite_device(d_all.ptr, host.size, device=comm.device)
+            except ValueError:
+                raise ValueError('features are not valid (non-finite values)') from None
             d_all.download(host)
     finally:
         for buf in (d_wave, d_out, d_all):
             if buf is not None:
                 buf.free()
-    if not np.isfinite(host).all():
-        raise ValueError('features are not valid (non-finite values)')
     merged, pos = {}, 0
     for names_r, nframes_r in meta:
         for name, nf in zip(names_r, nframes_r):
-            merged[name] = host[pos:pos + nf * ndims].reshape(nf, ndims).copy()
+            merged[name] = host[pos:pos + nf * ndims].reshape(nf, ndims)  # (views of the one block)
             pos += nf * ndims
     return merged
 
@@ -393,8 +395,9 @@ def extract_features_sharded(configuration, utterances, warps=None, dst=0, group
     # on the outcome; the same after the extraction, before the gather
     error = None
     try:
-        if not all(u.load_audio().nchannels == 1 for u in mine):  # (what the pipeline refuses first)
-            raise ValueError('all audio files are not mono')
+        from shennong_amd.audio import Audio
+        if not all(Audio.scan(u.audio_file).nchannels == 1 for u in mine):  # (what the pipeline refuses
+            raise ValueError('all audio files are not mono')                # first; headers only)
     except Exception as exc:  # noqa: BLE001
         error = exc
     _agree(transport, error)
