@@ -271,8 +271,15 @@ __device__ __forceinline__ void scan_range(const float* __restrict__ fwd, int lo
   // and one minimum (costs are >= 0 and never NaN: the minimum IS the select of the cost).
   float d = static_cast<float>(lo) - fi;
   float b = __fadd_rn(__fmul_rn(d * d, factor), fwd[lo]), bd = d;
+  // the four forward costs of a step are read one step ahead (behind the window: the FLT_MAX padding): the
+  // LDS round trip of step n + 1 runs under the 28 vector instructions of step n instead of in front of them
+  float n0 = fwd[lo + 1], n1 = fwd[lo + 2], n2 = fwd[lo + 3], n3 = fwd[lo + 4];
   for (int j = lo + 1; j <= hi; j += 4) {
-    const float f0 = fwd[j], f1 = fwd[j + 1], f2 = fwd[j + 2], f3 = fwd[j + 3];
+    const float f0 = n0, f1 = n1, f2 = n2, f3 = n3;
+    n0 = fwd[j + 4];
+    n1 = fwd[j + 5];
+    n2 = fwd[j + 6];
+    n3 = fwd[j + 7];
     const float d0 = d + 1.0f, d1 = d + 2.0f, d2 = d + 3.0f, d3 = d + 4.0f;
     const float c0 = __fadd_rn(__fmul_rn(d0 * d0, factor), f0);
     const float c1 = __fadd_rn(__fmul_rn(d1 * d1, factor), f1);
