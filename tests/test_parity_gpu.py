@@ -256,14 +256,14 @@ def _synth_job(args):
     return synth.utterances(*args)
 
 
-@pytest.mark.parametrize('kind', ['fbank40', 'mfcc13', 'mfcc13_delta'])
+@pytest.mark.parametrize('kind', ['fbank40', 'mfcc13', 'mfcc13_delta', 'plp13'])
 def test_full_workload_every_frame(gpu, full_workload, kind):
     """The whole bench workload (2.98 M frames), EVERY frame against the oracle, through the same
     batched entry point the bench times; then order independence: the batch reversed gives the same
     rows bit for bit."""
     waves = full_workload
     proc = (FilterbankProcessor(num_bins=40, dither=0) if kind == 'fbank40'
-            else MfccProcessor(dither=0))
+            else PlpProcessor(dither=0) if kind == 'plp13' else MfccProcessor(dither=0))
     opts = proc._build_options()
     plan = _backend.get_plan(opts)
     got = plan.run(list(waves))
