@@ -448,6 +448,55 @@ def test_streamed_driver_logic(monkeypatch):
     assert all(k == 'apply' for k, _ in calls)
 
 
+def test_resident_waves_budget():
+    """the audio kept in HBM between the two streamed passes: a byte budget, every buffer handed back once"""
+    class Buffer:
+        def __init__(self, nbytes):
+            self.nbytes, self.freed = nbytes, 0
+
+        def free(self):
+            self.freed += 1
+
+    keep = pipeline._ResidentWaves(100)
+    a, b, c = Buffer(60), Buffer(50), Buffer(40)
+    assert keep.offer((0, 16000), a, 'soff a') and keep.held == 60
+    assert not keep.offer((1, 16000), b, 'soff b') and keep.held == 60     # over the budget: the caller frees
+    assert keep.offer((2, 16000), c, 'soff c') and keep.held == 100
+    assert keep.take((1, 16000)) is None
+    assert keep.take((0, 16000)) == (a, 'soff a') and keep.held == 40 and keep.take((0, 16000)) is None
+    keep.clear()
+    assert (a.freed, b.freed, c.freed) == (0, 0, 1) and keep.held == 0 and keep.take((2, 16000)) is None
+    assert not pipeline._ResidentWaves(0).offer('k', Buffer(1), None)
+
+
+def test_timed_launch_statistics(tmp_path):
+    """tools/timed_launch_stats.py keeps the last K dispatches of every kernel of a rocprofv3 kernel trace"""
+    import csv
+    import subprocess
+    import sys
+    trace = tmp_path / 'x_kernel_trace.csv'
+    with open(trace, 'w', newline='') as fh:
+        w = csv.writer(fh)
+        w.writerow(['Kind', 'Kernel_Name', 'Start_Timestamp', 'End_Timestamp'])
+        t = 0
+        for i in range(13):                      # 10 settle + 3 warm-up: slow
+            w.writerow(['KERNEL_DISPATCH', 'k<1>(int)', t, t + 2000])
+            t += 3000
+        for i in range(5):                       # 5 timed
+            w.writerow(['KERNEL_DISPATCH', 'k<1>(int)', t, t + 1000 + i])
+            t += 3000
+        w.writerow(['KERNEL_DISPATCH', 'other()', t, t + 50])
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools',
+                        'timed_launch_stats.py')
+    out = subprocess.run([sys.executable, tool, str(trace), '5'], capture_output=True, text=True, check=True)
+    rows = list(csv.DictReader(out.stdout.splitlines()))
+    assert [r['Name'] for r in rows] == ['k<1>(int)', 'other()']
+    assert rows[0]['Calls'] == '18' and rows[0]['TimedCalls'] == '5'
+    assert float(rows[0]['AverageNs']) == 1002.0 and rows[0]['MinNs'] == '1000' and rows[0]['MaxNs'] == '1004'
+    assert abs(float(rows[0]['AllCallsAverageNs']) - (13 * 2000 + 5010) / 18) < 0.1
+    assert rows[1]['TimedCalls'] == '1'
+
+
 @pytest.mark.parametrize('depth', [1, 2, 3, 8])
 def test_batches_in_flight(depth):
     """results in order whatever the completion order, never more than `depth` batches started and not
