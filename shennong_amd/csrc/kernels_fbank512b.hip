@@ -372,13 +372,31 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
         const float4* __restrict__ dw = t_dd_v + l;
         const float4* __restrict__ dx = reinterpret_cast<const float4*>(ptile);
         float v = 0.0f;
+        if (p.dd_groups == 6) {
+          // 21-24 mel bins (the reference's default 23): straight-line, the twelve operand reads issued
+          // before the first multiply-add (same products in the same order as the loop below)
+          float4 w[6], x[6];
+#pragma unroll
+          for (int g4 = 0; g4 < 6; ++g4) {
+            w[g4] = dw[g4 * 16];
+            x[g4] = dx[g4];
+          }
+#pragma unroll
+          for (int g4 = 0; g4 < 6; ++g4) {
+            v += w[g4].x * x[g4].x;
+            v += w[g4].y * x[g4].y;
+            v += w[g4].z * x[g4].z;
+            v += w[g4].w * x[g4].w;
+          }
+        } else {
 #pragma unroll 2
-        for (int g4 = 0; g4 < p.dd_groups; ++g4) {
-          const float4 w = dw[g4 * 16], x = dx[g4];
-          v += w.x * x.x;
-          v += w.y * x.y;
-          v += w.z * x.z;
-          v += w.w * x.w;
+          for (int g4 = 0; g4 < p.dd_groups; ++g4) {
+            const float4 w = dw[g4 * 16], x = dx[g4];
+            v += w.x * x.x;
+            v += w.y * x.y;
+            v += w.z * x.z;
+            v += w.w * x.w;
+          }
         }
         v *= t_lifter[l];
         if (l == 0 && p.use_energy) v = log_energy;
