@@ -659,8 +659,10 @@ def test_result_blocks_and_pooled_buffers(gpu):
     del rows
     gc.collect()
     assert block_cls._held == held0
-    b = _backend.result_array((300000, 4), np.float32)          # the block came back to the pool
-    assert b.ctypes.data == address
+    pooled = {blk[1] for blk in _backend.STAGING._free}
+    assert address in pooled                                    # the block came back to the pool
+    b = _backend.result_array((300000, 4), np.float32)          # ... and a pooled block serves the next batch
+    assert isinstance(b.base, block_cls) and b.ctypes.data in pooled
     small = _backend.result_array((10, 4), np.float32)          # not worth a pinned buffer
     assert not isinstance(small.base, block_cls)
     fresh, block_cls._FRESH = block_cls._FRESH, 1 << 20
