@@ -676,8 +676,10 @@ def test_result_blocks_and_pooled_buffers(gpu):
     d = _backend.DeviceBuffer(3 << 20)
     ptr = d.ptr
     d.free()
+    parked = {blk[1] for blocks in _backend.DEVICE_POOL._free.values() for blk in blocks}
+    assert ptr in parked
     e = _backend.DeviceBuffer((3 << 20) - 4096)
-    assert e.ptr == ptr and e.nbytes == (3 << 20) - 4096
+    assert e.ptr in parked and e.nbytes == (3 << 20) - 4096 and e._capacity >= e.nbytes
     e.free()
     rows = [np.full(50000 + 7 * k, k, dtype=np.int16) for k in range(120)]   # 12 MB: the threaded path
     buf = _backend.upload_rows(rows, np.int16)
