@@ -667,8 +667,11 @@ def test_result_blocks_and_pooled_buffers(gpu):
     assert not isinstance(small.base, block_cls)
     fresh, block_cls._FRESH = block_cls._FRESH, 1 << 20
     try:
-        c = _backend.result_array((400000, 4), np.float32)      # no pooled block fits, none may be made
+        # larger than every pooled block, and none may be made: plain memory
+        rows_c = (max([blk[0] for blk in _backend.STAGING._free] + [0]) >> 4) + 400000
+        c = _backend.result_array((rows_c, 4), np.float32)
         assert not isinstance(c.base, block_cls)
+        del c
     finally:
         block_cls._FRESH = fresh
     del b
