@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Kernel statistics over the TIMED launches only, from a rocprofv3 --kernel-trace CSV of
-`bench.py --steps K --warmup W --no-extra`: bench.py launches every timed kernel 10 (settle) + W (warm-up) +
+`bench.py --steps K --warmup W --no-extra`: bench.py launches every timed kernel S (settle, default 50) + W (warm-up) +
 K (timed) times in that order, so the last K dispatches of a kernel are the ones between the barriers.
 
     python tools/timed_launch_stats.py <..._kernel_trace.csv> K > profiles/rNN_bench_timed_launches_stats.csv"""
