@@ -189,6 +189,89 @@ __device__ __forceinline__ void fft16(float2 (&v)[16]) {
   for (int m = 0; m < 4; ++m) dft4(t[m][0], t[m][1], t[m][2], t[m][3], v[m], v[4 + m], v[8 + m], v[12 + m]);
 }
 
+
+// ---- the 512- / 256-point kernels' butterflies with their twiddles folded in (Linzer-Feig form, round 4) ----
+// A twiddle W = c (1 + i t) costs two fused multiply-adds for u = b (1 + i t) and its real scale c rides
+// on the fused multiply-adds of the butterfly that consumes it: a0 +- c u.  Against complex multiply +
+// add / subtract that is 6 instead of 8 vector instructions per twiddled radix-2 pair.
+__device__ __forceinline__ float2 lf_u(float2 b, float t) {  // b (1 + i t)
+  return make_float2(__builtin_fmaf(-t, b.y, b.x), __builtin_fmaf(t, b.x, b.y));
+}
+__device__ __forceinline__ float2 lf_add(float2 a, float c, float2 u) {  // a + c u
+  return make_float2(__builtin_fmaf(c, u.x, a.x), __builtin_fmaf(c, u.y, a.y));
+}
+// second radix-4 layer of the 16-point FFT with the twiddles W16^(q m) folded into the butterflies
+__device__ __forceinline__ void fft16_layer2_lf(float2 (&t)[4][4], float2 (&v)[16]) {
+  constexpr float c1 = 0.92387953251128675613f;  // cos(pi/8)
+  constexpr float t1 = 0.41421356237309504880f;  // tan(pi/8)
+  constexpr float r2 = 0.70710678118654752440f;  // sqrt(1/2)
+  dft4(t[0][0], t[0][1], t[0][2], t[0][3], v[0], v[4], v[8], v[12]);
+  {  // row 1: W^1 = c1 (1 - i t1), W^2 = r2 (1 - i), W^3 = -i c1 (1 + i t1)
+    const float2 b0 = t[1][0], b1 = t[1][1], b2 = t[1][2], b3 = t[1][3];
+    const float2 u2 = make_float2(b2.x + b2.y, b2.y - b2.x);
+    const float2 s0 = lf_add(b0, r2, u2), s1 = lf_add(b0, -r2, u2);
+    const float2 u1 = lf_u(b1, -t1), u3 = lf_u(b3, t1);
+    const float2 e = make_float2(u1.x + u3.y, u1.y - u3.x);  // (a1 + a3) / c1
+    const float2 f = make_float2(u1.x - u3.y, u1.y + u3.x);  // (a1 - a3) / c1
+    v[1] = lf_add(s0, c1, e);
+    v[9] = lf_add(s0, -c1, e);
+    v[5] = make_float2(__builtin_fmaf(c1, f.y, s1.x), __builtin_fmaf(-c1, f.x, s1.y));
+    v[13] = make_float2(__builtin_fmaf(-c1, f.y, s1.x), __builtin_fmaf(c1, f.x, s1.y));
+  }
+  {  // row 2: W^2 = r2 (1 - i), W^4 = -i, W^6 = -r2 (1 + i)
+    const float2 b0 = t[2][0], b1 = t[2][1], b2 = t[2][2], b3 = t[2][3];
+    const float2 s0 = make_float2(b0.x + b2.y, b0.y - b2.x), s1 = make_float2(b0.x - b2.y, b0.y + b2.x);
+    const float2 u1 = make_float2(b1.x + b1.y, b1.y - b1.x), u3 = make_float2(b3.x - b3.y, b3.y + b3.x);
+    const float2 e = csub(u1, u3), f = cadd(u1, u3);
+    v[2] = lf_add(s0, r2, e);
+    v[10] = lf_add(s0, -r2, e);
+    v[6] = make_float2(__builtin_fmaf(r2, f.y, s1.x), __builtin_fmaf(-r2, f.x, s1.y));
+    v[14] = make_float2(__builtin_fmaf(-r2, f.y, s1.x), __builtin_fmaf(r2, f.x, s1.y));
+  }
+  {  // row 3: W^3 = -i c1 (1 + i t1), W^6 = -r2 (1 + i), W^9 = -c1 (1 - i t1)
+    const float2 b0 = t[3][0], b1 = t[3][1], b2 = t[3][2], b3 = t[3][3];
+    const float2 u2 = make_float2(b2.x - b2.y, b2.y + b2.x);
+    const float2 s0 = lf_add(b0, -r2, u2), s1 = lf_add(b0, r2, u2);
+    const float2 u1 = lf_u(b1, t1), u3 = lf_u(b3, -t1);
+    const float2 e = make_float2(u1.y - u3.x, u1.x + u3.y);  // (a1 + a3) / c1 = (e.x, -e.y)
+    const float2 f = make_float2(u1.y + u3.x, u3.y - u1.x);  // (a1 - a3) / c1
+    v[3] = make_float2(__builtin_fmaf(c1, e.x, s0.x), __builtin_fmaf(-c1, e.y, s0.y));
+    v[11] = make_float2(__builtin_fmaf(-c1, e.x, s0.x), __builtin_fmaf(c1, e.y, s0.y));
+    v[7] = make_float2(__builtin_fmaf(c1, f.y, s1.x), __builtin_fmaf(-c1, f.x, s1.y));
+    v[15] = make_float2(__builtin_fmaf(-c1, f.y, s1.x), __builtin_fmaf(c1, f.x, s1.y));
+  }
+}
+__device__ __forceinline__ void fft16_lf(float2 (&v)[16]) {
+  float2 t[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dft4(v[q], v[q + 4], v[q + 8], v[q + 12], t[0][q], t[1][q], t[2][q], t[3][q]);
+  fft16_layer2_lf(t, v);
+}
+// 16-point FFT of r[m] * W[m] with the input twiddles W[m] = c[m] (1 + i t[m]) given as (c, t) pairs
+// (W[0] = 1): the first radix-4 layer consumes them in its butterflies.  An exact -i is stored as
+// (2^-40, -2^40): the products are exact powers of two and the absorbed term is the one a true zero
+// cosine would have removed.
+__device__ __forceinline__ void fft16_twin(float2 (&v)[16], const float2 (&ct)[16]) {
+  float2 t[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float2 u1 = lf_u(v[q + 4], ct[q + 4].y), u2 = lf_u(v[q + 8], ct[q + 8].y), u3 = lf_u(v[q + 12], ct[q + 12].y);
+    float2 p0 = v[q];
+    if (q != 0) {
+      const float2 u0 = lf_u(v[q], ct[q].y);
+      p0 = make_float2(ct[q].x * u0.x, ct[q].x * u0.y);
+    }
+    const float2 p1 = make_float2(ct[q + 4].x * u1.x, ct[q + 4].x * u1.y);
+    const float2 s0 = lf_add(p0, ct[q + 8].x, u2), s1 = lf_add(p0, -ct[q + 8].x, u2);
+    const float2 s2 = lf_add(p1, ct[q + 12].x, u3), d13 = lf_add(p1, -ct[q + 12].x, u3);
+    t[0][q] = cadd(s0, s2);
+    t[2][q] = csub(s0, s2);
+    t[1][q] = make_float2(s1.x + d13.y, s1.y - d13.x);
+    t[3][q] = make_float2(s1.x - d13.y, s1.y + d13.x);
+  }
+  fft16_layer2_lf(t, v);
+}
+
 }  // namespace
 
 }  // namespace snf

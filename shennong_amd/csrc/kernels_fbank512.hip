@@ -357,21 +357,26 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- B: pass 1 (FFT over j), inter-pass twiddle, transpose -------------------------------------
-    float4 tw4[8];
-    read_quads<8>(t_tw16 + l * 18, tw4);  // W256^(l k2), lands while the butterflies run
-    fft16(z);
-    lds_wait();
-#pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2)
-      z[k2] = cmul(z[k2], (k2 & 1) ? make_float2(tw4[k2 >> 1].z, tw4[k2 >> 1].w)
-                                   : make_float2(tw4[k2 >> 1].x, tw4[k2 >> 1].y));
+    // (round 4: the butterflies carry their twiddles, device_fft.h; the inter-pass twiddle W256^(n l) sits
+    // behind the transpose, in the first butterflies of pass 2 - the table is symmetric in n and l)
+    fft16_lf(z);
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) tile[k2 * kTileRow + l] = z[k2];
     wave_lds_sync();
+    float2 ct[16];
+    {
+      float4 tw4[8];
+      read_quads<8>(t_tw16 + l * 18, tw4);  // (cos, tan) pairs, read while the tile lands
+#pragma unroll
+      for (int m = 0; m < 16; m += 2) {
+        ct[m] = make_float2(tw4[m >> 1].x, tw4[m >> 1].y);
+        ct[m + 1] = make_float2(tw4[m >> 1].z, tw4[m >> 1].w);
+      }
+    }
     read16_b64(tile + l * kTileRow, z);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- C: pass 2 (FFT over n1): z[k1] = Z[l + 16 k1] ---------------------------------------------
-    fft16(z);
+    // ---- C: pass 2 (twiddle + FFT over n1): z[k1] = Z[l + 16 k1] -----------------------------------
+    fft16_twin(z, ct);
     __builtin_amdgcn_sched_barrier(0);
     wave_lds_sync();
 
@@ -399,9 +404,10 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
                                 : make_float2(w512q[k1 >> 1].x, w512q[k1 >> 1].y);
       const float c_re = zk.x + zp.x, c_im = zk.y - zp.y;
       const float d_re = zk.y + zp.y, d_im = zp.x - zk.x;
-      const float t_re = d_re * w.x - d_im * w.y, t_im = d_re * w.y + d_im * w.x;
-      const float a_re = c_re + t_re, a_im = c_im + t_im;
-      const float b_re = c_re - t_re, b_im = t_im - c_im;
+      // w = (cos, tan): d w = cos * u, u = d (1 + i tan); the scale rides on the butterfly
+      const float u_re = __builtin_fmaf(-w.y, d_im, d_re), u_im = __builtin_fmaf(w.y, d_re, d_im);
+      const float a_re = __builtin_fmaf(w.x, u_re, c_re), a_im = __builtin_fmaf(w.x, u_im, c_im);
+      const float b_re = __builtin_fmaf(-w.x, u_re, c_re), b_im = __builtin_fmaf(w.x, u_im, -c_im);
       pk[k1] = a_re * a_re + a_im * a_im;
       pm[k1] = b_re * b_re + b_im * b_im;
     }
@@ -883,20 +889,23 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- B / C: the 256-point complex transform (identical to fbank512_kernel) ------------------------
-    float4 tw4[8];
-    read_quads<8>(t_tw16 + l * 18, tw4);
-    fft16(z);
-    lds_wait();
-#pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2)
-      z[k2] = cmul(z[k2], (k2 & 1) ? make_float2(tw4[k2 >> 1].z, tw4[k2 >> 1].w)
-                                   : make_float2(tw4[k2 >> 1].x, tw4[k2 >> 1].y));
+    fft16_lf(z);
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) tile[k2 * kTileRow + l] = z[k2];
     wave_lds_sync();
+    float2 ct[16];
+    {
+      float4 tw4[8];
+      read_quads<8>(t_tw16 + l * 18, tw4);  // (cos, tan) pairs
+#pragma unroll
+      for (int m = 0; m < 16; m += 2) {
+        ct[m] = make_float2(tw4[m >> 1].x, tw4[m >> 1].y);
+        ct[m + 1] = make_float2(tw4[m >> 1].z, tw4[m >> 1].w);
+      }
+    }
     read16_b64(tile + l * kTileRow, z);
     __builtin_amdgcn_sched_barrier(0);
-    fft16(z);
+    fft16_twin(z, ct);
     __builtin_amdgcn_sched_barrier(0);
     wave_lds_sync();
 
@@ -1238,20 +1247,30 @@ int fast512_build(const MelParams& mp, const std::vector<float>& window, const M
       blob->push_back(j < 16 && 2 * n < mp.win_len ? window[2 * n] : 0.0f);
       blob->push_back(j < 16 && 2 * n + 1 < mp.win_len ? window[2 * n + 1] : 0.0f);
     }
+  // Twiddles as (cos, tan) pairs: W = cos (1 + i tan) (device_fft.h, Linzer-Feig butterflies).  An exact
+  // -i (zero cosine) is (2^-40, -2^40): every product with it is an exact power-of-two scaling.
+  auto push_cos_tan = [&](int num, int den) {
+    const int r = ((num % den) + den) % den;  // exp(-2 pi i r / den)
+    if (4 * r == den) {                        // -i
+      blob->push_back(9.094947017729282e-13f);
+      blob->push_back(-1099511627776.0f);
+      return;
+    }
+    if (4 * r == 3 * den) {                    // +i
+      blob->push_back(9.094947017729282e-13f);
+      blob->push_back(1099511627776.0f);
+      return;
+    }
+    const double a = -kTwoPi * r / den;
+    blob->push_back(static_cast<float>(std::cos(a)));
+    blob->push_back(static_cast<float>(std::tan(a)));
+  };
   // inter-pass twiddles, lane-major: row n1 = exp(-2 pi i n1 k2 / 256), k2 < 16
   for (int n1 = 0; n1 < 16; ++n1)
-    for (int k2 = 0; k2 < 18; ++k2) {
-      const double a = -kTwoPi * (n1 * (k2 < 16 ? k2 : 0)) / 256.0;
-      blob->push_back(static_cast<float>(std::cos(a)));
-      blob->push_back(static_cast<float>(std::sin(a)));
-    }
-  // unpack twiddles, lane-major: row l = exp(-2 pi i (l + 16 k1) / 512), k1 < 8
+    for (int k2 = 0; k2 < 18; ++k2) push_cos_tan(n1 * (k2 < 16 ? k2 : 0), 256);
+  // unpack twiddles, lane-major: row l = exp(-2 pi i (l + 16 k1) / 512), k1 < 8 (angles in (-pi/2, 0])
   for (int l = 0; l < 16; ++l)
-    for (int k1 = 0; k1 < 10; ++k1) {
-      const double a = -kTwoPi * (l + 16 * (k1 < 8 ? k1 : 0)) / 512.0;
-      blob->push_back(static_cast<float>(std::cos(a)));
-      blob->push_back(static_cast<float>(std::sin(a)));
-    }
+    for (int k1 = 0; k1 < 10; ++k1) push_cos_tan(l + 16 * (k1 < 8 ? k1 : 0), 512);
   // ---- mel filterbank as MFMA blocks --------------------------------------------------------------
   // Group g = mel bins 4 g .. 4 g + 3 spans the FFT bins [glo, ghi); it is cut into parts[g] runs of at
   // most 4 mm_quads bins, one MFMA block each.  More parts for the widest groups shorten the chain;

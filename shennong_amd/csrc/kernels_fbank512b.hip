@@ -46,11 +46,16 @@ constexpr int kHeaderFloats = 16;   // (= kFastHeaderFloats of kernels_fbank512.
 constexpr int kTileRow = 17;        // complex per row of the exchange tile (16 + 1 pad: conflict-free)
 constexpr int kTileBytes = 16 * kTileRow * 8;  // wave-private LDS per frame (2176 B)
 
+
 }  // namespace
 
 // ENERGY: 0 = no log-energy column, 1 = raw (before pre-emphasis / window), 2 = after the window.
 // BST: the rows of a set are whole groups of 4 values without an energy column (fbank with num_bins % 4
 // == 0, MFCC): one unconditional buffer store per set (see above); otherwise the stores of fbank512_kernel.
+// Round 4: the butterflies carry their twiddles (device_fft.h, Linzer-Feig form): the second radix-4 layer of
+// both register passes, the inter-pass twiddle (now behind the transpose, in the first butterflies of pass
+// 2) and the twiddle of the real-FFT unpack; the tables hold (cos, tan) pairs.  -52 of 722 vector
+// instructions per frame set, -1.9 % time.  fbank512_kernel uses the same arithmetic.
 template <int NJ, int KIND, int ENERGY, bool BST>
 __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512Params p, const BatchArgs b,
                                                                   float* __restrict__ out,
@@ -193,23 +198,26 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- B: pass 1 (FFT over j), inter-pass twiddle W256^(l k2), 16 x 16 transpose -----------------
-    fft16(z);
-#pragma unroll
-    for (int kk = 0; kk < 16; kk += 4) {
-      const float4 ta = *reinterpret_cast<const float4*>(__builtin_assume_aligned(t_tw16 + l * 18 + kk, 16));
-      const float4 tb = *reinterpret_cast<const float4*>(__builtin_assume_aligned(t_tw16 + l * 18 + kk + 2, 16));
-      if (kk != 0) z[kk] = cmul(z[kk], make_float2(ta.x, ta.y));
-      z[kk + 1] = cmul(z[kk + 1], make_float2(ta.z, ta.w));
-      z[kk + 2] = cmul(z[kk + 2], make_float2(tb.x, tb.y));
-      z[kk + 3] = cmul(z[kk + 3], make_float2(tb.z, tb.w));
-    }
+    fft16_lf(z);
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) tile[k2 * kTileRow + l] = z[k2];
     wave_lds_sync();
+    // the inter-pass twiddle W256^(n l) of element n of this lane's row (the table is symmetric in n and
+    // l) as (cos, tan) pairs: read while the tile lands
+    float2 ct[16];
+    {
+      float4 q8[8];
+      read_quads<8>(t_tw16 + l * 18, q8);
+#pragma unroll
+      for (int m = 0; m < 16; m += 2) {
+        ct[m] = make_float2(q8[m >> 1].x, q8[m >> 1].y);
+        ct[m + 1] = make_float2(q8[m >> 1].z, q8[m >> 1].w);
+      }
+    }
     read16_b64(tile + l * kTileRow, z);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- C: pass 2 (FFT over n1): z[k1] = Z[l + 16 k1] ---------------------------------------------
-    fft16(z);
+    // ---- C: pass 2 (twiddle + FFT over n1): z[k1] = Z[l + 16 k1] -----------------------------------
+    fft16_twin(z, ct);
     __builtin_amdgcn_sched_barrier(0);
     wave_lds_sync();
 
@@ -232,9 +240,10 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
                                   : make_float2(w512q[k1 >> 1].x, w512q[k1 >> 1].y);
         const float c_re = zk.x + zp.x, c_im = zk.y - zp.y;
         const float d_re = zk.y + zp.y, d_im = zp.x - zk.x;
-        const float t_re = d_re * w.x - d_im * w.y, t_im = d_re * w.y + d_im * w.x;
-        const float a_re = c_re + t_re, a_im = c_im + t_im;
-        const float b_re = c_re - t_re, b_im = t_im - c_im;
+        // w = (cos, tan): d w = cos * u, u = d (1 + i tan); the scale rides on the butterfly
+        const float u_re = __builtin_fmaf(-w.y, d_im, d_re), u_im = __builtin_fmaf(w.y, d_re, d_im);
+        const float a_re = __builtin_fmaf(w.x, u_re, c_re), a_im = __builtin_fmaf(w.x, u_im, c_im);
+        const float b_re = __builtin_fmaf(-w.x, u_re, c_re), b_im = __builtin_fmaf(w.x, u_im, -c_im);
         pk[k1] = a_re * a_re + a_im * a_im;
         pm[k1] = b_re * b_re + b_im * b_im;
       }
