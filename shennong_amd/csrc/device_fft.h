@@ -61,6 +61,26 @@ __device__ __forceinline__ void read16_b64(const void* base, float2 (&d)[16]) {
       : "v"(lds_addr(base))
       : "memory");
 }
+// the 8 float4 of a twiddle row at `tw` (16-byte aligned) and the 16 float2 of a tile row at `base` in one
+// batch: the compiler turns plain 16-byte loads whose first half is unused into ds_read2_b64 (half rate)
+__device__ __forceinline__ void read_tw8_row16(const void* tw, const void* base, float4 (&q)[8], float2 (&d)[16]) {
+  asm volatile(
+      "ds_read_b128 %0, %24\n ds_read_b128 %1, %24 offset:16\n ds_read_b128 %2, %24 offset:32\n"
+      "ds_read_b128 %3, %24 offset:48\n ds_read_b128 %4, %24 offset:64\n ds_read_b128 %5, %24 offset:80\n"
+      "ds_read_b128 %6, %24 offset:96\n ds_read_b128 %7, %24 offset:112\n"
+      "ds_read_b64 %8, %25\n ds_read_b64 %9, %25 offset:8\n ds_read_b64 %10, %25 offset:16\n"
+      "ds_read_b64 %11, %25 offset:24\n ds_read_b64 %12, %25 offset:32\n ds_read_b64 %13, %25 offset:40\n"
+      "ds_read_b64 %14, %25 offset:48\n ds_read_b64 %15, %25 offset:56\n ds_read_b64 %16, %25 offset:64\n"
+      "ds_read_b64 %17, %25 offset:72\n ds_read_b64 %18, %25 offset:80\n ds_read_b64 %19, %25 offset:88\n"
+      "ds_read_b64 %20, %25 offset:96\n ds_read_b64 %21, %25 offset:104\n ds_read_b64 %22, %25 offset:112\n"
+      "ds_read_b64 %23, %25 offset:120\n s_waitcnt lgkmcnt(0)"
+      : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7]),
+        "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]),
+        "=&v"(d[7]), "=&v"(d[8]), "=&v"(d[9]), "=&v"(d[10]), "=&v"(d[11]), "=&v"(d[12]), "=&v"(d[13]),
+        "=&v"(d[14]), "=&v"(d[15])
+      : "v"(lds_addr(tw)), "v"(lds_addr(base))
+      : "memory");
+}
 // dst[i] = the float2 at byte offset 128 (7 - i) from `base`, i < 8 (partner rows, reversed)
 __device__ __forceinline__ void read8_b64_rev128(const void* base, float2 (&d)[8]) {
   asm volatile(

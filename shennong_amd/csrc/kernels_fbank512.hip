@@ -366,14 +366,13 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     float2 ct[16];
     {
       float4 tw4[8];
-      read_quads<8>(t_tw16 + l * 18, tw4);  // (cos, tan) pairs, read while the tile lands
+      read_tw8_row16(t_tw16 + l * 18, tile + l * kTileRow, tw4, z);  // (cos, tan) pairs + the transposed row
 #pragma unroll
       for (int m = 0; m < 16; m += 2) {
         ct[m] = make_float2(tw4[m >> 1].x, tw4[m >> 1].y);
         ct[m + 1] = make_float2(tw4[m >> 1].z, tw4[m >> 1].w);
       }
     }
-    read16_b64(tile + l * kTileRow, z);
     __builtin_amdgcn_sched_barrier(0);
     // ---- C: pass 2 (twiddle + FFT over n1): z[k1] = Z[l + 16 k1] -----------------------------------
     fft16_twin(z, ct);
@@ -896,14 +895,13 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
     float2 ct[16];
     {
       float4 tw4[8];
-      read_quads<8>(t_tw16 + l * 18, tw4);  // (cos, tan) pairs
+      read_tw8_row16(t_tw16 + l * 18, tile + l * kTileRow, tw4, z);  // (cos, tan) pairs + the transposed row
 #pragma unroll
       for (int m = 0; m < 16; m += 2) {
         ct[m] = make_float2(tw4[m >> 1].x, tw4[m >> 1].y);
         ct[m + 1] = make_float2(tw4[m >> 1].z, tw4[m >> 1].w);
       }
     }
-    read16_b64(tile + l * kTileRow, z);
     __builtin_amdgcn_sched_barrier(0);
     fft16_twin(z, ct);
     __builtin_amdgcn_sched_barrier(0);

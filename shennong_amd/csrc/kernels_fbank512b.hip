@@ -123,6 +123,10 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
     for (int j = 0; j < NJ; ++j)
       raw[j] = *reinterpret_cast<const int_a2*>((NJ == 13 && j < NJ - 1) || in_window(j) ? wl + 32 * j : wp);
   };
+  // the unpack twiddles stay in registers for the whole kernel: the kernel uses 103 of the 128 registers
+  // 4 waves per SIMD leave it, and LDS bandwidth is what it is short of (4 ds_read_b128 per set less)
+  float4 w512q[4];
+  read_quads<4>(t_tw512 + l * 10, w512q);
   int64_t start_next = start_of(set + set_stride);
   request(start_of(set));
   if (BST) {
@@ -206,15 +210,14 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
     // l) as (cos, tan) pairs: read while the tile lands
     float2 ct[16];
     {
-      float4 q8[8];
-      read_quads<8>(t_tw16 + l * 18, q8);
+      float4 tw4[8];
+      read_tw8_row16(t_tw16 + l * 18, tile + l * kTileRow, tw4, z);  // (cos, tan) pairs + the transposed row
 #pragma unroll
       for (int m = 0; m < 16; m += 2) {
-        ct[m] = make_float2(q8[m >> 1].x, q8[m >> 1].y);
-        ct[m + 1] = make_float2(q8[m >> 1].z, q8[m >> 1].w);
+        ct[m] = make_float2(tw4[m >> 1].x, tw4[m >> 1].y);
+        ct[m + 1] = make_float2(tw4[m >> 1].z, tw4[m >> 1].w);
       }
     }
-    read16_b64(tile + l * kTileRow, z);
     __builtin_amdgcn_sched_barrier(0);
     // ---- C: pass 2 (twiddle + FFT over n1): z[k1] = Z[l + 16 k1] -----------------------------------
     fft16_twin(z, ct);
@@ -230,8 +233,10 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
     {
       float2 zpart[8];
       read8_b64_rev128(tile + (16 - l), zpart);  // zpart[k1] = Z[256 - l - 16 k1]
-      float4 w512q[4];
-      read_quads<4>(t_tw512 + l * 10, w512q);  // W512^(l + 16 k1)
+      // (W512^(l + 16 k1) as (cos, tan) pairs: 16 registers read once before the loop, see below)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        asm volatile("" : "+v"(w512q[i].x), "+v"(w512q[i].y), "+v"(w512q[i].z), "+v"(w512q[i].w));
 #pragma unroll
       for (int k1 = 0; k1 < 8; ++k1) {
         const float2 zk = z[k1];
@@ -258,12 +263,19 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
     wave_lds_sync();
     // ---- E: power tile ------------------------------------------------------------------------------
     {
-      float* __restrict__ pmirror = ptile + (144 - l);
-#pragma unroll
-      for (int k1 = 0; k1 < 8; ++k1) {
-        ptile[l + 16 * k1] = pk[k1];
-        pmirror[16 * (7 - k1)] = pm[k1];  // index 256 - l - 16 k1
-      }
+      // two rows per instruction (ds_write2_b32: 3 LDS-path clocks per dword against 4 for ds_write_b32)
+      const unsigned pk_addr = lds_addr(ptile + l), pm_addr = lds_addr(ptile + (144 - l));
+#define SNF_W2(ADDR_, A_, B_, O0_, O1_) \
+  asm volatile("ds_write2_b32 %0, %1, %2 offset0:" #O0_ " offset1:" #O1_ : : "v"(ADDR_), "v"(A_), "v"(B_) : "memory")
+      SNF_W2(pk_addr, pk[0], pk[1], 0, 16);
+      SNF_W2(pk_addr, pk[2], pk[3], 32, 48);
+      SNF_W2(pk_addr, pk[4], pk[5], 64, 80);
+      SNF_W2(pk_addr, pk[6], pk[7], 96, 112);
+      SNF_W2(pm_addr, pm[7], pm[6], 0, 16);  // index 256 - l - 16 k1 = (144 - l) + 16 (7 - k1)
+      SNF_W2(pm_addr, pm[5], pm[4], 32, 48);
+      SNF_W2(pm_addr, pm[3], pm[2], 64, 80);
+      SNF_W2(pm_addr, pm[1], pm[0], 96, 112);
+#undef SNF_W2
       if (l == 0) ptile[128] = p128;
     }
     wave_lds_sync();
