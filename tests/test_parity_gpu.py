@@ -1142,3 +1142,32 @@ def test_mfcc_with_deltas_fused_form(gpu, audio, monkeypatch):
             proc44.process_with_deltas(Audio(np.zeros(44100, np.int16), 44100))
     finally:
         _backend.clear_plans()
+
+@pytest.mark.parametrize('opts', [dict(), dict(use_energy=False), dict(htk_compat=True, use_energy=False),
+                                  dict(num_bins=40, num_ceps=13), dict(frame_length=0.02, num_ceps=16)])
+def test_mfcc_dct_mfma(gpu, audio, wave, monkeypatch, opts):
+    """SNF_DCT_MFMA=1: the DCT-II + lifter of MFCC as a second v_mfma_f32_4x4x1 chain behind the mel chain
+    (the north_star's "DCT-II cepstral lifter as MFMA tiles"; the vector-pipe form ships because it is
+    faster, bench.py extra.mfcc13_dct_mfma) against the oracle on test.wav and on 1 000 synthetic
+    utterances, through a private plan.  Reference: shennong/processor/mfcc.py:84-86"""
+    monkeypatch.setenv('SNF_DCT_MFMA', '1')
+    _backend.clear_plans()
+    try:
+        proc = MfccProcessor(dither=0, **opts)
+        a = audio
+        got = proc.process(a)
+        assert_close(got.data, _oracle(proc, a.data), what='mfcc dct mfma %s' % opts, family='mfcc')
+        # (the chain form lives on fbank512_kernel only: fbank512b_kernel refuses plans with dct_mfma set)
+        plan = _backend.get_plan(proc._build_options())
+        assert plan.kernel_name(1) == 'fbank512_kernel', plan.kernel_name(1)
+        sr = 16000
+        waves = synth.ragged_utterances(4242, 1000, min_s=0.2, max_s=0.6, sample_rate=sr)
+        batch = proc._process_batch([Audio(w, sr, validate=False) for w in waves])
+        for i in range(0, 1000, 37):
+            assert_close(batch[i].data, _oracle(proc, waves[i]), what='mfcc dct mfma batch', family='mfcc')
+    finally:
+        _backend.clear_plans()
+    monkeypatch.delenv('SNF_DCT_MFMA')
+    shipped = MfccProcessor(dither=0, **opts).process(a)
+    assert_close(got.data, shipped.data, what='mfcc dct mfma vs vector form', family='mfcc')
+    _backend.clear_plans()

@@ -12,7 +12,7 @@ try:
     print('value %.4g frames/s  ms/step %.3f  kernel_ms %.3f  frac %.4f' % (
         d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac']))
     for k, v in d['extra'].items():
-        print(' ', k, v if not isinstance(v, dict) else {a: round(b, 4) for a, b in v.items()})
+        print(' ', k, v if not isinstance(v, dict) else {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items()})
 except Exception as e:
     print('bench parse failed', e)
     print(open('gpurun_out/bench.log').read()[-2000:])
