@@ -286,6 +286,7 @@ int build_mel_plan(snf_plan* plan) {
     q.log_energy_floor = q.has_floor ? std::log(static_cast<double>(o.energy_floor)) : 0.0;
     q.rasta = o.rasta;
     q.compress_factor = o.compress_factor;
+    q.exact_pow = getenv("SNF_PLP_EXACT_POW") != nullptr ? 1 : 0;
     q.cepstral_scale = o.cepstral_scale;
     std::vector<float> idft, lifter;
     make_idft_bases(o.lpc_order + 1, o.mel.num_bins + 2, &idft);

@@ -281,12 +281,135 @@ __global__ __launch_bounds__(64) void plp_tail_small_kernel(const PlpParams p, c
   }
 }
 
+// x^e for the PLP compression exponent e = float(1/3) (the reference's compress_factor, plp.py:588) and
+// x >= 0.  Hardware log2 / exp2 give x^(1/3) to ~1e-6; one Newton step on y^3 = x takes it to float
+// round-off; a second one with the residual x - y^3 formed exactly (the roundings of y*y and of (y*y)*y
+// recovered with fused multiply-adds) leaves half an ulp; the distance of float(1/3) from 1/3 is the factor
+// 1 + (e - 1/3) ln x.  ~28 vector instructions against ~120 for the correctly-rounded powf, within 1-2 ulp
+// of it.
+__device__ __forceinline__ float pow_third(float x, float e) {
+  const float l2 = __builtin_amdgcn_logf(x);                    // log2 x
+  const float y0 = __builtin_amdgcn_exp2f(l2 * 0.33333334f);
+  const float r = x * __builtin_amdgcn_rcpf(y0 * y0 * y0);      // x / y0^3 = 1 + O(1e-6)
+  const float y1 = y0 * __builtin_fmaf(r, 0.33333334f, 0.66666669f);   // y0 (2 + r) / 3
+  const float sq = y1 * y1, sq_err = __builtin_fmaf(y1, y1, -sq);
+  const float cu = sq * y1, cu_err = __builtin_fmaf(sq, y1, -cu) + sq_err * y1;  // y1^3 = cu + cu_err
+  const float res = (x - cu) - cu_err;
+  float y = __builtin_fmaf(res, __builtin_amdgcn_rcpf(3.0f * sq), y1);
+  const float d = static_cast<float>(static_cast<double>(e) - 1.0 / 3.0);
+  y = __builtin_fmaf(y * d, l2 * 0.69314718f, y);
+  return x > 0.0f ? y : 0.0f;
+}
+
+// The same arithmetic in the same order once more, for ONE exact shape (the reference's defaults: 23 mel
+// bins, LPC order 12, 13 cepstra; round 4).  plp_tail_small_kernel<32, 16> predicates every loop of the
+// 32 x 16 bound on the run-time sizes: 1.8 x the multiply-adds of the 25 x 13 IDFT, 1.8 x those of the
+// Durbin and cepstrum recursions, ~1 200 scalar branches and ~580 single-dword scalar loads with their waits
+// (tools/count_isa.py).  Here every bound is a template argument, the IDFT bases, the equal-loudness curve
+// and the lifter are staged in LDS once per 256-frame workgroup and read as 16-byte broadcasts, and the mel
+// rows arrive through the same coalesced LDS staging.
+template <int NB, int ORD, int NC>
+__global__ __launch_bounds__(256) void plp_tail_exact_kernel(const PlpParams p, const BatchArgs b,
+                                                             const float* __restrict__ mel,
+                                                             const double* __restrict__ energy,
+                                                             float* __restrict__ out) {
+  constexpr int kRowPad = NB + 1;                      // (odd row pitch: conflict-free per-thread rows)
+  constexpr int kBasis = (ORD + 1) * (NB + 2);
+  constexpr int kBasisPad = (kBasis + 3) & ~3;
+  __shared__ float rows[256 * kRowPad];
+  __shared__ __attribute__((aligned(16))) float basis[kBasisPad];
+  __shared__ float lift[NC];
+  const int64_t g0 = static_cast<int64_t>(blockIdx.x) * 256;
+  const int64_t limit = b.total_frames * NB;
+  for (int i = threadIdx.x; i < 256 * NB; i += 256) {
+    const int64_t a = g0 * NB + i;
+    rows[(i / NB) * kRowPad + i % NB] = a < limit ? mel[a] : 1.0f;
+  }
+  for (int i = threadIdx.x; i < kBasisPad; i += 256) basis[i] = i < kBasis ? p.idft[i] : 0.0f;
+  if (threadIdx.x < NC) lift[threadIdx.x] = p.lifter ? p.lifter[threadIdx.x] : 1.0f;
+  __syncthreads();
+  const int64_t g = g0 + threadIdx.x;
+  if (g >= b.total_frames) return;
+  int warp_id = 0;
+  if (b.utt_warp) warp_id = b.utt_warp[find_utt(b.frame_offsets, b.n_utts, g)];
+  const float* __restrict__ eql = p.eql + warp_id * NB;
+  float m[NB + 2];
+  if (p.compress_factor == 0.33333334f && !p.exact_pow) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) m[i + 1] = pow_third(rows[threadIdx.x * kRowPad + i] * eql[i], p.compress_factor);
+  } else {
+#pragma unroll 1
+    for (int i = 0; i < NB; ++i) m[i + 1] = powf(rows[threadIdx.x * kRowPad + i] * eql[i], p.compress_factor);
+  }
+  m[0] = m[1];
+  m[NB + 1] = m[NB];
+  float ac[ORD + 1], lpc[ORD], tmp[ORD], cep[ORD];
+#pragma unroll
+  for (int i = 0; i <= ORD; ++i) {
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NB + 2; ++j) s += basis[i * (NB + 2) + j] * m[j];
+    ac[i] = s;
+  }
+  float E = ac[0];
+#pragma unroll
+  for (int i = 0; i < ORD; ++i) lpc[i] = tmp[i] = cep[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < ORD; ++i) {
+    float ki = ac[i + 1];
+#pragma unroll
+    for (int j = 0; j < i; ++j) ki += lpc[j] * ac[i - j];
+    ki = ki / E;
+    float c = 1 - ki * ki;
+    if (c < 1.0e-5f) c = 1.0e-5f;
+    E *= c;
+    tmp[i] = -ki;
+#pragma unroll
+    for (int j = 0; j < i; ++j) tmp[j] = lpc[j] - ki * lpc[i - j - 1];
+#pragma unroll
+    for (int j = 0; j <= i; ++j) lpc[j] = tmp[j];
+  }
+  const float res_f = static_cast<float>(-log(1.0 / static_cast<double>(E)));
+  const double res = fmax(static_cast<double>(res_f), DBL_EPSILON);
+#pragma unroll
+  for (int i = 0; i < ORD; ++i) {
+    double sum = 0.0;
+#pragma unroll
+    for (int j = 0; j < i; ++j)
+      sum += static_cast<double>(i - j) * static_cast<double>(lpc[j]) * static_cast<double>(cep[i - j - 1]);
+    cep[i] = static_cast<float>(-static_cast<double>(lpc[i]) - sum / static_cast<double>(i + 1));
+  }
+  float* __restrict__ row = out + g * NC;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    float v = c == 0 ? static_cast<float>(res) : cep[c > 0 ? c - 1 : 0];
+    if (p.lifter) v *= lift[c];
+    if (p.cepstral_scale != 1.0f) v *= p.cepstral_scale;
+    if (c == 0 && p.use_energy) {
+      double le = log(fmax(energy[g], DBL_EPSILON));  // (linear frame energy from the mel kernel)
+      if (p.has_floor && le < p.log_energy_floor) le = p.log_energy_floor;
+      v = static_cast<float>(le);
+    }
+    int oc = c;
+    if (p.htk_compat) oc = c == 0 ? NC - 1 : c - 1;
+    row[oc] = v;
+  }
+}
+
 int launch_plp_tail(const PlpParams& p, const BatchArgs& b, const float* mel, const double* energy,
                     float* out, hipStream_t stream) {
   if (b.total_frames <= 0) return SNF_OK;
   if (p.num_bins > kMaxBins || p.lpc_order > kMaxLpc)
     return set_error(SNF_E_RUNTIME, "PLP: num_bins > 126 or lpc_order > 63 not supported");
   const int threads = 64;
+  if (p.num_bins == 23 && p.lpc_order == 12 && p.num_ceps == 13 && !getenv("SNF_PLP_GENERIC_TAIL") &&
+      !getenv("SNF_PLP_SMALL_TAIL")) {
+    hipLaunchKernelGGL((plp_tail_exact_kernel<23, 12, 13>),
+                       dim3(static_cast<unsigned>((b.total_frames + 255) / 256)), dim3(256), 0, stream, p, b, mel,
+                       energy, out);
+    SNF_HIP_CHECK(hipGetLastError());
+    return SNF_OK;
+  }
   if (p.num_bins <= 32 && p.lpc_order <= 16 && !getenv("SNF_PLP_GENERIC_TAIL")) {
     hipLaunchKernelGGL((plp_tail_small_kernel<32, 16>),
                        dim3(static_cast<unsigned>((b.total_frames + threads - 1) / threads)),

@@ -161,6 +161,7 @@ __device__ __forceinline__ uint64_t wave_noise_id(const int16_t* __restrict__ wa
 
 struct PlpParams {
   int num_bins, lpc_order, num_ceps, use_energy, htk_compat, has_floor, rasta;
+  int exact_pow;  // SNF_PLP_EXACT_POW=1: the correctly-rounded powf in plp_tail_exact_kernel (A/B runs)
   float compress_factor, cepstral_scale;
   double log_energy_floor;
   const float* eql;     // [n_warps][num_bins]
