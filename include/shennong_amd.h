@@ -332,6 +332,11 @@ int snf_count_nonfinite_device(int device_id, const float* d_data, uint64_t n, u
 /* ---- device memory + timing (so hosts without torch can keep data resident in HBM) ---------- */
 int snf_malloc(void** dptr, uint64_t bytes);
 int snf_free(void* dptr);
+/* A host that pools freed device buffers (shennong_amd/_backend.py DEVICE_POOL) registers a callback that
+ * releases them: an allocation of the library's own scratch that fails with out-of-memory calls it and tries
+ * once more (NULL removes the hook).  No counterpart in the reference (CPU only). */
+typedef void (*snf_oom_hook)(void);
+int snf_set_oom_hook(snf_oom_hook hook);
 int snf_memcpy_h2d(void* dst, const void* src, uint64_t bytes);
 int snf_memcpy_d2h(void* dst, const void* src, uint64_t bytes);
 int snf_memset(void* dst, int value, uint64_t bytes);  /* complete when it returns (the plans use their own streams) */

@@ -37,7 +37,20 @@ EXPORTS = [
     'snf_stream_create', 'snf_stream_destroy', 'snf_stream_synchronize', 'snf_memcpy_h2d_async',
     'snf_memcpy_d2h_async', 'snf_comm_unique_id', 'snf_comm_init', 'snf_comm_rank', 'snf_comm_world_size',
     'snf_comm_destroy', 'snf_comm_gatherv', 'snf_comm_allreduce_f64',
-    'snf_plan_last_kernel_ms', 'snf_plan_kernel_name']
+    'snf_plan_last_kernel_ms', 'snf_plan_kernel_name', 'snf_set_oom_hook']
+
+
+_OOM_HOOK_TYPE = C.CFUNCTYPE(None)
+
+
+def _release_pool():
+    try:
+        DEVICE_POOL.clear()
+    except Exception:  # pragma: nocover  (a callback must not raise into C)
+        pass
+
+
+_OOM_HOOK = _OOM_HOOK_TYPE(_release_pool)
 
 
 def lib():
@@ -125,6 +138,10 @@ def lib():
         L.snf_plan_last_kernel_ms.restype = f32
         L.snf_plan_kernel_name.argtypes = [vp, i32]
         L.snf_plan_kernel_name.restype = C.c_char_p
+        L.snf_set_oom_hook.argtypes = [_OOM_HOOK_TYPE]
+        # the library's own allocations (plan scratch: ~19 GB for a 10 000-utterance pitch batch) reclaim
+        # what DEVICE_POOL has parked before they give up
+        L.snf_set_oom_hook(_OOM_HOOK)
         _LIB = L
     return _LIB
 
@@ -491,7 +508,9 @@ class _Staging:
 
     def __init__(self):
         self._free = []  # (capacity, pointer)
-        self._lock = threading.Lock()
+        # re-entrant: a garbage-collection pass triggered by an allocation inside the lock may finalise a
+        # _ResultBlock on this very thread, whose __del__ comes back here (release)
+        self._lock = threading.RLock()
 
     def array(self, shape, dtype, allocate=True):
         """-> (numpy array of `shape` / `dtype`, token to pass to :func:`release`); with `allocate` false a
@@ -543,7 +562,7 @@ class _ResultBlock:
     _LIMIT = 4 << 30   # page-locked result memory handed out and not yet returned, at most
     _FRESH = 1 << 30   # ... below which a result may page-lock a new buffer (see result_array)
     _held = 0
-    _lock = threading.Lock()
+    _lock = threading.RLock()   # (re-entrant for the same reason as _Staging._lock)
 
     def __init__(self, shape, dtype, token, address):
         self._token = token
@@ -786,11 +805,18 @@ class DeviceBuffer:
                                          array.nbytes, C.c_void_p(stream)))
         return lambda: check(lib().snf_stream_synchronize(C.c_void_p(stream)))
 
-    def free(self):
+    def free(self, synced=False):
+        """Gives the block back (to the pool, or to the driver when the pool is full).  Like hipFree, which
+        it used to be, this waits for the device first: work that was enqueued on any stream and still reads
+        or writes the block (``run_device(stream=...)``, ``download_async`` before its wait) is complete
+        before another owner - possibly another thread - can get the same memory from the pool.  Callers
+        that have just synchronised pass ``synced=True`` and skip the wait (~10 us on an idle device)."""
         if self.ptr:
             ptr, self.ptr = self.ptr, None
+            bind_device(self.device)
+            if not synced:
+                lib().snf_device_synchronize()
             if not DEVICE_POOL.give(self.device, (self._capacity, ptr)):
-                bind_device(self.device)
                 lib().snf_free(C.c_void_p(ptr))
 
     def __del__(self):

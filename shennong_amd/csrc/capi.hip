@@ -4,6 +4,7 @@
 // banks per VTLN warp, DCT, lifter, IDFT bases, resampler taps), resident in HBM, (b) grow-only
 // device scratch for the host-pointer entry points, (c) one HIP stream and the events that time the
 // kernels on that stream.
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -14,6 +15,22 @@ using namespace snf;
 
 namespace {
 
+// Out-of-memory hook (snf_set_oom_hook): the host side parks freed device buffers in a pool of its own
+// (shennong_amd/_backend.py, up to 8 GiB); an allocation of the library that fails asks it to give them
+// back and tries once more.
+std::atomic<snf_oom_hook> g_oom_hook{nullptr};
+hipError_t malloc_with_hook(void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipErrorOutOfMemory) {
+    if (snf_oom_hook hook = g_oom_hook.load()) {
+      (void)hipGetLastError();
+      hook();
+      e = hipMalloc(p, bytes);
+    }
+  }
+  return e;
+}
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -23,7 +40,7 @@ struct DevBuf {
     p = nullptr;
     cap = 0;
     size_t want = bytes + bytes / 8 + 256;
-    SNF_HIP_CHECK(hipMalloc(&p, want));
+    SNF_HIP_CHECK(malloc_with_hook(&p, want));
     cap = want;
     return SNF_OK;
   }
@@ -1542,6 +1559,10 @@ int snf_count_nonfinite_device(int device_id, const float* d_data, uint64_t n, u
 
 int snf_malloc(void** dptr, uint64_t bytes) {
   SNF_HIP_CHECK(hipMalloc(dptr, bytes));
+  return SNF_OK;
+}
+int snf_set_oom_hook(snf_oom_hook hook) {
+  g_oom_hook.store(hook);
   return SNF_OK;
 }
 int snf_free(void* dptr) {

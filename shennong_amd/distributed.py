@@ -12,38 +12,19 @@ The reference's only parallelism is a joblib thread pool over utterances sharing
     in rank order, so the result does not depend on the collective's internal reduction order.
 Transport: every function takes a ``group``.  An ``shennong_amd.comm.RcclComm`` runs the exchange
 steps over RCCL through the C ABI (``snf_comm_*``: device pointers, no framework).  ``group=None`` is
-that transport too whenever the process was started by a launcher (``WORLD_SIZE`` in the environment) on
-a machine with a GPU: one ``RcclComm.from_env()`` per process, created on first use.  A
-``torch.distributed`` process group is used only when the caller passes one (or has initialised
-``torch.distributed`` in a process without launcher variables / without a GPU): that is how the
-multi-process logic is tested on CPU with the gloo backend.
+that transport too whenever the process was started by a launcher (``WORLD_SIZE`` in the environment):
+one ``RcclComm.from_env()`` per process, created on first use; without a launcher it is the single-process
+identity.  Any other object with the same five members - ``rank``, ``world_size``,
+``all_gather_object(obj)``, ``gather_features(local, dst)``, ``allreduce(float64 array, op)`` - is used as
+it is: that is how the multi-process logic is tested on a box without GPUs (``tests/tools``: a gloo process
+group behind this interface, and the real ``RcclComm`` over a socket-backed stand-in of ``snf_comm_*``).
+This package never imports torch.
 """
 
 import os
 
 
 import numpy as np
-
-
-class _TorchTransport:
-    """``torch.distributed`` process group (gloo on CPU, nccl = RCCL on GPU)"""
-    def __init__(self, group=None):
-        import torch.distributed as dist
-        self.group = group
-        self.rank, self.world_size = dist.get_rank(group), dist.get_world_size(group)
-
-    def all_gather_object(self, obj):
-        import torch.distributed as dist
-        out = [None] * self.world_size
-        dist.all_gather_object(out, obj, group=self.group)
-        return out
-
-    def gather_features(self, local, dst=0, device=None):
-        return _torch_gather_features(local, dst, self.group, device)
-
-    def allreduce(self, array, op='sum'):
-        assert op == 'sum'
-        return _torch_allreduce_stats(array, self.group, None)
 
 
 def _agree(transport, error):
@@ -83,24 +64,19 @@ _ENV_COMM = None
 def _transport(group):
     """The object that carries out the exchange steps for `group` (see the module docstring)"""
     global _ENV_COMM
-    from shennong_amd.comm import RcclComm
-    if isinstance(group, (RcclComm, _SingleTransport, _TorchTransport)):
-        return group
     if group is not None:
-        return _TorchTransport(group)      # an explicitly passed torch process group
+        missing = [m for m in ('rank', 'world_size', 'all_gather_object', 'gather_features', 'allreduce')
+                   if not hasattr(group, m)]
+        if missing:
+            raise TypeError('group %r is not a transport: it lacks %s (pass an shennong_amd.comm.RcclComm)'
+                            % (group, ', '.join(missing)))
+        return group
     if _ENV_COMM is not None:
         return _ENV_COMM
-    from shennong_amd import _backend
-    launched = int(os.environ.get('WORLD_SIZE', '0')) > 0 and 'RANK' in os.environ
-    if launched and _backend.device_count() > 0:
+    if int(os.environ.get('WORLD_SIZE', '0')) > 0 and 'RANK' in os.environ:
+        from shennong_amd.comm import RcclComm
         _ENV_COMM = RcclComm.from_env()
         return _ENV_COMM
-    try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            return _TorchTransport(None)   # (CPU tests: the caller initialised gloo itself)
-    except ImportError:  # pragma: nocover
-        pass
     return _SingleTransport()
 
 
@@ -124,54 +100,13 @@ def shard_utterances(lengths, world_size):
     return [sorted(s) for s in shards]
 
 
-def gather_features(local, dst=0, group=None, device=None):
+def gather_features(local, dst=0, group=None):
     """Gathers per-rank ``{name: float32 [nframes, ndims]}`` dicts on rank `dst`.
 
     Names and shapes travel as a small all-gathered object; the matrices travel as ONE contiguous
     float32 buffer per peer, sent point-to-point to `dst`.  Returns the merged dict on `dst`, None
     elsewhere."""
-    transport = _transport(group)
-    if isinstance(transport, _TorchTransport):
-        return _torch_gather_features(local, dst, transport.group, device)
-    return transport.gather_features(local, dst)
-
-
-def _torch_gather_features(local, dst, group, device):
-    import torch
-    import torch.distributed as dist
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    names = list(local.keys())
-    shapes = [tuple(local[n].shape) for n in names]
-    meta = [None] * world
-    dist.all_gather_object(meta, (names, shapes), group=group)
-    sizes = [sum(int(np.prod(s)) for s in m[1]) for m in meta]
-    if device is None:
-        device = torch.device('cuda', torch.cuda.current_device()) \
-            if dist.get_backend(group) == 'nccl' else torch.device('cpu')
-    flat = np.concatenate([np.ascontiguousarray(local[n], dtype=np.float32).reshape(-1)
-                           for n in names]) if names else np.zeros(0, np.float32)
-    send = torch.from_numpy(flat).to(device)
-    if rank == dst:
-        bufs = {r: torch.empty(sizes[r], dtype=torch.float32, device=device)
-                for r in range(world) if r != dst and sizes[r] > 0}
-        ops = [dist.P2POp(dist.irecv, buf, r, group) for r, buf in bufs.items()]
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        merged = {}
-        for r in range(world):
-            data = (send if r == dst else bufs.get(r))
-            host = data.cpu().numpy() if data is not None else np.zeros(0, np.float32)
-            pos = 0
-            for name, shape in zip(*meta[r]):
-                n = int(np.prod(shape))
-                merged[name] = host[pos:pos + n].reshape(shape).copy()
-                pos += n
-        return merged
-    if sizes[rank] > 0:
-        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, send, dst, group)]):
-            req.wait()
-    return None
+    return _transport(group).gather_features(local, dst)
 
 
 def process_all_sharded(processor, utterances, dst=0, group=None, **kwargs):
@@ -253,42 +188,11 @@ def _gather_device_resident(processor, names, signals, warps, comm, dst):
     return merged
 
 
-def _default_device(group):
-    import torch
-    import torch.distributed as dist
-    return torch.device('cuda', torch.cuda.current_device()) \
-        if dist.get_backend(group) == 'nccl' else torch.device('cpu')
-
-
-def allreduce_cmvn_stats(stats, group=None, device=None):
-    """Sums float64 CMVN statistics blocks [n_speakers, 2, dim + 1] over the ranks.
-
-    torch transport: one all-gather of the (tiny) blocks, then a rank-ordered host sum; RCCL transport:
-    one float64 ncclAllReduce on the device.  Identical on every rank."""
-    transport = _transport(group)
-    if isinstance(transport, _TorchTransport):
-        return _torch_allreduce_stats(stats, transport.group, device)
+def allreduce_cmvn_stats(stats, group=None):
+    """Sums float64 CMVN statistics blocks [n_speakers, 2, dim + 1] over the ranks: one float64
+    ncclAllReduce on the device (``snf_comm_allreduce_f64``).  Identical on every rank."""
     stats = np.ascontiguousarray(stats, dtype=np.float64)
-    return transport.allreduce(stats, 'sum').reshape(stats.shape)
-
-
-def _torch_allreduce_stats(stats, group, device):
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    stats = np.ascontiguousarray(stats, dtype=np.float64)
-    if world == 1:
-        return stats.copy()
-    if device is None:
-        device = _default_device(group)
-    send = torch.from_numpy(stats.reshape(-1)).to(device)
-    recv = torch.empty(world * send.numel(), dtype=torch.float64, device=device)
-    dist.all_gather_into_tensor(recv, send, group=group)
-    parts = recv.cpu().numpy().reshape((world,) + stats.shape)
-    total = np.zeros_like(stats)
-    for r in range(world):
-        total += parts[r]
-    return total
+    return np.asarray(_transport(group).allreduce(stats, 'sum')).reshape(stats.shape)
 
 
 def apply_cmvn_sharded(local_feats, utt2speak=None, norm_vars=True, weights=None,
