@@ -269,3 +269,284 @@ def pitch(wave, samp_freq=16000, frame_shift_ms=10.0, frame_length_ms=25.0, min_
         out[t] = (res_pov[t, best], 1.0 / lags[best])
         best = bp[t, best]
     return dict(out=out, nccf=res, states=states, lags=lags)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Round 4: float64 restatements of the remaining families - PLP (+ RASTA), VTLN-warped mel banks, delta,
+# CMVN, sliding-window CMVN and the pitch post-processing -, written from the algorithm descriptions
+# ([KALDI-UPSTREAM] mel-computations.cc / feature-plp.cc / feature-functions.cc /
+# cmvn.cc / pitch-functions.cc, and the reference's in-tree recipe plp.py:64-168, :548-626) with numpy's own
+# operations and summation orders; no code is shared with oracle/kaldi_oracle.c.  tests/test_spec_f64.py
+# bounds |C oracle - float64| for each; tools/f64_report.py writes the table (profiles/r04_f64_report.txt).
+# ---------------------------------------------------------------------------------------------------------
+def inverse_mel_scale(m):
+    return 700.0 * (np.exp(m / 1127.0) - 1.0)
+
+
+def vtln_warp_freq(vtln_low, vtln_high, low_freq, high_freq, warp, freq):
+    """mel-computations.cc VtlnWarpFreq: piecewise-linear warp of [low_freq, high_freq] onto itself"""
+    freq = np.asarray(freq, dtype=np.float64)
+    l = vtln_low * max(1.0, warp)
+    h = vtln_high * min(1.0, warp)
+    scale = 1.0 / warp
+    fl, fh = scale * l, scale * h
+    scale_left = (fl - low_freq) / (l - low_freq)
+    scale_right = (high_freq - fh) / (high_freq - h)
+    out = np.where(freq < l, low_freq + scale_left * (freq - low_freq),
+                   np.where(freq < h, scale * freq, high_freq + scale_right * (freq - high_freq)))
+    return np.where((freq < low_freq) | (freq > high_freq), freq, out)
+
+
+def mel_banks_vtln(num_bins, sample_rate, padded, low_freq=20.0, high_freq=0.0, vtln_low=100.0,
+                   vtln_high=-500.0, warp=1.0):
+    """(dense [num_bins, padded / 2] weights, centre frequencies) with the bin edges warped in the
+    mel domain (reference processor/base.py:376-406 -> MelBanks(..., vtln_warp))"""
+    nyquist = 0.5 * sample_rate
+    high = high_freq if high_freq > 0 else nyquist + high_freq
+    vhigh = vtln_high if vtln_high >= 0 else nyquist + vtln_high
+    mlow, mhigh = mel_scale(low_freq), mel_scale(high)
+    delta = (mhigh - mlow) / (num_bins + 1)
+    edges = mlow + delta * np.arange(num_bins + 2)
+    if warp != 1.0:
+        edges = mel_scale(vtln_warp_freq(vtln_low, vhigh, low_freq, high, warp, inverse_mel_scale(edges)))
+    nfft = padded // 2
+    mel = mel_scale(np.arange(nfft) * sample_rate / padded)
+    w = np.zeros((num_bins, nfft))
+    for b in range(num_bins):
+        left, center, right = edges[b], edges[b + 1], edges[b + 2]
+        inside = (mel > left) & (mel < right)
+        w[b] = np.where(inside, np.where(mel <= center, (mel - left) / (center - left),
+                                         (right - mel) / (right - center)), 0.0)
+    return w, inverse_mel_scale(edges[1:-1])
+
+
+def equal_loudness(center_freqs):
+    fsq = np.asarray(center_freqs, dtype=np.float64) ** 2
+    fsub = fsq / (fsq + 1.6e5)
+    return fsub * fsub * ((fsq + 1.44e6) / (fsq + 9.61e6))
+
+
+def idft_bases(n_bases, dim):
+    """feature-functions.cc InitIdftBases: cosine bases of the inverse DFT of a symmetric spectrum"""
+    angle = np.pi / (dim - 1)
+    scale = 1.0 / (2.0 * (dim - 1))
+    i = np.arange(n_bases)[:, None]
+    j = np.arange(dim)[None, :]
+    m = 2.0 * scale * np.cos(angle * i * j)
+    m[:, 0] = scale
+    m[:, dim - 1] = scale * np.cos(angle * np.arange(n_bases) * (dim - 1))
+    return m
+
+
+def durbin(autocorr):
+    """(lpc [order], residual energy): Levinson-Durbin with Kaldi's 1e-5 floor on 1 - k^2"""
+    order = len(autocorr) - 1
+    lpc = np.zeros(order)
+    e = float(autocorr[0])
+    for i in range(order):
+        ki = (autocorr[i + 1] + np.dot(lpc[:i], autocorr[i:0:-1])) / e
+        e *= max(1.0 - ki * ki, 1.0e-5)
+        new = lpc.copy()
+        new[i] = -ki
+        new[:i] = lpc[:i] - ki * lpc[:i][::-1]
+        lpc = new
+    return lpc, e
+
+
+def lpc_to_cepstrum(lpc):
+    order = len(lpc)
+    cep = np.zeros(order)
+    for i in range(order):
+        s = sum((i - j) * lpc[j] * cep[i - j - 1] for j in range(i))
+        cep[i] = -lpc[i] - s / (i + 1)
+    return cep
+
+
+def rasta(mel, do_log=True):
+    """RASTA over the frames of one utterance, [n, bins] -> [n, bins] (reference plp.py:64-146: numerator
+    -[-2 .. 2] / 10, denominator [1, -0.94]; the first four frames emit zeros in the log domain - ones after
+    the exponential - and prime the FIR delay line)"""
+    import scipy.signal
+    x = np.asarray(mel, dtype=np.float64)
+    if do_log:
+        x = np.log(x + np.finfo(np.float64).eps)
+    numer = -np.arange(-2, 3) / np.sum(np.arange(-2, 3) ** 2)
+    denom = np.array([1.0, -0.94])
+    out = np.zeros_like(x)
+    n = x.shape[0]
+    head = min(4, n)
+    # the FIR part sees every frame from the first; the IIR part starts at frame 4 from a zero state
+    fir_state = np.zeros((4, x.shape[1]))
+    if head:
+        _, fir_state = scipy.signal.lfilter(numer, [1.0], x[:head], axis=0, zi=fir_state)
+    if n > 4:
+        # one filter with both parts, started with the FIR delay line primed and no recursive memory: in
+        # direct form II transposed that is exactly the state a pure FIR run leaves behind
+        y, _ = scipy.signal.lfilter(numer, denom, x[4:], axis=0, zi=fir_state)
+        out[4:] = y
+    return np.exp(out) if do_log else out
+
+
+def plp(wave, sample_rate=16000, frame_shift=0.01, frame_length=0.025, preemph=0.97, remove_dc=True,
+        window='povey', snip_edges=True, num_bins=23, low_freq=20.0, high_freq=0.0, vtln_low=100.0,
+        vtln_high=-500.0, warp=1.0, lpc_order=12, num_ceps=13, cepstral_lifter=22.0, cepstral_scale=1.0,
+        compress_factor=1.0 / 3.0, use_energy=True, raw_energy=True, energy_floor=0.0, htk_compat=False,
+        use_rasta=False):
+    """PlpProcessor (reference plp.py:510-626) in float64"""
+    shift, length, padded = frame_geometry(sample_rate, frame_shift, frame_length)
+    x = extract_frames(wave, shift, length, snip_edges)
+    if x.shape[0] == 0:
+        return np.zeros((0, num_ceps))
+    if remove_dc:
+        x = x - x.mean(axis=1, keepdims=True)
+    eps64 = np.finfo(np.float64).eps
+    raw_log_energy = np.log(np.maximum((x * x).sum(axis=1), eps64))
+    if preemph != 0:
+        y = x.copy()
+        y[:, 1:] = x[:, 1:] - preemph * x[:, :-1]
+        y[:, 0] = x[:, 0] - preemph * x[:, 0]
+        x = y
+    x = x * window_function(length, window)[None, :]
+    post_log_energy = np.log(np.maximum((x * x).sum(axis=1), eps64))
+    spec = np.fft.rfft(x, n=padded, axis=1)
+    power = (spec.real ** 2 + spec.imag ** 2)[:, :padded // 2]
+    w, centers = mel_banks_vtln(num_bins, sample_rate, padded, low_freq, high_freq, vtln_low, vtln_high, warp)
+    mel = power @ w.T
+    if use_rasta:
+        mel = rasta(mel, do_log=True)
+    mel = (mel * equal_loudness(centers)[None, :]) ** float(np.float32(compress_factor))
+    dup = np.concatenate([mel[:, :1], mel, mel[:, -1:]], axis=1)
+    ac = dup @ idft_bases(lpc_order + 1, num_bins + 2).T
+    out = np.zeros((x.shape[0], num_ceps))
+    for t in range(x.shape[0]):
+        lpc, e = durbin(ac[t])
+        out[t, 0] = max(np.log(e), eps64)
+        out[t, 1:] = lpc_to_cepstrum(lpc)[:num_ceps - 1]
+    if cepstral_lifter:
+        out = out * (1 + 0.5 * cepstral_lifter * np.sin(np.pi * np.arange(num_ceps) / cepstral_lifter))[None, :]
+    out = out * cepstral_scale
+    if use_energy:
+        le = raw_log_energy if raw_energy else post_log_energy
+        if energy_floor > 0:
+            le = np.maximum(le, np.log(energy_floor))
+        out[:, 0] = le
+    if htk_compat:
+        out = np.concatenate([out[:, 1:], out[:, :1]], axis=1)
+    return out
+
+
+def delta_scales(order, window):
+    """scales[i] of the i-th derivative: i-fold convolution of [-w..w] / sum(j^2)"""
+    scales = [np.array([1.0])]
+    base = np.arange(-window, window + 1, dtype=np.float64) / float(sum(j * j for j in range(-window, window + 1)))
+    for _ in range(order):
+        scales.append(np.convolve(scales[-1], base))
+    return scales
+
+
+def delta(feats, order=2, window=2):
+    """DeltaPostProcessor (reference delta.py:113-136): [n, d] -> [n, d (order + 1)], frames clamped"""
+    x = np.asarray(feats, dtype=np.float64)
+    n = x.shape[0]
+    blocks = []
+    for s in delta_scales(order, window):
+        half = (len(s) - 1) // 2
+        acc = np.zeros_like(x)
+        for k, c in enumerate(s):
+            idx = np.clip(np.arange(n) + k - half, 0, n - 1)
+            acc += c * x[idx]
+        blocks.append(acc)
+    return np.concatenate(blocks, axis=1)
+
+
+def cmvn_stats(feats, weights=None):
+    """[2, d + 1]: row 0 = weighted sums and the count, row 1 = weighted sums of squares"""
+    x = np.asarray(feats, dtype=np.float64)
+    w = np.ones(x.shape[0]) if weights is None else np.asarray(weights, dtype=np.float64)
+    stats = np.zeros((2, x.shape[1] + 1))
+    stats[0, :-1] = (w[:, None] * x).sum(axis=0)
+    stats[1, :-1] = (w[:, None] * x * x).sum(axis=0)
+    stats[0, -1] = w.sum()
+    return stats
+
+
+def cmvn_apply(feats, stats, norm_vars=True, reverse=False):
+    x = np.asarray(feats, dtype=np.float64)
+    count = stats[0, -1]
+    mean = stats[0, :-1] / count
+    if not norm_vars:
+        return x + mean if reverse else x - mean
+    var = np.maximum(stats[1, :-1] / count - mean * mean, 1.0e-20)
+    if reverse:
+        return x * np.sqrt(var) + mean
+    return (x - mean) / np.sqrt(var)
+
+
+def sliding_cmvn(feats, center=True, cmn_window=600, min_window=100, normalize_variance=False):
+    """SlidingWindowCmvnPostProcessor -> [KALDI-UPSTREAM] SlidingWindowCmn"""
+    x = np.asarray(feats, dtype=np.float64)
+    n = x.shape[0]
+    out = np.zeros_like(x)
+    for t in range(n):
+        if center:
+            begin = t - cmn_window // 2
+            end = begin + cmn_window
+        else:
+            begin, end = t - cmn_window, t + 1
+        if begin < 0:
+            end -= begin
+            begin = 0
+        if not center:
+            if end > t:
+                end = max(t + 1, min_window)
+        if end > n:
+            begin -= end - n
+            end = n
+            if begin < 0:
+                begin = 0
+        seg = x[begin:end]
+        mean = seg.mean(axis=0)
+        out[t] = x[t] - mean
+        if normalize_variance:
+            if end - begin == 1:
+                out[t] = 0.0
+            else:
+                var = np.maximum((seg * seg).mean(axis=0) - mean * mean, 1.0e-10)
+                out[t] = out[t] / np.sqrt(var)
+    return out
+
+
+def nccf_to_pov_feature(n):
+    n = np.clip(n, -1.0, 1.0)
+    return (1.0001 - n) ** 0.15 - 1.0
+
+
+def nccf_to_pov(n):
+    nd = np.minimum(np.abs(n), 1.0)
+    r = -5.2 + 5.4 * np.exp(7.5 * (nd - 1.0)) + 4.8 * nd - 2.0 * np.exp(-10.0 * nd) + 4.2 * np.exp(20.0 * (nd - 1.0))
+    return 1.0 / (1.0 + np.exp(-r))
+
+
+def process_pitch(raw, pitch_scale=2.0, pov_scale=2.0, pov_offset=0.0, delta_pitch_scale=10.0,
+                  left_context=75, right_context=75, delta_window=2, add_pov_feature=True,
+                  add_normalized_log_pitch=True, add_delta_pitch=True, add_raw_log_pitch=False):
+    """KaldiPitchPostProcessor (reference pitch_kaldi.py:497-540 -> ProcessPitch) without the noise term:
+    [n, 2] (NCCF, pitch) -> [n, k]"""
+    raw = np.asarray(raw, dtype=np.float64)
+    nccf, log_pitch = raw[:, 0], np.log(raw[:, 1])
+    n = raw.shape[0]
+    cols = []
+    if add_pov_feature:
+        cols.append(pov_scale * nccf_to_pov_feature(nccf) + pov_offset)
+    if add_normalized_log_pitch:
+        pov = nccf_to_pov(nccf)
+        norm = np.zeros(n)
+        for t in range(n):
+            lo, hi = max(0, t - left_context), min(n, t + right_context + 1)
+            norm[t] = log_pitch[t] - np.sum(pov[lo:hi] * log_pitch[lo:hi]) / np.sum(pov[lo:hi])
+        cols.append(pitch_scale * norm)
+    if add_delta_pitch:
+        cols.append(delta_pitch_scale * delta(log_pitch[:, None], 1, delta_window)[:, 1])
+    if add_raw_log_pitch:
+        cols.append(log_pitch)
+    return np.stack(cols, axis=1)

@@ -114,5 +114,6 @@ def assert_close(got, want, rtol=1e-4, atol=None, what='', family=None):
                 'family': family or 'other',
                 'max_abs': float(err.max()), 'max_rel': float((err / np.maximum(np.abs(want), 1e-30)).max()),
                 'needed_atol_at_rtol': float(max(excess.max(), 0.0)), 'rtol': rtol, 'atol': atol,
+                'inside_1e-4_rel': int((err <= 1e-4 * np.abs(want.astype(np.float64))).sum()),
                 'size': int(got.size)}) + '\n')
     np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=what)
