@@ -179,7 +179,7 @@ def _gather_device_resident(processor, names, signals, warps, comm, dst):
     finally:
         for buf in (d_wave, d_out, d_all):
             if buf is not None:
-                buf.free()
+                buf.free(synced=True)   # (launch, gather and download have all completed)
     merged, pos = {}, 0
     for names_r, nframes_r in meta:
         for name, nf in zip(names_r, nframes_r):

@@ -507,7 +507,7 @@ class _ResidentWaves:
 
     def clear(self):
         for d_wave, _ in self._items.values():
-            d_wave.free()
+            d_wave.free(synced=True)
         self._items.clear()
         self.held = 0
 
@@ -557,6 +557,10 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             ', '.join(str(s) + 'Hz' for s in samplerates))
 
     from shennong_amd.processor.base import check_signal
+    # (every launch below goes through an entry point that synchronises its stream before it returns, and the
+    # one asynchronous copy is waited for before its buffer is released: the buffers are given back with
+    # synced=True, without the device-wide wait DeviceBuffer.free() otherwise makes - which would stall this
+    # thread behind the pitch tracker of the side thread)
     DB = _backend.DeviceBuffer
     frame_length = frame_shift = None
     cache = {}          # properties per processing history (see _Meta)
@@ -623,11 +627,11 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
                     return d_pitch
                 except BaseException:
                     if d_pitch is not None:
-                        d_pitch.free()
+                        d_pitch.free(synced=True)
                     raise
                 finally:
                     if d_raw is not None:
-                        d_raw.free()
+                        d_raw.free(synced=True)
 
             st.update(pfoff=pfoff, pdim=pdim, pitch_job=_backend.side_pool().submit(track))
             step = {}
@@ -685,13 +689,13 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             d_vad = DB(max(int(foff[-1]) * 4, 16))
             _backend.get_plan(vad._build_options()).run_post_device(
                 d_energy.ptr, 1, foff, d_vad.ptr)
-            d_energy.free()
+            d_energy.free(synced=True)
             st['d_vad'] = d_vad
 
         if 'pitch_job' in st:
             pass  # (the tracker still reads the audio: released where it is waited for)
         elif not (stats_only and resident is not None and resident.offer((batch_id, rate), d_wave, soff)):
-            d_wave.free()
+            d_wave.free(synced=True)
         groups_state.append(st)
 
     # ---- CMVN: statistics of every utterance in one launch per sample rate, summed per speaker (or
@@ -717,10 +721,10 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
                 groups=np.arange(len(st['idx']), dtype=np.int32))
             per_utt[st['idx']] = local
             if 'd_vad' in st:
-                st['d_vad'].free()
+                st['d_vad'].free(synced=True)
         if stats_only:
             for st in groups_state:
-                st['d_feat'].free()
+                st['d_feat'].free(synced=True)
             return [names[g] for g in group_of], per_utt
         stats = np.zeros((len(names), 2, dim + 1), dtype=np.float64)
         for i in range(n):
@@ -739,7 +743,7 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             cplan.cmvn_apply_device(
                 st['d_feat'].ptr, dim, st['foff'], stats, d_out.ptr,
                 groups=group_of[st['idx']], norm_vars=True)
-            st['d_feat'].free()
+            st['d_feat'].free(synced=True)
             st['d_feat'] = d_out
         step = {}  # (the utterances of a group that share a _Meta take this step once)
         for i, g in enumerate(group_of.tolist()):
@@ -758,7 +762,7 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             odim = dplan.post_ndims(st['dim'])
             d_out = DB(max(int(st['foff'][-1]) * odim * 4, 16))
             dplan.run_post_device(st['d_feat'].ptr, st['dim'], st['foff'], d_out.ptr)
-            st['d_feat'].free()
+            st['d_feat'].free(synced=True)
             st['d_feat'], st['dim'] = d_out, odim
             step = {}
             for i in st['idx']:
@@ -778,7 +782,7 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             try:
                 st['d_pitch'] = st.pop('pitch_job').result()
             finally:
-                st['d_wave'].free()
+                st['d_wave'].free(synced=True)
             rows, step = [], {}
             for i in idx:
                 hit = step.get((meta[i], pmeta[i]))
@@ -800,8 +804,8 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             _backend.concat_columns_device(
                 st['d_feat'].ptr, st['dim'], st['foff'], st['d_pitch'].ptr, st['pdim'],
                 st['pfoff'], d_out.ptr, ooff)
-            st['d_feat'].free()
-            st['d_pitch'].free()
+            st['d_feat'].free(synced=True)
+            st['d_pitch'].free(synced=True)
             st['d_feat'], st['dim'], st['foff'] = d_out, odim, ooff
         host = _backend.result_array((int(st['foff'][-1]), st['dim']), np.float32)
         if host.size:
@@ -811,7 +815,7 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             _backend.check_finite_device(st['d_feat'].ptr, host.size)
             pending.append((st['d_feat'].download_async(host), st['d_feat']))
         else:
-            st['d_feat'].free()
+            st['d_feat'].free(synced=True)
         cuts = st['foff'].tolist()
         for k, i in enumerate(idx):
             results[i] = host[cuts[k]:cuts[k + 1]]  # views of the one downloaded array
@@ -830,7 +834,7 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
         out[utt.name] = of_batch(results[i], meta[i].times, meta[i].properties, extra)
     for wait, d_feat in pending:
         wait()
-        d_feat.free()
+        d_feat.free(synced=True)
     return out
 
 
