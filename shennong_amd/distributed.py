@@ -306,17 +306,27 @@ def extract_features_sharded(configuration, utterances, warps=None, dst=0, group
         error = exc
     _agree(transport, error)
     local = FeaturesCollection()
+    blocks = []   # RCCL: the final matrices of this rank stay in HBM until the gather has sent them
+    from shennong_amd.comm import RcclComm
+    on_device = isinstance(transport, RcclComm)
     try:
         if mine:
             local = pipeline._extract_features(
                 config, Utterances(mine), {u.name: warps[u.name] for u in mine} if warps else None, log,
-                stats_hook=hook)
+                stats_hook=hook, device_out=blocks if on_device else None)
         elif hook is not None:  # still take part in the reduction
             hook([], np.zeros((0, 2, 1), dtype=np.float64))
     except Exception as exc:  # noqa: BLE001
         error = exc
-    _agree(transport, error)
-    merged = gather_features({k: v.data for k, v in local.items()}, dst=dst, group=group)
+    try:
+        _agree(transport, error)
+        if on_device:
+            merged = _gather_blocks(transport, local, blocks, dst)
+        else:
+            merged = gather_features({k: v.data for k, v in local.items()}, dst=dst, group=group)
+    finally:
+        for d_buf, _, _ in blocks:
+            d_buf.free(synced=True)
     meta = transport.all_gather_object({k: (v.times, v.properties) for k, v in local.items()})
     if merged is None:
         return None
@@ -326,6 +336,53 @@ def extract_features_sharded(configuration, utterances, warps=None, dst=0, group
         times, properties = everything[u.name]
         out[u.name] = Features(merged[u.name], times, properties=properties, validate=False)
     return out
+
+
+def _gather_blocks(comm, local, blocks, dst):
+    """The device-resident gather of `extract_features_sharded`: every rank's final [rows, ndims] blocks (one
+    per sample rate, still in HBM) go point to point to `dst` (``snf_comm_gatherv``, one call per block
+    position), which downloads everything once.  ``{name: float32 [nframes, ndims]}`` on `dst` (views of the
+    one downloaded block), None elsewhere."""
+    from shennong_amd import _backend
+    mine = [(names, [int(local[n].shape[0]) for n in names], ndims) for _, names, ndims in blocks]
+    meta = comm.all_gather_object(mine)
+    rounds = max(len(m) for m in meta)
+    sizes = [[sum(m[k][1]) * m[k][2] if k < len(m) else 0 for m in meta] for k in range(rounds)]
+    total = sum(sum(row) for row in sizes)
+    d_all = host = None
+    placeholder = None
+    try:
+        if comm.rank == dst:
+            d_all = _backend.DeviceBuffer(max(4 * total, 16), device=comm.device)
+        base = 0
+        for k in range(rounds):
+            count = sizes[k][comm.rank]
+            if k < len(blocks):
+                send_ptr = blocks[k][0].ptr
+            else:   # (this rank has no block at this position: it still takes part with a count of 0)
+                if placeholder is None:
+                    placeholder = _backend.DeviceBuffer(16, device=comm.device)
+                send_ptr = placeholder.ptr
+            comm.gatherv_device(send_ptr, count, d_all.ptr + 4 * base if d_all else None, sizes[k], dst)
+            base += sum(sizes[k])
+        if comm.rank != dst:
+            return None
+        host = _backend.result_array((total,), np.float32)
+        if total:
+            d_all.download(host)
+    finally:
+        for buf in (d_all, placeholder):
+            if buf is not None:
+                buf.free(synced=True)
+    merged, pos = {}, 0
+    for k in range(rounds):
+        for m in meta:
+            if k < len(m):
+                names, nframes, ndims = m[k]
+                for name, nf in zip(names, nframes):
+                    merged[name] = host[pos:pos + nf * ndims].reshape(nf, ndims)
+                    pos += nf * ndims
+    return merged
 
 
 def extract_features_streamed_sharded(configuration, utterances, sink, warps=None,

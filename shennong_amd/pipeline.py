@@ -513,7 +513,7 @@ class _ResidentWaves:
 
 
 def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=None,
-                      stats_only=False, resident=None, batch_id=None):
+                      stats_only=False, resident=None, batch_id=None, device_out=None):
     """The whole pipeline with the intermediate features resident in HBM: the waveforms go up once,
     every stage is one batched launch on device buffers (features, energy -> VAD, CMVN statistics and
     apply, delta, pitch and its post-processing, column concatenation), the final matrices come down
@@ -522,7 +522,11 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
     `stats_only` (first pass of :func:`extract_features_streamed`): stop after the CMVN accumulation
     and return ``(group name of every utterance, per-utterance statistics [n, 2, dim + 1])``; the
     pitch stage, which the statistics do not depend on, is skipped.  `resident` (a _ResidentWaves) keeps
-    the uploaded waveforms of batch `batch_id` in HBM after that pass and hands them to the next one."""
+    the uploaded waveforms of batch `batch_id` in HBM after that pass and hands them to the next one.
+    `device_out` (a list; :func:`shennong_amd.distributed.extract_features_sharded`): the final matrices
+    STAY in HBM - one ``(DeviceBuffer [rows, ndims], names in row order, ndims)`` per sample rate is appended
+    and the caller owns the buffers; the returned Features carry times and properties over data that were
+    never downloaded (untouched host pages)."""
     features_name = [k for k in config.keys() if k in valid_features()][0]
     with_cmvn = 'cmvn' in config
     if with_cmvn and config['cmvn']['by_speaker'] and not utterances.has_speakers():
@@ -807,8 +811,16 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
             st['d_feat'].free(synced=True)
             st['d_pitch'].free(synced=True)
             st['d_feat'], st['dim'], st['foff'] = d_out, odim, ooff
-        host = _backend.result_array((int(st['foff'][-1]), st['dim']), np.float32)
-        if host.size:
+        if device_out is not None:
+            host = np.empty((int(st['foff'][-1]), st['dim']), dtype=np.float32)   # (never written, never read)
+            if host.size:
+                _backend.check_finite_device(st['d_feat'].ptr, host.size)
+            device_out.append((st['d_feat'], [utts[i].name for i in idx], st['dim']))
+        else:
+            host = _backend.result_array((int(st['foff'][-1]), st['dim']), np.float32)
+        if device_out is not None:
+            pass
+        elif host.size:
             # (Features.validate's data check, once for the batch and before it leaves HBM; the copy then
             # runs while the per-utterance objects below are made - they only need to know WHERE their rows
             # will be)

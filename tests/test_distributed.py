@@ -239,6 +239,66 @@ def test_streamed_sharded(tmp_path, kind):
     assert _run_pair(_streamed_worker, kind, tmp_path) == ['1', '1']
 
 
+def _sharded_worker(kind, rank, world, port, tmpdir):
+    transport, close = _open(kind, rank, world, port)
+    from conftest import GOLDEN
+    from shennong_amd import Features, FeaturesCollection, Utterances, _backend, pipeline
+    from shennong_amd.distributed import extract_features_sharded
+    wav = os.path.join(GOLDEN, 'test.wav')
+    index = Utterances([(f'u{i}', wav, f's{i % 3}', 0.1 * (i % 4), 0.1 * (i % 4) + 0.3 + 0.1 * (i % 5))
+                        for i in range(1, 10)])
+
+    def want(name):
+        k = int(name[1:])
+        return np.full((3 + k % 5, 4), float(k), np.float32) + np.arange(4, dtype=np.float32)
+
+    def fake(config, utterances, warps, log, tolerance=2, stats_hook=None, device_out=None, **_rest):
+        # stand-in for the device pipeline: utterance u<k> yields a known matrix; the even and the odd
+        # utterances stand for two sample rates (two blocks); with `device_out` the rows stay "in HBM"
+        # (host memory behind the stand-in's DeviceBuffer) and the Features carry untouched placeholders
+        coll = FeaturesCollection()
+        utts = list(utterances)
+        for parity in (0, 1):
+            names = [u.name for u in utts if int(u.name[1:]) % 2 == parity]
+            if not names:
+                continue
+            mats = [want(n) for n in names]
+            if device_out is not None:
+                flat = np.concatenate([m.reshape(-1) for m in mats])
+                buf = _backend.DeviceBuffer(flat.nbytes)
+                buf.upload(flat)
+                device_out.append((buf, names, 4))
+            for n, m in zip(names, mats):
+                data = m if device_out is None else np.full_like(m, np.nan)
+                coll[n] = Features(data, np.arange(m.shape[0], dtype=np.float64), properties={'name': n},
+                                   validate=False)
+        return coll
+
+    pipeline._extract_features = fake
+    config = pipeline.get_default_config('mfcc', with_cmvn=False)
+    out = extract_features_sharded(config, index, dst=0, group=transport)
+    ok = True
+    if rank == 0:
+        ok = sorted(out.keys()) == sorted(f'u{i}' for i in range(1, 10))
+        ok = ok and all(np.array_equal(out[k].data, want(k)) for k in out.keys())
+        ok = ok and all(out[k].properties == {'name': k} for k in out.keys())
+        ok = ok and all(np.array_equal(out[k].times, np.arange(want(k).shape[0])) for k in out.keys())
+    else:
+        ok = out is None
+    if kind == 'rccl_stub':   # the rows went through snf_comm_gatherv, one call per block position
+        ok = ok and sum(1 for c in transport.fake.calls if c[0] == 'gatherv') == 2
+    close()
+    open(os.path.join(tmpdir, f'out{rank}'), 'w').write('1' if ok else '0')
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize('kind', TRANSPORTS)
+def test_extract_features_sharded(tmp_path, kind):
+    """the whole-pipeline driver over two ranks: shards, agreement, gather (device-resident blocks over the
+    communicator class; host dictionaries over the gloo transport), times and properties as objects"""
+    assert _run_pair(_sharded_worker, kind, tmp_path) == ['1', '1']
+
+
 def _mixed_failure_worker(kind, rank, world, port, tmpdir):
     transport, close = _open(kind, rank, world, port)
     from shennong_amd import distributed
@@ -451,6 +511,38 @@ def test_rccl_comm_world_of_one():
     assert distributed.process_all_sharded(proc, index, group=comm, vtln_warp=warps) == \
         proc.process_all(index, vtln_warp=warps)
     assert distributed.process_all_sharded(proc, index, group=comm) == proc.process_all(index)
+    comm.close()
+
+
+@pytest.mark.gpu
+def test_extract_features_sharded_world_of_one():
+    """extract_features_sharded through RcclComm on one GPU: the final blocks (two sample rates = two blocks)
+    go from the pipeline's device buffers through snf_comm_gatherv and come down once; same collection as
+    pipeline.extract_features"""
+    from shennong_amd import Audio, Utterances, _backend, distributed, pipeline, synth
+    from shennong_amd.comm import RcclComm
+    from shennong_amd.logger import get_logger
+    if _backend.device_count() < 1:
+        pytest.skip('no HIP device visible')
+    comm = RcclComm(0, 1)
+    waves = synth.ragged_utterances(321, 8, min_s=0.3, max_s=0.8)
+    items = [(f'u{i}', Audio(w, 16000), f's{i % 3}') for i, w in enumerate(waves)]
+    items += [(f'v{i}', Audio(w[:len(w) // 2], 8000), f's{i % 3}') for i, w in enumerate(waves[:3])]
+    index = Utterances(items)
+    quiet = get_logger('test', 'error')
+    for cfg in (pipeline.get_default_config('mfcc', with_cmvn=True, with_delta=True, with_pitch='kaldi'),
+                pipeline.get_default_config('filterbank', with_cmvn=False, with_delta=False, with_pitch=False)):
+        if 'mfcc' in cfg:
+            cfg['mfcc']['dither'] = 0
+            cfg['cmvn']['with_vad'] = False
+            cfg['pitch']['postprocessing']['delta_pitch_noise_stddev'] = 0
+        else:
+            cfg['filterbank']['dither'] = 0
+        want = pipeline.extract_features(cfg, index, log=quiet)
+        got = distributed.extract_features_sharded(cfg, index, group=comm, log=quiet)
+        assert got.keys() == want.keys()
+        for k in want.keys():
+            assert got[k] == want[k], k
     comm.close()
 
 
