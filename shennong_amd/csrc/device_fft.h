@@ -126,6 +126,15 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+// The same ordering point for a tile that only ONE wave touches: the LDS executes the instructions of a wave
+// in the order they were issued, so a read behind a write of the same wave needs no s_waitcnt - only the
+// compiler has to keep the two in program order (wavefront-scope fences emit no instruction, where the
+// workgroup-scope ones above make the wave sit until every LDS store is acknowledged)
+__device__ __forceinline__ void wave_lds_order() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // sum over the 16 lanes of a DPP row (= one frame), result in every lane of the row
 template <int CTRL>

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
     fft16_lf(z);
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) tile[k2 * kTileRow + l] = z[k2];
-    wave_lds_sync();
+    wave_lds_order();
     // the inter-pass twiddle W256^(n l) of element n of this lane's row (the table is symmetric in n and
     // l) as (cos, tan) pairs: read while the tile lands
     float2 ct[16];
@@ -222,13 +222,13 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
     // ---- C: pass 2 (twiddle + FFT over n1): z[k1] = Z[l + 16 k1] -----------------------------------
     fft16_twin(z, ct);
     __builtin_amdgcn_sched_barrier(0);
-    wave_lds_sync();
+    wave_lds_order();
 
     // ---- D: real-FFT unpack + power (x4): the partner Z[256 - k] of k = l + 16 k1 (k1 < 8) is
     // (16 - l) + 16 (15 - k1): the upper half of the spectrum goes through the tile, rows 0..7 ---------
 #pragma unroll
     for (int r = 0; r < 8; ++r) tile[r * 16 + l] = z[r + 8];
-    wave_lds_sync();
+    wave_lds_order();
     float pk[8], pm[8];  // 4 P[k], 4 P[256 - k]
     {
       float2 zpart[8];
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
       pm[0] = 4.0f * ny * ny;
     }
     const float p128 = 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y);  // k = 128: lane 0, register 8
-    wave_lds_sync();
+    wave_lds_order();
     // ---- E: power tile ------------------------------------------------------------------------------
     {
       // two rows per instruction (ds_write2_b32: 3 LDS-path clocks per dword against 4 for ds_write_b32)
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
 #undef SNF_W2
       if (l == 0) ptile[128] = p128;
     }
-    wave_lds_sync();
+    wave_lds_order();
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- log-energy column ---------------------------------------------------------------------------
@@ -384,12 +384,12 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
       if (KIND == SNF_KIND_MFCC) {
         // log-mel of frame j back to its (now idle) power tile; DCT-II + lifter on the vector pipe: lane l
         // of a frame's row owns cepstrum l and walks the log-mel 4 bins at a time
-        wave_lds_sync();
+        wave_lds_order();
         if (mm_out >= 0)
           *reinterpret_cast<float4*>(const_cast<float*>(mtile) + mm_out) =
               make_float4(fast_log(floor_eps(mel[0])), fast_log(floor_eps(mel[1])),
                           fast_log(floor_eps(mel[2])), fast_log(floor_eps(mel[3])));
-        wave_lds_sync();
+        wave_lds_order();
         const float4* __restrict__ dw = t_dd_v + l;
         const float4* __restrict__ dx = reinterpret_cast<const float4*>(ptile);
         float v = 0.0f;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
         }
       }
     }
-    wave_lds_sync();  // the tile is reused by the next frame set
+    wave_lds_order();  // the tile is reused by the next frame set
   }
 }
 
