@@ -91,7 +91,7 @@ struct snf_plan {
   // ... and its per-warp-factor tables (VTLN): one blob per warp id, `fp_warp.table_stride` apart
   std::vector<float> h_window, h_dct, h_lifter;
   Fast512Params fp_warp{};
-  DevBuf d_fast_warp_tables, s_blk_utt, s_blk_set0;
+  DevBuf d_fast_warp_tables, s_blk_utt, s_blk_set0, s_noise;
   size_t fast_warps_built = 0;   // number of warp ids covered by d_fast_warp_tables
   bool fast_warps_ok = true;     // false: some warp's banks do not fit the fast kernel
   // register-resident 2048-point path (frames that pad to 2048 or 1024 samples)
@@ -1072,6 +1072,15 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
   if (plan->mp.dither != 0.0f) {
     const unsigned long long stream_key = plan->o.seed + 0x9E3779B97F4A7C15ull * (named_call ? named_call : ++plan->noise_calls);
     plan->mp.seed = plan->fp.seed = plan->fp_warp.seed = stream_key;
+    // fbank512b_kernel reads the noise key of a frame from a table (the keys hold the utterance's first two
+    // samples: made with every batch; 8 bytes per frame)
+    b.frame_noise = nullptr;
+    if (use_fast && !any_warp && !fused && !plan->fp.dual && b.frame_utt != nullptr && plan->mp.snip_edges &&
+        !getenv("SNF_FBANK512_OLD")) {
+      if ((rc = plan->s_noise.ensure(sizeof(uint64_t) * static_cast<size_t>(total_frames)))) return rc;
+      if ((rc = launch_build_frame_noise(b, plan->s_noise.as<uint64_t>(), s))) return rc;
+      b.frame_noise = plan->s_noise.as<uint64_t>();
+    }
   }
   // the register-resident 512-point family: one launch, or two over disjoint utterances (split_dual)
   auto run_fast = [&](float* out, int cols, double* energy) -> int {

@@ -113,10 +113,12 @@ __device__ __forceinline__ unsigned fmix32(unsigned h) {
   return h;
 }
 __device__ __forceinline__ float2 gauss_pair(unsigned key_lo, unsigned key_hi, unsigned n) {
-  const unsigned h1 = fmix32(key_lo + n * 0x9E3779B1u);
-  const unsigned h2 = fmix32(key_hi ^ h1);
-  const float u1 = (static_cast<float>(h1 >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
-  const float u2 = static_cast<float>(h2 >> 8) * (1.0f / 16777216.0f);           // [0, 1)
+  // one 32-bit mix per pair of normals (round 4; two before): its upper half is the radius' uniform, its
+  // lower half the angle's - 16 bits each: the radius reaches 4.7 sigma (2.5e-6 of the mass lies beyond), the
+  // angle has 65 536 steps
+  const unsigned h = fmix32((key_lo + n * 0x9E3779B1u) ^ key_hi);
+  const float u1 = (static_cast<float>(h >> 16) + 1.0f) * (1.0f / 65536.0f);   // (0, 1]
+  const float u2 = static_cast<float>(h & 0xffffu) * (1.0f / 65536.0f);        // [0, 1)
   const float r = __builtin_amdgcn_sqrtf(-1.38629436111989f * __builtin_amdgcn_logf(u1));
   return make_float2(r * __builtin_amdgcn_cosf(u2), r * __builtin_amdgcn_sinf(u2));
 }

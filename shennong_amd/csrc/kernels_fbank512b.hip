@@ -56,7 +56,12 @@ constexpr int kTileBytes = 16 * kTileRow * 8;  // wave-private LDS per frame (21
 // both register passes, the inter-pass twiddle (now behind the transpose, in the first butterflies of pass
 // 2) and the twiddle of the real-FFT unpack; the tables hold (cos, tan) pairs.  -52 of 722 vector
 // instructions per frame set, -1.9 % time.  fbank512_kernel uses the same arithmetic.
-template <int NJ, int KIND, int ENERGY, bool BST>
+// DITHER (round 4): Kaldi's per-window dither, N(0, dither^2) added to every sample before the DC removal -
+// the reference's default (dither = 1.0, shennong/processor/base.py:122).  The stream is the one of
+// fbank512_kernel (same key per frame, same generator: bit-identical features from either kernel); the key
+// of a frame comes from a table made once per call (launch_build_frame_noise) and is prefetched with the
+// frame's first-sample index.
+template <int NJ, int KIND, int ENERGY, bool BST, bool DITHER>
 __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512Params p, const BatchArgs b,
                                                                   float* __restrict__ out,
                                                                   double* __restrict__ energy_out) {
@@ -112,6 +117,10 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
     const int64_t gi = s * 4 + q;
     return b.frame_start[gi < last_frame ? gi : last_frame];
   };
+  auto noise_of = [&](int64_t s) -> unsigned long long {  // ... and its noise key
+    const int64_t gi = s * 4 + q;
+    return DITHER ? b.frame_noise[gi < last_frame ? gi : last_frame] : 0ull;
+  };
   // Software pipeline over frame sets: one dword (two int16 samples) per element, requested a whole
   // iteration before it is converted; the start offset of the set after that arrives meanwhile.
   typedef int __attribute__((aligned(2))) int_a2;
@@ -128,6 +137,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
   float4 w512q[4];
   read_quads<4>(t_tw512 + l * 10, w512q);
   int64_t start_next = start_of(set + set_stride);
+  unsigned long long noise_cur = noise_of(set), noise_next = noise_of(set + set_stride);
   request(start_of(set));
   if (BST) {
     // one dropped store behind the first request: the loop is entered with the same sequence of vector-
@@ -145,16 +155,32 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
     // ---- A: DC removal, pre-emphasis, window (Kaldi's ProcessWindow order) -------------------------
     float xe[NJ], xo[NJ];
     // the samples are integers whose sums stay below 2^24: the float32 sum Kaldi forms is exact in any
-    // order, so v_dot2c_i32_i16 adds both halves of a dword in one instruction
+    // order, so v_dot2c_i32_i16 adds both halves of a dword in one instruction (not with dither: the sum
+    // of the dithered samples is formed like fbank512_kernel forms it)
     int part_i = 0;
+    float part = 0.0f;
+    unsigned dkey_lo = 0, dkey_hi = 0;
+    if (DITHER) {
+      const unsigned long long k = noise_cur ^ p.seed;
+      dkey_lo = fmix32(static_cast<unsigned>(k));
+      dkey_hi = fmix32(static_cast<unsigned>(k >> 32) ^ dkey_lo);
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       xe[j] = static_cast<float>(static_cast<short>(raw[j] & 0xffff));
       xo[j] = static_cast<float>(raw[j] >> 16);
-      const int both = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, raw[j]), short2v{1, 1}, part_i, false);
-      part_i = in_window(j) ? both : part_i;
+      if (DITHER) {
+        const float2 nz = gauss_pair(dkey_lo, dkey_hi, static_cast<unsigned>(l + 16 * j));
+        xe[j] += p.dither * nz.x;
+        xo[j] += p.dither * nz.y;
+        const float s2 = xe[j] + xo[j];
+        part += in_window(j) ? s2 : 0.0f;
+      } else {
+        const int both = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, raw[j]), short2v{1, 1}, part_i, false);
+        part_i = in_window(j) ? both : part_i;
+      }
     }
-    float part = static_cast<float>(part_i);
+    if (!DITHER) part = static_cast<float>(part_i);
     // the conversions are the last readers of `raw`: pin them so that the loads of the next set reuse the
     // same registers
 #pragma unroll
@@ -162,6 +188,10 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
     asm volatile("" : "+v"(part) : : "memory");
     request(start_next);  // (the final request of a wave re-reads the last frame)
     start_next = start_of(set + 2 * set_stride);
+    if (DITHER) {
+      noise_cur = noise_next;
+      noise_next = noise_of(set + 2 * set_stride);
+    }
 
     float neg_mean = 0.0f;
     if (p.remove_dc) {
@@ -169,6 +199,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
       // sum / N correctly rounded without the IEEE division sequence (see fbank512_kernel)
       const float qv = sum * inv_win_len;
       neg_mean = -__builtin_fmaf(__builtin_fmaf(-qv, win_len_f, sum), inv_win_len, qv);
+      if (DITHER) neg_mean = -sum / win_len_f;  // (not an integer sum: the division, like fbank512_kernel)
     }
     float2 z[16];
     float e_raw = 0.0f, e_post = 0.0f;
@@ -442,13 +473,15 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
-// Flat batches (no per-utterance warps, no fused deltas), snip_edges, no dither, vector-pipe DCT.
+// Flat batches (no per-utterance warps, no fused deltas), snip_edges, vector-pipe DCT; dither when the caller
+// made the frames' key table (capi.hip).
 // SNF_FBANK512_OLD=1 keeps every batch on fbank512_kernel (A/B runs: tools/ab_fbank512.cpp, bench.py).
 bool fbank512b_eligible(const Fast512Params& p, const BatchArgs& b) {
   if (const char* knob = getenv("SNF_FBANK512_OLD"))
     if (knob[0] == '1') return false;
   if (p.dual || p.fused_delta || b.blk_utt != nullptr) return false;
-  if (!p.snip_edges || p.dither != 0.0f || p.dct_mfma) return false;
+  if (!p.snip_edges || p.dct_mfma) return false;
+  if (p.dither != 0.0f && b.frame_noise == nullptr) return false;  // (no key table: fbank512_kernel draws its own)
   // (the spectrogram's four 16-byte row stores per lane measured 7 % slower here than on fbank512_kernel)
   if (p.kind != SNF_KIND_FBANK && p.kind != SNF_KIND_MFCC && p.kind != SNF_KIND_PLP) return false;
   return static_cast<size_t>((p.table_floats * 4 + 255) & ~255) + kWaves * 4 * kTileBytes <= 160 * 1024;
@@ -456,13 +489,13 @@ bool fbank512b_eligible(const Fast512Params& p, const BatchArgs& b) {
 
 namespace {
 
-template <int NJ, int KIND, int ENERGY, bool BST>
-int launch_one(const Fast512Params& q, const BatchArgs& b, float* out, double* energy_out, hipStream_t stream) {
+template <int NJ, int KIND, int ENERGY, bool BST, bool DITHER>
+int launch_dither(const Fast512Params& q, const BatchArgs& b, float* out, double* energy_out, hipStream_t stream) {
   const size_t lds = static_cast<size_t>((q.table_floats * 4 + 255) & ~255) + kWaves * 4 * kTileBytes;
   const int64_t n_sets = (b.total_frames + 3) / 4;
   int64_t blocks = (n_sets + kWaves - 1) / kWaves;
   if (blocks > 256) blocks = 256;  // one resident workgroup per CU, grid-stride over the frame sets
-  auto kern = fbank512b_kernel<NJ, KIND, ENERGY, BST>;
+  auto kern = fbank512b_kernel<NJ, KIND, ENERGY, BST, DITHER>;
   if (lds > 64 * 1024)
     SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
@@ -470,6 +503,12 @@ int launch_one(const Fast512Params& q, const BatchArgs& b, float* out, double* e
                      energy_out);
   SNF_HIP_CHECK(hipGetLastError());
   return SNF_OK;
+}
+
+template <int NJ, int KIND, int ENERGY, bool BST>
+int launch_one(const Fast512Params& q, const BatchArgs& b, float* out, double* energy_out, hipStream_t stream) {
+  if (q.dither != 0.0f) return launch_dither<NJ, KIND, ENERGY, BST, true>(q, b, out, energy_out, stream);
+  return launch_dither<NJ, KIND, ENERGY, BST, false>(q, b, out, energy_out, stream);
 }
 
 template <int NJ, int KIND>
@@ -498,6 +537,23 @@ int launch_kind(const Fast512Params& q, const BatchArgs& b, float* out, double* 
 }
 
 }  // namespace
+
+namespace {
+__global__ void build_frame_noise_kernel(const BatchArgs b, uint64_t* __restrict__ keys) {
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= b.total_frames) return;
+  const int64_t u = b.frame_utt[g];
+  keys[g] = wave_noise_id(b.wave, b.sample_offsets, u, g - b.frame_offsets[u]);
+}
+}  // namespace
+
+int launch_build_frame_noise(const BatchArgs& b, uint64_t* d_keys, hipStream_t stream) {
+  if (b.total_frames <= 0) return SNF_OK;
+  hipLaunchKernelGGL(build_frame_noise_kernel, dim3(static_cast<unsigned>((b.total_frames + 255) / 256)), dim3(256),
+                     0, stream, b, d_keys);
+  SNF_HIP_CHECK(hipGetLastError());
+  return SNF_OK;
+}
 
 int launch_fbank512b(const Fast512Params& p, const BatchArgs& b, float* out, int out_cols, double* energy_out,
                      hipStream_t stream) {

@@ -128,6 +128,7 @@ struct BatchArgs {
   const int32_t* blk_utt;         // [n_blocks] fast path with VTLN warps: utterance of every workgroup
   const int32_t* blk_set0;        // [n_blocks] ... and its first frame set inside that utterance
   const uint8_t* utt_mask;        // [n_utts] generic kernel: when set, only the utterances marked 1 are computed
+  const uint64_t* frame_noise;    // [total_frames] fbank512b_kernel with dither: wave_noise_id of every frame
   const PairRec* pair_tab;        // [n_pairs] fbank256x2_kernel only
   int64_t n_pairs;
   int64_t n_blocks;
@@ -238,7 +239,10 @@ int launch_build_frame_start(const int64_t* d_frame_offsets, const int64_t* d_sa
                              int32_t* d_frame_utt, hipStream_t stream);
 int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int out_cols,
                     double* energy_out, hipStream_t stream);
-// the occupancy-first form of the same kernel (kernels_fbank512b.hip): flat, undithered, snip_edges batches
+// per-call table of the frames' noise keys (wave_noise_id: the dither of fbank512b_kernel; the keys hold
+// the first two samples of the utterance, so they are rebuilt with every batch)
+int launch_build_frame_noise(const BatchArgs& b, uint64_t* d_keys, hipStream_t stream);
+// the occupancy-first form of the same kernel (kernels_fbank512b.hip): flat, snip_edges batches
 bool fbank512b_eligible(const Fast512Params& p, const BatchArgs& b);
 int launch_fbank512b(const Fast512Params& p, const BatchArgs& b, float* out, int out_cols,
                      double* energy_out, hipStream_t stream);

@@ -1171,3 +1171,34 @@ def test_mfcc_dct_mfma(gpu, audio, wave, monkeypatch, opts):
     shipped = MfccProcessor(dither=0, **opts).process(a)
     assert_close(got.data, shipped.data, what='mfcc dct mfma vs vector form', family='mfcc')
     _backend.clear_plans()
+
+
+@pytest.mark.parametrize('cls', [FilterbankProcessor, MfccProcessor, PlpProcessor])
+def test_dither_is_the_same_stream_on_both_512_point_kernels(gpu, monkeypatch, cls):
+    """fbank512b_kernel with dither (round 4: keys from a per-call table) draws exactly the noise
+    fbank512_kernel draws (keys computed in the kernel): same call id -> the same bits, so which of the two
+    kernels an utterance lands on (flat batch / batch with VTLN warps) cannot be seen in its features.
+    Reference default: dither = 1.0, shennong/processor/base.py:122"""
+    waves = synth.ragged_utterances(4711, 37, min_s=0.1, max_s=0.7)
+    soff = np.zeros(len(waves) + 1, dtype=np.int64)
+    np.cumsum([w.shape[0] for w in waves], out=soff[1:])
+    opts = cls(dither=1.0)._build_options()
+
+    def run(call):
+        plan = _backend.Plan(opts)
+        foff = np.zeros(len(waves) + 1, dtype=np.int64)
+        np.cumsum([plan.num_frames(w.shape[0]) for w in waves], out=foff[1:])
+        d_wave = _backend.upload_rows(waves, np.int16)
+        d_out = _backend.DeviceBuffer(int(foff[-1]) * plan.ndims * 4)
+        plan.run_device(d_wave.ptr, soff, foff, d_out.ptr, noise_call=call)
+        out = np.empty((int(foff[-1]), plan.ndims), dtype=np.float32)
+        d_out.download(out)
+        return out, plan.kernel_name(1)
+    new, kernel_new = run(7)
+    again, _ = run(7)
+    other, _ = run(8)
+    monkeypatch.setenv('SNF_FBANK512_OLD', '1')
+    old, kernel_old = run(7)
+    assert (kernel_new, kernel_old) == ('fbank512b_kernel', 'fbank512_kernel')
+    assert np.array_equal(new, old) and np.array_equal(new, again)
+    assert not np.array_equal(new, other) and np.isfinite(new).all()
