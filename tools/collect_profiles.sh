@@ -13,7 +13,18 @@ timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp
   python $root/bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-extra > $out/bench_profiled.json 2> /dev/null
 cp $(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1) $out/bench_fbank40_rocprofv3_kernel_stats.csv
 # the same trace restricted to the 20 timed launches of each kernel (settle and warm-up launches dropped)
-python $root/tools/timed_launch_stats.py $(find /tmp/prof_stats -name '*kernel_trace.csv' | head -1) 20 > $out/bench_fbank40_timed_launches_stats.csv
+# (20 steps x 12 passes per step = 240 timed launches per leg since round 4)
+python $root/tools/timed_launch_stats.py $(find /tmp/prof_stats -name '*kernel_trace.csv' | head -1) 240 > $out/bench_fbank40_timed_launches_stats.csv
+# the same bench as the driver launches it for N > 1 (torch.distributed.run as a process spawner, one rank):
+# RcclComm.from_env(), the barrier / max all-reduce and the gather of the Features block over RCCL
+timeout -s KILL 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 \
+  --master-port 29533 $root/bench.py --gpus 1 --steps 20 --warmup 3 --cpu-sample 0 --no-extra \
+  > $out/bench_torchrun_1rank.json 2> $out/bench_torchrun_1rank.err
+# parity log of the whole GPU suite (tests/conftest.py::assert_close) -> per-family worst errors and the
+# fraction of elements inside the pure 1e-4 relative tolerance
+rm -f /tmp/parity_log.txt
+(cd $root && SNF_PARITY_LOG=/tmp/parity_log.txt timeout -s KILL 600 python -m pytest tests -m gpu -q -x > $out/pytest_gpu.log 2>&1)
+python $root/tools/parity_errors.py /tmp/parity_log.txt > $out/parity_errors.txt 2>&1
 rm -rf /tmp/prof_pitch
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pitch -- \
   python $root/tools/profile_pitch.py 4000 > $out/pitch_plp_run.txt 2> /dev/null
@@ -50,7 +61,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   i=$((i+1)); rm -rf /tmp/prof_pmc_$i
   timeout -s KILL 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/prof_pmc_$i -- \
-    python $root/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-extra > /dev/null 2>&1
+    python $root/bench.py --steps 3 --warmup 1 --inner 1 --cpu-sample 0 --no-extra > /dev/null 2>&1
   f=$(find /tmp/prof_pmc_$i -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && cp $f $out/pmc_group_$i.csv
 done
