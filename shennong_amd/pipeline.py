@@ -327,28 +327,45 @@ def _batches(utterances, max_duration):
         yield batch
 
 
+_BATCH_POOL = None
+
+
+def _batch_pool():
+    """The threads of the batches in flight, made once: a thread keeps its copy stream (``_backend._copy_stream``
+    is per thread) and its staging buffers from one corpus to the next instead of leaking them with a
+    short-lived pool per call.  Eight threads: the most batches `extract_features_streamed` keeps in flight."""
+    global _BATCH_POOL
+    if _BATCH_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _BATCH_POOL = ThreadPoolExecutor(max_workers=8, thread_name_prefix='snf-batch')
+    return _BATCH_POOL
+
+
 def _in_flight(batches, work, depth):
     """``work(b, batch)`` for every batch, results in order, at most `depth` batches started and not yet
     handed over.  With `depth` > 1 the batches run on threads: the staging copy, the transfers and the
-    launches of one (all outside the interpreter lock) overlap the per-utterance bookkeeping of another."""
+    launches of one (all outside the interpreter lock) overlap the per-utterance bookkeeping of another.
+    Closing the generator early (an error in the consumer) cancels what has not started and WAITS for what
+    is running: nothing touches the caller's buffers after it returns."""
     if depth <= 1:
         for b, batch in enumerate(batches):
             yield work(b, batch)
         return
     from collections import deque
-    from concurrent.futures import ThreadPoolExecutor
+    from concurrent.futures import wait
     pending = deque()
-    with ThreadPoolExecutor(max_workers=depth) as pool:
-        try:
-            for b, batch in enumerate(batches):
-                pending.append(pool.submit(work, b, batch))
-                if len(pending) >= depth:
-                    yield pending.popleft().result()
-            while pending:
+    pool = _batch_pool()
+    try:
+        for b, batch in enumerate(batches):
+            pending.append(pool.submit(work, b, batch))
+            if len(pending) >= depth:
                 yield pending.popleft().result()
-        finally:
-            for future in pending:
-                future.cancel()
+        while pending:
+            yield pending.popleft().result()
+    finally:
+        for future in pending:
+            future.cancel()
+        wait(list(pending))
 
 
 def extract_features_streamed(configuration, utterances, sink, warps=None,
@@ -397,6 +414,9 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
 
     hook = None
     resident = _ResidentWaves(resident_bytes) if by_speaker and resident_bytes > 0 else None
+    running = None   # the generator of the batches in flight: closed (its threads joined) before the audio
+                     # buffers are released, whatever ends the pass - the end of the corpus, an error in a
+                     # batch, an exception from `sink`
     try:
         if by_speaker:
             total = {}
@@ -405,12 +425,14 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
                 return _extract_features(config, Utterances(batch), sub(batch), log, stats_only=True,
                                          resident=resident, batch_id=b)
 
-            for speakers, per_utt in _in_flight(_batches(utts, max_batch_duration), first_pass, depth):
+            running = _in_flight(_batches(utts, max_batch_duration), first_pass, depth)
+            for speakers, per_utt in running:
                 for speaker, stats in zip(speakers, per_utt):
                     if speaker in total:
                         total[speaker] += stats
                     else:
                         total[speaker] = stats.copy()
+            running = None
             if stats_reduce is not None:
                 names = list(total)
                 reduced = stats_reduce(names, np.stack([total[k] for k in names]) if names
@@ -425,7 +447,7 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
                                      resident=resident, batch_id=b)
 
         count = 0
-        batches = _in_flight(_batches(utts, max_batch_duration), second_pass, depth)
+        batches = running = _in_flight(_batches(utts, max_batch_duration), second_pass, depth)
         while True:
             # (nothing of batch k is referenced here while batch k + 1 is made: its page-locked result block
             # is back in the pool by then, see _backend.result_array)
@@ -437,6 +459,8 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
             del features
         return count
     finally:
+        if running is not None:
+            running.close()   # (GeneratorExit inside _in_flight: pending batches cancelled, its pool joined)
         if resident is not None:
             resident.clear()
 
@@ -506,10 +530,12 @@ class _ResidentWaves:
             return item
 
     def clear(self):
-        for d_wave, _ in self._items.values():
+        with self._lock:   # (a batch thread that is still running may offer / take meanwhile)
+            items = list(self._items.values())
+            self._items.clear()
+            self.held = 0
+        for d_wave, _ in items:
             d_wave.free(synced=True)
-        self._items.clear()
-        self.held = 0
 
 
 def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=None,

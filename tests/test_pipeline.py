@@ -454,7 +454,7 @@ def test_resident_waves_budget():
         def __init__(self, nbytes):
             self.nbytes, self.freed = nbytes, 0
 
-        def free(self):
+        def free(self, synced=False):
             self.freed += 1
 
     keep = pipeline._ResidentWaves(100)
@@ -528,6 +528,34 @@ def test_batches_in_flight(depth):
     assert list(pipeline._in_flight(iter([]), work, depth)) == []
     with pytest.raises(ValueError, match='batch 2'):
         list(pipeline._in_flight(iter(['a', 'b', 'bad', 'c', 'bad']), work, depth))
+
+
+def test_batches_in_flight_closed_early():
+    """a consumer that stops early (its sink raised): what has not started is cancelled, what is running has
+    FINISHED when close() returns - the audio buffers behind the batches may then be released"""
+    import threading
+    import time
+    lock = threading.Lock()
+    state = {'running': 0, 'done': []}
+
+    def work(b, batch):
+        with lock:
+            state['running'] += 1
+        time.sleep(0.05)
+        with lock:
+            state['running'] -= 1
+            state['done'].append(b)
+        return b
+
+    gen = pipeline._in_flight(iter(range(12)), work, 3)
+    assert next(gen) == 0
+    gen.close()
+    with lock:
+        assert state['running'] == 0, state
+        assert len(state['done']) < 12   # (the tail of the corpus never ran)
+    done = list(state['done'])
+    time.sleep(0.12)
+    assert state['done'] == done        # (and nothing starts afterwards)
 
 
 @pytest.mark.gpu
