@@ -195,10 +195,22 @@ __global__ void pitch_stats_kernel(const PitchDevTables t, const PitchBatch b,
 
 namespace {
 
+// Ordering point between the phases of ONE wave over LDS that only this wave touches (every wave of the
+// Viterbi / NCCF kernels owns its slice; the one shared table is written before the __syncthreads of the
+// prologue): the LDS executes a wave's instructions in issue order, so only the compiler must keep the
+// accesses in program order - wavefront-scope fences emit no instruction, where workgroup scope costs an
+// s_waitcnt lgkmcnt(0) (the wave sits until every store is acknowledged) at each of the ~12 points per frame
+// (round 4; SNF_PITCH_WG_FENCE restores the old form at build time for A/B runs)
 __device__ __forceinline__ void wave_sync() {
+#ifdef SNF_PITCH_WG_FENCE
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 }
 
 // Cross-lane steps on the VALU (DPP + v_readlane); __shfl_xor lowers to ds_bpermute_b32, an LDS round
