@@ -16,8 +16,13 @@
  * Frames/boundaries literals of test/test_frames.py, the energy identity of
  * test/processor/test_energy.py:36-44, the exp(50) known answer of test_plp.py:77-81, the htk_compat
  * rules of test_mfcc.py:100-111 / test_plp.py:50-61, RASTA and lpc2cepstrum against fixtures
- * generated from the reference's runnable numpy code (tests/golden/make_golden.py), and an
- * independent float64 numpy restatement (oracle/spec_f64.py).
+ * generated from the reference's runnable numpy code (tests/golden/make_golden.py), an independent
+ * float64 numpy restatement of EVERY family (oracle/spec_f64.py: fbank / MFCC / spectrogram / pitch,
+ * and since round 4 PLP + RASTA, VTLN-warped banks, delta, CMVN, sliding CMVN, pitch post-processing;
+ * tests/test_spec_f64.py, profiles/r04_f64_report.txt), and the PLP recipe against the reference's OWN
+ * control flow (plp.py:171-260, :510-626) run over numpy stand-ins of the pykaldi primitives
+ * (tests/golden/make_golden_plp.py: glue pinned, primitives are stand-ins).  The float32 round-off of
+ * Kaldi's own kernels remains unpinned.
  *
  * Each function cites the reference file:line it follows, or [KALDI-UPSTREAM] + the Kaldi source
  * file when the algorithm lives in Kaldi (restated from the published sources).
