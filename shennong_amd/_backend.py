@@ -622,11 +622,11 @@ _COPY_THREADS = int(os.environ.get('SNF_COPY_THREADS', '4'))  # (8 / 16 threads 
 
 
 def upload_rows(mats, dtype, device=None):
-    """`mats` concatenated along axis 0 in a new DeviceBuffer.  Large batches are cut in `_COPY_THREADS`
-    runs of whole rows: each thread gathers its run in its part of one page-locked staging buffer and
-    sends it (numpy's copy loops and the HIP call both release the interpreter lock), so the host-side
-    gather of one run overlaps the transfer of another - a single thread gathers at ~20 GB/s, less than
-    half of what the link takes."""
+    """`mats` concatenated along axis 0 in a new DeviceBuffer.  Large batches are cut in 4 pieces of whole
+    rows per copy thread: a thread gathers a piece into its part of one page-locked staging buffer, starts
+    the piece's copy on its own stream and gathers the next one meanwhile (numpy's copy loops and the HIP
+    calls release the interpreter lock) - a single thread gathers at ~20 GB/s, less than half of what the
+    link takes, four reach the host's memory bandwidth (46 GB/s)."""
     global _COPY_POOL
     dtype = np.dtype(dtype)
     mats = [np.asarray(m, dtype=dtype) for m in mats]
@@ -652,23 +652,29 @@ def upload_rows(mats, dtype, device=None):
             with _LOCK:
                 if _COPY_POOL is None:
                     _COPY_POOL = ThreadPoolExecutor(max_workers=_COPY_THREADS, thread_name_prefix='snf-copy')
-        cuts = [int(np.searchsorted(rows, rows[-1] * k // _COPY_THREADS)) for k in range(_COPY_THREADS + 1)]
+        # 4 pieces per thread: a thread gathers a piece, starts its copy on the thread's own stream and gathers
+        # the next one meanwhile (measured on 115 MB: 3.7 ms against 4.7 for one gather + one blocking copy per
+        # thread; the gather alone takes 2.5 ms with 4 threads - host memory bandwidth -, the copy alone 2.3)
+        pieces = 4 * _COPY_THREADS
+        cuts = [int(np.searchsorted(rows, rows[-1] * k // pieces)) for k in range(pieces + 1)]
         cuts[0], cuts[-1] = 0, len(mats)
         base = staged.ctypes.data
 
-        def run(k):
-            a, b = cuts[k], cuts[k + 1]
-            if b <= a:
-                return
-            part = staged[rows[a]:rows[b]]
-            np.concatenate(mats[a:b], axis=0, out=part)
+        def run(w):
             bind_device(buf.device)
-            check(lib().snf_memcpy_h2d(C.c_void_p(buf.ptr + int(rows[a]) * row_bytes),
-                                       C.c_void_p(base + int(rows[a]) * row_bytes),
-                                       int(rows[b] - rows[a]) * row_bytes))
+            stream = _copy_stream(buf.device)
+            for k in range(w, pieces, _COPY_THREADS):
+                a, b = cuts[k], cuts[k + 1]
+                if b <= a:
+                    continue
+                np.concatenate(mats[a:b], axis=0, out=staged[rows[a]:rows[b]])
+                check(lib().snf_memcpy_h2d_async(C.c_void_p(buf.ptr + int(rows[a]) * row_bytes),
+                                                 C.c_void_p(base + int(rows[a]) * row_bytes),
+                                                 int(rows[b] - rows[a]) * row_bytes, C.c_void_p(stream)))
+            check(lib().snf_stream_synchronize(C.c_void_p(stream)))
 
         try:
-            for future in [_COPY_POOL.submit(run, k) for k in range(_COPY_THREADS)]:
+            for future in [_COPY_POOL.submit(run, w) for w in range(_COPY_THREADS)]:
                 future.result()
         except BaseException:
             buf.free()
