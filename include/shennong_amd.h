@@ -314,7 +314,7 @@ int snf_concat_columns_device(int device_id, const float* d_a, int32_t cols_a,
 /*
  * Random terms (dither, reference processor/base.py:122; delta-pitch noise, pitch_kaldi.py:321-327).  A
  * draw is keyed by (options seed, noise call, the frame's index inside its utterance, the utterance's
- * length and first samples): never by the frame's position in the batch.  The noise call is the plan's own
+ * length and a hash of 64 samples spread over it): never by the frame's position in the batch.  The noise call is the plan's own
  * count of calls that draw - every call a new stream, like the reference's global rand() - unless the
  * calling thread names it for its NEXT such call with snf_set_noise_call(call != 0): a caller that must see
  * the same noise for the same utterance in two passes over a corpus (streamed CMVN by speaker: statistics

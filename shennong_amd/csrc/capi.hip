@@ -91,7 +91,7 @@ struct snf_plan {
   // ... and its per-warp-factor tables (VTLN): one blob per warp id, `fp_warp.table_stride` apart
   std::vector<float> h_window, h_dct, h_lifter;
   Fast512Params fp_warp{};
-  DevBuf d_fast_warp_tables, s_blk_utt, s_blk_set0, s_noise;
+  DevBuf d_fast_warp_tables, s_blk_utt, s_blk_set0, s_noise, s_unoise;
   size_t fast_warps_built = 0;   // number of warp ids covered by d_fast_warp_tables
   bool fast_warps_ok = true;     // false: some warp's banks do not fit the fast kernel
   // register-resident 2048-point path (frames that pad to 2048 or 1024 samples)
@@ -962,6 +962,12 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
   b.utt_warp = any_warp ? plan->s_uwarp.as<int32_t>() : nullptr;
   b.n_utts = n_utts;
   b.total_frames = total_frames;
+  if (plan->mp.dither != 0.0f) {
+    // what the dither streams know about an utterance: a hash of 64 of its samples (wave_noise_id)
+    if ((rc = plan->s_unoise.ensure(sizeof(uint32_t) * static_cast<size_t>(n_utts > 0 ? n_utts : 1)))) return rc;
+    if ((rc = launch_build_utt_noise(b, plan->s_unoise.as<uint32_t>(), s))) return rc;
+    b.utt_noise = plan->s_unoise.as<uint32_t>();
+  }
 
   if (plan->kind == SNF_KIND_PLP) {
     const int nb = plan->o.mel.num_bins;
@@ -1072,8 +1078,8 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
   if (plan->mp.dither != 0.0f) {
     const unsigned long long stream_key = plan->o.seed + 0x9E3779B97F4A7C15ull * (named_call ? named_call : ++plan->noise_calls);
     plan->mp.seed = plan->fp.seed = plan->fp_warp.seed = stream_key;
-    // fbank512b_kernel reads the noise key of a frame from a table (the keys hold the utterance's first two
-    // samples: made with every batch; 8 bytes per frame)
+    // fbank512b_kernel reads the noise key of a frame from a table (the keys hold the utterance's noise
+    // word: made with every batch; 8 bytes per frame)
     b.frame_noise = nullptr;
     if (use_fast && !any_warp && !fused && !plan->fp.dual && b.frame_utt != nullptr && plan->mp.snip_edges &&
         !getenv("SNF_FBANK512_OLD")) {

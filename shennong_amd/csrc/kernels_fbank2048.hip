@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
     }
     if (DITHER) {  // Kaldi dithers before the DC removal
       const unsigned long long k =
-          wave_noise_id(b.wave, b.sample_offsets, u, g - b.frame_offsets[u]) ^ p.seed;  // (batch-independent)
+          wave_noise_id(b, u, g - b.frame_offsets[u]) ^ p.seed;  // (batch-independent)
       const unsigned dkey_lo = fmix32(static_cast<unsigned>(k));
       const unsigned dkey_hi = fmix32(static_cast<unsigned>(k >> 32) ^ dkey_lo);
 #pragma unroll

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
       // (keyed by the frame's place in its utterance, not in the batch: snf_internal.h)
       const int64_t du = PERUTT ? pu_u : static_cast<int64_t>(b.frame_utt[g < b.total_frames ? g : last_frame]);
       const unsigned long long k =
-          wave_noise_id(b.wave, b.sample_offsets, du, PERUTT ? gl : g - b.frame_offsets[du]) ^ p.seed;
+          wave_noise_id(b, du, PERUTT ? gl : g - b.frame_offsets[du]) ^ p.seed;
       dkey_lo = fmix32(static_cast<unsigned>(k));
       dkey_hi = fmix32(static_cast<unsigned>(k >> 32) ^ dkey_lo);
     }
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const unsigned long long k =
-            wave_noise_id(b.wave, b.sample_offsets, du, ga + s2 - b.frame_offsets[du]) ^ p.seed;
+            wave_noise_id(b, du, ga + s2 - b.frame_offsets[du]) ^ p.seed;
         dk[2 * s2] = fmix32(static_cast<unsigned>(k));
         dk[2 * s2 + 1] = fmix32(static_cast<unsigned>(k >> 32) ^ dk[2 * s2]);
       }

@@ -543,9 +543,38 @@ __global__ void build_frame_noise_kernel(const BatchArgs b, uint64_t* __restrict
   const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (g >= b.total_frames) return;
   const int64_t u = b.frame_utt[g];
-  keys[g] = wave_noise_id(b.wave, b.sample_offsets, u, g - b.frame_offsets[u]);
+  keys[g] = wave_noise_id(b, u, g - b.frame_offsets[u]);
 }
 }  // namespace
+
+namespace {
+__global__ void build_utt_noise_kernel(const BatchArgs b, uint32_t* __restrict__ words) {
+  const int64_t u = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (u >= b.n_utts) return;
+  const int64_t s0 = b.sample_offsets[u], n = b.sample_offsets[u + 1] - s0;
+  uint32_t h = 0x811C9DC5u ^ static_cast<uint32_t>(n);
+  const int taps = n < 64 ? static_cast<int>(n) : 64;
+  for (int k = 0; k < taps; ++k) {
+    // sample k of `taps`, the first and the last included; murmur-style mixing of one sample per step
+    const int64_t i = taps > 1 ? (n - 1) * k / (taps - 1) : 0;
+    uint32_t v = static_cast<uint16_t>(b.wave[s0 + i]);
+    v *= 0xCC9E2D51u;
+    v = (v << 15) | (v >> 17);
+    v *= 0x1B873593u;
+    h ^= v;
+    h = ((h << 13) | (h >> 19)) * 5u + 0xE6546B64u;
+  }
+  words[u] = fmix32(h);
+}
+}  // namespace
+
+int launch_build_utt_noise(const BatchArgs& b, uint32_t* d_words, hipStream_t stream) {
+  if (b.n_utts <= 0) return SNF_OK;
+  hipLaunchKernelGGL(build_utt_noise_kernel, dim3(static_cast<unsigned>((b.n_utts + 255) / 256)), dim3(256), 0,
+                     stream, b, d_words);
+  SNF_HIP_CHECK(hipGetLastError());
+  return SNF_OK;
+}
 
 int launch_build_frame_noise(const BatchArgs& b, uint64_t* d_keys, hipStream_t stream) {
   if (b.total_frames <= 0) return SNF_OK;

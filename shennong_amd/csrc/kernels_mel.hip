@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kWaves * 64, 8) void mel_features_generic_kernel(
                               : f * p.win_shift + p.win_shift / 2 - p.win_len / 2;
     const int16_t* __restrict__ w = b.wave + s0;
 
-    const uint64_t noise_id = p.dither != 0.0f ? wave_noise_id(b.wave, b.sample_offsets, u, f) : 0;
+    const uint64_t noise_id = p.dither != 0.0f ? wave_noise_id(b, u, f) : 0;
     // ---- ExtractWindow: copy L samples, reflecting at the utterance edges ------------------------
     float part = 0.0f;
     for (int i = lane; i < L; i += 64) {

@@ -129,6 +129,7 @@ struct BatchArgs {
   const int32_t* blk_set0;        // [n_blocks] ... and its first frame set inside that utterance
   const uint8_t* utt_mask;        // [n_utts] generic kernel: when set, only the utterances marked 1 are computed
   const uint64_t* frame_noise;    // [total_frames] fbank512b_kernel with dither: wave_noise_id of every frame
+  const uint32_t* utt_noise;      // [n_utts] dither: a hash of 64 samples spread over every utterance (per call)
   const PairRec* pair_tab;        // [n_pairs] fbank256x2_kernel only
   int64_t n_pairs;
   int64_t n_blocks;
@@ -137,8 +138,8 @@ struct BatchArgs {
 };
 
 // The noise stream of a frame (dither, delta-pitch noise) is keyed by what the frame IS, not by where it
-// sits in the batch: its index inside its utterance, the utterance's length and the bits of its first
-// element (two samples / the first pitch value).  An utterance therefore draws the same noise alone and in
+// sits in the batch: its index inside its utterance, the utterance's length and 32 bits that stand for the
+// utterance (a hash of 64 samples spread over the waveform / the bits of the first pitch value).  An utterance therefore draws the same noise alone and in
 // any batch of the same call count (the per-call stream key is in `seed`), and the utterances of a batch draw
 // different noise.  The reference draws from C rand(): no stream is "the" Kaldi one.
 #if defined(__HIPCC__)
@@ -149,14 +150,13 @@ __device__ __forceinline__ uint64_t frame_noise_id(int64_t local_frame, int64_t 
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
   return x ^ (x >> 31);
 }
-// ... of the frame `local_frame` of utterance `u` of a waveform batch
-__device__ __forceinline__ uint64_t wave_noise_id(const int16_t* __restrict__ wave,
-                                                  const int64_t* __restrict__ sample_offsets, int64_t u,
-                                                  int64_t local_frame) {
-  const int64_t s0 = sample_offsets[u], n = sample_offsets[u + 1] - s0;
-  uint32_t first = n > 0 ? static_cast<uint16_t>(wave[s0]) : 0u;
-  if (n > 1) first |= static_cast<uint32_t>(static_cast<uint16_t>(wave[s0 + 1])) << 16;
-  return frame_noise_id(local_frame, n, first);
+// ... of the frame `local_frame` of utterance `u` of a waveform batch.  What stands for "the utterance" is a
+// 32-bit hash of 64 of its samples, spread evenly from its first to its last (launch_build_utt_noise, once
+// per call; round 4 - the first two samples alone, as before, made every equal-length utterance that begins
+// with digital silence draw the same dither: ADVICE r03).
+__device__ __forceinline__ uint64_t wave_noise_id(const BatchArgs& b, int64_t u, int64_t local_frame) {
+  const int64_t n = b.sample_offsets[u + 1] - b.sample_offsets[u];
+  return frame_noise_id(local_frame, n, b.utt_noise[u]);
 }
 #endif
 
@@ -242,6 +242,8 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
 // per-call table of the frames' noise keys (wave_noise_id: the dither of fbank512b_kernel; the keys hold
 // the first two samples of the utterance, so they are rebuilt with every batch)
 int launch_build_frame_noise(const BatchArgs& b, uint64_t* d_keys, hipStream_t stream);
+// per-call table of the utterances' noise words (every dithering kernel reads it through wave_noise_id)
+int launch_build_utt_noise(const BatchArgs& b, uint32_t* d_words, hipStream_t stream);
 // the occupancy-first form of the same kernel (kernels_fbank512b.hip): flat, snip_edges batches
 bool fbank512b_eligible(const Fast512Params& p, const BatchArgs& b);
 int launch_fbank512b(const Fast512Params& p, const BatchArgs& b, float* out, int out_cols,

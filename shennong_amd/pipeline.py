@@ -469,7 +469,7 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
 # (snf_set_noise_call): the features of an utterance are a function of the configuration and the utterance
 # alone - the same in the statistics pass and the apply pass of the streamed pipeline, in any batch split,
 # in every run (the reference, whose dither comes from Kaldi's global rand(), has none of these).
-_NOISE_CALL = 1
+_NOISE_CALL = int(os.environ.get('SNF_NOISE_CALL', '1'))   # (another run of the same corpus with other noise: export another number)
 
 
 class _Meta:

@@ -1202,3 +1202,30 @@ def test_dither_is_the_same_stream_on_both_512_point_kernels(gpu, monkeypatch, c
     assert (kernel_new, kernel_old) == ('fbank512b_kernel', 'fbank512_kernel')
     assert np.array_equal(new, old) and np.array_equal(new, again)
     assert not np.array_equal(new, other) and np.isfinite(new).all()
+
+
+@pytest.mark.parametrize('cls, sample_rate', [(FilterbankProcessor, 16000), (MfccProcessor, 8000),
+                                              (FilterbankProcessor, 44100)])
+def test_dither_differs_between_utterances_that_start_alike(gpu, cls, sample_rate):
+    """the dither stream of an utterance used to be keyed by its length and its first two samples
+    only, so equal-length utterances that begin with digital silence drew the same noise - bit-identical
+    leading frames across a corpus of fixed-length segments.  The key now holds a hash of 64 samples spread
+    over the waveform: same length, same first samples, different content -> different dither from frame 0;
+    identical utterances still draw identical noise inside one call (features are a function of the utterance)"""
+    n = sample_rate
+    lead = sample_rate // 4                      # a quarter of a second of digital silence
+    a = np.zeros(n, dtype=np.int16)
+    b = np.zeros(n, dtype=np.int16)
+    a[lead:] = synth.utterances(1, 1, n - lead, sample_rate)[0]
+    b[lead:] = synth.utterances(2, 1, n - lead, sample_rate)[0]
+    proc = cls(sample_rate=sample_rate, num_bins=40)    # dither = 1.0, the reference's default
+    fa, fb, fa2 = proc._process_batch([Audio(a, sample_rate), Audio(b, sample_rate), Audio(a.copy(), sample_rate)])
+    silent = int(0.2 * fa.nframes * lead / (n // 4))    # frames that lie wholly inside the silence
+    assert silent >= 4
+    assert not np.array_equal(fa.data[:silent], fb.data[:silent])
+    # on silence the features are pure dither: around the common spectral shape of the noise (the column
+    # means) the two utterances' draws must be uncorrelated, not copies
+    da = fa.data[:silent] - fa.data[:silent].mean(axis=0)
+    db = fb.data[:silent] - fb.data[:silent].mean(axis=0)
+    assert abs(np.corrcoef(da.ravel(), db.ravel())[0, 1]) < 0.35
+    assert np.array_equal(fa.data, fa2.data)
