@@ -101,6 +101,22 @@ __device__ __forceinline__ void read_quads(const void* base, float4 (&dst)[N]) {
 #pragma unroll
   for (int i = 0; i < N; ++i) dst[i] = q[i];
 }
+// The same with volatile accesses: a quad whose first half is never used (a twiddle row that starts with
+// W^0 = 1) is otherwise re-cut by the compiler into 8-byte pieces and merged into ds_read2_b64, which runs at
+// half the bandwidth of ds_read_b128 and, 8-byte aligned, is where the 512-point kernel's bank conflicts
+// came from (round 4); a volatile 16-byte access stays one ds_read_b128 and is still waited for at first use
+template <int N>
+__device__ __forceinline__ void read_quads_whole(const void* base, float4 (&dst)[N]) {
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  // (an explicit LDS pointer: a volatile access through a generic pointer becomes a flat load)
+  typedef const volatile f32x4v __attribute__((address_space(3))) * lds_quad_ptr;
+  lds_quad_ptr q = (lds_quad_ptr)(__builtin_assume_aligned(base, 16));
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const f32x4v v = q[i];
+    dst[i] = make_float4(v.x, v.y, v.z, v.w);
+  }
+}
 // counter-based N(0,1) pair for Kaldi's per-frame dither (statistical stand-in for RandGauss(), which
 // draws from C rand() and is not reproducible): murmur-style 32-bit finalisers + Box-Muller on the
 // hardware log2 / sqrt / sin / cos (v_sin_f32 and v_cos_f32 take revolutions)

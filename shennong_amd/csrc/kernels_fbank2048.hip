@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
     // ---- B: pass 1 (FFT over j), twiddle W1024^(L k1), transpose ---------------------------------------
     fft16(z);
     float4 tw4[8];
-    read_quads<8>(t_tw1, tw4);
+    read_quads_whole<8>(t_tw1, tw4);
     lds_wait();
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1)
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
 #pragma unroll
       for (int a = 0; a < 4; ++a) z[4 * i + a] = base_quad[16 * a + 4 * i];
     float4 tw2q[8];
-    read_quads<8>(t_tw2, tw2q);
+    read_quads_whole<8>(t_tw2, tw2q);
     lds_wait();
     wave_lds_sync();
 #pragma unroll
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
 #pragma unroll
     for (int d = 0; d < 8; ++d) zpart[d] = base_part[(7 - d) * 64];
     float4 twuq[4];
-    read_quads<4>(t_twu, twuq);
+    read_quads_whole<4>(t_twu, twuq);
     lds_wait();
     wave_lds_sync();
     float pk[8], pm[8];
