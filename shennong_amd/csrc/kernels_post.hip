@@ -288,6 +288,10 @@ __global__ __launch_bounds__(64) void plp_tail_small_kernel(const PlpParams p, c
 // 1 + (e - 1/3) ln x.  ~28 vector instructions against ~120 for the correctly-rounded powf, within 1-2 ulp
 // of it.
 __device__ __forceinline__ float pow_third(float x, float e) {
+  // (the hardware log2 takes a subnormal for zero: an energy below 1e-30 - not reachable from int16 audio -
+  // is scaled by 2^96 on the way in and by 2^(-96 e) on the way out; no branch)
+  const bool tiny = x < 1.0e-30f;
+  x *= tiny ? 7.9228162514264338e28f : 1.0f;
   const float l2 = __builtin_amdgcn_logf(x);                    // log2 x
   const float y0 = __builtin_amdgcn_exp2f(l2 * 0.33333334f);
   const float r = x * __builtin_amdgcn_rcpf(y0 * y0 * y0);      // x / y0^3 = 1 + O(1e-6)
@@ -298,6 +302,7 @@ __device__ __forceinline__ float pow_third(float x, float e) {
   float y = __builtin_fmaf(res, __builtin_amdgcn_rcpf(3.0f * sq), y1);
   const float d = static_cast<float>(static_cast<double>(e) - 1.0 / 3.0);
   y = __builtin_fmaf(y * d, l2 * 0.69314718f, y);
+  y *= tiny ? __builtin_amdgcn_exp2f(-96.0f * e) : 1.0f;
   return x > 0.0f ? y : 0.0f;
 }
 
