@@ -330,6 +330,10 @@ constexpr bool kSplitLevel5 = false;  // refine 4 -> 2 -> 1 instead of 4 -> 1: 2
 constexpr bool kTracePrefetch = true; // traceback: touch the backpointer rows of a 64-frame chunk first
 constexpr int kQueueEntries = 128;                // long-window queue of a wave: int4 (state, lo, hi, -)
 constexpr int kQueueFloats = kQueueEntries * 4;
+constexpr int kTeam4Utts = 768;    // batches up to this many utterances: four waves per utterance,
+constexpr int kTeam2Utts = 1280;   // up to this many: two (tools/time_pitch.py: 250 / 500 / 1 000 / 1 500
+                                   // utterances take 3.20 / 3.29 / 3.46 / 3.61 ms with one wave, 2.40 / 2.63 /
+                                   // 3.06 / 3.69 with two, 2.23 / 2.43 / 3.20 / 4.14 with four)
 constexpr int kVitWaves = 8;   // utterances (= wavefronts) per workgroup of the Viterbi kernel
 
 // LDS layout of one frame of an NCCF wave: the window (wl floats), then the NCCF at the integer lags.
@@ -562,6 +566,114 @@ struct VitShared {
   int4* queue;   // [64]           (state, lo, hi) of the long windows of a pass
 };
 
+// ordering point between two levels of the search: one wave owns the whole state space (W == 1: see
+// wave_sync) or a team of W waves shares it (a workgroup barrier)
+template <int W>
+__device__ __forceinline__ void level_sync() {
+  if (W == 1) wave_sync();
+  else __syncthreads();
+}
+
+// Levels 3 - 5 of a Viterbi step (see viterbi_forward), for one wave (W == 1) or a team of W waves per
+// utterance; `queue`: the calling wave's own long-window queue
+template <int W>
+__device__ __forceinline__ void refine_levels(const VitShared& sh, int4* __restrict__ queue, const int S,
+                                              const float factor, const int lane, const int wid) {
+  // Level 3: the states 8, 16, 24, 40, ... (multiples of 8 that are not multiples of 32) between the
+  // backpointers of their two level-2 neighbours; level 4: every other state between the backpointers
+  // of its two neighbours at the multiples of 8.  One lane per state, 64 states per pass, a serial
+  // exact scan of the window (4 candidates in flight); the states whose window is long - a step of the
+  // backpointer function from one attracting state to the next - go to teams of 8 lanes (below).
+  // (Round 2 refined through the strides 16, 8, 4, 2, 1: fewer candidates - 2 350 against 4 000 per
+  // frame - but five levels of setup; measured with the same long-window teams: 9.6 against 8.5 ms.)
+  for (int level = 3; level <= (kSplitLevel5 ? 6 : 5); ++level) {
+    level_sync<W>();
+    // level 3: multiples of 8 that are not multiples of 32, neighbours 32 apart; level 4: the states
+    // 4, 12, 20, ..., neighbours 8 apart; level 5: every other state, neighbours 4 apart (split form:
+    // level 5 the states 2, 6, 10, ..., level 6 the odd states, neighbours 2 apart)
+    const int gap = level == 3 ? 32 : (level == 4 ? 8 : (level == 5 ? 4 : 2));
+    const int count = level == 3 ? ((S + 7) >> 3) - ((S + 31) >> 5)
+                      : level == 4 ? (S + 3) >> 3
+                      : !kSplitLevel5 ? S - ((S + 3) >> 2)
+                      : level == 5 ? (S + 1) >> 2 : S >> 1;
+    const int long_range = level == 3 ? kLongRange3 : kLongRange4;
+    // a team of W waves deals the states of a level round robin: wave `wid` owns k = kk W + wid
+    const int count_w = W == 1 ? count : (count - wid + W - 1) / W;
+    int n_queued = 0;
+    for (int k0 = 0; k0 < count_w; k0 += 64) {
+      const int kk = k0 + lane < count_w ? k0 + lane : 0;
+      const int k = W == 1 ? kk : kk * W + wid;
+      const int i = level == 3 ? (k + k / 3 + 1) << 3
+                    : level == 4 ? 4 + 8 * k
+                    : !kSplitLevel5 ? k + k / 3 + 1
+                    : level == 5 ? 2 + 4 * k : 1 + 2 * k;
+      const bool active = k0 + lane < count_w;
+      const int below = i & ~(gap - 1), above = below + gap;
+      const int lo = sh.bpw[below];
+      const int hi = above < S ? sh.bpw[above] : S - 1;
+      const bool is_long = active && hi - lo >= long_range;
+      float best = FLT_MAX;
+      int best_j = lo;
+      if (active && !is_long) scan_range(sh.fwd, lo, hi, static_cast<float>(i), factor, best, best_j);
+      if (active && !is_long) {
+        sh.bpw[i] = best_j;
+        sh.nxt[i] = best + sh.nxt[i];
+      }
+      // Long windows (a step of the backpointer function between two attracting states: ~5 states of
+      // level 3 and ~15-45 of levels 4 and 5 per frame) are queued in LDS; the queue is worked off once
+      // per level (nothing in a level reads another state of the level), so that the rounds below run
+      // full: teams of 8 lanes, 8 windows per round, 32 candidates per step, a 3-step DPP argmin, the
+      // team's first lane stores.  (Round 2 handed them to 16-lane rows four at a time through
+      // v_readlane broadcasts: ~250 instructions per round; that was most of the tracker's time.)
+      const unsigned long long long_mask = __ballot(is_long);
+      if (long_mask != 0) {
+        if (is_long)
+          queue[n_queued + __popcll(long_mask & ((1ull << lane) - 1ull))] = make_int4(i, lo, hi, 0);
+        n_queued += __popcll(long_mask);
+      }
+      if (n_queued > kQueueEntries - 64 || (k0 + 64 >= count_w && n_queued > 0)) {
+        wave_sync();
+        const int team = lane >> 3, tl = lane & 7;
+        for (int q0 = 0; q0 < n_queued; q0 += 8) {
+          const bool on = q0 + team < n_queued;
+          const int4 e = queue[on ? q0 + team : 0];
+          const float fi = static_cast<float>(e.x);
+          float cb = FLT_MAX, cd = 1.0e9f;   // best cost, its d = j - i (no candidate: beyond every state)
+          int cj = 0x7fffffff;
+          if (on) {
+            // four candidates of the lane in flight per step; a step may look up to 31 states beyond the
+            // window: the argmin over ALL states lies inside it (monotonicity), so the extra candidates
+            // cannot win, and the forward costs are padded with FLT_MAX behind the last state
+            float d = static_cast<float>(e.y + tl) - fi;
+            for (int j = e.y + tl; j <= e.z; j += 32) {
+              float ff[4];
+#pragma unroll
+              for (int w = 0; w < 4; ++w) ff[w] = sh.fwd[j + 8 * w];
+#pragma unroll
+              for (int w = 0; w < 4; ++w) {
+                const float dw = d + static_cast<float>(8 * w);
+                const float c = __fadd_rn(__fmul_rn(dw * dw, factor), ff[w]);
+                cd = c < cb ? dw : cd;
+                cb = fminf(cb, c);
+              }
+              d += 32.0f;
+            }
+            cj = static_cast<int>(fi + cd);
+          }
+          quad_argmin(cb, cj);
+          argmin_take(cb, cj, dpp_f<0x141>(cb), dpp_i<0x141>(cj));  // row_half_mirror: the other quad
+          if (on && tl == 0) {
+            sh.bpw[e.x] = cj;
+            sh.nxt[e.x] = cb + sh.nxt[e.x];
+          }
+        }
+        n_queued = 0;
+        wave_sync();
+      }
+    }
+  }
+}
+
 // one forward pass over all frames; returns with sh.fwd = final normalised forward cost
 // NK: 64-state slices of the state space held in registers (7: up to 448 states - the default 417 -,
 // 8: up to 512); 0: any size, rows read from HBM where they are used
@@ -708,96 +820,7 @@ __device__ void viterbi_forward(const PitchDevTables& t, const float* __restrict
         sh.nxt[i_rep] = best + sh.nxt[i_rep];
       }
     }
-    // Level 3: the states 8, 16, 24, 40, ... (multiples of 8 that are not multiples of 32) between the
-    // backpointers of their two level-2 neighbours; level 4: every other state between the backpointers
-    // of its two neighbours at the multiples of 8.  One lane per state, 64 states per pass, a serial
-    // exact scan of the window (4 candidates in flight); the states whose window is long - a step of the
-    // backpointer function from one attracting state to the next - go to teams of 8 lanes (below).
-    // (Round 2 refined through the strides 16, 8, 4, 2, 1: fewer candidates - 2 350 against 4 000 per
-    // frame - but five levels of setup; measured with the same long-window teams: 9.6 against 8.5 ms.)
-    for (int level = 3; level <= (kSplitLevel5 ? 6 : 5); ++level) {
-      wave_sync();
-      // level 3: multiples of 8 that are not multiples of 32, neighbours 32 apart; level 4: the states
-      // 4, 12, 20, ..., neighbours 8 apart; level 5: every other state, neighbours 4 apart (split form:
-      // level 5 the states 2, 6, 10, ..., level 6 the odd states, neighbours 2 apart)
-      const int gap = level == 3 ? 32 : (level == 4 ? 8 : (level == 5 ? 4 : 2));
-      const int count = level == 3 ? ((S + 7) >> 3) - ((S + 31) >> 5)
-                        : level == 4 ? (S + 3) >> 3
-                        : !kSplitLevel5 ? S - ((S + 3) >> 2)
-                        : level == 5 ? (S + 1) >> 2 : S >> 1;
-      const int long_range = level == 3 ? kLongRange3 : kLongRange4;
-      int n_queued = 0;
-      for (int k0 = 0; k0 < count; k0 += 64) {
-        const int k = k0 + lane < count ? k0 + lane : 0;
-        const int i = level == 3 ? (k + k / 3 + 1) << 3
-                      : level == 4 ? 4 + 8 * k
-                      : !kSplitLevel5 ? k + k / 3 + 1
-                      : level == 5 ? 2 + 4 * k : 1 + 2 * k;
-        const bool active = k0 + lane < count;
-        const int below = i & ~(gap - 1), above = below + gap;
-        const int lo = sh.bpw[below];
-        const int hi = above < S ? sh.bpw[above] : S - 1;
-        const bool is_long = active && hi - lo >= long_range;
-        float best = FLT_MAX;
-        int best_j = lo;
-        if (active && !is_long) scan_range(sh.fwd, lo, hi, static_cast<float>(i), factor, best, best_j);
-        if (active && !is_long) {
-          sh.bpw[i] = best_j;
-          sh.nxt[i] = best + sh.nxt[i];
-        }
-        // Long windows (a step of the backpointer function between two attracting states: ~5 states of
-        // level 3 and ~15-45 of levels 4 and 5 per frame) are queued in LDS; the queue is worked off once
-        // per level (nothing in a level reads another state of the level), so that the rounds below run
-        // full: teams of 8 lanes, 8 windows per round, 32 candidates per step, a 3-step DPP argmin, the
-        // team's first lane stores.  (Round 2 handed them to 16-lane rows four at a time through
-        // v_readlane broadcasts: ~250 instructions per round; that was most of the tracker's time.)
-        const unsigned long long long_mask = __ballot(is_long);
-        if (long_mask != 0) {
-          if (is_long)
-            sh.queue[n_queued + __popcll(long_mask & ((1ull << lane) - 1ull))] = make_int4(i, lo, hi, 0);
-          n_queued += __popcll(long_mask);
-        }
-        if (n_queued > kQueueEntries - 64 || (k0 + 64 >= count && n_queued > 0)) {
-          wave_sync();
-          const int team = lane >> 3, tl = lane & 7;
-          for (int q0 = 0; q0 < n_queued; q0 += 8) {
-            const bool on = q0 + team < n_queued;
-            const int4 e = sh.queue[on ? q0 + team : 0];
-            const float fi = static_cast<float>(e.x);
-            float cb = FLT_MAX, cd = 1.0e9f;   // best cost, its d = j - i (no candidate: beyond every state)
-            int cj = 0x7fffffff;
-            if (on) {
-              // four candidates of the lane in flight per step; a step may look up to 31 states beyond the
-              // window: the argmin over ALL states lies inside it (monotonicity), so the extra candidates
-              // cannot win, and the forward costs are padded with FLT_MAX behind the last state
-              float d = static_cast<float>(e.y + tl) - fi;
-              for (int j = e.y + tl; j <= e.z; j += 32) {
-                float ff[4];
-#pragma unroll
-                for (int w = 0; w < 4; ++w) ff[w] = sh.fwd[j + 8 * w];
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                  const float dw = d + static_cast<float>(8 * w);
-                  const float c = __fadd_rn(__fmul_rn(dw * dw, factor), ff[w]);
-                  cd = c < cb ? dw : cd;
-                  cb = fminf(cb, c);
-                }
-                d += 32.0f;
-              }
-              cj = static_cast<int>(fi + cd);
-            }
-            quad_argmin(cb, cj);
-            argmin_take(cb, cj, dpp_f<0x141>(cb), dpp_i<0x141>(cj));  // row_half_mirror: the other quad
-            if (on && tl == 0) {
-              sh.bpw[e.x] = cj;
-              sh.nxt[e.x] = cb + sh.nxt[e.x];
-            }
-          }
-          n_queued = 0;
-          wave_sync();
-        }
-      }
-    }
+    refine_levels<1>(sh, sh.queue, S, factor, lane, 0);
     wave_sync();
     float lane_min = FLT_MAX;
     if (in_regs) {
@@ -828,49 +851,12 @@ __device__ void viterbi_forward(const PitchDevTables& t, const float* __restrict
   wave_sync();
 }
 
-}  // namespace
 
-__global__ __launch_bounds__(kVitWaves * 64, 4) void pitch_viterbi_kernel(
-    const PitchDevTables t, const PitchBatch b, const float* __restrict__ nccf_res,
-    const float* __restrict__ anp, const float* __restrict__ ub, int16_t* __restrict__ backptr,
-    int32_t* __restrict__ states, const float* __restrict__ pov_all, float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int S = t.num_states, L = t.num_lags, S4 = (S + 3) & ~3;
-  float* st_lag = reinterpret_cast<float*>(smem);
-  for (int s = threadIdx.x; s < S; s += blockDim.x) st_lag[s] = t.lags[s];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int64_t slot = static_cast<int64_t>(blockIdx.x) * kVitWaves + wid;
-  if (slot >= b.n_utts) return;
-  const int64_t u = b.order ? b.order[slot] : slot;
-  const int64_t f0 = b.frame_offsets[u], T = b.frame_offsets[u + 1] - f0;
-  if (T <= 0) return;
-  const int64_t T1 = b.frames_phase1[u];
-  const int per_wave = 3 * S4 + kFwdPad + kQueueFloats;  // (S4 and kFwdPad are multiples of 4: 16-byte queue)
-  VitShared sh;
-  sh.fwd = st_lag + S4 + wid * per_wave;
-  sh.nxt = sh.fwd + S4 + kFwdPad;
-  sh.bpw = reinterpret_cast<int*>(sh.nxt + S4);
-  sh.queue = reinterpret_cast<int4*>(sh.bpw + S4);
-  int16_t* __restrict__ bp = backptr + f0 * S;
-  const float* __restrict__ res = nccf_res + f0 * static_cast<int64_t>(S);
-  const float* __restrict__ pov_nccf = pov_all + f0 * L;
-  const float* __restrict__ o = ub + u * 6;
-
-  // InputFinished(): Kaldi runs RecomputeBacktraces when the utterance is shorter than recompute_frame and
-  // some frame saw a mean-square energy more than 1 % away from the final one (pitch_stats_kernel).  That
-  // pass starts from zero forward costs and overwrites every backpointer: nothing of the first (online)
-  // pass survives it, so an offline batch runs ONE forward pass - the recomputing one when Kaldi would
-  // recompute, the plain one otherwise (round 2 ran both: half of the Viterbi kernel's time).
-  // (... or when frame recompute_frame - 1 falls into the frames the flush adds: T1 < recompute_frame <= T,
-  // utterances of 500 - 502 frames; frames >= T1 rescale by exactly 1, so it is the same pass)
-  const bool recompute = (T < t.recompute_frame || T1 < t.recompute_frame) && o[5] != 0.0f;
-  const float ob1 = recompute ? o[2] : 0.0f, ob2 = recompute ? o[3] : 0.0f, nb = recompute ? o[4] : 0.0f;
-  if (S <= 448) viterbi_forward<7>(t, res, anp + f0, T, T1, recompute, ob1, ob2, nb, bp, sh, st_lag, lane);
-  else if (S <= 512) viterbi_forward<8>(t, res, anp + f0, T, T1, recompute, ob1, ob2, nb, bp, sh, st_lag, lane);
-  else viterbi_forward<0>(t, res, anp + f0, T, T1, recompute, ob1, ob2, nb, bp, sh, st_lag, lane);
-
-  // traceback: best final state (lowest index wins ties), then the chain of backpointers
+// traceback of one utterance by ONE wave: best final state (lowest index wins ties), then the chain of
+// backpointers -> states[f0 ...]; `sh.fwd` holds the final forward costs, `sh.nxt` is scratch
+__device__ __forceinline__ void viterbi_traceback(const int S, const int64_t T, const int64_t f0,
+                                                  const int16_t* __restrict__ bp, int32_t* __restrict__ states,
+                                                  const VitShared& sh, const int lane) {
   __threadfence_block();
   {
     float bv = FLT_MAX;
@@ -916,11 +902,14 @@ __global__ __launch_bounds__(kVitWaves * 64, 4) void pitch_viterbi_kernel(
       }
     }
   }
-  wave_sync();
-  __threadfence_block();
+}
 
-  // output rows: (POV NCCF resampled at the chosen lag, 1 / lag)
-  for (int64_t frame = lane; frame < T; frame += 64) {
+// output rows of one utterance: (POV NCCF resampled at the chosen lag, 1 / lag); frames first, first + stride, ...
+__device__ __forceinline__ void pitch_output_rows(const PitchDevTables& t, const int L, const int64_t T,
+                                                  const int64_t f0, const int32_t* __restrict__ states,
+                                                  const float* __restrict__ pov_nccf, float* __restrict__ out,
+                                                  const int first, const int stride) {
+  for (int64_t frame = first; frame < T; frame += stride) {
     const int s = states[f0 + frame];
     const float* __restrict__ wt = t.ar_w + s * t.ar_max_taps;
     const float* __restrict__ src = pov_nccf + frame * L + t.ar_first[s];
@@ -930,6 +919,263 @@ __global__ __launch_bounds__(kVitWaves * 64, 4) void pitch_viterbi_kernel(
     out[(f0 + frame) * 2 + 0] = pov;
     out[(f0 + frame) * 2 + 1] = 1.0f / t.lags[s];
   }
+}
+
+// ---- 4b. the same forward pass by a TEAM of W wavefronts per utterance (small batches) ----------------
+// One wave per utterance walks its frames at ~11 us per frame whatever its neighbours do: below ~2 000
+// utterances most SIMDs hold one wave and the tracker's time is that wave's latency (the LDS round trips of
+// five levels in series), not the machine's throughput.  Here the W waves of a workgroup share ONE utterance:
+// the 64-state slices of the row (local cost, normalisation, backpointer rows) are dealt round robin, level 1
+// gives every exact scan 16 W lanes, level 2 4 W lanes per state, the states of levels 3 - 5 are dealt round
+// robin (refine_levels<W>: every wave has its own long-window queue), and workgroup barriers stand where the
+// single wave has its ordering points.  Same candidates, same arithmetic, same tie-breaks per state: the
+// result is bit-identical to viterbi_forward (the pitch tests run both).  Up to 512 states.
+template <int W>
+__device__ void viterbi_forward_team(const PitchDevTables& t, const float* __restrict__ res,
+                                     const float* __restrict__ anp, int64_t T, int64_t T1, bool rescale,
+                                     float old_b1, float old_b2, float new_ballast, int16_t* __restrict__ bp,
+                                     const VitShared& sh, int4* __restrict__ queue, float* __restrict__ red,
+                                     const float* __restrict__ st_lag, const int lane, const int wid) {
+  constexpr int NKW = 8 / W;                   // 64-state slices per wave
+  constexpr int LPS = 16 * W;                  // lanes per exact scan of level 1
+  constexpr int LP2 = 4 * W;                   // lanes per state of level 2
+  constexpr int IF2 = 32 / LP2;                // its candidates in flight per lane: 32 per step and state
+  const int S = t.num_states, tid = wid * 64 + lane;
+  for (int s = tid; s < S; s += 64 * W) sh.fwd[s] = 0.0f;
+  for (int s = S + tid; s < S + kFwdPad; s += 64 * W) sh.fwd[s] = FLT_MAX;  // scan read-ahead padding
+  const float factor = t.inter_frame_factor;
+  float ahead[NKW], soft_lag[NKW];
+  int col[NKW], bpv[NKW];
+#pragma unroll
+  for (int k = 0; k < NKW; ++k) {
+    const int c = lane + 64 * (k * W + wid);   // (slots beyond the last state redo the last state)
+    col[k] = c < S ? c : S - 1;
+    ahead[k] = T > 0 ? res[col[k]] : 0.0f;
+    soft_lag[k] = t.soft_min_f0 * st_lag[col[k]];
+    bpv[k] = 0;
+  }
+  const int n_super = (S + 127) >> 7;          // states 0, 128, 256, ... (at most 4)
+  for (int64_t frame = 0; frame < T; ++frame) {
+    float scale = 1.0f;
+    if (rescale) {
+      const float old_ballast = frame < T1 ? old_b1 : old_b2, a = anp[frame];
+      scale = sqrtf((old_ballast + a) / (new_ballast + a));
+    }
+    const float* __restrict__ row = res + frame * static_cast<int64_t>(S);
+#pragma unroll
+    for (int k = 0; k < NKW; ++k) {
+      float v = ahead[k];
+      if (rescale) v *= scale;
+      float local = 1.0f - v;
+      local += soft_lag[k] * v;
+      sh.nxt[col[k]] = local;
+    }
+    if (frame > 0) {
+      int16_t* __restrict__ bp_row = bp + (frame - 1) * S;
+#pragma unroll
+      for (int k = 0; k < NKW; ++k) bp_row[col[k]] = static_cast<int16_t>(bpv[k]);
+    }
+    const float* __restrict__ nrow = frame + 1 < T ? row + S : row;
+#pragma unroll
+    for (int k = 0; k < NKW; ++k) ahead[k] = nrow[col[k]];
+    __syncthreads();   // local costs and the forward costs of the last frame are in LDS
+    // ---- level 1: exact argmin of the states 0, 128, 256, 384 - LPS lanes each
+    {
+      const int r = wid * (64 / LPS) + lane / LPS, sub = lane % LPS;
+      const int i_rep = r << 7;
+      float best = FLT_MAX;
+      int best_j = 0x7fffffff;
+      if (r < n_super) {
+        const float fi = static_cast<float>(i_rep);
+        float d = static_cast<float>(sub) - fi, bd = 1.0e9f;
+#pragma unroll 4
+        for (int j = sub; j < S; j += LPS) {
+          const float c = __fadd_rn(__fmul_rn(d * d, factor), sh.fwd[j]);
+          bd = c < best ? d : bd;
+          best = fminf(best, c);
+          d += static_cast<float>(LPS);
+        }
+        best_j = static_cast<int>(fi + bd);
+      }
+      quad_argmin(best, best_j);
+      argmin_take(best, best_j, dpp_f<0x124>(best), dpp_i<0x124>(best_j));
+      argmin_take(best, best_j, dpp_f<0x128>(best), dpp_i<0x128>(best_j));
+      if (LPS > 16) {
+        // the 16-lane rows of a scan: row values through v_readlane, combined in index order
+        float c0 = lane_f(best, 0), c1 = lane_f(best, 16), c2 = lane_f(best, 32), c3 = lane_f(best, 48);
+        int j0 = __builtin_amdgcn_readlane(best_j, 0), j1 = __builtin_amdgcn_readlane(best_j, 16);
+        int j2 = __builtin_amdgcn_readlane(best_j, 32), j3 = __builtin_amdgcn_readlane(best_j, 48);
+        argmin_take(c0, j0, c1, j1);
+        argmin_take(c2, j2, c3, j3);
+        if (LPS == 64) {
+          argmin_take(c0, j0, c2, j2);
+          best = c0;
+          best_j = j0;
+        } else {
+          best = lane < 32 ? c0 : c2;
+          best_j = lane < 32 ? j0 : j2;
+        }
+      }
+      if (sub == 0 && r < n_super) {
+        if (best_j >= S) best_j = 0;  // (only if every cost was NaN / inf: no runaway scans below)
+        sh.bpw[i_rep] = best_j;
+        sh.nxt[i_rep] = best + sh.nxt[i_rep];
+      }
+    }
+    __syncthreads();
+    // ---- level 2: the other multiples of 32 between the backpointers of their level-1 neighbours, LP2
+    // lanes per state (at most 12 states: 64 / LP2 per wave), 32 candidates per step
+    {
+      const int k = wid * (64 / LP2) + lane / LP2, sub = lane % LP2;
+      const int m = k + k / 3 + 1;
+      const int i_rep = m << 5;
+      float best = FLT_MAX;
+      int best_j = 0x7fffffff;
+      if (i_rep < S) {
+        const int below = i_rep & ~127, above = below + 128;
+        const int lo = sh.bpw[below];
+        const int hi = above < S ? sh.bpw[above] : S - 1;
+        const float fi = static_cast<float>(i_rep);
+        float d = static_cast<float>(lo + sub) - fi, bd = d;
+        for (int j = lo + sub; j <= hi; j += 32) {
+          float ff[IF2];
+#pragma unroll
+          for (int w = 0; w < IF2; ++w) ff[w] = sh.fwd[j + LP2 * w];
+#pragma unroll
+          for (int w = 0; w < IF2; ++w) {
+            const float dw = d + static_cast<float>(LP2 * w);
+            const float c = __fadd_rn(__fmul_rn(dw * dw, factor), ff[w]);
+            bd = c < best ? dw : bd;
+            best = fminf(best, c);
+          }
+          d += 32.0f;
+        }
+        best_j = static_cast<int>(fi + bd);
+      }
+      quad_argmin(best, best_j);
+      if (LP2 == 8) {
+        argmin_take(best, best_j, dpp_f<0x141>(best), dpp_i<0x141>(best_j));  // row_half_mirror
+      } else {
+        argmin_take(best, best_j, dpp_f<0x124>(best), dpp_i<0x124>(best_j));
+        argmin_take(best, best_j, dpp_f<0x128>(best), dpp_i<0x128>(best_j));
+      }
+      if (sub == 0 && i_rep < S) {
+        if (best_j >= S) best_j = sh.bpw[i_rep & ~127];
+        sh.bpw[i_rep] = best_j;
+        sh.nxt[i_rep] = best + sh.nxt[i_rep];
+      }
+    }
+    refine_levels<W>(sh, queue, S, factor, lane, wid);   // (starts with the barrier behind level 2)
+    __syncthreads();
+    // ---- normalisation: the minimum over all states, through one LDS slot per wave
+    float nx[NKW], lane_min = FLT_MAX;
+#pragma unroll
+    for (int k = 0; k < NKW; ++k) {
+      nx[k] = sh.nxt[col[k]];
+      bpv[k] = sh.bpw[col[k]];
+      lane_min = fminf(lane_min, nx[k]);
+    }
+    const float wave_mn = wave_min_f(lane_min);
+    if (lane == 0) red[wid] = wave_mn;
+    __syncthreads();
+    float mn = red[0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) mn = fminf(mn, red[w]);
+#pragma unroll
+    for (int k = 0; k < NKW; ++k) sh.fwd[col[k]] = nx[k] + (-mn);
+  }
+  if (T > 0) {
+    int16_t* __restrict__ bp_row = bp + (T - 1) * S;
+#pragma unroll
+    for (int k = 0; k < NKW; ++k) bp_row[col[k]] = static_cast<int16_t>(bpv[k]);
+  }
+  __syncthreads();
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kVitWaves * 64, 4) void pitch_viterbi_kernel(
+    const PitchDevTables t, const PitchBatch b, const float* __restrict__ nccf_res,
+    const float* __restrict__ anp, const float* __restrict__ ub, int16_t* __restrict__ backptr,
+    int32_t* __restrict__ states, const float* __restrict__ pov_all, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int S = t.num_states, L = t.num_lags, S4 = (S + 3) & ~3;
+  float* st_lag = reinterpret_cast<float*>(smem);
+  for (int s = threadIdx.x; s < S; s += blockDim.x) st_lag[s] = t.lags[s];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t slot = static_cast<int64_t>(blockIdx.x) * kVitWaves + wid;
+  if (slot >= b.n_utts) return;
+  const int64_t u = b.order ? b.order[slot] : slot;
+  const int64_t f0 = b.frame_offsets[u], T = b.frame_offsets[u + 1] - f0;
+  if (T <= 0) return;
+  const int64_t T1 = b.frames_phase1[u];
+  const int per_wave = 3 * S4 + kFwdPad + kQueueFloats;  // (S4 and kFwdPad are multiples of 4: 16-byte queue)
+  VitShared sh;
+  sh.fwd = st_lag + S4 + wid * per_wave;
+  sh.nxt = sh.fwd + S4 + kFwdPad;
+  sh.bpw = reinterpret_cast<int*>(sh.nxt + S4);
+  sh.queue = reinterpret_cast<int4*>(sh.bpw + S4);
+  int16_t* __restrict__ bp = backptr + f0 * S;
+  const float* __restrict__ res = nccf_res + f0 * static_cast<int64_t>(S);
+  const float* __restrict__ pov_nccf = pov_all + f0 * L;
+  const float* __restrict__ o = ub + u * 6;
+
+  // InputFinished(): Kaldi runs RecomputeBacktraces when the utterance is shorter than recompute_frame and
+  // some frame saw a mean-square energy more than 1 % away from the final one (pitch_stats_kernel).  That
+  // pass starts from zero forward costs and overwrites every backpointer: nothing of the first (online)
+  // pass survives it, so an offline batch runs ONE forward pass - the recomputing one when Kaldi would
+  // recompute, the plain one otherwise (round 2 ran both: half of the Viterbi kernel's time).
+  // (... or when frame recompute_frame - 1 falls into the frames the flush adds: T1 < recompute_frame <= T,
+  // utterances of 500 - 502 frames; frames >= T1 rescale by exactly 1, so it is the same pass)
+  const bool recompute = (T < t.recompute_frame || T1 < t.recompute_frame) && o[5] != 0.0f;
+  const float ob1 = recompute ? o[2] : 0.0f, ob2 = recompute ? o[3] : 0.0f, nb = recompute ? o[4] : 0.0f;
+  if (S <= 448) viterbi_forward<7>(t, res, anp + f0, T, T1, recompute, ob1, ob2, nb, bp, sh, st_lag, lane);
+  else if (S <= 512) viterbi_forward<8>(t, res, anp + f0, T, T1, recompute, ob1, ob2, nb, bp, sh, st_lag, lane);
+  else viterbi_forward<0>(t, res, anp + f0, T, T1, recompute, ob1, ob2, nb, bp, sh, st_lag, lane);
+
+  viterbi_traceback(S, T, f0, bp, states, sh, lane);
+  wave_sync();
+  __threadfence_block();
+  pitch_output_rows(t, L, T, f0, states, pov_nccf, out, lane, 64);
+}
+
+// W waves per utterance, one utterance per workgroup (viterbi_forward_team); up to 512 states
+template <int W>
+__global__ __launch_bounds__(W * 64, 4) void pitch_viterbi_team_kernel(
+    const PitchDevTables t, const PitchBatch b, const float* __restrict__ nccf_res,
+    const float* __restrict__ anp, const float* __restrict__ ub, int16_t* __restrict__ backptr,
+    int32_t* __restrict__ states, const float* __restrict__ pov_all, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int S = t.num_states, L = t.num_lags, S4 = (S + 3) & ~3;
+  float* st_lag = reinterpret_cast<float*>(smem);
+  for (int s = threadIdx.x; s < S; s += blockDim.x) st_lag[s] = t.lags[s];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t slot = blockIdx.x;
+  const int64_t u = b.order ? b.order[slot] : slot;
+  const int64_t f0 = b.frame_offsets[u], T = b.frame_offsets[u + 1] - f0;
+  if (T <= 0) return;   // (the whole workgroup: one utterance)
+  const int64_t T1 = b.frames_phase1[u];
+  VitShared sh;
+  sh.fwd = st_lag + S4;
+  sh.nxt = sh.fwd + S4 + kFwdPad;
+  sh.bpw = reinterpret_cast<int*>(sh.nxt + S4);
+  sh.queue = reinterpret_cast<int4*>(sh.bpw + S4);          // W queues, then W floats
+  float* red = reinterpret_cast<float*>(sh.queue + W * kQueueEntries);
+  int16_t* __restrict__ bp = backptr + f0 * S;
+  const float* __restrict__ res = nccf_res + f0 * static_cast<int64_t>(S);
+  const float* __restrict__ o = ub + u * 6;
+  // (which pass runs: see pitch_viterbi_kernel)
+  const bool recompute = (T < t.recompute_frame || T1 < t.recompute_frame) && o[5] != 0.0f;
+  const float ob1 = recompute ? o[2] : 0.0f, ob2 = recompute ? o[3] : 0.0f, nb = recompute ? o[4] : 0.0f;
+  viterbi_forward_team<W>(t, res, anp + f0, T, T1, recompute, ob1, ob2, nb, bp, sh, sh.queue + wid * kQueueEntries,
+                          red, st_lag, lane, wid);
+  __threadfence_block();
+  if (wid == 0) viterbi_traceback(S, T, f0, bp, states, sh, lane);
+  __threadfence_block();
+  __syncthreads();
+  pitch_output_rows(t, L, T, f0, states, pov_all + f0 * L, out, static_cast<int>(threadIdx.x), 64 * W);
 }
 
 int launch_pitch(const PitchDevTables& t, const PitchBatch& b, const PitchScratch& w, float* out,
@@ -991,15 +1237,30 @@ int launch_pitch(const PitchDevTables& t, const PitchBatch& b, const PitchScratc
     if (stage_done("nccf", 2)) return SNF_OK;
   }
   {
-    const size_t lds = sizeof(float) * (S4 + static_cast<size_t>(kVitWaves) * (3 * S4 + kFwdPad + kQueueFloats));
-    if (lds > 160 * 1024) return set_error(SNF_E_RUNTIME, "pitch state space does not fit in LDS");
-    if (lds > 64 * 1024)
-      SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pitch_viterbi_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    const unsigned blocks = static_cast<unsigned>((b.n_utts + kVitWaves - 1) / kVitWaves);
-    hipLaunchKernelGGL(pitch_viterbi_kernel, dim3(blocks), dim3(kVitWaves * 64), lds, stream, t, b,
-                       w.nccf_res, w.anp, w.ub, w.backptr, w.states, w.pov_nccf, out);
-    SNF_HIP_CHECK(hipGetLastError());
+    // Small batches: several waves per utterance (viterbi_forward_team) - one wave per utterance leaves most
+    // SIMDs with a single wave whose latency is the kernel's time.  SNF_PITCH_TEAM=1|2|4 forces a form.
+    const char* knob = getenv("SNF_PITCH_TEAM");   // (read per call: the tests run every form in one process)
+    const int forced = knob ? atoi(knob) : 0;
+    int team = forced == 1 || forced == 2 || forced == 4 ? forced
+               : b.n_utts <= kTeam4Utts ? 4 : b.n_utts <= kTeam2Utts ? 2 : 1;
+    if (S > 512 || S < 128) team = 1;
+    if (team > 1) {
+      const size_t lds = sizeof(float) * (4 * static_cast<size_t>(S4) + kFwdPad + team * (kQueueFloats + 1));
+      auto kern = team == 4 ? pitch_viterbi_team_kernel<4> : pitch_viterbi_team_kernel<2>;
+      hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(b.n_utts)), dim3(team * 64), lds, stream, t, b,
+                         w.nccf_res, w.anp, w.ub, w.backptr, w.states, w.pov_nccf, out);
+      SNF_HIP_CHECK(hipGetLastError());
+    } else {
+      const size_t lds = sizeof(float) * (S4 + static_cast<size_t>(kVitWaves) * (3 * S4 + kFwdPad + kQueueFloats));
+      if (lds > 160 * 1024) return set_error(SNF_E_RUNTIME, "pitch state space does not fit in LDS");
+      if (lds > 64 * 1024)
+        SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pitch_viterbi_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+      const unsigned blocks = static_cast<unsigned>((b.n_utts + kVitWaves - 1) / kVitWaves);
+      hipLaunchKernelGGL(pitch_viterbi_kernel, dim3(blocks), dim3(kVitWaves * 64), lds, stream, t, b,
+                         w.nccf_res, w.anp, w.ub, w.backptr, w.states, w.pov_nccf, out);
+      SNF_HIP_CHECK(hipGetLastError());
+    }
     (void)stage_done("viterbi", 3);
   }
   return SNF_OK;

@@ -159,10 +159,18 @@ def _pitch_close(got, want):
     np.testing.assert_array_equal(got[:, 0], want[:, 0])
 
 
+@pytest.fixture(params=[1, 2, 4])
+def vit_team(request, monkeypatch):
+    """every form of the Viterbi kernel: one wave per utterance (what large batches run on), or a team of two /
+    four waves per utterance (small batches; kernels_pitch.hip viterbi_forward_team) - all bit-identical"""
+    monkeypatch.setenv('SNF_PITCH_TEAM', str(request.param))
+    return request.param
+
+
 @pytest.mark.parametrize('opts', [dict(), dict(frame_shift=0.02),
                                   dict(frame_shift=0.02, frame_length=0.05),
                                   dict(min_f0=60, max_f0=350, penalty_factor=0.2)])
-def test_pitch(gpu, audio, wave, opts):
+def test_pitch(gpu, audio, wave, opts, vit_team):
     proc = KaldiPitchProcessor(**opts)
     got = proc.process(audio)
     want = orc.pitch(proc._options, wave)
@@ -176,7 +184,7 @@ def test_pitch(gpu, audio, wave, opts):
     dict(upsample_filter_width=7),     # 14 sinc taps per state: 16-lag quad windows (run-time step count)
     dict(min_f0=70, max_f0=300, delta_pitch=0.01, lowpass_cutoff=800, resample_freq=3200),
 ])
-def test_pitch_option_paths(gpu, synth_waves, opts):
+def test_pitch_option_paths(gpu, synth_waves, opts, vit_team):
     """option sets that leave the instantiations the default configuration runs on (kernels_pitch.hip:
     viterbi_forward<7> / <8> / <0>, the overlaid NCCF, the straight-line 12-lag resampling)"""
     proc = KaldiPitchProcessor(**opts)
@@ -186,7 +194,7 @@ def test_pitch_option_paths(gpu, synth_waves, opts):
         _pitch_close(o.data, orc.pitch(proc._options, w))
 
 
-def test_pitch_recompute_backtraces_corner(gpu):
+def test_pitch_recompute_backtraces_corner(gpu, vit_team):
     """utterances of 500 - 503 pitch frames whose last samples move the mean square (the T1 < 500 <= T corner
     of Kaldi's RecomputeBacktraces, tests/test_oracle_pins.py): every frame equals the oracle, in one batch
     and for the settings of recompute_frame that force / forbid the second pass"""
@@ -200,7 +208,7 @@ def test_pitch_recompute_backtraces_corner(gpu):
             _pitch_close(o, orc.pitch(opts.pitch, w))
 
 
-def test_pitch_batch(gpu, synth_waves):
+def test_pitch_batch(gpu, synth_waves, vit_team):
     proc = KaldiPitchProcessor()
     outs = proc._process_batch([Audio(w, 16000) for w in synth_waves])
     for w, o in zip(synth_waves, outs):

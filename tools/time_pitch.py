@@ -1,7 +1,7 @@
 """Dev helper: HIP-event times of the pitch kernels for a batch of N x 3 s utterances (min / median of
 `reps` calls after a few settle calls).  A/B of a build knob = two processes on the same box:
 
-    python tools/time_pitch.py 10000; SNF_PITCH_VIT4=1 python tools/time_pitch.py 10000
+    python tools/time_pitch.py 1000; SNF_PITCH_TEAM=1 python tools/time_pitch.py 1000
 """
 import os
 import sys
@@ -30,6 +30,6 @@ rows = np.array(rows)
 names = ['total'] + [plan.kernel_name(i) for i in range(1, 6) if plan.kernel_name(i)]
 out = np.empty((nf * n, plan.ndims), dtype=np.float32)
 d_out.download(out)
-print('utts %d knob %s checksum %.6f' % (n, os.environ.get('SNF_PITCH_VIT4', '-'), float(out.astype(np.float64).sum())))
+print('utts %d team %s checksum %.6f' % (n, os.environ.get('SNF_PITCH_TEAM', '-'), float(out.astype(np.float64).sum())))
 for k, name in enumerate(names):
     print('  %-28s min %.3f  median %.3f ms' % (name[:28], rows[:, k].min(), np.median(rows[:, k])))
