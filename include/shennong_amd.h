@@ -348,6 +348,15 @@ int snf_stream_destroy(void* stream);
 int snf_stream_synchronize(void* stream);
 int snf_memcpy_h2d_async(void* dst, const void* src, uint64_t bytes, void* stream);
 int snf_memcpy_d2h_async(void* dst, const void* src, uint64_t bytes, void* stream);
+/* Timing marks on a caller's stream (hipEvent_t behind a plain pointer): a caller that enqueues several
+   *_device calls on its own stream without waiting for each - the way a pipeline uses the path, and what
+   bench.py times - brackets every call with two marks and reads the elapsed device time of each pair after
+   ONE synchronisation (snf_plan_last_kernel_ms is for calls on the plan's own stream and waits for the call).
+   snf_event_elapsed_ms waits for `stop`. */
+int snf_event_create(void** event);
+int snf_event_destroy(void* event);
+int snf_event_record(void* event, void* stream);
+int snf_event_elapsed_ms(void* start, void* stop, float* ms);
 /* Page-locked host staging memory for the host-pointer entry points (snf_plan_run_batch, ...): a
    batch assembled in it (the reference hands over one numpy array per utterance, processor/base.py:428)
    crosses the link at full rate and its pages are faulted in once, not once per call.  Plain host

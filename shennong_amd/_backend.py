@@ -37,7 +37,8 @@ EXPORTS = [
     'snf_stream_create', 'snf_stream_destroy', 'snf_stream_synchronize', 'snf_memcpy_h2d_async',
     'snf_memcpy_d2h_async', 'snf_comm_unique_id', 'snf_comm_init', 'snf_comm_rank', 'snf_comm_world_size',
     'snf_comm_destroy', 'snf_comm_gatherv', 'snf_comm_allreduce_f64',
-    'snf_plan_last_kernel_ms', 'snf_plan_kernel_name', 'snf_set_oom_hook']
+    'snf_plan_last_kernel_ms', 'snf_plan_kernel_name', 'snf_set_oom_hook',
+    'snf_event_create', 'snf_event_destroy', 'snf_event_record', 'snf_event_elapsed_ms']
 
 
 _OOM_HOOK_TYPE = C.CFUNCTYPE(None)
@@ -126,6 +127,10 @@ def lib():
         L.snf_stream_destroy.argtypes = [vp]
         L.snf_stream_synchronize.argtypes = [vp]
         L.snf_memcpy_h2d_async.argtypes = [vp, vp, C.c_uint64, vp]
+        L.snf_event_create.argtypes = [C.POINTER(vp)]
+        L.snf_event_destroy.argtypes = [vp]
+        L.snf_event_record.argtypes = [vp, vp]
+        L.snf_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
         L.snf_memcpy_d2h_async.argtypes = [vp, vp, C.c_uint64, vp]
         L.snf_comm_unique_id.argtypes = [vp]
         L.snf_comm_init.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]

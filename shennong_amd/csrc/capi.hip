@@ -1607,6 +1607,28 @@ int snf_stream_synchronize(void* stream) {
   SNF_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   return SNF_OK;
 }
+int snf_event_create(void** event) {
+  if (!event) return set_error(SNF_E_INVALID, "null pointer");
+  hipEvent_t e;
+  SNF_HIP_CHECK(hipEventCreate(&e));
+  *event = e;
+  return SNF_OK;
+}
+int snf_event_destroy(void* event) {
+  if (event) SNF_HIP_CHECK(hipEventDestroy(static_cast<hipEvent_t>(event)));
+  return SNF_OK;
+}
+int snf_event_record(void* event, void* stream) {
+  if (!event) return set_error(SNF_E_INVALID, "null event");
+  SNF_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)));
+  return SNF_OK;
+}
+int snf_event_elapsed_ms(void* start, void* stop, float* ms) {
+  if (!start || !stop || !ms) return set_error(SNF_E_INVALID, "null pointer");
+  SNF_HIP_CHECK(hipEventSynchronize(static_cast<hipEvent_t>(stop)));
+  SNF_HIP_CHECK(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+  return SNF_OK;
+}
 int snf_memcpy_h2d_async(void* dst, const void* src, uint64_t bytes, void* stream) {
   SNF_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
   return SNF_OK;
