@@ -146,6 +146,10 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
   const int n_waves = blockDim.x >> 6;
   // flat mode: sets of 4 consecutive global frames, grid-stride.  PERUTT: sets of 4 consecutive frames
   // of the workgroup's utterance, kSetsPerBlock of them per workgroup.
+  // spectrogram rows that are dense and whose buffer starts on a 16-byte boundary leave as aligned quads
+  // of the set's four rows (see the store below); any other layout row by row
+  const bool spec_flat = KIND == SNF_KIND_SPECTROGRAM && !PERUTT && p.out_cols == 257 &&
+                         (reinterpret_cast<uintptr_t>(out) & 15) == 0;
   int64_t n_sets = (b.total_frames + 3) >> 2;
   int64_t set_stride = static_cast<int64_t>(gridDim.x) * n_waves;
   if (PERUTT) {
@@ -422,14 +426,16 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     const float p128 = 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y);
     wave_lds_sync();  // (the transposed reads of the tile are complete; keeps the compiler in order)
     // ---- E: power tile ------------------------------------------------------------------------------
-    float* __restrict__ pmirror = ptile + (144 - l);
+    if (!(KIND == SNF_KIND_SPECTROGRAM && spec_flat)) {
+      float* __restrict__ pmirror = ptile + (144 - l);
 #pragma unroll
-    for (int k1 = 0; k1 < 8; ++k1) {
-      ptile[l + 16 * k1] = pk[k1];
-      pmirror[16 * (7 - k1)] = pm[k1];  // index 256 - l - 16 k1
+      for (int k1 = 0; k1 < 8; ++k1) {
+        ptile[l + 16 * k1] = pk[k1];
+        pmirror[16 * (7 - k1)] = pm[k1];  // index 256 - l - 16 k1
+      }
+      if (l == 0) ptile[128] = p128;
+      wave_lds_sync();
     }
-    if (l == 0) ptile[128] = p128;
-    wave_lds_sync();
 
     // ---- log-energy column ---------------------------------------------------------------------------
     float log_energy = 0.0f;
@@ -443,7 +449,44 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     }
 
     float* __restrict__ row = out + g * static_cast<int64_t>(p.out_cols);
-    if (KIND == SNF_KIND_SPECTROGRAM) {
+    if (KIND == SNF_KIND_SPECTROGRAM && spec_flat) {
+      // Dense rows of 257 floats (the Features layout): the four rows of a set are 4 112 contiguous bytes
+      // that start on a 16-byte boundary whatever the frame - a row alone is only 4-byte aligned (1 028 B),
+      // and 16-byte stores to it split.  The log power spectrum goes from the registers to the wave's LDS
+      // in that flat order (the frame tiles are dead: 4 x 257 floats over the first two) and leaves as 257
+      // aligned quads, 1 KB per wave instruction (spectrogram-257, 2.98 M frames, same box: 1.22-1.23 ms row
+      // by row, 1.17-1.20 ms this way).  Same values as the row-wise form below: same logs of the same powers.
+      float* __restrict__ stage = reinterpret_cast<float*>(smem + tab_bytes + wid * 4 * kFrameTileBytes);
+      float* __restrict__ mine = stage + q * 257;
+#pragma unroll
+      for (int k1 = 0; k1 < 8; ++k1) {
+        float lo_bin = fast_log(fmaxf(0.25f * pk[k1], FLT_EPSILON));
+        if (k1 == 0 && l == 0) lo_bin = log_energy;   // bin 0 = energy
+        mine[l + 16 * k1] = lo_bin;
+        mine[256 - l - 16 * k1] = fast_log(fmaxf(0.25f * pm[k1], FLT_EPSILON));
+      }
+      if (l == 0) mine[128] = fast_log(fmaxf(0.25f * p128, FLT_EPSILON));
+      wave_lds_sync();
+      const int64_t rows_left = b.total_frames - set * 4;
+      const int n_floats = rows_left < 4 ? static_cast<int>(rows_left) * 257 : 1028;
+      float* __restrict__ dst = out + set * 1028;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int at = 4 * (lane + 64 * i);
+        const float4 v = *reinterpret_cast<const float4*>(stage + at);
+        if (at + 4 <= n_floats) {
+          __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(dst + at));
+        } else {   // the last rows of the batch: a quad that the batch ends in
+          if (at < n_floats) dst[at] = v.x;
+          if (at + 1 < n_floats) dst[at + 1] = v.y;
+          if (at + 2 < n_floats) dst[at + 2] = v.z;
+        }
+      }
+      if (lane == 0 && n_floats == 1028) {
+        const float4 v = *reinterpret_cast<const float4*>(stage + 1024);
+        __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(dst + 1024));
+      }
+    } else if (KIND == SNF_KIND_SPECTROGRAM) {
       // log power spectrum, 257 bins: lane l stores bins l + 16 i (64-byte segments), bin 0 = energy
       // (lane l stores bins 4 l + 64 i as 16-byte vectors: 256 contiguous bytes per frame and instruction;
       // the rows are 1028 bytes, 4-byte aligned; written once -> nontemporal)
