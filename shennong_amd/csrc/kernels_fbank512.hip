@@ -43,6 +43,8 @@
 
 namespace snf {
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 namespace {
 
 constexpr int kMaxWaves = 16;             // wavefronts per workgroup: 8 when two workgroups fit the LDS
@@ -146,10 +148,6 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
   const int n_waves = blockDim.x >> 6;
   // flat mode: sets of 4 consecutive global frames, grid-stride.  PERUTT: sets of 4 consecutive frames
   // of the workgroup's utterance, kSetsPerBlock of them per workgroup.
-  // spectrogram rows that are dense and whose buffer starts on a 16-byte boundary leave as aligned quads
-  // of the set's four rows (see the store below); any other layout row by row
-  const bool spec_flat = KIND == SNF_KIND_SPECTROGRAM && !PERUTT && p.out_cols == 257 &&
-                         (reinterpret_cast<uintptr_t>(out) & 15) == 0;
   int64_t n_sets = (b.total_frames + 3) >> 2;
   int64_t set_stride = static_cast<int64_t>(gridDim.x) * n_waves;
   if (PERUTT) {
@@ -206,6 +204,15 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     const int64_t gn = (set + set_stride) * 4 + q;
     start_next = start_of(gn);
     if (!SNIP) edge_next = edge_of(g);
+    if (KIND == SNF_KIND_SPECTROGRAM) {
+      // five dropped stores behind the first request: the loop is entered with the same sequence of vector-
+      // memory operations in flight as its back edge carries (loads, then the five stores of a set), so the
+      // waits at the top of the body are counted instead of draining every store (see the stores below)
+      const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < 5; ++i)   // (distinct offsets: identical stores would be merged into one)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, none, -1 - 16 * i, 0, 2);
+    }
   }
   // output row of the MFMA view (lane 4 b + j -> frame j of the set), advanced by a constant per set
   float* __restrict__ mrow =
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     const float p128 = 4.0f * (z[8].x * z[8].x + z[8].y * z[8].y);
     wave_lds_sync();  // (the transposed reads of the tile are complete; keeps the compiler in order)
     // ---- E: power tile ------------------------------------------------------------------------------
-    if (!(KIND == SNF_KIND_SPECTROGRAM && spec_flat)) {
+    if (KIND != SNF_KIND_SPECTROGRAM) {
       float* __restrict__ pmirror = ptile + (144 - l);
 #pragma unroll
       for (int k1 = 0; k1 < 8; ++k1) {
@@ -449,13 +456,17 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
     }
 
     float* __restrict__ row = out + g * static_cast<int64_t>(p.out_cols);
-    if (KIND == SNF_KIND_SPECTROGRAM && spec_flat) {
-      // Dense rows of 257 floats (the Features layout): the four rows of a set are 4 112 contiguous bytes
-      // that start on a 16-byte boundary whatever the frame - a row alone is only 4-byte aligned (1 028 B),
-      // and 16-byte stores to it split.  The log power spectrum goes from the registers to the wave's LDS
-      // in that flat order (the frame tiles are dead: 4 x 257 floats over the first two) and leaves as 257
-      // aligned quads, 1 KB per wave instruction (spectrogram-257, 2.98 M frames, same box: 1.22-1.23 ms row
-      // by row, 1.17-1.20 ms this way).  Same values as the row-wise form below: same logs of the same powers.
+    if (KIND == SNF_KIND_SPECTROGRAM) {
+      // The rows are dense (257 floats: the kernel takes spectrograms of 512-point frames only), so the four
+      // rows of a set are 4 112 contiguous bytes - a row alone is 4-byte aligned (1 028 B) and a 16-byte store
+      // to it splits.  The log power spectrum goes from the registers to the wave's LDS in that flat order
+      // (the frame tiles are dead: 4 x 257 floats over the first two) and leaves as 257 quads, 1 KB per wave
+      // instruction.  Five UNCONDITIONAL buffer stores per set: what lies behind the last row of the batch is
+      // dropped by the range check (per dword), lanes 1-63 of the fifth point outside the buffer.  A store
+      // under a branch costs more than the branch: loads and stores share one in-order counter, the compiler
+      // cannot count stores it may not issue, and the wait for the next set's samples at the top of the loop
+      // becomes a wait for every store of this set (vmcnt(0)): 1.22 ms row by row under `if (valid)`, 1.19 ms
+      // with aligned quads under a bounds test, see DESIGN.md 4.1 for this form.
       float* __restrict__ stage = reinterpret_cast<float*>(smem + tab_bytes + wid * 4 * kFrameTileBytes);
       float* __restrict__ mine = stage + q * 257;
 #pragma unroll
@@ -467,39 +478,23 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
       }
       if (l == 0) mine[128] = fast_log(fmaxf(0.25f * p128, FLT_EPSILON));
       wave_lds_sync();
-      const int64_t rows_left = b.total_frames - set * 4;
-      const int n_floats = rows_left < 4 ? static_cast<int>(rows_left) * 257 : 1028;
-      float* __restrict__ dst = out + set * 1028;
+      // (the set index is the same in every lane: through v_readfirstlane, or the descriptor lives in vector
+      // registers and every store becomes a loop over its distinct values)
+      const int64_t set_u = (static_cast<int64_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(set >> 32))) << 32) |
+                            static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(set)));
+      const int64_t rows_left = b.total_frames - set_u * 4;
+      const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
+          out + set_u * 1028, 0, (rows_left < 4 ? static_cast<int>(rows_left) : 4) * 1028, 0x00020000);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int at = 4 * (lane + 64 * i);
-        const float4 v = *reinterpret_cast<const float4*>(stage + at);
-        if (at + 4 <= n_floats) {
-          __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(dst + at));
-        } else {   // the last rows of the batch: a quad that the batch ends in
-          if (at < n_floats) dst[at] = v.x;
-          if (at + 1 < n_floats) dst[at + 1] = v.y;
-          if (at + 2 < n_floats) dst[at + 2] = v.z;
-        }
+        const float4 v = *reinterpret_cast<const float4*>(stage + 4 * (lane + 64 * i));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v.x, v.y, v.z, v.w}), srsrc,
+                                               16 * (lane + 64 * i), 0, 2);
       }
-      if (lane == 0 && n_floats == 1028) {
+      {
         const float4 v = *reinterpret_cast<const float4*>(stage + 1024);
-        __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(dst + 1024));
-      }
-    } else if (KIND == SNF_KIND_SPECTROGRAM) {
-      // log power spectrum, 257 bins: lane l stores bins l + 16 i (64-byte segments), bin 0 = energy
-      // (lane l stores bins 4 l + 64 i as 16-byte vectors: 256 contiguous bytes per frame and instruction;
-      // the rows are 1028 bytes, 4-byte aligned; written once -> nontemporal)
-      if (valid) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float4 pw = *reinterpret_cast<const float4*>(ptile + 4 * l + 64 * i);
-          f32x4_a4 v = {fast_log(fmaxf(0.25f * pw.x, FLT_EPSILON)), fast_log(fmaxf(0.25f * pw.y, FLT_EPSILON)),
-                        fast_log(fmaxf(0.25f * pw.z, FLT_EPSILON)), fast_log(fmaxf(0.25f * pw.w, FLT_EPSILON))};
-          if (i == 0 && l == 0) v[0] = log_energy;
-          __builtin_nontemporal_store(v, reinterpret_cast<f32x4_a4*>(row + 4 * l + 64 * i));
-        }
-        if (l == 0) row[256] = fast_log(fmaxf(0.25f * ptile[256], FLT_EPSILON));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v.x, v.y, v.z, v.w}), srsrc,
+                                               lane == 0 ? 4096 : 0x7ffffff0, 0, 2);
       }
     } else {
       // ---- F: mel filterbank on the matrix pipe -----------------------------------------------------
