@@ -1237,3 +1237,48 @@ def test_dither_differs_between_utterances_that_start_alike(gpu, cls, sample_rat
     db = fb.data[:silent] - fb.data[:silent].mean(axis=0)
     assert abs(np.corrcoef(da.ravel(), db.ravel())[0, 1]) < 0.35
     assert np.array_equal(fa.data, fa2.data)
+
+
+def test_calls_enqueued_on_a_callers_stream(gpu, synth_waves):
+    """the *_device entry points are asynchronous on a caller's stream (include/shennong_amd.h): several calls
+    enqueued without waiting for each, a pair of snf_event_* marks around every one (what bench.py times), give
+    the bits of the synchronous call and positive device times"""
+    import ctypes as C
+    L = _backend.lib()
+    waves = [w for w in synth_waves][:8]
+    flat = np.ascontiguousarray(np.concatenate(waves))
+    plan = _backend.get_plan(FilterbankProcessor(num_bins=40, dither=0)._build_options())
+    frames = [plan.num_frames(len(w)) for w in waves]
+    soff = np.concatenate([[0], np.cumsum([len(w) for w in waves])]).astype(np.int64)
+    foff = np.concatenate([[0], np.cumsum(frames)]).astype(np.int64)
+    d_wave = _backend.DeviceBuffer(flat.nbytes)
+    d_wave.upload(flat)
+    outs = [_backend.DeviceBuffer(int(foff[-1]) * 40 * 4) for _ in range(3)]
+    plan.run_device(d_wave.ptr, soff, foff, outs[0].ptr)          # the plan's own stream: waited for
+    want = np.empty((int(foff[-1]), 40), np.float32)
+    outs[0].download(want)
+    stream = C.c_void_p()
+    _backend.check(L.snf_stream_create(C.byref(stream)))
+    marks = []
+    for dst in outs[1:]:
+        a, b = C.c_void_p(), C.c_void_p()
+        _backend.check(L.snf_event_create(C.byref(a)))
+        _backend.check(L.snf_event_create(C.byref(b)))
+        _backend.check(L.snf_event_record(a, stream))
+        plan.run_device(d_wave.ptr, soff, foff, dst.ptr, stream=stream.value)
+        _backend.check(L.snf_event_record(b, stream))
+        marks.append((a, b))
+    _backend.check(L.snf_stream_synchronize(stream))
+    for (a, b), dst in zip(marks, outs[1:]):
+        ms = C.c_float(-1.0)
+        _backend.check(L.snf_event_elapsed_ms(a, b, C.byref(ms)))
+        assert 0.0 < ms.value < 1000.0
+        got = np.empty_like(want)
+        dst.download(got)
+        np.testing.assert_array_equal(got, want)
+        _backend.check(L.snf_event_destroy(a))
+        _backend.check(L.snf_event_destroy(b))
+    assert L.snf_event_record(None, stream) != 0      # a null event is an error, not a crash
+    _backend.check(L.snf_stream_destroy(stream))
+    for buf in outs + [d_wave]:
+        buf.free()
