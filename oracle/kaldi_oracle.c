@@ -605,7 +605,11 @@ ORC_API int orc_compute(const snf_options* o, const int16_t* wave16, int64_t n, 
     /* ... the banks of a warp factor other than 1 are built lazily by the first frame
        ([KALDI-UPSTREAM] MfccComputer::GetMelBanks from Compute; reference plp.py:521-522 returns
        before _compute_frame): an utterance without frames never sees their option errors */
-    int rc = melbanks_init(&mb, &o->mel, fo, (kind == SNF_KIND_PLP && T > 0) ? vtln_warp : 1.0f);
+    /* ... and the reference's PLP builds ALL its banks that way (plp.py:482-494, called from _compute_frame
+       only): no frames, no banks, no option errors; frames with a warp factor: that factor's banks only */
+    int rc = 0;
+    if (!(kind == SNF_KIND_PLP && T == 0))
+      rc = melbanks_init(&mb, &o->mel, fo, kind == SNF_KIND_PLP ? vtln_warp : 1.0f);
     if (rc) return rc;
     if (kind != SNF_KIND_PLP && vtln_warp != 1.0f && T > 0) {
       melbanks_free(&mb);
@@ -622,7 +626,7 @@ ORC_API int orc_compute(const snf_options* o, const int16_t* wave16, int64_t n, 
   }
   if (kind == SNF_KIND_PLP) {
     eql = (float*)malloc(sizeof(float) * (size_t)nb);
-    equal_loudness(&mb, eql);
+    if (T > 0) equal_loudness(&mb, eql);
     idft = (float*)malloc(sizeof(float) * (size_t)(o->lpc_order + 1) * (size_t)(nb + 2));
     idft_bases(o->lpc_order + 1, nb + 2, idft);
     lift = (float*)malloc(sizeof(float) * (size_t)o->num_ceps);

@@ -80,6 +80,7 @@ struct snf_plan {
   MelParams mp{};
   DevBuf d_window, d_tw_fft, d_tw_unpack, d_tw_dft, d_dct, d_lifter, d_idft;
   std::vector<float> warps;  // distinct VTLN warp factors seen so far (index = warp id)
+  std::string base_banks_error;  // PLP: why the unwarped banks (id 0) cannot be built; empty = they can
   std::vector<MelBanksHost> banks;
   DevBuf d_mel_first, d_mel_size, d_mel_off, d_mel_w, d_eql, d_mel_w32, d_mel_off32;
   bool warps_dirty = true;
@@ -266,9 +267,19 @@ int build_mel_plan(snf_plan* plan) {
   if (plan->kind != SNF_KIND_SPECTROGRAM && plan->kind != SNF_KIND_ENERGY) {
     p.need_raw = (o.use_energy && o.raw_energy) ? 1 : 0;
     p.need_post = (o.use_energy && !o.raw_energy) ? 1 : 0;
-    // Kaldi builds the warp-1.0 banks in the computer's constructor: option errors surface here
+    // Kaldi builds the warp-1.0 banks in the computer's constructor: option errors surface here.  Not for
+    // PLP: the reference's own recipe builds the banks of a warp factor when the first frame asks for them
+    // (shennong/processor/plp.py:482-494, :559) - an utterance without frames, or a batch in which every
+    // utterance carries another warp factor, never sees the errors of the unwarped banks.  The plan then
+    // holds zero-weight placeholders as bank 0 and reports the error when an utterance with frames needs it.
     MelBanksHost mb;
-    if ((rc = make_mel_banks(o.mel, fo, 1.0f, &mb))) return rc;
+    if ((rc = make_mel_banks(o.mel, fo, 1.0f, &mb))) {
+      if (plan->kind != SNF_KIND_PLP || rc != SNF_E_RUNTIME || o.mel.num_bins < 3 ||
+          padded_window_size(fo) % 2 != 0)
+        return rc;
+      plan->base_banks_error = last_error();
+      make_placeholder_banks(o.mel, fo, &mb);
+    }
     plan->warps.assign(1, 1.0f);
     plan->banks.assign(1, mb);
     plan->warps_dirty = true;
@@ -941,6 +952,12 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
   std::vector<int32_t> warp_ids;
   bool any_warp = false;
   if ((rc = resolve_warps(plan, vtln_warp, frame_offsets, n_utts, &warp_ids, &any_warp))) return rc;
+  if (!plan->base_banks_error.empty()) {
+    // (PLP, see snf_plan_create) an utterance with frames that needs the unwarped banks
+    for (int64_t u = 0; u < n_utts; ++u)
+      if (frame_offsets[u + 1] > frame_offsets[u] && (warp_ids.empty() || warp_ids[u] == 0))
+        return set_error(SNF_E_RUNTIME, plan->base_banks_error);
+  }
   if ((rc = sync_warp_tables(plan))) return rc;
 
   if (!same_tables) {

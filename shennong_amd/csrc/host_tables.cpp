@@ -166,6 +166,23 @@ int make_mel_banks(const snf_mel_options& mo, const snf_frame_options& fo, float
   return SNF_OK;
 }
 
+void make_placeholder_banks(const snf_mel_options& mo, const snf_frame_options& fo, MelBanksHost* out) {
+  const int nb = mo.num_bins > 0 ? mo.num_bins : 1;
+  const int padded = padded_window_size(fo);
+  const int nfft = padded / 2 > 0 ? padded / 2 : 1;
+  out->num_bins = nb;
+  out->num_fft_bins = nfft;
+  out->first.assign(nb, 0);
+  out->size.assign(nb, 1);
+  out->offset.resize(nb);
+  for (int b = 0; b < nb; ++b) {
+    out->first[b] = b < nfft ? b : nfft - 1;
+    out->offset[b] = b;
+  }
+  out->w.assign(nb, 0.0f);
+  out->center_freqs.assign(nb, 1000.0f);
+}
+
 void make_dct_matrix(int num_rows, int num_cols, std::vector<float>* m) {
   m->assign(static_cast<size_t>(num_rows) * num_cols, 0.0f);
   const float n_f = static_cast<float>(num_cols);

@@ -49,6 +49,9 @@ struct MelBanksHost {
 };
 int make_mel_banks(const snf_mel_options& mo, const snf_frame_options& fo, float vtln_warp,
                    MelBanksHost* out);
+// structurally valid banks with zero weights: what a PLP plan holds in place of unwarped banks that the
+// options do not allow, until an utterance asks for them (capi.hip: snf_plan::base_banks_error)
+void make_placeholder_banks(const snf_mel_options& mo, const snf_frame_options& fo, MelBanksHost* out);
 void make_dct_matrix(int num_rows, int num_cols, std::vector<float>* m);  // first rows of NxN DCT
 void make_lifter(float q, int n, std::vector<float>* c);
 void make_equal_loudness(const MelBanksHost& mb, std::vector<float>* out);

@@ -1282,3 +1282,35 @@ def test_calls_enqueued_on_a_callers_stream(gpu, synth_waves):
     _backend.check(L.snf_stream_destroy(stream))
     for buf in outs + [d_wave]:
         buf.free()
+
+
+def test_plp_banks_are_built_when_a_frame_asks(gpu):
+    """The reference's PLP builds the mel banks of a warp factor when the first frame asks for them
+    (shennong/processor/plp.py:482-494, :559) - unlike Kaldi's Fbank / Mfcc computers, whose constructors build the
+    unwarped banks.  8 ms frames at 8 kHz with 23 bins leave an unwarped bin empty: a warped utterance runs, an
+    unwarped one is an error, an utterance without frames is empty and sees no error - here as in the oracle."""
+    opts = dict(sample_rate=8000, frame_length=0.008, frame_shift=0.02, num_bins=23, num_ceps=7, dither=0,
+                window_type='rectangular', snip_edges=False, low_freq=0, high_freq=-200, vtln_low=100, vtln_high=-500)
+    proc = PlpProcessor(**opts)
+    wave = synth.utterances(7, 1, 9670, 8000)[0]
+    got = proc.process(Audio(wave, 8000), vtln_warp=0.85)
+    want = orc.compute(proc._build_options(), wave, 0.85)
+    assert_close(got.data, want, family='plp', what='warped utterance, unwarped banks impossible')
+    with pytest.raises(RuntimeError, match='num_bins too large'):
+        proc.process(Audio(wave, 8000))
+    with pytest.raises(RuntimeError, match='num_bins too large'):
+        orc.compute(proc._build_options(), wave, 1.0)
+    # (a frameless utterance - shorter than half a shift with centred frames - asks for no banks at all)
+    both = proc._process_batch([Audio(wave, 8000), Audio(wave[:5000], 8000), Audio(wave[:40], 8000)],
+                               vtln_warp=[0.85, 0.85, 1.0])
+    assert_close(both[1].data, orc.compute(proc._build_options(), wave[:5000], 0.85), family='plp')
+    assert both[2].data.size == 0 and orc.compute(proc._build_options(), wave[:40], 1.0).size == 0
+    with pytest.raises(RuntimeError, match='num_bins too large'):
+        proc._process_batch([Audio(wave, 8000), Audio(wave[:5000], 8000)], vtln_warp=[0.85, 1.0])
+    # fbank builds the unwarped banks when the plan is made, like Kaldi's FbankComputer
+    with pytest.raises(RuntimeError, match='num_bins too large'):
+        FilterbankProcessor(**{k: v for k, v in opts.items() if k != 'num_ceps'}).process(
+            Audio(wave, 8000), vtln_warp=0.85)
+    with pytest.raises(RuntimeError, match='num_bins too large'):
+        fb = FilterbankProcessor(**{k: v for k, v in opts.items() if k != 'num_ceps'})
+        orc.compute(fb._build_options(), wave, 0.85)
