@@ -174,6 +174,33 @@ def test_option_errors():
         orc.compute(o, wave)
 
 
+def test_when_the_mel_banks_are_built():
+    """Kaldi's Fbank / Mfcc computers build the banks of warp factor 1 in their constructors: their option errors
+    come with or without frames, whatever the utterance's own warp factor.  The reference's PLP is its own recipe and
+    builds the banks of a warp factor when a frame asks for them (shennong/processor/plp.py:482-494, :559): no frames,
+    no error; a warped utterance never sees the errors of the unwarped banks.  8 ms frames at 8 kHz leave bin 0 of 23
+    unwarped bins empty; the banks of warp factor 0.85 are complete."""
+    wave = synth.utterances(7, 1, 9670, 8000)[0]
+
+    def options(kind):
+        o = _abi.default_options(kind)
+        o.frame.samp_freq, o.frame.frame_length_ms, o.frame.frame_shift_ms = 8000, 8.0, 20.0
+        o.frame.dither, o.frame.snip_edges, o.frame.window_type = 0, 0, _abi.WINDOW_TYPES['rectangular']
+        o.mel.num_bins, o.mel.low_freq, o.mel.high_freq, o.mel.vtln_low, o.mel.vtln_high = 23, 0, -200, 100, -500
+        return o
+    plp = options(_abi.KIND_PLP)
+    plp.num_ceps = 7
+    assert orc.compute(plp, wave, 0.85).shape == (60, 7)
+    with pytest.raises(RuntimeError, match='num_bins too large'):
+        orc.compute(plp, wave, 1.0)
+    assert orc.compute(plp, wave[:40], 1.0).size == 0          # no frames: no banks
+    for kind in (_abi.KIND_FBANK, _abi.KIND_MFCC):
+        o = options(kind)
+        for length, warp in ((len(wave), 0.85), (len(wave), 1.0), (40, 1.0), (40, 0.85)):
+            with pytest.raises(RuntimeError, match='num_bins too large'):
+                orc.compute(o, wave[:length], warp)
+
+
 # ---- float64 restatement -------------------------------------------------------------------------------
 @pytest.mark.parametrize('kind, code, kw', [
     ('fbank', _abi.KIND_FBANK, dict(num_bins=40)),
