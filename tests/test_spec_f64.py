@@ -177,3 +177,15 @@ def test_fraction_within_pure_rtol():
         inside[kind] = ok / total
     assert inside['fbank'] == 1.0, inside
     assert inside['mfcc'] > 0.98 and inside['plp'] > 0.98, inside   # (99.2 % / 98.6 %: signed cepstra near zero)
+
+
+def test_random_option_sets(monkeypatch):
+    """tests/tools/fuzz_oracle_f64.py: random option sets of the four spectral families, the C oracle against the
+    float64 restatement (1 650 cases in profiles/r04_f64_report.txt; a short run here)"""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'fuzz_oracle_f64.py')
+    spec = importlib.util.spec_from_file_location('fuzz_oracle_f64', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr('sys.argv', ['fuzz_oracle_f64.py', '40', '11'])
+    assert mod.main() == 0
