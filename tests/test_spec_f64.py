@@ -189,3 +189,15 @@ def test_random_option_sets(monkeypatch):
     spec.loader.exec_module(mod)
     monkeypatch.setattr('sys.argv', ['fuzz_oracle_f64.py', '40', '11'])
     assert mod.main() == 0
+
+
+def test_random_post_processing_cases(monkeypatch):
+    """tests/tools/fuzz_oracle_f64_post.py: random delta / CMVN / sliding CMVN / pitch post-processing cases, the C
+    oracle against the float64 restatement (2 300 cases in profiles/r04_f64_report.txt; a short run here)"""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'fuzz_oracle_f64_post.py')
+    spec = importlib.util.spec_from_file_location('fuzz_oracle_f64_post', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr('sys.argv', ['fuzz_oracle_f64_post.py', '60', '12'])
+    assert mod.main() == 0
