@@ -24,27 +24,35 @@ def random_case(rng):
         preemph_coeff=float(rng.choice([0.0, 0.5, 0.97])),
         remove_dc_offset=bool(rng.integers(2)), snip_edges=bool(rng.integers(2)),
         window_type=str(rng.choice(['povey', 'hamming', 'hanning', 'rectangular', 'blackman'])),
-        round_to_power_of_two=bool(rng.integers(8) > 0))
+        round_to_power_of_two=bool(rng.integers(8) > 0),
+        blackman_coeff=float(rng.choice([0.42, 0.42, 0.3])))
     kind = str(rng.choice(['fbank', 'fbank', 'mfcc', 'mfcc', 'plp', 'spectrogram', 'energy']))
     nyquist = sample_rate / 2
     mel = dict(num_bins=int(rng.integers(8, 65 if sample_rate < 30000 else 100)), low_freq=float(rng.choice([0, 20, 100])),
-               high_freq=float(rng.choice([0, -200, nyquist - 300])))
+               high_freq=float(rng.choice([0, -200, nyquist - 300])),
+               vtln_low=float(rng.choice([100, 100, 150])), vtln_high=float(rng.choice([-500, -500, -700])))
+    floor = float(rng.choice([0.0, 0.0, 1.0, 1.0e4]))   # (energy_floor: the log-energy column never below its log)
     if kind == 'fbank':
-        proc = FilterbankProcessor(use_energy=bool(rng.integers(2)), raw_energy=bool(rng.integers(2)),
+        proc = FilterbankProcessor(use_energy=bool(rng.integers(2)), raw_energy=bool(rng.integers(2)), energy_floor=floor,
                                    htk_compat=bool(rng.integers(2)), use_log_fbank=bool(rng.integers(4) > 0),
                                    use_power=bool(rng.integers(4) > 0), **frame, **mel)
     elif kind == 'mfcc':
         mel['num_bins'] = max(mel['num_bins'], 13)
-        proc = MfccProcessor(num_ceps=int(rng.integers(2, 14)), use_energy=bool(rng.integers(2)),
+        proc = MfccProcessor(num_ceps=int(rng.integers(2, 14)), use_energy=bool(rng.integers(2)), energy_floor=floor,
                              raw_energy=bool(rng.integers(2)), htk_compat=bool(rng.integers(2)),
                              cepstral_lifter=float(rng.choice([0, 22])), **frame, **mel)
     elif kind == 'plp':
         mel['num_bins'] = int(rng.integers(15, 41))
-        proc = PlpProcessor(num_ceps=int(rng.integers(2, 14)), use_energy=bool(rng.integers(2)),
+        order = int(rng.choice([8, 12, 12, 16, 20]))
+        proc = PlpProcessor(num_ceps=int(rng.integers(2, min(14, order + 2))), lpc_order=order,
+                            use_energy=bool(rng.integers(2)), energy_floor=floor,
                             raw_energy=bool(rng.integers(2)), htk_compat=bool(rng.integers(2)),
+                            cepstral_scale=float(rng.choice([1.0, 1.0, 2.0])),
+                            cepstral_lifter=float(rng.choice([22, 22, 0])),
+                            compress_factor=float(rng.choice([1.0 / 3.0, 1.0 / 3.0, 0.5])),
                             rasta=bool(rng.integers(3) == 0), **frame, **mel)
     elif kind == 'spectrogram':
-        proc = SpectrogramProcessor(raw_energy=bool(rng.integers(2)), **frame)
+        proc = SpectrogramProcessor(raw_energy=bool(rng.integers(2)), energy_floor=floor, **frame)
     else:
         proc = EnergyProcessor(raw_energy=bool(rng.integers(2)),
                                compression=str(rng.choice(['log', 'sqrt', 'off'])), **frame)
