@@ -56,7 +56,8 @@ def random_case(rng):
     warp = float(rng.choice([1.0, 1.0, 0.85, 0.93, 1.1, 1.2]))
     opts = dict(lpc_order=order, num_ceps=nc, cepstral_lifter=float(rng.choice([0.0, 22.0])),
                 cepstral_scale=float(rng.choice([1.0, 2.0])), use_energy=bool(rng.integers(2)), raw_energy=raw,
-                htk_compat=bool(rng.integers(2)))
+                htk_compat=bool(rng.integers(2)), compress_factor=float(rng.choice([1.0 / 3.0, 1.0 / 3.0, 0.5])),
+                energy_floor=float(rng.choice([0.0, 0.0, 1.0, 1.0e4])))
     rasta = bool(rng.integers(2))
     proc = PlpProcessor(rasta=rasta, **opts, **mel, **common)
     return kind, proc, dict(use_rasta=rasta, warp=warp, **opts, **mel, **f64), warp
