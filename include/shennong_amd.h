@@ -352,7 +352,8 @@ int snf_memcpy_d2h_async(void* dst, const void* src, uint64_t bytes, void* strea
    *_device calls on its own stream without waiting for each - the way a pipeline uses the path, and what
    bench.py times - brackets every call with two marks and reads the elapsed device time of each pair after
    ONE synchronisation (snf_plan_last_kernel_ms is for calls on the plan's own stream and waits for the call).
-   snf_event_elapsed_ms waits for `stop`. */
+   snf_event_elapsed_ms waits for `stop`.  Marks belong to the calling thread's current device (the one of the
+   stream they are recorded on). */
 int snf_event_create(void** event);
 int snf_event_destroy(void* event);
 int snf_event_record(void* event, void* stream);
