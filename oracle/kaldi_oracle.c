@@ -914,8 +914,12 @@ static int64_t linres_num_out(const linres_t* r, int64_t n_in, int flush) {
   int64_t ticks_per_in = tick_freq / r->rate_in;
   int64_t interval = n_in * ticks_per_in;
   if (!flush) {
+    /* resample.cc: `BaseFloat window_width = num_zeros_ / (2.0 * filter_cutoff_); int32 window_width_ticks =
+       floor(window_width * tick_freq);` - a FLOAT product (float x int32), rounded to float before the floor:
+       800 Hz at 16 kHz is 9.99999978 in exact arithmetic and 10.0f as a float product (round 4: this line used a
+       double product, one tick short for cutoffs whose width is not a dyadic fraction; the default 1 000 Hz is) */
     float window_width = (float)((double)r->num_zeros / (2.0 * (double)r->cutoff));
-    int window_ticks = (int)floor((double)window_width * (double)tick_freq);
+    int window_ticks = (int)floorf(window_width * (float)tick_freq);
     interval -= window_ticks;
   }
   if (interval <= 0) return 0;

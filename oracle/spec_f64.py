@@ -161,7 +161,8 @@ def linear_resample(wave, rate_in=16000, rate_out=4000, cutoff=1000.0, num_zeros
     tick = rate_in // base * rate_out
     interval = n * (tick // rate_in)
     if not flush:
-        interval -= int(np.floor(num_zeros / (2.0 * cutoff) * tick))
+        # (an index decision, not arithmetic: Kaldi floors the FLOAT32 product of a float32 width and the tick rate)
+        interval -= int(np.floor(np.float32(np.float32(num_zeros / (2.0 * cutoff)) * np.float32(tick))))
     if interval <= 0:
         return np.zeros(0)
     per_out = tick // rate_out

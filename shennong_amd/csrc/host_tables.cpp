@@ -309,8 +309,10 @@ int64_t LinearResampleHost::num_output(int64_t n_in, bool flush) const {
   const int64_t ticks_per_in = tick_freq / rate_in;
   int64_t interval = n_in * ticks_per_in;
   if (!flush) {
+    // [KALDI-UPSTREAM] resample.cc GetNumOutputSamples: BaseFloat window_width; floor(window_width * tick_freq) -
+    // a float product (float x int32) rounded to float before the floor
     const float half_width = static_cast<float>(num_zeros / (2.0 * cutoff));
-    interval -= static_cast<int>(std::floor(static_cast<double>(half_width) * tick_freq));
+    interval -= static_cast<int>(std::floor(half_width * static_cast<float>(tick_freq)));
   }
   if (interval <= 0) return 0;
   const int64_t ticks_per_out = tick_freq / rate_out;

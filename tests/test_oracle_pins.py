@@ -516,3 +516,29 @@ def test_known_answer_delta_ramp():
 def scipy_wave():
     import scipy.io.wavfile
     return scipy.io.wavfile.read(os.path.join(GOLDEN, 'test.wav'))[1]
+
+
+def test_linear_resample_window_in_ticks():
+    """[KALDI-UPSTREAM] resample.cc LinearResample::GetNumOutputSamples: `BaseFloat window_width = num_zeros_ /
+    (2.0 * filter_cutoff_); int32 window_width_ticks = floor(window_width * tick_freq);` - the product is a FLOAT
+    product.  A cutoff of 800 Hz at 16 kHz -> 4 kHz (tick rate 16 000): the width is 0.000624999986 as a float, times
+    16 000 = 9.99999978 exactly and 10.0f as a float: 10 ticks.  16 002 input samples without flush: 15 992 ticks = 4 x
+    3 998 exactly -> outputs 0 .. 3 997 (with 9 ticks there would be 3 999).  Found by
+    tests/tools/fuzz_oracle_f64_pitch.py in round 4: until then the oracle and the product formed that product in
+    double; the default cutoff (1 000 Hz: 8.0000004 -> 8 either way) never showed it."""
+    wave = synth.utterances(3, 1, 16002)[0]
+    assert orc.linear_resample(wave, 16000, 4000, 800.0, 1, False).shape == (3998,)
+    assert spec_f64.linear_resample(wave, 16000, 4000, 800.0, 1, False).shape == (3998,)
+    assert orc.linear_resample(wave, 16000, 4000, 1000.0, 1, False).shape == (3999,)
+
+
+def test_random_pitch_option_sets(monkeypatch):
+    """tests/tools/fuzz_oracle_f64_pitch.py: random option sets of the pitch tracker, the C oracle against the float64
+    restatement with a full-search Viterbi (800 cases in profiles/r04_f64_report.txt; a short run here)"""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'fuzz_oracle_f64_pitch.py')
+    spec = importlib.util.spec_from_file_location('fuzz_oracle_f64_pitch', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr('sys.argv', ['fuzz_oracle_f64_pitch.py', '12', '21'])
+    assert mod.main() == 0
