@@ -25,12 +25,16 @@ def main():
                   min_f0=float(rng.choice([50.0, 50.0, 70.0])), max_f0=float(rng.choice([400.0, 400.0, 300.0])),
                   soft_min_f0=float(rng.choice([10.0, 10.0, 30.0])), penalty_factor=float(rng.choice([0.1, 0.1, 0.3])),
                   delta_pitch=float(rng.choice([0.005, 0.005, 0.01])), nccf_ballast=float(rng.choice([7000.0, 7000.0, 1000.0])),
-                  upsample_filter_width=int(rng.choice([5, 5, 7])), lowpass_cutoff=float(rng.choice([1000.0, 1000.0, 800.0])))
+                  upsample_filter_width=int(rng.choice([5, 5, 7])), lowpass_cutoff=float(rng.choice([1000.0, 1000.0, 800.0, 900.0])),
+                  samp_freq=int(rng.choice([16000, 16000, 8000, 22050])), resample_freq=int(rng.choice([4000, 4000, 3200])),
+                  lowpass_filter_width=int(rng.choice([1, 1, 2])))
+        if 2 * kw['lowpass_cutoff'] > kw['resample_freq']:
+            kw['lowpass_cutoff'] = kw['resample_freq'] / 4.0
         po = _abi.default_pitch_options()
         for k, v in kw.items():
             setattr(po, k, v)
         n = int(rng.integers(8000, 40000))
-        wave = synth.utterances(5000 + 100 * seed + case, 1, n)[0]
+        wave = synth.utterances(5000 + 100 * seed + case, 1, n * kw['samp_freq'] // 16000, kw['samp_freq'])[0]
         ref = spec_f64.pitch(wave, **kw)
         out, _, res, _, states = orc.pitch_debug(po, wave)
         what = f'case {case} (seed {seed}): {kw} samples {n}'
