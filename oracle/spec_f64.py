@@ -87,8 +87,9 @@ def mel_banks(num_bins, sample_rate, padded, low_freq=20.0, high_freq=0.0):
 def features(wave, kind='fbank', sample_rate=16000, frame_shift=0.01, frame_length=0.025,
              preemph=0.97, remove_dc=True, window='povey', snip_edges=True, num_bins=23,
              low_freq=20.0, high_freq=0.0, use_energy=None, raw_energy=True, num_ceps=13,
-             cepstral_lifter=22.0, use_log_fbank=True, use_power=True):
-    shift, length, padded = frame_geometry(sample_rate, frame_shift, frame_length)
+             cepstral_lifter=22.0, use_log_fbank=True, use_power=True, energy_floor=0.0, htk_compat=False,
+             blackman_coeff=0.42, round_pow2=True):
+    shift, length, padded = frame_geometry(sample_rate, frame_shift, frame_length, round_pow2)
     x = extract_frames(wave, shift, length, snip_edges)
     if remove_dc:
         x = x - x.mean(axis=1, keepdims=True)
@@ -98,9 +99,11 @@ def features(wave, kind='fbank', sample_rate=16000, frame_shift=0.01, frame_leng
         y[:, 1:] = x[:, 1:] - preemph * x[:, :-1]
         y[:, 0] = x[:, 0] - preemph * x[:, 0]
         x = y
-    x = x * window_function(length, window)[None, :]
+    x = x * window_function(length, window, blackman_coeff)[None, :]
     post_log_energy = np.log(np.maximum((x * x).sum(axis=1), EPS32))
     log_energy = raw_log_energy if raw_energy else post_log_energy
+    if energy_floor > 0:   # the log-energy column is never below log(energy_floor)
+        log_energy = np.maximum(log_energy, np.log(energy_floor))
     spec = np.fft.rfft(x, n=padded, axis=1)
     power = spec.real ** 2 + spec.imag ** 2
     if kind == 'spectrogram':
@@ -114,8 +117,8 @@ def features(wave, kind='fbank', sample_rate=16000, frame_shift=0.01, frame_leng
     mel = p @ w.T
     if kind == 'fbank':
         out = np.log(np.maximum(mel, EPS32)) if use_log_fbank else mel
-        if use_energy:
-            out = np.hstack((log_energy[:, None], out))
+        if use_energy:   # energy first; last with htk_compat
+            out = np.hstack((out, log_energy[:, None])) if htk_compat else np.hstack((log_energy[:, None], out))
         return out
     logmel = np.log(np.maximum(mel, EPS32))
     n = np.arange(num_bins)
@@ -128,6 +131,9 @@ def features(wave, kind='fbank', sample_rate=16000, frame_shift=0.01, frame_leng
             np.pi * np.arange(num_ceps) / cepstral_lifter))[None, :]
     if use_energy is None or use_energy:
         out[:, 0] = log_energy
+    if htk_compat:   # C0 (or the energy) moves to the end; a C0 that is not the energy is scaled by sqrt(2)
+        c0 = out[:, :1] if (use_energy is None or use_energy) else out[:, :1] * np.sqrt(2.0)
+        out = np.hstack((out[:, 1:], c0))
     return out
 
 
@@ -392,9 +398,9 @@ def plp(wave, sample_rate=16000, frame_shift=0.01, frame_length=0.025, preemph=0
         window='povey', snip_edges=True, num_bins=23, low_freq=20.0, high_freq=0.0, vtln_low=100.0,
         vtln_high=-500.0, warp=1.0, lpc_order=12, num_ceps=13, cepstral_lifter=22.0, cepstral_scale=1.0,
         compress_factor=1.0 / 3.0, use_energy=True, raw_energy=True, energy_floor=0.0, htk_compat=False,
-        use_rasta=False):
+        use_rasta=False, blackman_coeff=0.42, round_pow2=True):
     """PlpProcessor (reference plp.py:510-626) in float64"""
-    shift, length, padded = frame_geometry(sample_rate, frame_shift, frame_length)
+    shift, length, padded = frame_geometry(sample_rate, frame_shift, frame_length, round_pow2)
     x = extract_frames(wave, shift, length, snip_edges)
     if x.shape[0] == 0:
         return np.zeros((0, num_ceps))
@@ -407,7 +413,7 @@ def plp(wave, sample_rate=16000, frame_shift=0.01, frame_length=0.025, preemph=0
         y[:, 1:] = x[:, 1:] - preemph * x[:, :-1]
         y[:, 0] = x[:, 0] - preemph * x[:, 0]
         x = y
-    x = x * window_function(length, window)[None, :]
+    x = x * window_function(length, window, blackman_coeff)[None, :]
     post_log_energy = np.log(np.maximum((x * x).sum(axis=1), eps64))
     spec = np.fft.rfft(x, n=padded, axis=1)
     power = (spec.real ** 2 + spec.imag ** 2)[:, :padded // 2]

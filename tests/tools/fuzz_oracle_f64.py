@@ -19,18 +19,25 @@ from shennong_amd.processor import (  # noqa: E402
 
 def random_case(rng):
     kind = str(rng.choice(['fbank', 'mfcc', 'plp', 'spectrogram']))
-    sr = int(rng.choice([8000, 16000, 22050]))
-    frame_length = float(rng.choice([0.02, 0.025, 0.03]))
-    frame_shift = float(rng.choice([0.01, 0.015]))
-    window = str(rng.choice(['povey', 'hamming', 'hanning', 'rectangular']))
+    sr = int(rng.choice([8000, 16000, 16000, 22050, 32000, 44100]))
+    frame_length = float(rng.choice([0.01, 0.02, 0.025, 0.025, 0.03, 0.05]))
+    frame_shift = float(rng.choice([0.005, 0.01, 0.01, 0.015]))
+    window = str(rng.choice(['povey', 'hamming', 'hanning', 'rectangular', 'blackman']))
+    bc = float(rng.choice([0.42, 0.42, 0.3]))
+    pow2 = bool(rng.integers(6) > 0)
+    if not pow2 and int(sr * frame_length) % 2:   # (an odd transform size is an option error on both sides)
+        pow2 = True
     common = dict(sample_rate=sr, frame_shift=frame_shift, frame_length=frame_length, window_type=window,
                   snip_edges=bool(rng.integers(2)), remove_dc_offset=bool(rng.integers(2)),
-                  preemph_coeff=float(rng.choice([0.0, 0.9, 0.97])), dither=0)
+                  preemph_coeff=float(rng.choice([0.0, 0.9, 0.97])), dither=0, blackman_coeff=bc,
+                  round_to_power_of_two=pow2)
     f64 = dict(sample_rate=sr, frame_shift=frame_shift, frame_length=frame_length, window=window,
                snip_edges=common['snip_edges'], remove_dc=common['remove_dc_offset'], preemph=common['preemph_coeff'])
+    floor = float(rng.choice([0.0, 0.0, 1.0, 1.0e4]))
     if kind == 'spectrogram':
         raw = bool(rng.integers(2))
-        return kind, SpectrogramProcessor(raw_energy=raw, **common), dict(kind='spectrogram', raw_energy=raw, **f64), 1.0
+        return kind, SpectrogramProcessor(raw_energy=raw, energy_floor=floor, **common), \
+            dict(kind='spectrogram', raw_energy=raw, energy_floor=floor, blackman_coeff=bc, round_pow2=pow2, **f64), 1.0
     nb = int(rng.choice([20, 23, 26, 40]))
     low = float(rng.choice([0.0, 20.0, 100.0]))
     high = float(rng.choice([0.0, -200.0, -400.0]))
@@ -40,17 +47,22 @@ def random_case(rng):
         use_energy = bool(rng.integers(2))
         use_log = bool(rng.integers(2))
         use_power = bool(rng.integers(2))
-        proc = FilterbankProcessor(use_energy=use_energy, raw_energy=raw, use_log_fbank=use_log,
-                                   use_power=use_power, **mel, **common)
+        htk = bool(rng.integers(2))
+        proc = FilterbankProcessor(use_energy=use_energy, raw_energy=raw, use_log_fbank=use_log, energy_floor=floor,
+                                   htk_compat=htk, use_power=use_power, **mel, **common)
         return kind, proc, dict(kind='fbank', use_energy=use_energy, raw_energy=raw, use_log_fbank=use_log,
-                                use_power=use_power, **mel, **f64), 1.0
+                                use_power=use_power, energy_floor=floor, htk_compat=htk, blackman_coeff=bc,
+                                round_pow2=pow2, **mel, **f64), 1.0
     if kind == 'mfcc':
         nc = int(rng.choice([5, 13, nb]))
         lift = float(rng.choice([0.0, 22.0]))
         use_energy = bool(rng.integers(2))
-        proc = MfccProcessor(num_ceps=nc, cepstral_lifter=lift, use_energy=use_energy, raw_energy=raw, **mel, **common)
+        htk = bool(rng.integers(2))
+        proc = MfccProcessor(num_ceps=nc, cepstral_lifter=lift, use_energy=use_energy, raw_energy=raw,
+                             energy_floor=floor, htk_compat=htk, **mel, **common)
         return kind, proc, dict(kind='mfcc', num_ceps=nc, cepstral_lifter=lift, use_energy=use_energy,
-                                raw_energy=raw, **mel, **f64), 1.0
+                                raw_energy=raw, energy_floor=floor, htk_compat=htk, blackman_coeff=bc,
+                                round_pow2=pow2, **mel, **f64), 1.0
     order = int(rng.choice([8, 12, 16]))
     nc = int(rng.choice([5, order + 1, min(13, order + 1)]))
     warp = float(rng.choice([1.0, 1.0, 0.85, 0.93, 1.1, 1.2]))
@@ -60,7 +72,7 @@ def random_case(rng):
                 energy_floor=float(rng.choice([0.0, 0.0, 1.0, 1.0e4])))
     rasta = bool(rng.integers(2))
     proc = PlpProcessor(rasta=rasta, **opts, **mel, **common)
-    return kind, proc, dict(use_rasta=rasta, warp=warp, **opts, **mel, **f64), warp
+    return kind, proc, dict(use_rasta=rasta, warp=warp, blackman_coeff=bc, round_pow2=pow2, **opts, **mel, **f64), warp
 
 
 def main():
