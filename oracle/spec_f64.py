@@ -557,3 +557,19 @@ def process_pitch(raw, pitch_scale=2.0, pov_scale=2.0, pov_offset=0.0, delta_pit
     if add_raw_log_pitch:
         cols.append(log_pitch)
     return np.stack(cols, axis=1)
+
+
+def vad_energy(feats, energy_threshold=5.0, energy_mean_scale=0.5, frames_context=0, proportion_threshold=0.6):
+    """VadPostProcessor (reference postprocessor/vad.py:84-113 -> [KALDI-UPSTREAM] ComputeVadEnergy): column 0 of the
+    features is the log energy; a frame is voiced when at least `proportion_threshold` of the frames within
+    `frames_context` of it (inside the utterance) lie above energy_threshold + energy_mean_scale * mean(log energy).
+    -> ([n] of 0 / 1, the margin of the closest frame to the threshold)"""
+    e = np.asarray(feats, dtype=np.float64)[:, 0]
+    n = e.shape[0]
+    threshold = energy_threshold + (energy_mean_scale * e.sum() / n if energy_mean_scale != 0 else 0.0)
+    above = e > threshold
+    out = np.zeros(n)
+    for t in range(n):
+        lo, hi = max(0, t - frames_context), min(n, t + frames_context + 1)
+        out[t] = 1.0 if above[lo:hi].sum() >= (hi - lo) * proportion_threshold else 0.0
+    return out, float(np.abs(e - threshold).min()) if n else 0.0

@@ -1,5 +1,5 @@
 """Randomised comparison of the C oracle with the float64 restatement for the post-processing families: delta,
-CMVN (statistics, apply, reverse, weights), sliding-window CMVN and the pitch post-processing (noise term at 0) - CPU
+energy VAD, CMVN (statistics, apply, reverse, weights), sliding-window CMVN and the pitch post-processing (noise term at 0) - CPU
 only.  Inputs are random float32 matrices shaped like features (and synthetic (NCCF, pitch) tracks), so every
 difference is float32 round-off of the oracle or a transcription error in one of the two statements.
 
@@ -26,7 +26,7 @@ def main():
     rng = np.random.default_rng(seed)
     worst, count = {}, {}
     for case in range(n_cases):
-        family = str(rng.choice(['delta', 'cmvn', 'sliding', 'pitch_post']))
+        family = str(rng.choice(['delta', 'cmvn', 'sliding', 'pitch_post', 'vad']))
         n, d = int(rng.integers(1, 400)), int(rng.integers(1, 45))
         scale = float(rng.choice([0.1, 1.0, 20.0]))
         x = (rng.standard_normal((n, d)) * scale + rng.standard_normal(d) * scale).astype(np.float32)
@@ -55,6 +55,16 @@ def main():
             want = spec_f64.sliding_cmvn(x, center, cmn_window, min_window, nv)
             ok, w = close(got, want, 1e-4, 2e-4 * max(scale, 1.0))
             what += f' center {center} window {cmn_window} min {min_window} norm_vars {nv}'
+        elif family == 'vad':
+            kw = dict(energy_threshold=float(rng.choice([5.0, 0.0, -1.0, 2.0])) * scale,
+                      energy_mean_scale=float(rng.choice([0.5, 0.0, 1.0])), frames_context=int(rng.choice([0, 1, 2, 5])),
+                      proportion_threshold=float(rng.choice([0.6, 0.5, 0.25, 1.0])))
+            got = orc.vad_energy(x, **kw)
+            want, margin = spec_f64.vad_energy(x, **kw)
+            # (a frame whose energy sits within float32 round-off of the threshold may fall on either side)
+            w = float(np.abs(got - want).max()) if margin > 1e-5 * max(scale, 1.0) else 0.0
+            ok = w == 0.0
+            what += f' {kw}'
         else:
             nccf = np.clip(rng.standard_normal(n) * 0.5, -1.0, 1.0)
             pitch = np.exp(rng.uniform(np.log(50.0), np.log(400.0), n))
@@ -80,7 +90,7 @@ def main():
         if not ok:
             print('FAIL', what, 'worst', w)
             return 1
-        worst[family] = max(worst.get(family, 0.0), w / (scale if family != 'pitch_post' else 1.0))
+        worst[family] = max(worst.get(family, 0.0), w / (scale if family not in ('pitch_post', 'vad') else 1.0))
         count[family] = count.get(family, 0) + 1
     print(f'{n_cases} random cases (seed {seed}): the C oracle agrees with the float64 restatement; cases {count}; '
           f'worst difference per family, relative to the scale of the data '
