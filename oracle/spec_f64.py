@@ -573,3 +573,27 @@ def vad_energy(feats, energy_threshold=5.0, energy_mean_scale=0.5, frames_contex
         lo, hi = max(0, t - frames_context), min(n, t + frames_context + 1)
         out[t] = 1.0 if above[lo:hi].sum() >= (hi - lo) * proportion_threshold else 0.0
     return out, float(np.abs(e - threshold).min()) if n else 0.0
+
+
+def energy(wave, sample_rate=16000, frame_shift=0.01, frame_length=0.025, preemph=0.97, remove_dc=True,
+           window='povey', snip_edges=True, raw_energy=True, compression='log', blackman_coeff=0.42):
+    """EnergyProcessor (reference processor/energy.py:150-183): Kaldi's ExtractWindow (DC removal, pre-emphasis,
+    window; raw_energy = no pre-emphasis and a rectangular window), then the float64 sum of squares of the frame,
+    floored at the smallest normal double, compressed -> [n, 1]"""
+    shift, length, _ = frame_geometry(sample_rate, frame_shift, frame_length)
+    x = extract_frames(wave, shift, length, snip_edges)
+    if x.shape[0] == 0:
+        return np.zeros((0, 1))
+    if remove_dc:
+        x = x - x.mean(axis=1, keepdims=True)
+    if raw_energy:
+        preemph, window = 0.0, 'rectangular'
+    if preemph != 0:
+        y = x.copy()
+        y[:, 1:] = x[:, 1:] - preemph * x[:, :-1]
+        y[:, 0] = x[:, 0] - preemph * x[:, 0]
+        x = y
+    x = x * window_function(length, window, blackman_coeff)[None, :]
+    e = np.maximum((x * x).sum(axis=1), np.finfo(np.float64).tiny)
+    e = {'log': np.log, 'sqrt': np.sqrt, 'off': lambda v: v}[compression](e)
+    return e[:, None]

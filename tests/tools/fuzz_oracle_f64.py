@@ -14,11 +14,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from oracle import oracle as orc, spec_f64  # noqa: E402
 from shennong_amd import synth  # noqa: E402
 from shennong_amd.processor import (  # noqa: E402
-    FilterbankProcessor, MfccProcessor, PlpProcessor, SpectrogramProcessor)
+    EnergyProcessor, FilterbankProcessor, MfccProcessor, PlpProcessor, SpectrogramProcessor)
 
 
 def random_case(rng):
-    kind = str(rng.choice(['fbank', 'mfcc', 'plp', 'spectrogram']))
+    kind = str(rng.choice(['fbank', 'mfcc', 'plp', 'spectrogram', 'energy']))
     sr = int(rng.choice([8000, 16000, 16000, 22050, 32000, 44100]))
     frame_length = float(rng.choice([0.01, 0.02, 0.025, 0.025, 0.03, 0.05]))
     frame_shift = float(rng.choice([0.005, 0.01, 0.01, 0.015]))
@@ -34,6 +34,10 @@ def random_case(rng):
     f64 = dict(sample_rate=sr, frame_shift=frame_shift, frame_length=frame_length, window=window,
                snip_edges=common['snip_edges'], remove_dc=common['remove_dc_offset'], preemph=common['preemph_coeff'])
     floor = float(rng.choice([0.0, 0.0, 1.0, 1.0e4]))
+    if kind == 'energy':
+        raw, comp = bool(rng.integers(2)), str(rng.choice(['log', 'sqrt', 'off']))
+        return kind, EnergyProcessor(raw_energy=raw, compression=comp, **common), \
+            dict(raw_energy=raw, compression=comp, blackman_coeff=bc, **f64), 1.0
     if kind == 'spectrogram':
         raw = bool(rng.integers(2))
         return kind, SpectrogramProcessor(raw_energy=raw, energy_floor=floor, **common), \
@@ -92,7 +96,8 @@ def main():
             # an option error of the oracle (empty mel bin, VTLN limits): the restatement has no error model
             skipped += 1
             continue
-        want = spec_f64.plp(wave, **f64) if kind == 'plp' else spec_f64.features(wave, **f64)
+        want = spec_f64.plp(wave, **f64) if kind == 'plp' else (
+            spec_f64.energy(wave, **f64) if kind == 'energy' else spec_f64.features(wave, **f64))
         if got.shape != want.shape:
             print('FAIL shape', got.shape, want.shape, what)
             return 1
@@ -102,8 +107,10 @@ def main():
         # float32 round-off of a log-domain value: relative to the value, plus an absolute term for values near
         # zero (cepstra cross zero; a log of a sum of float32 products carries ~1e-6 of absolute error; the PLP
         # recursion amplifies the round-off of 23 compressed energies)
-        atol = {'fbank': 2e-4, 'mfcc': 2e-4, 'spectrogram': 2e-3, 'plp': 5e-4}[kind]
-        if kind == 'fbank' and not proc.use_log_fbank:
+        atol = {'fbank': 2e-4, 'mfcc': 2e-4, 'spectrogram': 2e-3, 'plp': 5e-4, 'energy': 1e-5}[kind]
+        if kind == 'energy':
+            bound = 2e-5 * np.abs(want) + 1e-5
+        elif kind == 'fbank' and not proc.use_log_fbank:
             bound = 2e-4 * np.abs(want) + 1e-3 * np.abs(want).max() * 1e-3
         else:
             bound = 1e-4 * np.abs(want) + atol
