@@ -386,7 +386,7 @@ def _gather_blocks(comm, local, blocks, dst):
 
 
 def extract_features_streamed_sharded(configuration, utterances, sink, warps=None,
-                                      max_batch_duration=7200.0, group=None, log=None):
+                                      max_batch_duration=14400.0, group=None, log=None):
     """``pipeline.extract_features_streamed`` over the ranks of one node (BASELINE config 5): every
     rank passes the same `utterances`, streams its length-balanced shard batch by batch through the
     device-resident pipeline and hands the batches to ITS OWN `sink` (e.g. one

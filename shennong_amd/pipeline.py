@@ -369,17 +369,17 @@ def _in_flight(batches, work, depth):
 
 
 def extract_features_streamed(configuration, utterances, sink, warps=None,
-                              max_batch_duration=7200.0, njobs=1, stats_reduce=None,
+                              max_batch_duration=14400.0, njobs=1, stats_reduce=None,
                               resident_bytes=16 << 30,
                               log=get_logger('pipeline', 'warning')):
     """:func:`extract_features` for a corpus that must not sit in memory at once (BASELINE config 5)
 
     The utterances are processed in consecutive batches of at most `max_batch_duration` seconds of
     audio (one hour of 16 kHz audio is 115 MB of int16 up and, for 123 columns, 177 MB of float32
-    down; the default of two hours was measured on an 8 h corpus of 3 s utterances: 30 min batches 42-45 hours
-    of audio per second, 1 h 54-57, 2 h 54-62, 4 h 59-64 - the pitch tracker's cost per utterance halves
-    between 1 000 and 4 000 utterances per call -, 8 h in one batch 35: its 1.4 GB of results no longer fit
-    the pooled page-locked blocks, which is also why the default stops at 2 h: 257 columns then take 735 MB);
+    down; the default of four hours was measured on an 8 h corpus of 3 s utterances: 1 h batches 54-57 hours of
+    audio per second, 2 h 54-65, 4 h 59-64, the whole 8 h in one batch 70 - the pitch tracker's cost per utterance
+    halves between 1 000 and 4 000 utterances per call; the results of a batch must fit a pooled page-locked block
+    of at most 2 GiB (_backend._ResultBlock._FRESH): 4 h of 257 columns are 1.5 GB);
     each batch goes through the device-resident pipeline and its FeaturesCollection is
     handed to `sink` (a callable, e.g. ``KaldiStreamWriter.write``) and dropped.  The results are
     those of :func:`extract_features` on the whole corpus - bit for bit when no random term is
