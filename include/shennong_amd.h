@@ -332,6 +332,10 @@ int snf_count_nonfinite_device(int device_id, const float* d_data, uint64_t n, u
 /* ---- device memory + timing (so hosts without torch can keep data resident in HBM) ---------- */
 int snf_malloc(void** dptr, uint64_t bytes);
 int snf_free(void* dptr);
+/* Free and total bytes of HBM on the calling thread's current device (hipMemGetInfo): the streamed pipeline
+ * sizes its batches from it (shennong_amd/pipeline.py extract_features_streamed) and bench.py reports the peak
+ * use of BASELINE config 5.  No counterpart in the reference (CPU only). */
+int snf_mem_info(uint64_t* free_bytes, uint64_t* total_bytes);
 /* A host that pools freed device buffers (shennong_amd/_backend.py DEVICE_POOL) registers a callback that
  * releases them: an allocation of the library's own scratch that fails with out-of-memory calls it and tries
  * once more (NULL removes the hook).  No counterpart in the reference (CPU only). */

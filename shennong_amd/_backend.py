@@ -38,7 +38,7 @@ EXPORTS = [
     'snf_memcpy_d2h_async', 'snf_comm_unique_id', 'snf_comm_init', 'snf_comm_rank', 'snf_comm_world_size',
     'snf_comm_destroy', 'snf_comm_gatherv', 'snf_comm_allreduce_f64',
     'snf_plan_last_kernel_ms', 'snf_plan_kernel_name', 'snf_set_oom_hook',
-    'snf_event_create', 'snf_event_destroy', 'snf_event_record', 'snf_event_elapsed_ms']
+    'snf_event_create', 'snf_event_destroy', 'snf_event_record', 'snf_event_elapsed_ms', 'snf_mem_info']
 
 
 _OOM_HOOK_TYPE = C.CFUNCTYPE(None)
@@ -144,6 +144,7 @@ def lib():
         L.snf_plan_kernel_name.argtypes = [vp, i32]
         L.snf_plan_kernel_name.restype = C.c_char_p
         L.snf_set_oom_hook.argtypes = [_OOM_HOOK_TYPE]
+        L.snf_mem_info.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         # the library's own allocations (plan scratch: ~19 GB for a 10 000-utterance pitch batch) reclaim
         # what DEVICE_POOL has parked before they give up
         L.snf_set_oom_hook(_OOM_HOOK)
@@ -181,6 +182,14 @@ def bind_device(device_id=None):
 
 def get_device():
     return _DEVICE
+
+
+def mem_info(device_id=None):
+    """(free, total) bytes of HBM on the selected GPU; the blocks parked in DEVICE_POOL count as used"""
+    bind_device(device_id)
+    free, total = C.c_uint64(0), C.c_uint64(0)
+    check(lib().snf_mem_info(C.byref(free), C.byref(total)))
+    return int(free.value), int(total.value)
 
 
 def device_name(device_id=None):
@@ -707,18 +716,26 @@ def upload_rows(mats, dtype, device=None):
         def run(w):
             bind_device(buf.device)
             stream = _copy_stream(buf.device)
-            for k in range(w, pieces, _COPY_THREADS):
-                a, b = cuts[k], cuts[k + 1]
-                if b <= a:
-                    continue
-                np.concatenate(mats[a:b], axis=0, out=staged[rows[a]:rows[b]])
-                check(lib().snf_memcpy_h2d_async(C.c_void_p(buf.ptr + int(rows[a]) * row_bytes),
-                                                 C.c_void_p(base + int(rows[a]) * row_bytes),
-                                                 int(rows[b] - rows[a]) * row_bytes, C.c_void_p(stream)))
-            check(lib().snf_stream_synchronize(C.c_void_p(stream)))
+            try:
+                for k in range(w, pieces, _COPY_THREADS):
+                    a, b = cuts[k], cuts[k + 1]
+                    if b <= a:
+                        continue
+                    np.concatenate(mats[a:b], axis=0, out=staged[rows[a]:rows[b]])
+                    check(lib().snf_memcpy_h2d_async(C.c_void_p(buf.ptr + int(rows[a]) * row_bytes),
+                                                     C.c_void_p(base + int(rows[a]) * row_bytes),
+                                                     int(rows[b] - rows[a]) * row_bytes, C.c_void_p(stream)))
+            finally:
+                # whatever happened, nothing of this thread is in flight from `staged` into `buf` afterwards
+                lib().snf_stream_synchronize(C.c_void_p(stream))
 
+        # every copy thread has finished (and synchronised its stream) before the staging block and the
+        # device buffer can go back to their pools: a failure in one thread must not free them under the others
+        from concurrent.futures import wait
+        futures = [_COPY_POOL.submit(run, w) for w in range(_COPY_THREADS)]
+        wait(futures)
         try:
-            for future in [_COPY_POOL.submit(run, w) for w in range(_COPY_THREADS)]:
+            for future in futures:
                 future.result()
         except BaseException:
             buf.free()
@@ -805,6 +822,9 @@ class _DevicePool:
             blocks = [(d, b) for d, bs in self._free.items() for b in bs]
             self._free.clear()
             self._bytes = 0
+        # (binds the thread to every device that has parked blocks: callers re-bind afterwards -
+        # DeviceBuffer.__init__ below; the library's out-of-memory hook, which also runs this in the middle of
+        # a plan call, saves and restores the thread's device around it: csrc/capi.hip malloc_with_hook)
         for device, block in blocks:
             bind_device(device)
             lib().snf_free(C.c_void_p(block[1]))
@@ -824,6 +844,7 @@ class DeviceBuffer:
             ptr = C.c_void_p()
             if lib().snf_malloc(C.byref(ptr), want) != 0:
                 DEVICE_POOL.clear()  # (out of memory with buffers parked in the pool: give them back first)
+                bind_device(self.device)   # (clear() walks over the devices that had parked blocks)
                 check(lib().snf_malloc(C.byref(ptr), want))
             block = (want, ptr.value)
         elif DEVICE_POOL.poison:

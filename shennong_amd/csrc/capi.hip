@@ -24,7 +24,13 @@ hipError_t malloc_with_hook(void** p, size_t bytes) {
   if (e == hipErrorOutOfMemory) {
     if (snf_oom_hook hook = g_oom_hook.load()) {
       (void)hipGetLastError();
+      // the hook frees pooled blocks of EVERY device and binds each one to do it: the retry (and the
+      // launches of the plan call we are in the middle of) must find the calling thread on its own device
+      int dev = -1;
+      const bool have_dev = hipGetDevice(&dev) == hipSuccess;
       hook();
+      if (have_dev) (void)hipSetDevice(dev);
+      (void)hipGetLastError();
       e = hipMalloc(p, bytes);
     }
   }
@@ -1591,6 +1597,13 @@ int snf_count_nonfinite_device(int device_id, const float* d_data, uint64_t n, u
 
 int snf_malloc(void** dptr, uint64_t bytes) {
   SNF_HIP_CHECK(hipMalloc(dptr, bytes));
+  return SNF_OK;
+}
+int snf_mem_info(uint64_t* free_bytes, uint64_t* total_bytes) {
+  size_t f = 0, t = 0;
+  SNF_HIP_CHECK(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
   return SNF_OK;
 }
 int snf_set_oom_hook(snf_oom_hook hook) {

@@ -74,7 +74,16 @@ def _transport(group):
     if _ENV_COMM is not None:
         return _ENV_COMM
     if int(os.environ.get('WORLD_SIZE', '0')) > 0 and 'RANK' in os.environ:
+        from shennong_amd import _backend
         from shennong_amd.comm import RcclComm
+        if int(os.environ['WORLD_SIZE']) > 1 and _backend.device_count() < 1:
+            # (rounds 1-3 fell back to an initialised torch process group here; the package no longer imports
+            # torch: a launched job without GPUs has to pass its transport explicitly)
+            raise RuntimeError(
+                'WORLD_SIZE=%s but no GPU is visible: the default transport is RCCL (shennong_amd.comm.RcclComm); '
+                'pass group=<an object with rank, world_size, all_gather_object, gather_features, allreduce> '
+                'to run the exchange steps over something else (tests/tools/torch_transport.py wraps a gloo '
+                'process group that way)' % os.environ['WORLD_SIZE'])
         _ENV_COMM = RcclComm.from_env()
         return _ENV_COMM
     return _SingleTransport()
@@ -386,7 +395,7 @@ def _gather_blocks(comm, local, blocks, dst):
 
 
 def extract_features_streamed_sharded(configuration, utterances, sink, warps=None,
-                                      max_batch_duration=14400.0, group=None, log=None):
+                                      max_batch_duration=None, group=None, log=None):
     """``pipeline.extract_features_streamed`` over the ranks of one node (BASELINE config 5): every
     rank passes the same `utterances`, streams its length-balanced shard batch by batch through the
     device-resident pipeline and hands the batches to ITS OWN `sink` (e.g. one

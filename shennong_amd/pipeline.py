@@ -337,7 +337,9 @@ def _batch_pool():
     global _BATCH_POOL
     if _BATCH_POOL is None:
         from concurrent.futures import ThreadPoolExecutor
-        _BATCH_POOL = ThreadPoolExecutor(max_workers=8, thread_name_prefix='snf-batch')
+        with _backend._LOCK:   # (two first callers must not build two pools: the loser's never shuts down)
+            if _BATCH_POOL is None:
+                _BATCH_POOL = ThreadPoolExecutor(max_workers=8, thread_name_prefix='snf-batch')
     return _BATCH_POOL
 
 
@@ -368,15 +370,32 @@ def _in_flight(batches, work, depth):
         wait(list(pending))
 
 
+_BATCH_BYTES_PER_HOUR = 4 << 30   # HBM one hour of audio needs while its batch is in flight: 2.3 GB of pitch
+                                  # scratch (19 GB per 10 000 x 3 s), audio, features, CMVN / delta copies
+
+
+def default_batch_duration(depth=1):
+    """Seconds of audio per streamed batch when the caller names none: four hours (measured best on a
+    288 GB MI355X, see extract_features_streamed) unless `depth` such batches in flight would need more than
+    half of the HBM that is free right now (_BATCH_BYTES_PER_HOUR each) - smaller devices get smaller batches
+    instead of an out-of-memory error half way through a corpus; never below ten minutes."""
+    if _backend.device_count() < 1:   # (host-logic tests with the device pipeline replaced by a stand-in)
+        return 14400.0
+    free, _ = _backend.mem_info()
+    hours = (free // 2) / float(_BATCH_BYTES_PER_HOUR * max(int(depth), 1))
+    return float(min(14400.0, max(600.0, 3600.0 * hours)))
+
+
 def extract_features_streamed(configuration, utterances, sink, warps=None,
-                              max_batch_duration=14400.0, njobs=1, stats_reduce=None,
+                              max_batch_duration=None, njobs=1, stats_reduce=None,
                               resident_bytes=16 << 30,
                               log=get_logger('pipeline', 'warning')):
     """:func:`extract_features` for a corpus that must not sit in memory at once (BASELINE config 5)
 
     The utterances are processed in consecutive batches of at most `max_batch_duration` seconds of
-    audio (one hour of 16 kHz audio is 115 MB of int16 up and, for 123 columns, 177 MB of float32
-    down; the default of four hours was measured on an 8 h corpus of 3 s utterances: 1 h batches 54-57 hours of
+    audio (None: :func:`default_batch_duration` - four hours unless `njobs` batches of that size in flight
+    would need more than half of the free HBM; one hour of 16 kHz audio is 115 MB of int16 up and, for 123
+    columns, 177 MB of float32 down and needs ~4 GB of HBM while in flight; four hours were measured on an 8 h corpus of 3 s utterances: 1 h batches 54-57 hours of
     audio per second, 2 h 54-65, 4 h 59-64, the whole 8 h in one batch 70 - the pitch tracker's cost per utterance
     halves between 1 000 and 4 000 utterances per call; the results of a batch must fit a pooled page-locked block
     of at most 2 GiB (_backend._ResultBlock._FRESH): 4 h of 257 columns are 1.5 GB);
@@ -402,7 +421,7 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
     from shennong_amd.utterances import Utterances
     depth = min(get_njobs(njobs, log=log), 8)
     config = _init_config(configuration, log=log)
-    if not max_batch_duration > 0:
+    if max_batch_duration is not None and not max_batch_duration > 0:
         raise ValueError('max_batch_duration must be strictly positive')
     if warps:
         warps = _init_warps(warps, config, utterances, log)
@@ -412,6 +431,8 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
             'cmvn normalization by speaker requested '
             'but no speaker information provided')
     utts = list(utterances)
+    if max_batch_duration is None:
+        max_batch_duration = default_batch_duration(depth)
 
     def sub(batch):
         return {u.name: warps[u.name] for u in batch} if warps else None
@@ -658,14 +679,15 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
                     pplan.run_device(d_wave.ptr, soff, pfoff, d_raw.ptr)
                     d_pitch = DB(max(int(pfoff[-1]) * pdim * 4, 16))
                     qplan.run_post_device(d_raw.ptr, 2, pfoff, d_pitch.ptr, noise_call=_NOISE_CALL)
-                    return d_pitch
                 except BaseException:
-                    if d_pitch is not None:
-                        d_pitch.free(synced=True)
+                    # a call that failed half way may have kernels enqueued that still write these blocks:
+                    # the plain free() waits for the device before the pool can hand them to another thread
+                    for block in (d_pitch, d_raw):
+                        if block is not None:
+                            block.free()
                     raise
-                finally:
-                    if d_raw is not None:
-                        d_raw.free(synced=True)
+                d_raw.free(synced=True)   # (both calls returned: their streams are synchronised)
+                return d_pitch
 
             st.update(pfoff=pfoff, pdim=pdim, pitch_job=_backend.side_pool().submit(track))
             step = {}
@@ -815,8 +837,10 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
         if 'pitch_job' in st:
             try:
                 st['d_pitch'] = st.pop('pitch_job').result()
-            finally:
-                st['d_wave'].free(synced=True)
+            except BaseException:
+                st['d_wave'].free()   # (a tracker that failed half way may still have readers enqueued)
+                raise
+            st['d_wave'].free(synced=True)
             rows, step = [], {}
             for i in idx:
                 hit = step.get((meta[i], pmeta[i]))
