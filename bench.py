@@ -3,20 +3,23 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is `--inner` (default 12, `config.passes_per_step`) passes of the hot path over one batch of
+A "step" is `--inner` (default 120, `config.passes_per_step`) passes of the hot path over one batch of
 synthetic input that is already resident in HBM: ``FilterbankProcessor(num_bins=40, dither=0)`` (25 ms /
 10 ms, 16 kHz) over 10 000 unique synthetic 3 s utterances per GPU (BASELINE.json configs[1]; 2 980 000
 frames per GPU per pass).  One pass is one 0.9 ms kernel launch: the repeat makes the timed region of the
-default 20 steps ~0.22 s, long enough for an outside GPU-busy sampler to see it; every rate counts every
-pass, `roofline.kernel_ms` is the mean HIP-event time of ONE launch.  The passes of a timed region are
-enqueued on one stream through the asynchronous `*_device` entry points (a pair of `snf_event_*` marks around
-each) and the region ends with one synchronisation - the way a pipeline drives the path; waiting for every
-pass before launching the next costs ~2 % of the rate in launch latency.
+default 20 steps ~2.2 s (long enough for the driver's GPU-busy sampler); every rate
+counts every pass, `roofline.kernel_ms` is the mean HIP-event time of ONE launch.  The passes of a timed
+region are enqueued on one stream through the asynchronous `*_device` entry points (a pair of `snf_event_*`
+marks around each) and the region ends with one synchronisation - the way a pipeline drives the path.
 With N > 1 (launched through torch.distributed.run, used as a process spawner only: torch is never
-imported) the utterances shard across ranks with no data-path collective (weak scaling: every GPU owns
-10 000 utterances); the barrier / max-over-ranks and the gather of the Features blocks to rank 0 go
-over RCCL through the C ABI (shennong_amd.comm.RcclComm -> snf_comm_*), device pointers in and out;
-the gather runs once after the timed region and is reported separately.
+imported) the utterances shard across ranks with no data-path collective; the barrier / max-over-ranks and
+the gather of the Features blocks to rank 0 go over RCCL through the C ABI (shennong_amd.comm.RcclComm ->
+snf_comm_*), device pointers in and out.  `--scaling weak` (default): every GPU owns 10 000 utterances;
+`--scaling strong`: ONE 10 000-utterance corpus is dealt over the ranks by `shard_utterances`.  Two values:
+`value` (compute only, as in earlier rounds) and `value_with_gather`: a second timed region of the same K
+steps in which EVERY pass is followed, on the compute stream, by the `snf_comm_gatherv` of every rank's
+[frames, 40] block to rank 0 - the whole job including its one collective; `rccl_ranks_seen` is what the
+RCCL communicator itself reports (ncclCommCount).
 
 Rank 0 prints ONE JSON line.  `value` = frames of all ranks per second of the slowest rank.
 `roofline` prices the dominant kernel against the 8 TB/s HBM peak with the algorithmic bytes of
@@ -26,7 +29,6 @@ utterances on this box's host cores.
 """
 
 import argparse
-import inspect
 import json
 import os
 import sys
@@ -54,10 +56,16 @@ def parse_args():
                     help='untimed launches before the W warm-up steps: the GPU idles during the host-side '
                          'set-up and its clocks take ~30 launches to come back (10: 0.97 ms per step, '
                          '50 / 200 / 1000: 0.92 ms; gpurun_out/settle.txt)')
-    ap.add_argument('--inner', type=int, default=12,
+    ap.add_argument('--inner', type=int, default=120,
                     help='passes over the batch inside ONE step (stated in config.passes_per_step): 20 steps '
                          'of one 0.9 ms pass are an 18 ms timed region, too short for the driver\'s GPU-busy '
-                         'sampler; 12 passes per step make it ~0.22 s.  Rates count every pass.')
+                         'sampler; 120 passes per step make it ~2.2 s.  Rates count every pass.')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help='N > 1: weak = --utts utterances per GPU; strong = --utts utterances in all, dealt over '
+                         'the ranks by shennong_amd.distributed.shard_utterances')
+    ap.add_argument('--stream-hours', type=float, default=125.0,
+                    help='hours of audio of the streamed-pipeline leg (BASELINE config 5: 1 000 h / 8 GPUs = 125 h '
+                         'per GPU; the 10 000 waves of the batch are reused round robin, 1 000 speakers)')
     ap.add_argument('--no-extra', action='store_true',
                     help='skip the MFCC / spectrogram side measurements')
     return ap.parse_args()
@@ -94,6 +102,28 @@ def make_batch(first_id, count, nsamples):
 def _gen(args):
     from shennong_amd import synth
     return synth.utterances(*args)
+
+
+def _gen_ids(args):
+    import numpy as np
+    from shennong_amd import synth
+    ids, nsamples = args
+    return np.concatenate([synth.utterances(i, 1, nsamples) for i in ids], axis=0)
+
+
+def make_batch_ids(ids, nsamples):
+    """The utterances `ids` of the seeded corpus (a rank's shard of it), same generator as make_batch"""
+    import numpy as np
+    from concurrent.futures import ProcessPoolExecutor
+    workers = max(1, min(effective_cores(), 16))
+    chunk = max(1, (len(ids) + workers - 1) // workers)
+    jobs = [(list(ids[i:i + chunk]), nsamples) for i in range(0, len(ids), chunk)]
+    if workers == 1 or len(ids) < 64:
+        parts = [_gen_ids(j) for j in jobs]
+    else:
+        with ProcessPoolExecutor(workers) as pool:
+            parts = list(pool.map(_gen_ids, jobs))
+    return np.ascontiguousarray(np.concatenate(parts, axis=0))
 
 
 def cpu_baseline(opts, waves, nthreads):
@@ -188,8 +218,16 @@ def main():
         comm = RcclComm.from_env(device=local_rank)
 
     nsamples = int(args.seconds * 16000)
-    n_utts = args.utts
-    waves = make_batch(rank * n_utts, n_utts, nsamples)          # [n_utts, nsamples] int16
+    if args.scaling == 'strong' and world > 1:
+        # ONE corpus of --utts utterances for the whole job: every rank takes its shard of it (equal lengths:
+        # the greedy partition deals them round robin) and generates only those
+        from shennong_amd.distributed import shard_utterances
+        mine = shard_utterances([nsamples] * args.utts, world)[rank]
+        n_utts = len(mine)
+        waves = make_batch_ids(mine, nsamples)
+    else:
+        n_utts = args.utts
+        waves = make_batch(rank * n_utts, n_utts, nsamples)          # [n_utts, nsamples] int16
     fbank = FilterbankProcessor(num_bins=40, dither=0)
     opts = fbank._build_options()
     plan = _backend.get_plan(opts)
@@ -240,8 +278,9 @@ def main():
                 L.snf_event_destroy(a)
                 L.snf_event_destroy(b)
 
-    def timed_region(p, d_dst):
-        """K steps of `inner` passes of plan `p` between two synchronisations -> (seconds, kernel ms of every pass)"""
+    def timed_region(p, d_dst, gather=None):
+        """K steps of `inner` passes of plan `p` between two synchronisations -> (seconds, kernel ms of every
+        pass); `gather(d_dst)` is enqueued on the same stream behind every pass when given"""
         marks = Marks(args.steps * inner)
         sync_all()
         t0 = time.perf_counter()
@@ -249,6 +288,8 @@ def main():
             L.snf_event_record(a, stream)
             p.run_device(d_wave.ptr, soff, foff, d_dst.ptr, stream=stream.value)
             L.snf_event_record(b, stream)
+            if gather is not None:
+                gather(d_dst)
         _backend.check(L.snf_stream_synchronize(stream))
         dt = time.perf_counter() - t0
         if comm is not None:
@@ -272,8 +313,57 @@ def main():
     elapsed, kernel_ms = timed_region(plan, d_out)
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = total_frames * inner * world * args.steps / elapsed
+    # frames of the whole job per pass: N x 10 000 utterances (weak) or the one corpus (strong)
+    job_frames = total_frames * world
+    if comm is not None and world > 1:
+        job_frames = int(comm.allreduce(np.array([float(total_frames)]), 'sum')[0])
+    value = job_frames * inner * args.steps / elapsed
     kms = float(np.mean(kernel_ms))
+
+    # ---- the same K steps with the job's ONE collective inside the timed region:
+    # behind every pass, on the compute stream, the gather of every rank's [frames, 40] block to rank 0
+    # (snf_comm_gatherv: ncclSend / ncclRecv pairs, every peer over its own xGMI link) ----
+    gathered = None
+    if comm is not None:
+        counts = [int(c) for c in comm.allreduce(
+            np.array([float(total_frames * 40) if r == rank else 0.0 for r in range(world)]), 'sum')]
+        d_all = _backend.DeviceBuffer(max(sum(counts) * 4, 16)) if rank == 0 else None
+
+        def gather(d_src):
+            comm.gatherv_device(d_src.ptr, total_frames * 40, d_all.ptr if d_all else None, counts, 0,
+                                stream=stream.value)
+        try:
+            for _ in range(args.warmup):
+                step()
+                gather(d_out)
+            g_elapsed, g_kernel_ms = timed_region(plan, d_out, gather=gather)
+            gathered = {'value': job_frames * inner * args.steps / g_elapsed,
+                        'ms_per_step': g_elapsed / args.steps * 1e3,
+                        'ms_per_pass': g_elapsed / args.steps / inner * 1e3,
+                        'gather_bytes_per_pass_at_root': int(sum(counts) - counts[0]) * 4,
+                        'kernel_ms': float(np.mean(g_kernel_ms)),
+                        'rccl_ranks_seen': comm.ranks_seen()}
+            if d_all is not None:
+                # what arrived: the root's own block unchanged, and (N > 1) the last peer's block is what that
+                # peer computed - its first rows, sent over the rendezvous sockets, compared on the root
+                mine = np.empty((2, 40), dtype=np.float32)
+                d_out.download(mine)
+                heads = comm.all_gather_object(mine) if world > 1 else [mine]
+                got_all = np.empty((sum(counts) // 40, 40), dtype=np.float32)
+                d_all.download(got_all)
+                ok, pos = True, 0
+                for r in range(world):
+                    ok = ok and bool(np.array_equal(got_all[pos:pos + 2], heads[r]))
+                    pos += counts[r] // 40
+                gathered['gathered_blocks_ok'] = ok
+            elif world > 1:
+                mine = np.empty((2, 40), dtype=np.float32)
+                d_out.download(mine)
+                comm.all_gather_object(mine)
+        except RuntimeError as exc:   # (the compute-only value must not be lost with it)
+            gathered = {'error': str(exc)}
+        if d_all is not None:
+            d_all.free()
 
     # ---- the other half of the metric: MfccProcessor() (13 cepstra) over the same batch, timed the same
     # way right behind the fbank-40 steps (the same K steps between the same barriers) -----------------
@@ -284,7 +374,7 @@ def main():
     for _ in range(args.warmup * inner):
         mfcc_plan.run_device(d_wave.ptr, soff, foff, d_mfcc.ptr, stream=stream.value)
     mfcc_elapsed, mfcc_kernel_ms = timed_region(mfcc_plan, d_mfcc)
-    value_mfcc13 = total_frames * inner * world * args.steps / mfcc_elapsed
+    value_mfcc13 = job_frames * inner * args.steps / mfcc_elapsed
     mfcc_kms = float(np.mean(mfcc_kernel_ms))
     achieved = total_frames * BYTES_PER_FRAME['fbank40'] / (kms * 1e-3) / 1e9
 
@@ -445,25 +535,66 @@ def main():
             'frames_per_s': nfr / dt, 'wall_s': dt, 'wall_s_min': min(walls), 'calls': len(walls),
             'utterances': pn, 'columns': int(next(iter(feats.values())).ndims)}
 
-        # the same pipeline streamed in bounded batches (BASELINE config 5): speaker statistics from
-        # a first pass that leaves the uploaded audio in HBM, features recomputed in the second, results
-        # dropped (null sink); batches of the function's default duration (four hours of audio), one warm-up batch
-        index2 = Utterances([(f'u{i}', Audio(waves[i], 16000, validate=False), f's{i % 20}')
-                             for i in range(min(n_utts, 4800))])
-        hours = len(index2) * args.seconds / 3600.0
-        pipeline.extract_features_streamed(cfg, Utterances(list(index2)[:1200]), lambda f: None, log=quiet)
+        # the same pipeline streamed in bounded batches at ONE GPU's share of BASELINE config 5: 1 000 h / 8 =
+        # 125 h = 150 000 utterances of 3 s (the 10 000 waves of the batch reused round robin: host synthesis
+        # is not what is measured; every utterance has its own name, 1 000 speakers round robin), CMVN by
+        # speaker with the reference's default VAD-weighted statistics (pipeline.py:584-596): a first pass
+        # (features + energy + VAD + statistics) that leaves the uploaded audio in HBM, features recomputed in
+        # the second, results handed to a counting sink and dropped; default batches, one warm-up corpus
+        import resource
+        cfg5 = pipeline.get_default_config('filterbank', with_pitch='kaldi', with_cmvn=True, with_delta=True)
+        cfg5['filterbank']['num_bins'] = 40
+        cfg5['filterbank']['dither'] = 0
+        cfg5['cmvn']['by_speaker'] = True     # (with_vad stays True: the reference's default)
+        n5 = max(1200, int(round(args.stream_hours * 3600.0 / args.seconds)))
+        audios = [Audio(waves[i], 16000, validate=False) for i in range(n_utts)]
+        index2 = Utterances([(f'u{i:06d}', audios[i % n_utts], f's{i % 1000:04d}') for i in range(n5)])
+        hours = n5 * args.seconds / 3600.0
+        pipeline.extract_features_streamed(cfg5, Utterances(list(index2)[:2400]), lambda f: None, log=quiet)
+        seen = {'utts': 0, 'batches': 0, 'peak_device': 0, 'frames': 0}
+        _, hbm_total = _backend.mem_info()
+
+        def counting_sink(feats):
+            seen['utts'] += len(feats)
+            seen['batches'] += 1
+            seen['frames'] += sum(f.nframes for f in feats.values())
+            free, total = _backend.mem_info()
+            seen['peak_device'] = max(seen['peak_device'], total - free)
+        t0 = time.perf_counter()
+        written = pipeline.extract_features_streamed(cfg5, index2, counting_sink, log=quiet)
+        dt = time.perf_counter() - t0
+        extra['pipeline_streamed'] = {
+            'hours_of_audio': hours, 'hours_of_audio_per_s': hours / dt, 'wall_s': dt,
+            'frames_per_s': seen['frames'] / dt,
+            'utterances': n5, 'utterances_written': int(written), 'every_utterance_once': seen['utts'] == n5,
+            'speakers': 1000, 'cmvn': 'by speaker, VAD-weighted (reference default)', 'columns': 123,
+            'batches': seen['batches'], 'batch_s': pipeline.default_batch_duration(1),
+            'peak_device_bytes': int(seen['peak_device']), 'device_total_bytes': int(hbm_total),
+            'host_max_rss_bytes': int(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss) * 1024,
+            'passes': 2, 'audio_resident_between_passes': True,
+            'note': 'BASELINE config 5 at one GPU\'s share (1 000 h / 8); wall clock includes loading, the '
+                    'uploads, both passes, the downloads and the per-utterance Features objects'}
+        del index2, audios
+
+        # FeaturesProcessor.process_all on the 10 000 in-memory utterances (the north_star's API surface,
+        # reference processor/base.py:56-107): wall clock from Audio objects to a FeaturesCollection, i.e.
+        # gather into page-locked memory + upload (960 MB: PCIe floor 22.4 ms at 42.8 GB/s) + kernel +
+        # download (477 MB) + one Features per utterance
+        pa_index = Utterances([(f'u{i:05d}', Audio(waves[i], 16000, validate=False)) for i in range(n_utts)])
+        fbank.process_all(pa_index)
         walls = []
-        for _ in range(3):
+        for _ in range(5):
             t0 = time.perf_counter()
-            pipeline.extract_features_streamed(cfg, index2, lambda f: None, log=quiet)
+            coll = fbank.process_all(pa_index)
             walls.append(time.perf_counter() - t0)
         dt = float(np.median(walls))
-        extra['pipeline_streamed'] = {
-            'hours_of_audio_per_s': hours / dt, 'wall_s': dt, 'wall_s_min': min(walls), 'calls': len(walls),
-            'utterances': len(index2),
-            'batch_s': inspect.signature(pipeline.extract_features_streamed).parameters[
-                'max_batch_duration'].default,
-            'passes': 2, 'audio_resident_between_passes': True}
+        extra['process_all'] = {
+            'frames_per_s': total_frames / dt, 'wall_ms': dt * 1e3, 'wall_ms_min': min(walls) * 1e3,
+            'utterances': n_utts, 'calls': len(walls), 'results': len(coll),
+            'pcie_floor_ms': n_utts * nsamples * 2 / 42.8e9 * 1e3,
+            'note': 'FilterbankProcessor(num_bins=40, dither=0).process_all(Utterances of in-memory Audio): '
+                    'host to host through the public API'}
+        del coll, pa_index
         # 8 kHz audio (256-sample frames): two frames per 16-lane row (fbank256x2_kernel)
         sub8 = min(n_utts, 4000)
         w8 = np.ascontiguousarray(waves[:sub8, :nsamples // 2])
@@ -498,30 +629,6 @@ def main():
         d_o44.free()
 
     d_mfcc.free()
-    # ---- RCCL gather of the Features blocks (once, untimed region): device pointers in
-    # and out, every peer sends its [frames, 40] block straight to the root over its own xGMI link ------
-    if comm is not None:
-        d_all = _backend.DeviceBuffer(total_frames * 40 * 4 * world) if rank == 0 else None
-        counts = [total_frames * 40] * world
-        comm.barrier()
-        t0 = time.perf_counter()
-        try:
-            comm.gatherv_device(d_out.ptr, total_frames * 40, d_all.ptr if d_all else None, counts, 0)
-            extra['gather_ms'] = (time.perf_counter() - t0) * 1e3
-        except RuntimeError as exc:  # (an untimed side measurement must not cost the run its JSON line)
-            extra['gather_error'] = str(exc)
-            if d_all is not None:
-                d_all.free()
-                d_all = None
-        if d_all is not None:
-            # the root's own block must have arrived unchanged, and the last peer's block is finite
-            check = np.empty((2, 40), dtype=np.float32)
-            mine = np.empty((2, 40), dtype=np.float32)
-            d_out.download(mine)
-            d_all.download(check)
-            extra['gather_root_block_ok'] = bool(np.array_equal(check, mine))
-            d_all.free()
-
     # ---- CPU baseline (rank 0, N = 1 only) -----------------------------------------------------------
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
@@ -570,19 +677,23 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'settle': args.settle, 'ms_per_step': ms_per_step,
             'ms_per_pass': ms_per_step / inner,
             'ms_per_step_mfcc13': mfcc_elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'value_with_gather': gathered.get('value') if gathered else None,
+            'rccl_ranks_seen': gathered.get('rccl_ranks_seen') if gathered else None,
+            'with_gather': gathered,
+            'higher_is_better': True, 'scaling': args.scaling if world > 1 else 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {
                 'workload': 'FilterbankProcessor(num_bins=40, dither=0) log-mel, 25 ms/10 ms, '
                             '16 kHz, %d unique synthetic %.1f s utterances per GPU (%d frames), '
                             'int16 waves resident in HBM' % (n_utts, args.seconds, total_frames),
-                'utterances_per_gpu': n_utts, 'frames_per_gpu': total_frames,
+                'utterances_per_gpu': n_utts, 'frames_per_gpu': total_frames, 'frames_per_pass_all_gpus': job_frames,
                 'passes_per_step': inner, 'frames_per_gpu_per_step': total_frames * inner,
                 'untimed_launches_before_the_timed_region': args.settle + args.warmup * inner,
                 'launches': 'the K x %d passes of a timed region are enqueued on one stream (asynchronous '
                             '*_device calls), one synchronisation at its end; a pair of HIP events around '
                             'every pass gives roofline.kernel_ms' % inner,
-                'parallelism': 'utterance-sharded x%d, no data-path collective' % world,
+                'parallelism': 'utterance-sharded x%d, no data-path collective in `value`; `value_with_gather` '
+                               'adds the gather of every Features block to rank 0 behind every pass' % world,
                 'device': _backend.device_name(local_rank)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,

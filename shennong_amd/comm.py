@@ -199,15 +199,21 @@ class RcclComm:
         return _loads(_recv_msg(self._peers[0], self._key))
 
     # ---- device data over RCCL -------------------------------------------------------------------------
-    def gatherv_device(self, d_send, send_count, d_recv, recv_counts, root=0):
-        """Device pointers in and out (see snf_comm_gatherv); `recv_counts` is needed on the root"""
+    def gatherv_device(self, d_send, send_count, d_recv, recv_counts, root=0, stream=None):
+        """Device pointers in and out (see snf_comm_gatherv); `recv_counts` is needed on the root.  With a
+        `stream` (a handle of snf_stream_create) the exchange is enqueued on it, behind the kernels that
+        produce `d_send`, and this returns without waiting; without one it is complete on return."""
         counts = None
         if self.rank == root:
             counts = np.ascontiguousarray(recv_counts, dtype=np.int64)
         _backend.check(_backend.lib().snf_comm_gatherv(
             self._handle, C.c_void_p(d_send), int(send_count), C.c_void_p(d_recv),
             counts.ctypes.data_as(C.POINTER(C.c_int64)) if counts is not None else None,
-            int(root), None))
+            int(root), C.c_void_p(stream) if stream else None))
+
+    def ranks_seen(self):
+        """World size as the RCCL communicator itself reports it (snf_comm_world_size)"""
+        return int(_backend.lib().snf_comm_world_size(self._handle))
 
     def allreduce(self, array, op='sum'):
         """Element-wise sum / max of a float64 array over the ranks (through a device buffer)"""

@@ -36,6 +36,7 @@ struct Rccl {
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;   // (optional: snf_comm_world_size falls back to the stored value)
 };
 
 Rccl* rccl() {
@@ -57,6 +58,7 @@ Rccl* rccl() {
     SNF_SYM(Recv, ncclRecv);
     SNF_SYM(AllReduce, ncclAllReduce);
     SNF_SYM(GetErrorString, ncclGetErrorString);
+    SNF_SYM(CommCount, ncclCommCount);
 #undef SNF_SYM
   });
   const bool ok = r.handle && r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart &&
@@ -122,7 +124,15 @@ int snf_comm_init(const void* id128, int32_t world_size, int32_t rank, int32_t d
 }
 
 int snf_comm_rank(const snf_comm* c) { return c ? c->rank : -1; }
-int snf_comm_world_size(const snf_comm* c) { return c ? c->world : -1; }
+// the number of ranks the RCCL communicator itself reports (ncclCommCount): what bench.py prints as
+// `rccl_ranks_seen`, so that a line claiming N GPUs shows that N processes really met in one communicator
+int snf_comm_world_size(const snf_comm* c) {
+  if (!c) return -1;
+  Rccl* r = rccl();
+  int n = 0;
+  if (r && r->CommCount && c->comm && r->CommCount(c->comm, &n) == ncclSuccess) return n;
+  return c->world;
+}
 
 int snf_comm_destroy(snf_comm* c) {
   if (!c) return SNF_OK;

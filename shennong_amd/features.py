@@ -77,7 +77,10 @@ class Features:
     def properties(self):
         """How the features were made"""
         if self._properties is None:
-            self._properties = copy_properties(self._shared[1])
+            shared = self._shared[1]
+            if type(shared) is not dict:   # (a pipeline history that makes its dictionary when first asked)
+                shared = shared.properties
+            self._properties = copy_properties(shared)
             if self._shared[2]:
                 self._properties.update(copy_properties(self._shared[2]))
         return self._properties

@@ -502,15 +502,29 @@ class _Meta:
     The properties of a stage are the same for every utterance that went through the same processors
     with the same per-utterance arguments (warp factor, CMVN group): `key` names that history and
     `cache` holds one properties dictionary per history, copied once per utterance at the end."""
-    __slots__ = ('properties', 'ndims', 'nframes', 'times', 'key', '_derived')
+    __slots__ = ('_properties', '_source', 'ndims', 'nframes', 'times', 'key', '_derived')
 
-    def __init__(self, properties, ndims, nframes, times, key=None):
-        self.properties = properties
+    def __init__(self, properties, ndims, nframes, times, key=None, source=None):
+        self._properties = properties
+        self._source = source      # (cache, parent, make_properties) while the properties are not made yet
         self.ndims = ndims
         self.nframes = nframes
         self.times = times
         self.key = key
         self._derived = {}
+
+    @property
+    def properties(self):
+        """The properties dictionary of this history, made when first read: a corpus run that writes the
+        matrices and never looks at the properties (1 000 speakers x CMVN statistics x delta x pitch columns
+        in every batch: two thirds of the host time of BASELINE config 5 before round 5) derives none"""
+        if self._properties is None:
+            cache, parent, make_properties = self._source
+            found = cache.get(self.key)
+            if found is None:
+                found = cache[self.key] = make_properties(parent)
+            self._properties, self._source = found, None
+        return self._properties
 
     def derive(self, cache, tag, make_properties, ndims=None, nframes=None, times=None):
         """The _Meta after one more stage.  Utterances with the same history and frame count share one
@@ -520,12 +534,10 @@ class _Meta:
         if found is not None:
             return found
         key = (self.key, tag)
-        if key not in cache:
-            cache[key] = make_properties(self)
         found = self._derived[memo] = _Meta(
-            cache[key], self.ndims if ndims is None else ndims,
+            cache.get(key), self.ndims if ndims is None else ndims,
             self.nframes if nframes is None else nframes,
-            self.times if times is None else times, key)
+            self.times if times is None else times, key, source=(cache, self, make_properties))
         return found
 
 
@@ -763,7 +775,8 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
         dim = dims.pop()
         if config['cmvn']['by_speaker']:
             names = list(dict.fromkeys(u.speaker for u in utts))
-            group_of = np.asarray([names.index(u.speaker) for u in utts], dtype=np.int32)
+            number = {name: g for g, name in enumerate(names)}
+            group_of = np.asarray([number[u.speaker] for u in utts], dtype=np.int32)
         else:
             names = [u.name for u in utts]
             group_of = np.arange(n, dtype=np.int32)
@@ -841,13 +854,19 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
                 st['d_wave'].free()   # (a tracker that failed half way may still have readers enqueued)
                 raise
             st['d_wave'].free(synced=True)
-            rows, step = [], {}
+            rows, step, trims = [], {}, {}
             for i in idx:
                 hit = step.get((meta[i], pmeta[i]))
                 if hit is None:  # (same frame counts, times and histories: trimmed and merged once)
-                    r, times = Features._concatenate_meta(
-                        meta[i].nframes, meta[i].ndims, meta[i].times, {},
-                        pmeta[i].nframes, pmeta[i].times, {}, tolerance, log)[:2]
+                    # (the trimmed frame count and times depend on the two time axes only: one comparison per
+                    # pair of axes, not one per speaker)
+                    tkey = (meta[i].nframes, id(meta[i].times), pmeta[i].nframes, id(pmeta[i].times))
+                    trim = trims.get(tkey)
+                    if trim is None:
+                        trim = trims[tkey] = Features._concatenate_meta(
+                            meta[i].nframes, meta[i].ndims, meta[i].times, {},
+                            pmeta[i].nframes, pmeta[i].times, {}, tolerance, log)[:2]
+                    r, times = trim
                     hit = step[(meta[i], pmeta[i])] = (r, meta[i].derive(
                         cache, ('concat', pmeta[i].key),
                         lambda m, o=pmeta[i]: Features._concatenate_meta(
@@ -897,7 +916,7 @@ def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=No
         audio['duration'] = utt.duration
         extra = {'audio': audio, 'speaker': utt.speaker} if utt.speaker else {'audio': audio}
         # (times are generated, hence sorted; the data were checked above: no per-utterance validate)
-        out[utt.name] = of_batch(results[i], meta[i].times, meta[i].properties, extra)
+        out[utt.name] = of_batch(results[i], meta[i].times, meta[i], extra)
     for wait, d_feat in pending:
         wait()
         d_feat.free(synced=True)

@@ -6,9 +6,12 @@ batched launches; a seeded sample of them is compared with the CPU oracle (pitch
 bit-identical; PLP: the parity tolerance) and with the same utterance processed alone (bit-identical:
 results do not depend on what else is in the batch).
 
-Config 5: fbank-40 + pitch + delta + CMVN by speaker streamed over a corpus that does not fit in one
-batch -> 10 h of synthetic audio through pipeline.extract_features_streamed in 30-minute batches; every
-utterance arrives exactly once, a sample equals the one-shot pipeline bit for bit.
+Config 5: fbank-40 + pitch + delta + CMVN by speaker (VAD-weighted statistics: the reference's default,
+pipeline.py:584-596) streamed over a corpus that does not fit in one batch -> (a) 10 h of unique synthetic
+audio through pipeline.extract_features_streamed in 30-minute batches, (b) ONE GPU's share of the 1 000 h
+corpus: 125 h = 150 000 utterances of 3 s (400 seeded waves reused round robin so that host synthesis is
+not the cost; names, speakers and statistics are per utterance), 1 000 speakers, default batches.  Every
+utterance arrives exactly once and finite, a sample equals the one-shot pipeline bit for bit.
 """
 
 import os
@@ -85,7 +88,7 @@ def test_config5_ten_hours_streamed(gpu):
     config['filterbank']['dither'] = 0
     config['pitch']['postprocessing']['delta_pitch_noise_stddev'] = 0
     config['cmvn']['by_speaker'] = True
-    config['cmvn']['with_vad'] = False
+    config['cmvn']['with_vad'] = True
     quiet = get_logger('test', 'error')
     seen, kept = [], {}
     keep = {f'u{i:05d}' for i in range(0, n, 997)}
@@ -110,3 +113,55 @@ def test_config5_ten_hours_streamed(gpu):
             assert f == whole[name], name
             checked += 1
     assert checked >= 3
+
+
+def test_config5_per_gpu_share_streamed(gpu):
+    """125 h (one GPU's eighth of BASELINE config 5) with the reference's default CMVN: by speaker,
+    VAD-weighted (reference shennong/pipeline.py:525-603)"""
+    import resource
+    from shennong_amd import _backend
+    n, unique, speakers, nsamples = 150000, 400, 1000, 48000
+    waves = np.concatenate(_pool_map(_uniform, [(i, 100, nsamples) for i in range(0, unique, 100)]))
+    index = Utterances([(f'u{i:06d}', Audio(waves[i % unique], 16000, validate=False), f's{i % speakers:04d}')
+                        for i in range(n)])
+    assert abs(sum(u.duration for u in index) / 3600.0 - 125.0) < 1e-6
+    config = pipeline.get_default_config('filterbank', with_pitch='kaldi', with_cmvn=True, with_delta=True)
+    config['filterbank']['num_bins'] = 40
+    config['filterbank']['dither'] = 0
+    config['pitch']['postprocessing']['delta_pitch_noise_stddev'] = 0
+    config['cmvn']['by_speaker'] = True
+    assert config['cmvn']['with_vad'] is True   # the reference's default
+    quiet = get_logger('test', 'error')
+    wanted = ('s0000', 's0417', 's0999')
+    count = {'utts': 0, 'batches': 0, 'peak_device': 0}
+    seen = np.zeros(n, dtype=np.int32)
+    kept = {}
+
+    def sink(feats):
+        count['batches'] += 1
+        blocks = {}
+        for name, f in feats.items():
+            seen[int(name[1:])] += 1
+            assert f.shape == (298, 123) and f.dtype == np.float32
+            base = f.data.base if f.data.base is not None else f.data
+            blocks[id(base)] = base
+            if f.properties['speaker'] in wanted:
+                kept[name] = f.copy()
+        for block in blocks.values():   # (the utterances of a batch are views of one downloaded array)
+            block = np.asarray(block)
+            assert np.isfinite(block.min()) and np.isfinite(block.max())
+        count['utts'] += len(feats)
+        free, total = _backend.mem_info()
+        count['peak_device'] = max(count['peak_device'], total - free)
+    written = pipeline.extract_features_streamed(config, index, sink, log=quiet)
+    assert written == n == count['utts'] and (seen == 1).all()
+    assert count['batches'] >= 125.0 * 3600 / pipeline.default_batch_duration(1) - 1
+    assert count['peak_device'] < 200 << 30
+    assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss < 64 << 20   # (KiB: 64 GiB)
+    # the wanted speakers extracted in one shot: same utterances per speaker, same order -> same bits
+    assert len(kept) == 3 * n // speakers
+    subset = Utterances([(u.name, u.load_audio(), u.speaker) for u in index if u.speaker in wanted])
+    whole = pipeline.extract_features(config, subset, log=quiet)
+    assert sorted(whole.keys()) == sorted(kept)
+    for name, f in kept.items():
+        assert f == whole[name], name

@@ -13,8 +13,8 @@ timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp
   python $root/bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-extra > $out/bench_profiled.json 2> /dev/null
 cp $(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1) $out/bench_fbank40_rocprofv3_kernel_stats.csv
 # the same trace restricted to the 20 timed launches of each kernel (settle and warm-up launches dropped)
-# (20 steps x 12 passes per step = 240 timed launches per leg since round 4)
-python $root/tools/timed_launch_stats.py $(find /tmp/prof_stats -name '*kernel_trace.csv' | head -1) 240 > $out/bench_fbank40_timed_launches_stats.csv
+# (20 steps x 120 passes per step = 2400 timed launches per leg since round 5)
+python $root/tools/timed_launch_stats.py $(find /tmp/prof_stats -name '*kernel_trace.csv' | head -1) 2400 > $out/bench_fbank40_timed_launches_stats.csv
 # the same bench as the driver launches it for N > 1 (torch.distributed.run as a process spawner, one rank):
 # RcclComm.from_env(), the barrier / max all-reduce and the gather of the Features block over RCCL
 timeout -s KILL 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 \
