@@ -276,10 +276,20 @@ class Plan:
         return name.decode() if name else None
 
     # -- Audio -> Features --
-    def run(self, waves, vtln_warps=None, check_finite=False):
+    def run(self, waves, vtln_warps=None, check_finite=False, wrap=None):
         """`waves`: list of 1-D int16 arrays -> list of float32 [nframes, ndims]; `check_finite`:
-        ONE validation of the whole batch (what Features.validate checks per utterance)"""
+        ONE validation of the whole batch (what Features.validate checks per utterance).  With `wrap` the
+        call returns ``wrap(matrices)`` instead - the caller's per-utterance objects, which a large batch
+        builds while its pieces are still on their way (they only need to know WHERE their rows will be)"""
+        if wrap is not None:
+            return self._run(waves, vtln_warps, check_finite, wrap)
+        return self._run(waves, vtln_warps, check_finite, lambda res: res)
+
+    def _run(self, waves, vtln_warps, check_finite, wrap):
         n = len(waves)
+        i16 = np.dtype(np.int16)
+        if any(w.dtype != i16 or w.ndim != 1 for w in waves):
+            waves = [np.ascontiguousarray(w, dtype=np.int16).reshape(-1) for w in waves]
         lengths = np.fromiter((w.shape[0] for w in waves), np.int64, n)
         soff = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(lengths, out=soff[1:])
@@ -295,9 +305,9 @@ class Plan:
             if np.all(warp == 1.0):
                 warp = None
         if n == 0:
-            return []
+            return wrap([])
         if int(soff[-1]) * 2 >= _LARGE_BATCH_BYTES and self.ndims > 0:
-            return self._run_large(waves, soff, foff, nfr, warp, check_finite)
+            return self._run_large(waves, soff, foff, nfr, warp, check_finite, wrap)
         wave, wave_token = stage_rows(waves, np.int16)
         # the per-utterance results are views of ONE array (cutting 4 000 fresh copies out of it
         # cost more than the launch and both transfers together)
@@ -324,40 +334,108 @@ class Plan:
         finally:
             del wave
             STAGING.release(wave_token)
-        return res
+        return wrap(res)
 
-    def _run_large(self, waves, soff, foff, nfr, warp, check_finite):
-        """`run` for batches of tens of megabytes and more (process_all over a corpus): the host arrays are
-        gathered into page-locked memory and uploaded piece by piece on the copy threads (gather and transfer
-        overlap: upload_rows), the batch is validated while it is in HBM instead of by two passes over the host
-        copy, and the per-utterance views are cut while the one download runs.  10 000 x 3 s utterances, fbank-40:
-        this call 76-99 -> 36 ms, `process_all` of the processor 138 -> 49-56 ms (MFCC-13: 106 -> 42)."""
+    def _clones(self, count):
+        """`count` private plans with this plan's options on its device (own stream, own offset tables): the
+        pieces of a large batch run through them side by side (a plan keeps ONE pair of offset tables in HBM
+        and a call that changes them waits for its stream first)"""
+        with _LOCK:
+            clones = _CLONES.setdefault((_abi.options_key(self.opts), self.device), [])
+            while len(clones) < count:
+                clones.append(Plan(self.opts, self.device))
+            return clones[:count]
+
+    def _run_large(self, waves, soff, foff, nfr, warp, check_finite, wrap):
+        """`run` for batches of tens of megabytes and more (process_all over a corpus).  The batch is cut into
+        pieces of whole utterances (~16); each copy thread takes every fourth piece through the whole path on
+        its own stream and its own clone of the plan: gather into page-locked memory -> upload -> kernel ->
+        download into the page-locked result, all stream ordered, so that the upload of one piece, the kernel
+        of another and the download of a third overlap (the link is full duplex) and the call costs little more
+        than its upload.  The batch is validated while it is in HBM (one count over the whole output instead of
+        two passes over the host copy); the per-utterance views are cut while the pieces are in flight.
+        10 000 x 3 s utterances, fbank-40: upload, kernel, download one after the other took 36 ms (round 4)."""
+        global _COPY_POOL
         n = len(waves)
         total = int(foff[-1])
-        d_wave = upload_rows(waves, np.int16, self.device)
-        d_out = None
+        total_samples = int(soff[-1])
+        ndims = self.ndims
+        d_wave = d_out = None
+        staged, token = STAGING.array((total_samples,), np.int16)
         try:
-            d_out = DeviceBuffer(max(total * self.ndims * 4, 16), self.device)
-            self.run_device(d_wave.ptr, soff, foff, d_out.ptr, vtln_warps=warp)
-            if check_finite and total:
-                check_finite_device(d_out.ptr, total * self.ndims, self.device)
-            out = result_array((total, self.ndims), np.float32)
-            wait = d_out.download_async(out) if total else (lambda: None)
+            d_wave = DeviceBuffer(max(total_samples * 2, 16), self.device)
+            d_out = DeviceBuffer(max(total * ndims * 4, 16), self.device)
+            out = result_array((total, ndims), np.float32)
+            pieces = max(1, min(_COPY_PIECES * _COPY_THREADS, n, total_samples * 2 // (8 << 20)))
+            cuts = [int(np.searchsorted(soff, total_samples * k // pieces)) for k in range(pieces + 1)]
+            cuts[0], cuts[-1] = 0, n
+            # (16-byte aligned device blocks: a piece starts on an even utterance boundary only if its sample
+            # and frame offsets are multiples of 8 samples / 4 floats - move the cut forward until they are)
+            for k in range(1, pieces):
+                c = max(cuts[k], cuts[k - 1])
+                while c < n and (int(soff[c]) % 8 or (int(foff[c]) * ndims) % 4):
+                    c += 1
+                cuts[k] = c
+            threads = min(_COPY_THREADS, pieces)
+            clones = self._clones(threads)
+            if _COPY_POOL is None:
+                from concurrent.futures import ThreadPoolExecutor
+                with _LOCK:
+                    if _COPY_POOL is None:
+                        _COPY_POOL = ThreadPoolExecutor(max_workers=_COPY_THREADS, thread_name_prefix='snf-copy')
+            base_in, base_out = staged.ctypes.data, out.ctypes.data
+
+            def run(w):
+                bind_device(self.device)
+                stream = _copy_stream(self.device)
+                try:
+                    for k in range(w, pieces, threads):
+                        a, b = cuts[k], cuts[k + 1]
+                        if b <= a:
+                            continue
+                        s0, s1, f0, f1 = int(soff[a]), int(soff[b]), int(foff[a]), int(foff[b])
+                        if s1 > s0:
+                            np.concatenate(waves[a:b], out=staged[s0:s1])
+                            check(lib().snf_memcpy_h2d_async(C.c_void_p(d_wave.ptr + 2 * s0), C.c_void_p(base_in + 2 * s0),
+                                                             2 * (s1 - s0), C.c_void_p(stream)))
+                        if f1 > f0:
+                            clones[w].run_device(d_wave.ptr + 2 * s0, soff[a:b + 1] - s0, foff[a:b + 1] - f0,
+                                                 d_out.ptr + 4 * ndims * f0,
+                                                 vtln_warps=None if warp is None else warp[a:b], stream=stream)
+                            check(lib().snf_memcpy_d2h_async(C.c_void_p(base_out + 4 * ndims * f0),
+                                                             C.c_void_p(d_out.ptr + 4 * ndims * f0),
+                                                             4 * ndims * (f1 - f0), C.c_void_p(stream)))
+                finally:
+                    # whatever happened, nothing of this thread is in flight on these buffers afterwards
+                    lib().snf_stream_synchronize(C.c_void_p(stream))
+
+            from concurrent.futures import wait
+            futures = [_COPY_POOL.submit(run, w) for w in range(threads)]
             res = []
-            for u in range(n):
+            for u in range(n):   # (cut while the pieces are in flight)
                 if nfr[u] == 0:
                     res.append(np.zeros((0, 0), dtype=np.float32))   # Kaldi: an empty (0, 0) matrix
                 elif n == 1:
                     res.append(out)
                 else:
                     res.append(out[foff[u]:foff[u + 1]])
-            wait()
+            try:
+                res = wrap(res)
+            finally:
+                wait(futures)   # (no thread is still enqueuing on these buffers when they are released)
+            for future in futures:
+                future.result()
+            if check_finite and total:
+                check_finite_device(d_out.ptr, total * ndims, self.device)
         except BaseException:
-            d_wave.free()          # (waits for the device: whatever was enqueued is done before the blocks
-            if d_out is not None:  # go back to the pool)
-                d_out.free()
+            for block in (d_wave, d_out):   # (free() waits for the device: whatever was enqueued is done
+                if block is not None:       # before the blocks go back to the pool)
+                    block.free()
             raise
-        d_wave.free(synced=True)   # the call on the plan's stream and the download were waited for
+        finally:
+            del staged
+            STAGING.release(token)
+        d_wave.free(synced=True)   # every copy thread synchronised its stream
         d_out.free(synced=True)
         return res
 
@@ -543,6 +621,7 @@ def get_plan(opts, device=None):
 def clear_plans():
     with _LOCK:
         _PLANS.clear()
+        _CLONES.clear()
 
 
 # ---- raw device memory (for hosts that keep batches resident in HBM) ----------
@@ -670,7 +749,9 @@ def stage_rows(mats, dtype):
 
 
 _COPY_POOL = None
+_CLONES = {}   # (options, device) -> private plans of Plan._clones
 _LARGE_BATCH_BYTES = 32 << 20   # Plan.run: batches from this many bytes of audio take the overlapped path
+_COPY_PIECES = int(os.environ.get('SNF_COPY_PIECES', '4'))    # pieces of a large batch per copy thread
 _COPY_THREADS = int(os.environ.get('SNF_COPY_THREADS', '4'))  # (8 / 16 threads measured slower: 6.4 / 5.1 against 4.1 ms per 96 MB)
 
 

@@ -159,11 +159,21 @@ class FramesProcessor(Configurable, FeaturesProcessor, metaclass=abc.ABCMeta):
         start = np.arange(nframes) * self.frame_shift
         return np.vstack((start, start + self.frame_length)).T
 
-    def _run(self, opts, signals, vtln_warps=None):
+    def _check_signals(self, signals):
+        """`check_signal` for every signal of a batch (the option is read once, the common case - a mono
+        signal at the processor's rate - costs two comparisons)"""
+        rate = self.sample_rate
+        for signal in signals:
+            if signal._data.ndim != 1 or signal._sample_rate != rate:
+                check_signal(self, signal)
+
+    def _run(self, opts, signals, vtln_warps=None, wrap=None):
         """One batched launch over `signals` (forced to 16 bits integers like the reference does
-        before Kaldi, processor/base.py:428); the batch is validated once"""
-        waves = [s.astype(np.int16).data for s in signals]
-        return _backend.get_plan(opts).run(waves, vtln_warps, check_finite=True)
+        before Kaldi, processor/base.py:428); the batch is validated once.  `wrap(matrices)` builds the
+        Features of the batch and is called while a large batch is still in flight (see Plan.run)"""
+        i16 = np.dtype(np.int16)
+        waves = [s._data if s._data.dtype == i16 else s.astype(np.int16).data for s in signals]
+        return _backend.get_plan(opts).run(waves, vtln_warps, check_finite=True, wrap=wrap)
 
 
 class MelFeaturesProcessor(FramesProcessor):
@@ -197,10 +207,10 @@ class MelFeaturesProcessor(FramesProcessor):
         return self._process_batch([signal], vtln_warp=[vtln_warp])[0]
 
     def _process_batch(self, signals, vtln_warp=None):
-        for signal in signals:
-            check_signal(self, signal)
+        self._check_signals(signals)
         warps = [1.0] * len(signals) if vtln_warp is None else list(vtln_warp)
-        return self._wrap_batch(self._run(self._build_options(), signals, warps), vtln_warp=warps)
+        return self._run(self._build_options(), signals, warps,
+                         wrap=lambda datas: self._wrap_batch(datas, vtln_warp=warps))
 
     def _wrap_batch(self, datas, vtln_warp=None):
         warps = [1.0] * len(datas) if vtln_warp is None else list(vtln_warp)
