@@ -128,15 +128,44 @@ __device__ __forceinline__ unsigned fmix32(unsigned h) {
   h ^= h >> 16;
   return h;
 }
-__device__ __forceinline__ float2 gauss_pair(unsigned key_lo, unsigned key_hi, unsigned n) {
-  // one 32-bit mix per pair of normals (round 4; two before): its upper half is the radius' uniform, its
-  // lower half the angle's - 16 bits each: the radius reaches 4.7 sigma (2.5e-6 of the mass lies beyond), the
-  // angle has 65 536 steps
-  const unsigned h = fmix32((key_lo + n * 0x9E3779B1u) ^ key_hi);
-  const float u1 = (static_cast<float>(h >> 16) + 1.0f) * (1.0f / 65536.0f);   // (0, 1]
-  const float u2 = static_cast<float>(h & 0xffffu) * (1.0f / 65536.0f);        // [0, 1)
-  const float r = __builtin_amdgcn_sqrtf(-1.38629436111989f * __builtin_amdgcn_logf(u1));
-  return make_float2(r * __builtin_amdgcn_cosf(u2), r * __builtin_amdgcn_sinf(u2));
+__device__ __forceinline__ float2 gauss_pair(unsigned key_lo, unsigned key_hi, unsigned n,
+                                             float k = -1.38629436111989f) {
+  // Round 5 (the reference's default costs 1.49 x the dither-0 kernel): 29 issue slots per
+  // pair of normals instead of 44.
+  //  * one multiply-fold per pair instead of a murmur finaliser: the keys of a frame are finaliser outputs
+  //    already (callers), the counter walks a Weyl sequence under them; x ^ x >> 15, then the high and the low
+  //    word of the 64-bit product with an odd constant xored (v_mad_u64_u32 + 3 full-rate instructions; the
+  //    finaliser was 2 v_mul_lo_u32 + 6);
+  //  * the two uniforms are made in the mantissa of a float in [1, 2) - shift + or, no conversion, no scaling:
+  //    the radius' uniform is 2 - f in (0, 1] (23 bits: the top 23 of the word, so the radius reaches 5.6 sigma),
+  //    the angle goes to v_sin_f32 / v_cos_f32 as it is (they take revolutions and are periodic: sin 2 pi f =
+  //    sin 2 pi (f - 1); 16 bits = 65 536 steps, the low 16 of the word);
+  //  * Box-Muller itself stays: log2, sqrt, sin, cos on the transcendental unit.
+  //  * the amplitude rides on the radius: `k` = -2 ln 2 x dither^2 (dither_scale), so that a sample takes its
+  //    noise with one fused multiply-add.
+  unsigned x = (key_lo + n * 0x9E3779B1u) ^ key_hi;
+  x ^= x >> 15;
+  const unsigned long long prod = static_cast<unsigned long long>(x) * 0x85EBCA6Bu;
+  const unsigned h = static_cast<unsigned>(prod) ^ static_cast<unsigned>(prod >> 32);
+  const float fr = __builtin_bit_cast(float, (h >> 9) | 0x3f800000u);               // [1, 2)
+  const float fa = __builtin_bit_cast(float, ((h << 7) & 0x007fff80u) | 0x3f800000u);  // [1, 2), 16 bits
+  const float r = __builtin_amdgcn_sqrtf(k * __builtin_amdgcn_logf(2.0f - fr));
+  return make_float2(r * __builtin_amdgcn_cosf(fa), r * __builtin_amdgcn_sinf(fa));
+}
+// k of gauss_pair for N(0, dither^2)
+__device__ __forceinline__ float dither_scale(float dither) { return -1.38629436111989f * dither * dither; }
+// xe, xo += N(0, dither^2): the form every 512-point / long-frame kernel uses (bit-identical across them)
+__device__ __forceinline__ void add_dither_pair(unsigned key_lo, unsigned key_hi, unsigned n, float k, float& xe,
+                                                float& xo) {
+  unsigned x = (key_lo + n * 0x9E3779B1u) ^ key_hi;
+  x ^= x >> 15;
+  const unsigned long long prod = static_cast<unsigned long long>(x) * 0x85EBCA6Bu;
+  const unsigned h = static_cast<unsigned>(prod) ^ static_cast<unsigned>(prod >> 32);
+  const float fr = __builtin_bit_cast(float, (h >> 9) | 0x3f800000u);
+  const float fa = __builtin_bit_cast(float, ((h << 7) & 0x007fff80u) | 0x3f800000u);
+  const float r = __builtin_amdgcn_sqrtf(k * __builtin_amdgcn_logf(2.0f - fr));
+  xe = __builtin_fmaf(r, __builtin_amdgcn_cosf(fa), xe);
+  xo = __builtin_fmaf(r, __builtin_amdgcn_sinf(fa), xo);
 }
 
 __device__ __forceinline__ void wave_lds_sync() {

@@ -195,9 +195,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
       const unsigned dkey_hi = fmix32(static_cast<unsigned>(k >> 32) ^ dkey_lo);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const float2 nz = gauss_pair(dkey_lo, dkey_hi, static_cast<unsigned>(lane_v + 64 * j));
-        xe[j] += p.dither * nz.x;
-        xo[j] += p.dither * nz.y;
+        add_dither_pair(dkey_lo, dkey_hi, static_cast<unsigned>(lane_v + 64 * j), dither_scale(p.dither), xe[j], xo[j]);
       }
     }
     float part = 0.0f;

@@ -276,9 +276,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       if (DITHER) {  // Kaldi dithers before the DC removal
-        const float2 nz = gauss_pair(dkey_lo, dkey_hi, static_cast<unsigned>(l + 16 * j));
-        xe[j] += p.dither * nz.x;
-        xo[j] += p.dither * nz.y;
+        add_dither_pair(dkey_lo, dkey_hi, static_cast<unsigned>(l + 16 * j), dither_scale(p.dither), xe[j], xo[j]);
       }
       if (!kIntSum) {
         const float s2 = xe[j] + xo[j];

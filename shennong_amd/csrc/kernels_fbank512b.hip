@@ -164,15 +164,16 @@ __global__ __launch_bounds__(kWaves * 64, 4) void fbank512b_kernel(const Fast512
       const unsigned long long k = noise_cur ^ p.seed;
       dkey_lo = fmix32(static_cast<unsigned>(k));
       dkey_hi = fmix32(static_cast<unsigned>(k >> 32) ^ dkey_lo);
+      // (finished values: without this the last xor-shift of the keys is redone for every element)
+      asm volatile("" : "+v"(dkey_lo), "+v"(dkey_hi));
     }
+    const float dscale = DITHER ? dither_scale(p.dither) : 0.0f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       xe[j] = static_cast<float>(static_cast<short>(raw[j] & 0xffff));
       xo[j] = static_cast<float>(raw[j] >> 16);
       if (DITHER) {
-        const float2 nz = gauss_pair(dkey_lo, dkey_hi, static_cast<unsigned>(l + 16 * j));
-        xe[j] += p.dither * nz.x;
-        xo[j] += p.dither * nz.y;
+        add_dither_pair(dkey_lo, dkey_hi, static_cast<unsigned>(l + 16 * j), dscale, xe[j], xo[j]);
         const float s2 = xe[j] + xo[j];
         part += in_window(j) ? s2 : 0.0f;
       } else {

@@ -321,6 +321,30 @@ def test_dither_statistics(gpu, snip_edges):
     assert np.abs(clean - noisy).max() < 0.05
 
 
+def test_dither_is_gaussian(gpu):
+    """The generator behind the default dither (round 5: a multiply-fold hash + Box-Muller on mantissa-built
+    uniforms, csrc/device_fft.h) against what N(0, 1) predicts on a long silent signal.  With a rectangular
+    window, no pre-emphasis and no DC removal the raw energy of a frame is the sum of 400 squared normals:
+    mean 400, variance 400 (kurtosis - 1) = 800, and log-energy std sqrt(2 / 400); the spectrogram of white
+    noise is flat: every bin of the power spectrum has the same expectation (400 x the window's energy)."""
+    wave = np.zeros(16000 * 60, dtype=np.int16)
+    proc = SpectrogramProcessor(dither=1.0, window_type='rectangular', preemph_coeff=0.0,
+                                remove_dc_offset=False, raw_energy=True)
+    spec = proc.process(Audio(wave, 16000)).data
+    n = spec.shape[0]
+    assert n > 5900
+    energy = np.exp(spec[:, 0].astype(np.float64))          # sum of 400 squared samples
+    assert abs(energy.mean() / 400.0 - 1.0) < 0.004          # variance of the samples: 1 (+- 3 sigma of the mean)
+    kurt = energy.var() / 400.0 + 1.0                        # E x^4 / sigma^4 of the samples
+    assert 2.8 < kurt < 3.2, kurt                            # (std of this estimate: ~0.04)
+    assert abs(np.corrcoef(energy[:-1], energy[1:])[0, 1]) < 0.05   # overlapping frames: independent draws
+    power = np.exp(spec[:, 1:].astype(np.float64)).mean(axis=0)     # bins 1..256: E |X_k|^2 = 400
+    assert np.abs(power / 400.0 - 1.0).max() < 0.08, (power.min(), power.max())
+    # two halves of the spectrum and even / odd bins agree (no periodic structure in the stream)
+    assert abs(power[:128].mean() / power[128:].mean() - 1.0) < 0.01
+    assert abs(power[0::2].mean() / power[1::2].mean() - 1.0) < 0.01
+
+
 # ---- SURVEY 8(f) rank 1: energy, VAD, CMVN, sliding-window CMVN -----------------------------------
 from shennong_amd import Features, FeaturesCollection  # noqa: E402
 from shennong_amd.processor import EnergyProcessor  # noqa: E402
