@@ -374,7 +374,10 @@ __global__ __launch_bounds__(256) void plp_tail_exact_kernel(const PlpParams p, 
 #pragma unroll
     for (int j = 0; j <= i; ++j) lpc[j] = tmp[j];
   }
-  const float res_f = static_cast<float>(-log(1.0 / static_cast<double>(E)));
+  // (round 5) -log(1 / E) is log E up to the rounding of the double quotient (1e-16, gone in the float the
+  // reference rounds to: plp.py:601-603): one double division less; likewise sum / (i + 1) as a product with
+  // the rounded reciprocal - a last-bit difference in a double that is rounded to float right after
+  const float res_f = static_cast<float>(log(static_cast<double>(E)));
   const double res = fmax(static_cast<double>(res_f), DBL_EPSILON);
 #pragma unroll
   for (int i = 0; i < ORD; ++i) {
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(256) void plp_tail_exact_kernel(const PlpParams p, 
 #pragma unroll
     for (int j = 0; j < i; ++j)
       sum += static_cast<double>(i - j) * static_cast<double>(lpc[j]) * static_cast<double>(cep[i - j - 1]);
-    cep[i] = static_cast<float>(-static_cast<double>(lpc[i]) - sum / static_cast<double>(i + 1));
+    cep[i] = static_cast<float>(-static_cast<double>(lpc[i]) - sum * (1.0 / static_cast<double>(i + 1)));
   }
   float* __restrict__ row = out + g * NC;
 #pragma unroll

@@ -14,6 +14,7 @@ import numpy as np
 
 from shennong_amd import _abi, _backend
 from shennong_amd._options import F32, FLAG, SECONDS_F32, Configurable, Option
+from shennong_amd.audio import Audio
 from shennong_amd.base import BaseProcessor
 from shennong_amd.features import Features, FeaturesCollection
 from shennong_amd.utils import copy_properties, get_njobs
@@ -105,7 +106,9 @@ class FeaturesProcessor(BaseProcessor, metaclass=abc.ABCMeta):
                 raise ValueError(
                     f'utterances and "{name}" have different names')
         utts = list(utterances)
-        signals = [u.load_audio() for u in utts]
+        # (an utterance that is a whole in-memory Audio needs no call: load_audio is for files and segments)
+        signals = [u._audio if type(u._audio) is Audio and not (u._tstart or u._tstop) else u.load_audio()
+                   for u in utts]
         per_utt = {k: [v[u.name] for u in utts] for k, v in kwargs.items()}
         feats = self._process_batch(signals, **per_utt)
         return FeaturesCollection(
