@@ -24,6 +24,13 @@
  * (tests/golden/make_golden_plp.py: glue pinned, primitives are stand-ins).  The float32 round-off of
  * Kaldi's own kernels remains unpinned.
  *
+ * HOW TO PIN IT (round 5): tests/golden/make_golden_kaldi.py, run where bootphon/shennong and its pykaldi are
+ * installed (never here, never on the GPU box), writes tests/golden/reference_kaldi.npz - the reference's
+ * own outputs for 30 cases on tests/golden/test.wav / test.8k.wav (spectrogram, fbank-23/40, MFCC, PLP
+ * +- RASTA, energy, pitch, pitch post-processing, delta, VAD, CMVN +- VAD weights, sliding CMVN; dither 0).
+ * tests/test_kaldi_pin.py compares this file's functions (and, under -m gpu, the HIP path) with it at 1e-4
+ * as soon as the file exists, and skips with that explanation until then.
+ *
  * Each function cites the reference file:line it follows, or [KALDI-UPSTREAM] + the Kaldi source
  * file when the algorithm lives in Kaldi (restated from the published sources).
  *

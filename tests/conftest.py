@@ -82,7 +82,13 @@ def gpu(_gpu_backend):
 # than 60 dB below the strongest bin of its frame is compared in the LINEAR domain, where the error of a
 # float32 transform lives - |P_got - P_want| <= 1e-4 P_want + 1e-9 P_max(frame) -, every other bin at the
 # north_star's 1e-4 relative + 1e-4 absolute in the log domain (`_spectrogram_close`).
-FAMILY_ATOL = {'fbank': 1e-5, 'mfcc': 1.5e-4, 'plp': 5e-6, 'spectrogram': 1e-4, 'delta': 2.5e-6,
+# Round 5: every parity assertion of the mel families now uses the north_star's 1e-4
+# relative term (14 of them carried 2e-4).  Measured over the whole GPU suite at rtol 1e-4
+# (profiles/r05_parity_errors.txt): fbank needs no absolute term, MFCC 8.1e-5, PLP 5.8e-6 (one case: VTLN warp
+# 1.2, a cepstrum near zero - the Durbin recursion amplifies the float32 round-off of the 23 mel energies), hence
+# PLP's absolute term goes from 5e-6 to 1.2e-5 (twice the measured need, the rule above) instead of its
+# relative term staying at 2e-4.
+FAMILY_ATOL = {'fbank': 1e-5, 'mfcc': 1.6e-4, 'plp': 1.2e-5, 'spectrogram': 1e-4, 'delta': 2.5e-6,
                'pitch_post': 7e-6, None: 1e-4}
 NULL_DB = 60.0
 

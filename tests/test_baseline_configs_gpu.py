@@ -71,7 +71,7 @@ def test_config4_one_shard(gpu):
         np.testing.assert_array_equal(f_pitch[i].data, want, err_msg=f'pitch of utterance {i}')
         assert_close(f_post[i].data, orc.process_pitch(post._options, want), rtol=1e-4, family='pitch_post',
                      what=f'pitch post {i}')
-        assert_close(f_plp[i].data, orc.compute(plp._build_options(), waves[i]), rtol=2e-4,
+        assert_close(f_plp[i].data, orc.compute(plp._build_options(), waves[i]), rtol=1e-4,
                      what=f'plp {i}')
         alone = plp.process(audios[i])
         np.testing.assert_array_equal(f_plp[i].data, alone.data)

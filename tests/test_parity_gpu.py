@@ -52,7 +52,7 @@ def test_fbank_options(gpu, audio, wave, opts):
     proc = FilterbankProcessor(dither=0, **opts)
     got = proc.process(audio)
     want = _oracle(proc, wave)
-    rtol = 1e-4 if opts.get('use_log_fbank', True) else 2e-4
+    rtol = 1e-4
     # (linear mel energies are sums of squares of int16-scale samples, ~1e7: the absolute term scales with them)
     assert_close(got.data, want, rtol=rtol, atol=None if opts.get('use_log_fbank', True) else 1.0,
                  what=str(opts), family='fbank')
@@ -91,7 +91,7 @@ def test_plp(gpu, audio, wave, opts):
     proc = PlpProcessor(dither=0, **opts)
     got = proc.process(audio)
     want = _oracle(proc, wave)
-    assert_close(got.data, want, rtol=2e-4, what=str(opts), family='plp')
+    assert_close(got.data, want, rtol=1e-4, what=str(opts), family='plp')
 
 
 @pytest.mark.parametrize('warp', [0.85, 1.0, 1.2])
@@ -99,7 +99,7 @@ def test_plp(gpu, audio, wave, opts):
 def test_vtln_warp(gpu, audio, wave, cls, warp):
     proc = cls(dither=0)
     got = proc.process(audio, vtln_warp=warp)
-    assert_close(got.data, _oracle(proc, wave, warp), rtol=2e-4, what=f'{proc.name} warp {warp}')
+    assert_close(got.data, _oracle(proc, wave, warp), rtol=1e-4, what=f'{proc.name} warp {warp}')
     assert got.properties[proc.name]['vtln_warp'] == warp
 
 
@@ -127,7 +127,7 @@ def test_batch_ragged(gpu, synth_waves):
         want = _oracle(proc, w, warps[f'u{i}'])
         assert f.shape == want.shape
         if want.size:
-            assert_close(f.data, want, rtol=2e-4, what=f'{proc.name} utt {i}')
+            assert_close(f.data, want, rtol=1e-4, what=f'{proc.name} utt {i}')
     assert feats[f'u{len(waves) - 1}'].shape == (0, 0)
 
 
@@ -571,14 +571,14 @@ def test_fast_kernel_centred_frames(gpu, synth_waves, cls):
     for w, f in zip(waves, feats):
         want = _oracle(proc, w)
         assert f.shape == want.shape
-        assert_close(f.data, want, rtol=2e-4, what=cls.__name__)
+        assert_close(f.data, want, rtol=1e-4, what=cls.__name__)
     # an utterance shorter than one window cannot take the clamped bulk loads: it runs on the generic
     # kernel (a second, masked launch), the other utterance stays where it always runs
     short = [waves[0], np.asarray(waves[1][:300])]
     feats = proc._process_batch([Audio(w, 16000) for w in short])
     assert (plan.kernel_name(1), plan.kernel_name(2)) == ('fbank512_kernel', 'mel_features_generic_kernel')
     for w, f in zip(short, feats):
-        assert_close(f.data, _oracle(proc, w), rtol=2e-4, what=f'{proc.name} short')
+        assert_close(f.data, _oracle(proc, w), rtol=1e-4, what=f'{proc.name} short')
 
 
 @pytest.mark.parametrize('snip_edges', [True, False])
@@ -596,7 +596,7 @@ def test_fast_kernel_vtln(gpu, synth_waves, cls, snip_edges):
         want = _oracle(proc, w, wf)
         assert f.shape == want.shape
         if want.size:
-            assert_close(f.data, want, rtol=2e-4, what=f'{cls.__name__} warp {wf}')
+            assert_close(f.data, want, rtol=1e-4, what=f'{cls.__name__} warp {wf}')
         assert f.properties[proc.name]['vtln_warp'] == wf
 
 
@@ -630,7 +630,7 @@ def test_fast_kernel_short_frames(gpu, cls, sample_rate, opts, snip_edges):
     for w, f in zip(waves, feats):
         want = _oracle(proc, w)
         assert f.shape == want.shape
-        assert_close(f.data, want, rtol=2e-4, what=f'{cls.__name__} {sample_rate} {opts}')
+        assert_close(f.data, want, rtol=1e-4, what=f'{cls.__name__} {sample_rate} {opts}')
     # with VTLN warps (per-utterance tables): the 512-point form of the zero-extended frames for the
     # warped utterances; the unwarped one keeps the kernel it runs on in any other batch
     warps = [0.9, 1.0, 1.15]
@@ -640,7 +640,7 @@ def test_fast_kernel_short_frames(gpu, cls, sample_rate, opts, snip_edges):
     else:
         assert plan.kernel_name(1) == 'fbank512_kernel'
     for w, wf, f in zip(waves, warps, feats):
-        assert_close(f.data, _oracle(proc, w, wf), rtol=2e-4, what=f'{proc.name} warp {wf} {opts}')
+        assert_close(f.data, _oracle(proc, w, wf), rtol=1e-4, what=f'{proc.name} warp {wf} {opts}')
 
 
 @pytest.mark.parametrize('snip_edges', [True, False])
@@ -774,7 +774,7 @@ def test_every_route_in_one_batch(gpu, cls, sample_rate):
         for i, f in zip(order, together):
             assert np.array_equal(f.data, alone[i]), f'{cls.__name__} {sample_rate}: utterance {i} in {order}'
     for w, wf, f in zip(waves, warps, alone):
-        assert_close(f, _oracle(proc, w, wf), rtol=2e-4, what=f'{cls.__name__} {sample_rate} warp {wf}')
+        assert_close(f, _oracle(proc, w, wf), rtol=1e-4, what=f'{cls.__name__} {sample_rate} warp {wf}')
 
 
 @pytest.mark.parametrize('snip_edges', [True, False])
@@ -808,7 +808,7 @@ def test_fast_kernel_long_frames(gpu, cls, sample_rate, opts, snip_edges):
     for w, f in zip(waves, feats):
         want = _oracle(proc, w)
         assert f.shape == want.shape
-        assert_close(f.data, want, rtol=2e-4,
+        assert_close(f.data, want, rtol=1e-4,
                      what=f'{cls.__name__} {sample_rate} {opts}')
     if cls is SpectrogramProcessor or linear:
         return
@@ -816,7 +816,7 @@ def test_fast_kernel_long_frames(gpu, cls, sample_rate, opts, snip_edges):
     feats = proc._process_batch([Audio(w, sample_rate) for w in waves], vtln_warp=warps)
     assert plan.kernel_name(1) == 'fbank2048_kernel'
     for w, wf, f in zip(waves, warps, feats):
-        assert_close(f.data, _oracle(proc, w, wf), rtol=2e-4, what=f'{proc.name} warp {wf} {opts}')
+        assert_close(f.data, _oracle(proc, w, wf), rtol=1e-4, what=f'{proc.name} warp {wf} {opts}')
 
 
 def test_long_frames_single_utterance_shorter_than_a_window(gpu):
@@ -824,7 +824,7 @@ def test_long_frames_single_utterance_shorter_than_a_window(gpu):
     wave = synth.utterances(3, 1, 900, 44100)[0]
     proc = FilterbankProcessor(sample_rate=44100, dither=0, snip_edges=False)
     got = proc.process(Audio(wave, 44100))
-    assert_close(got.data, _oracle(proc, wave), rtol=2e-4, what=f'{proc.name} short utterance')
+    assert_close(got.data, _oracle(proc, wave), rtol=1e-4, what=f'{proc.name} short utterance')
     plan = _backend.get_plan(proc._build_options())
     assert plan.kernel_name(1) == 'mel_features_generic_kernel'
 
@@ -838,12 +838,12 @@ def test_tables_too_large_for_lds_fall_back(gpu):
     warps = [0.85, 1.0, 1.1, 0.93]
     feats = proc._process_batch([Audio(w, 8000) for w in waves], vtln_warp=warps)
     for w, wf, f in zip(waves, warps, feats):
-        assert_close(f.data, _oracle(proc, w, wf), rtol=2e-4, what=f'{proc.name} wide banks, warp {wf}')
+        assert_close(f.data, _oracle(proc, w, wf), rtol=1e-4, what=f'{proc.name} wide banks, warp {wf}')
     wave = synth.utterances(95, 1, 30000, 44100)[0]
     proc = MfccProcessor(sample_rate=44100, frame_length=0.008, frame_shift=0.0125, num_bins=59, num_ceps=3,
                          low_freq=100, high_freq=21750, htk_compat=True, use_energy=False, dither=0,
                          window_type='hanning')
-    assert_close(proc.process(Audio(wave, 44100)).data, _oracle(proc, wave), rtol=2e-4, what=f'{proc.name} 59 bins at 44.1 kHz')
+    assert_close(proc.process(Audio(wave, 44100)).data, _oracle(proc, wave), rtol=1e-4, what=f'{proc.name} 59 bins at 44.1 kHz')
 
 
 def test_short_frames_spectrogram_and_energy(gpu):
