@@ -346,7 +346,30 @@ class Plan:
                 clones.append(Plan(self.opts, self.device))
             return clones[:count]
 
-    def _run_large(self, waves, soff, foff, nfr, warp, check_finite, wrap):
+    def run_pinned(self, corpus, vtln_warps=None, check_finite=False, wrap=None):
+        """`run` over every utterance of a :class:`PinnedCorpus`, uploaded straight from its page-locked block"""
+        soff = corpus.soff
+        n = soff.shape[0] - 1
+        lengths = np.diff(soff)
+        frames_of = {int(x): self.num_frames(int(x)) for x in np.unique(lengths)}
+        nfr = np.fromiter((frames_of[int(x)] for x in lengths), np.int64, n)
+        foff = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(nfr, out=foff[1:])
+        warp = None
+        if vtln_warps is not None:
+            warp = np.ascontiguousarray(vtln_warps, dtype=np.float32)
+            if warp.shape[0] != n:
+                raise ValueError('one vtln_warp per utterance is required')
+            if np.all(warp == 1.0):
+                warp = None
+        wrap = wrap or (lambda res: res)
+        if n == 0:
+            return wrap([])
+        if self.ndims <= 0 or int(soff[-1]) * 2 < _LARGE_BATCH_BYTES:
+            return self._run(corpus.views, vtln_warps, check_finite, wrap)
+        return self._run_large(corpus.views, soff, foff, nfr, warp, check_finite, wrap, pinned=corpus)
+
+    def _run_large(self, waves, soff, foff, nfr, warp, check_finite, wrap, pinned=None):
         """`run` for batches of tens of megabytes and more (process_all over a corpus).  The batch is cut into
         pieces of whole utterances (~16); each copy thread takes every fourth piece through the whole path on
         its own stream and its own clone of the plan: gather into page-locked memory -> upload -> kernel ->
@@ -361,7 +384,10 @@ class Plan:
         total_samples = int(soff[-1])
         ndims = self.ndims
         d_wave = d_out = None
-        staged, token = STAGING.array((total_samples,), np.int16)
+        if pinned is not None:   # (the source IS page-locked: pieces go up from where they are)
+            staged, token = pinned.block, None
+        else:
+            staged, token = STAGING.array((total_samples,), np.int16)
         try:
             d_wave = DeviceBuffer(max(total_samples * 2, 16), self.device)
             d_out = DeviceBuffer(max(total * ndims * 4, 16), self.device)
@@ -398,7 +424,8 @@ class Plan:
                             continue
                         s0, s1, f0, f1 = int(soff[a]), int(soff[b]), int(foff[a]), int(foff[b])
                         if s1 > s0:
-                            np.concatenate(waves[a:b], out=staged[s0:s1])
+                            if pinned is None:
+                                np.concatenate(waves[a:b], out=staged[s0:s1])
                             check(lib().snf_memcpy_h2d_async(C.c_void_p(d_wave.ptr + 2 * s0), C.c_void_p(base_in + 2 * s0),
                                                              2 * (s1 - s0), C.c_void_p(stream)))
                         if f1 > f0:
@@ -714,6 +741,46 @@ class _ResultBlock:
                 STAGING.release(token)
             except Exception:  # pragma: nocover (interpreter shutdown)
                 pass
+
+
+class _PinnedOwner:
+    """Owner of one page-locked allocation of its own (not pooled): numpy views made through
+    ``np.asarray(owner)`` keep it alive, the memory is released with the last of them"""
+    def __init__(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(shape)) * dtype.itemsize
+        ptr = C.c_void_p()
+        check(lib().snf_host_malloc(C.byref(ptr), max(self.nbytes, 16)))
+        self.address = ptr.value
+        self.__array_interface__ = {'shape': tuple(int(x) for x in shape), 'typestr': dtype.str,
+                                    'data': (self.address, False), 'version': 3}
+
+    def __del__(self):
+        address, self.address = getattr(self, 'address', None), None
+        if address and _LIB is not None:
+            try:
+                _LIB.snf_host_free(C.c_void_p(address))
+            except Exception:  # pragma: nocover (interpreter shutdown)
+                pass
+
+
+class PinnedCorpus:
+    """The int16 audio of a set of utterances in ONE page-locked block (``Utterances.pin()``): what the
+    processors force every signal to before they run (reference processor/base.py:428), loaded once.  A batch
+    made of these utterances in this order is uploaded straight from the block - no gather into a staging buffer
+    (which is what bounds `process_all` on pageable arrays: the host's memory traffic, not the link) and no
+    per-utterance checks: they were made when the block was built."""
+    def __init__(self, waves, sample_rate):
+        n = len(waves)
+        self.sample_rate = int(sample_rate)
+        self.soff = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([w.shape[0] for w in waves], out=self.soff[1:])
+        total = int(self.soff[-1])
+        self.owner = _PinnedOwner((max(total, 8),), np.int16)
+        self.block = np.asarray(self.owner)
+        for k, w in enumerate(waves):
+            self.block[self.soff[k]:self.soff[k + 1]] = w
+        self.views = [self.block[self.soff[k]:self.soff[k + 1]] for k in range(n)]
 
 
 def result_array(shape, dtype):

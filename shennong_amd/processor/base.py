@@ -106,6 +106,12 @@ class FeaturesProcessor(BaseProcessor, metaclass=abc.ABCMeta):
                 raise ValueError(
                     f'utterances and "{name}" have different names')
         utts = list(utterances)
+        corpus = getattr(utterances, '_pinned', None)
+        if corpus is not None and hasattr(self, '_process_pinned'):
+            # ``Utterances.pin()``: the audio sits in one page-locked block, checked and converted when it was built
+            per_utt = {k: [v[u.name] for u in utts] for k, v in kwargs.items()}
+            feats = self._process_pinned(corpus, **per_utt)
+            return FeaturesCollection(zip([u.name for u in utts], feats))
         # (an utterance that is a whole in-memory Audio needs no call: load_audio is for files and segments)
         signals = [u._audio if type(u._audio) is Audio and not (u._tstart or u._tstop) else u.load_audio()
                    for u in utts]
@@ -214,6 +220,16 @@ class MelFeaturesProcessor(FramesProcessor):
         warps = [1.0] * len(signals) if vtln_warp is None else list(vtln_warp)
         return self._run(self._build_options(), signals, warps,
                          wrap=lambda datas: self._wrap_batch(datas, vtln_warp=warps))
+
+    def _process_pinned(self, corpus, vtln_warp=None):
+        if self.sample_rate != corpus.sample_rate:
+            raise ValueError(
+                'processor and signal mismatch in sample rates: '
+                '{} != {}'.format(self.sample_rate, corpus.sample_rate))
+        n = corpus.soff.shape[0] - 1
+        warps = [1.0] * n if vtln_warp is None else list(vtln_warp)
+        return _backend.get_plan(self._build_options()).run_pinned(
+            corpus, warps, check_finite=True, wrap=lambda datas: self._wrap_batch(datas, vtln_warp=warps))
 
     def _wrap_batch(self, datas, vtln_warp=None):
         warps = [1.0] * len(datas) if vtln_warp is None else list(vtln_warp)

@@ -190,6 +190,32 @@ class Utterances:
     def by_name(self):
         return self._utterances
 
+    def pin(self):
+        """The same utterances with their audio loaded ONCE, as 16-bit integers - what every processor forces
+        a signal to before it runs (reference processor/base.py:428) -, into one page-locked block
+        (``_backend.PinnedCorpus``); segments are cut, files are not read again.  ``process_all`` on the
+        result uploads straight from that block: no gather into a staging buffer and no per-utterance
+        checks (they are made here: mono, one sample rate).  An extension of this backend - the reference
+        has no device to feed.  Needs the HIP library (page-locked memory comes from it)."""
+        import numpy as np
+        from shennong_amd import _backend
+        utts = list(self)
+        signals = [u.load_audio() for u in utts]
+        rates = sorted(set(s.sample_rate for s in signals))
+        if len(rates) != 1:
+            raise ValueError('utterances to pin must share one sample rate, found ' +
+                             ', '.join('%dHz' % r for r in rates))
+        for utt, signal in zip(utts, signals):
+            if signal.nchannels != 1:
+                raise ValueError('signal must have one dimension, but it has {} ({})'.format(
+                    signal.nchannels, utt.name))
+        corpus = _backend.PinnedCorpus([s.astype(np.int16).data for s in signals], rates[0])
+        fields = (lambda u: (u.speaker,)) if self.has_speakers() else (lambda u: ())
+        pinned = Utterances([(u.name, Audio(view, rates[0], validate=False)) + fields(u)
+                             for u, view in zip(utts, corpus.views)])
+        pinned._pinned = corpus
+        return pinned
+
     def duration(self):
         """Total duration of the utterances in seconds"""
         return sum(utt.duration for utt in self)

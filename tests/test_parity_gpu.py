@@ -1013,6 +1013,47 @@ def test_process_all_like_reference(gpu, wav_file, capsys):
         assert utterances.by_name().keys() == features.keys()
 
 
+def test_large_batches_and_pinned_utterances(gpu, wav_file):
+    """`process_all` on a batch large enough for the pipelined path (pieces through plan clones on the copy
+    threads, round 5) and on ``Utterances.pin()`` (upload straight from one page-locked block): the same bits
+    as one `process` call per utterance - ragged lengths, odd lengths (pieces start on 16-byte boundaries only
+    where an utterance does), an utterance without a frame, VTLN warps - and the reference's error for a
+    mismatched sample rate"""
+    from shennong_amd import Utterances
+    rng = np.random.default_rng(11)
+    lengths = [int(x) for x in rng.integers(16000, 64000, 900)]
+    lengths[5], lengths[6], lengths[400] = 16001, 399, 31999       # odd, shorter than a window, odd
+    waves = [synth.utterances(i, 1, n)[0] for i, n in enumerate(lengths)]
+    assert sum(lengths) * 2 > _backend._LARGE_BATCH_BYTES
+    utts = Utterances([(f'u{i:04d}', Audio(w, 16000, validate=False)) for i, w in enumerate(waves)])
+    warps = {u.name: (1.0, 0.9, 1.15)[i % 3] for i, u in enumerate(utts)}
+    pinned = utts.pin()
+    assert [u.name for u in pinned] == [u.name for u in utts]
+    for proc in (FilterbankProcessor(num_bins=40, dither=0), MfccProcessor(dither=0)):
+        for kwargs in ({}, {'vtln_warp': warps}):
+            plain = proc.process_all(utts, **kwargs)
+            fast = proc.process_all(pinned, **kwargs)
+            assert list(plain.keys()) == list(fast.keys()) == [u.name for u in utts]
+            for i in (0, 5, 6, 7, 399, 400, 401, 899):
+                name = f'u{i:04d}'
+                one = proc.process(Audio(waves[i], 16000), **({'vtln_warp': warps[name]} if kwargs else {}))
+                assert np.array_equal(plain[name].data, one.data), (proc.name, name)
+                assert plain[name] == one
+            for name in plain:
+                assert np.array_equal(plain[name].data, fast[name].data), (proc.name, name)
+                assert plain[name].properties == fast[name].properties
+    with pytest.raises(ValueError, match='mismatch in sample rates'):
+        FilterbankProcessor(sample_rate=8000).process_all(pinned)
+    # files and segments are loaded once; the audio of a pinned utterance is what load_audio gave
+    index = [('a', wav_file, 's1', 0.1, 0.6), ('b', wav_file, 's2', 0.0, 1.4), ('c', wav_file, 's1', 0.3, 0.9)]
+    segs = Utterances(index).pin()
+    assert segs.has_speakers() and [u.speaker for u in segs] == [u.speaker for u in Utterances(index)]
+    proc = MfccProcessor(dither=0)
+    got = proc.process_all(segs)
+    want = proc.process_all(Utterances(index))
+    assert all(got[k] == want[k] for k in 'abc')
+
+
 def test_threaded_callers(gpu, synth_waves):
     """the reference's callers are joblib THREADS (processor/base.py:104-107, pipeline.py:545-565):
     concurrent `process` / `process_all` calls on one shared plan and on different plans return what
