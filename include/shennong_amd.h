@@ -361,6 +361,10 @@ int snf_memcpy_d2h_async(void* dst, const void* src, uint64_t bytes, void* strea
 int snf_event_create(void** event);
 int snf_event_destroy(void* event);
 int snf_event_record(void* event, void* stream);
+/* Work enqueued on `stream` after this call starts only when `event` (recorded on another stream) has happened:
+   the upload stream of a large batch runs ahead of the stream that launches the kernels and downloads the rows
+   (shennong_amd/_backend.py Plan._run_large).  hipStreamWaitEvent; the host does not wait. */
+int snf_stream_wait_event(void* stream, void* event);
 int snf_event_elapsed_ms(void* start, void* stop, float* ms);
 /* Page-locked host staging memory for the host-pointer entry points (snf_plan_run_batch, ...): a
    batch assembled in it (the reference hands over one numpy array per utterance, processor/base.py:428)

@@ -577,6 +577,14 @@ class _ResidentWaves:
 
 def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=None,
                       stats_only=False, resident=None, batch_id=None, device_out=None):
+    from shennong_amd.utils import paused_gc
+    with paused_gc():   # (thousands of small objects per batch, none of them garbage: see utils.paused_gc)
+        return _extract_features_body(config, utterances, warps, log, tolerance, stats_hook, stats_only,
+                                      resident, batch_id, device_out)
+
+
+def _extract_features_body(config, utterances, warps, log, tolerance=2, stats_hook=None,
+                           stats_only=False, resident=None, batch_id=None, device_out=None):
     """The whole pipeline with the intermediate features resident in HBM: the waveforms go up once,
     every stage is one batched launch on device buffers (features, energy -> VAD, CMVN statistics and
     apply, delta, pitch and its post-processing, column concatenation), the final matrices come down

@@ -17,7 +17,7 @@ from shennong_amd._options import F32, FLAG, SECONDS_F32, Configurable, Option
 from shennong_amd.audio import Audio
 from shennong_amd.base import BaseProcessor
 from shennong_amd.features import Features, FeaturesCollection
-from shennong_amd.utils import copy_properties, get_njobs
+from shennong_amd.utils import copy_properties, get_njobs, paused_gc
 
 
 def check_signal(processor, signal, what='signal', dims='one dimension'):
@@ -99,6 +99,10 @@ class FeaturesProcessor(BaseProcessor, metaclass=abc.ABCMeta):
         keeps the whole batch in memory - `Features.copy()` detaches one.
         """
         njobs = get_njobs(njobs, log=self.log)
+        with paused_gc():
+            return self._process_all(utterances, **kwargs)
+
+    def _process_all(self, utterances, **kwargs):
         for name, value in kwargs.items():
             if not isinstance(value, dict):
                 raise ValueError(f'argument "{name}" is not a dict')

@@ -55,3 +55,22 @@ def copy_properties(value):
 def dict_equal(dict1, dict2):
     """True if the two dicts (which may hold numpy arrays) are equal"""
     return array2list(dict1) == array2list(dict2)
+
+
+class paused_gc:
+    """Cyclic garbage collection paused while a batched call makes its thousands of small objects (one
+    Features per utterance, views, tuples): none of them is garbage, and with a large corpus index alive every
+    generation-2 pass of the collector walks hundreds of thousands of objects - measured as 5-8 ms of a 36 ms
+    `process_all` inside bench.py (150 000-utterance index alive) against none in a fresh process.  Reference
+    counting frees everything as before; the collector is re-enabled on exit if it was enabled."""
+    def __enter__(self):
+        import gc
+        self._was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        if self._was:
+            import gc
+            gc.enable()
+        return False
