@@ -318,20 +318,22 @@ __global__ __launch_bounds__(256) void plp_tail_exact_kernel(const PlpParams p, 
                                                              const float* __restrict__ mel,
                                                              const double* __restrict__ energy,
                                                              float* __restrict__ out) {
-  constexpr int kRowPad = NB + 1;                      // (odd row pitch: conflict-free per-thread rows)
-  constexpr int kBasis = (ORD + 1) * (NB + 2);
-  constexpr int kBasisPad = (kBasis + 3) & ~3;
+  // Round 5: the tail was bound by the LDS pipe, not by its arithmetic (0.205 ms with a seventh of the
+  // instructions removed).  Rows 24 floats apart put the 64 lanes of a row read on 4-8 banks (24 t mod 32), and
+  // the 325 IDFT bases came as 86 broadcast ds_read_b128 per wave: ~1 800 LDS clocks per wave, 0.14 ms per CU.
+  // Now the row pitch is the odd row length itself (23: lane t reads bank 23 t + i, all different; the staging
+  // copy is linear) and the bases and the lifter are read where they are used through the scalar cache
+  // (uniform addresses with compile-time offsets: s_load_dwordx8/16, an SGPR operand per multiply-add).
+  constexpr int kRowPad = NB;
+  static_assert(NB % 2 == 1 && NC <= NB, "odd row pitch, output row inside the mel row's slot");
   __shared__ float rows[256 * kRowPad];
-  __shared__ __attribute__((aligned(16))) float basis[kBasisPad];
-  __shared__ float lift[NC];
+  const float* __restrict__ basis = p.idft;
   const int64_t g0 = static_cast<int64_t>(blockIdx.x) * 256;
   const int64_t limit = b.total_frames * NB;
   for (int i = threadIdx.x; i < 256 * NB; i += 256) {
     const int64_t a = g0 * NB + i;
-    rows[(i / NB) * kRowPad + i % NB] = a < limit ? mel[a] : 1.0f;
+    rows[i] = a < limit ? mel[a] : 1.0f;
   }
-  for (int i = threadIdx.x; i < kBasisPad; i += 256) basis[i] = i < kBasis ? p.idft[i] : 0.0f;
-  if (threadIdx.x < NC) lift[threadIdx.x] = p.lifter ? p.lifter[threadIdx.x] : 1.0f;
   __syncthreads();
   // (no early exit: the rows leave through LDS behind a barrier, see the end; a thread past the last frame
   // works on the row of ones the staging loop made and stores nothing)
@@ -376,18 +378,22 @@ __global__ __launch_bounds__(256) void plp_tail_exact_kernel(const PlpParams p, 
 #pragma unroll
     for (int j = 0; j <= i; ++j) lpc[j] = tmp[j];
   }
-  // (round 5) -log(1 / E) is log E up to the rounding of the double quotient (1e-16, gone in the float the
-  // reference rounds to: plp.py:601-603): one double division less; likewise sum / (i + 1) as a product with
-  // the rounded reciprocal - a last-bit difference in a double that is rounded to float right after
-  const float res_f = static_cast<float>(log(static_cast<double>(E)));
+  // (round 5) The reference forms -log(1 / E) and the frame's log-energy in float64 and rounds them to float32
+  // (plp.py:601-603, :615-620): a float32 logarithm that is good to an ulp gives the same float32 up to its last
+  // bit (1e-7 relative on values of 5-20, the parity tolerance is 1e-4) at a fifth of the instructions of the
+  // double one.  The LPC -> cepstrum recursion keeps the reference's double accumulation (plp.py:149-168) with
+  // the weights (k + 1) c[k] made once per cepstrum and one fused multiply-add per term: 78 double operations
+  // instead of 198 + 12 divisions, the same sums up to the last bit of a double that is rounded to float next.
+  const float res_f = logf(E);
   const double res = fmax(static_cast<double>(res_f), DBL_EPSILON);
+  double wcep[ORD];
 #pragma unroll
   for (int i = 0; i < ORD; ++i) {
     double sum = 0.0;
 #pragma unroll
-    for (int j = 0; j < i; ++j)
-      sum += static_cast<double>(i - j) * static_cast<double>(lpc[j]) * static_cast<double>(cep[i - j - 1]);
+    for (int j = 0; j < i; ++j) sum = fma(static_cast<double>(lpc[j]), wcep[i - j - 1], sum);
     cep[i] = static_cast<float>(-static_cast<double>(lpc[i]) - sum * (1.0 / static_cast<double>(i + 1)));
+    wcep[i] = static_cast<double>(i + 1) * static_cast<double>(cep[i]);
   }
   // Round 5: the 13 values of a frame used to leave as 13 dword stores per lane, 52 bytes apart from lane to lane
   // - every store instruction touched 52 cache lines, and the kernel took 0.26 ms whatever arithmetic was left in
@@ -400,12 +406,14 @@ __global__ __launch_bounds__(256) void plp_tail_exact_kernel(const PlpParams p, 
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     float v = c == 0 ? static_cast<float>(res) : cep[c > 0 ? c - 1 : 0];
-    if (p.lifter) v *= lift[c];
+    if (p.lifter) v *= p.lifter[c];
     if (p.cepstral_scale != 1.0f) v *= p.cepstral_scale;
     if (c == 0 && p.use_energy) {
-      double le = log(fmax(energy[g], DBL_EPSILON));  // (linear frame energy from the mel kernel)
+      // (linear frame energy from the mel kernel: a float sum widened to double; the floor of the reference's
+      // double logarithm, DBL_EPSILON, is a float32 number too)
+      float le = logf(fmaxf(static_cast<float>(energy[g]), 2.220446049250313e-16f));
       if (p.has_floor && le < p.log_energy_floor) le = p.log_energy_floor;
-      v = static_cast<float>(le);
+      v = le;
     }
     int oc = c;
     if (p.htk_compat) oc = c == 0 ? NC - 1 : c - 1;
