@@ -110,7 +110,7 @@ struct snf_plan {
   DevBuf d_scales, d_dims;
   // append_deltas: true = the MFCC kernel writes [T, num_ceps] to a scratch and the delta kernel forms the
   // rows (two launches: 1.17 + 0.11 ms per 2.98 M frames); false = fbank512_kernel's fused mode (one
-  // launch, 1.46 ms: it loses to the chain; SNF_FUSED_DELTA=1 selects it)
+  // launch, 1.46 ms: it loses to the chain, profiles/NOTEBOOK.md 4.4; SNF_FUSED_DELTA=1 selects it)
   bool chain_deltas = false;
   DevBuf s_cep, s_tile;
   bool tile_valid = false;  // s_tile describes the cached frame offsets table

@@ -464,7 +464,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank512_kernel(const Fast5
       // under a branch costs more than the branch: loads and stores share one in-order counter, the compiler
       // cannot count stores it may not issue, and the wait for the next set's samples at the top of the loop
       // becomes a wait for every store of this set (vmcnt(0)): 1.22 ms row by row under `if (valid)`, 1.19 ms
-      // with aligned quads under a bounds test, see DESIGN.md 4.1 for this form.
+      // with aligned quads under a bounds test, see profiles/NOTEBOOK.md 4.1 for this form.
       float* __restrict__ stage = reinterpret_cast<float*>(smem + tab_bytes + wid * 4 * kFrameTileBytes);
       float* __restrict__ mine = stage + q * 257;
 #pragma unroll

@@ -5,7 +5,7 @@
 // block chain) for the batches the benchmark and most callers run: flat scheduling (no per-utterance VTLN
 // tables, no fused deltas), snip_edges, no dither.  fbank512_kernel keeps every other mode.
 //
-// What round 3 measured about the 512-point kernel, and what this form does about it (DESIGN.md 4.1,
+// What round 3 measured about the 512-point kernel, and what this form does about it (profiles/NOTEBOOK.md 4.1,
 // profiles/r03_*, tools/ubench_r3.hip, ubench_ifetch.hip, ubench_vmem.hip, tools/experiments/):
 //   * Its time is the SUM of what its instructions cost at issue - vector 0.87 ns (4-byte encodings) /
 //     1.06 ns (8-byte VOP3) / 1.8-1.9 ns (DPP, SDWA, v_cndmask with an SGPR mask, v_dot2c, conversions) per
@@ -20,7 +20,7 @@
 //     with the stores inside `if`s the compiler cannot count the vector-memory operations behind the
 //     prefetched samples, waits with vmcnt(0) at the top of every iteration, and the wave sits there
 //     until the stores of the previous set are acknowledged (1300-2000 of 11 000 clocks per iteration).
-//   * Measured and dropped (numbers in DESIGN.md): typed buffer loads that convert int16 -> float in the
+//   * Measured and dropped (numbers in profiles/NOTEBOOK.md): typed buffer loads that convert int16 -> float in the
 //     texture path (9-11 ns per instruction and CU against 3.8 ns for global_load_dword: 26 of them are a
 //     0.70 ms floor of their own), the 16 x 16 exchange through MFMA transposes + v_permlane swaps instead
 //     of LDS (2.5 x slower), a split real / imaginary exchange tile for 6-8 waves per SIMD (no gain; the
@@ -55,7 +55,7 @@ constexpr int kTileBytes = 16 * kTileRow * 8;  // wave-private LDS per frame (21
 // Round 4: the butterflies carry their twiddles (device_fft.h, Linzer-Feig form): the second radix-4 layer of
 // both register passes, the inter-pass twiddle (now behind the transpose, in the first butterflies of pass
 // 2) and the twiddle of the real-FFT unpack; the tables hold (cos, tan) pairs.  -52 of 722 vector
-// instructions per frame set, -1.9 % time.  fbank512_kernel uses the same arithmetic.
+// instructions per frame set, -1.9 % time (profiles/NOTEBOOK.md 4.1c).  fbank512_kernel uses the same arithmetic.
 // DITHER (round 4): Kaldi's per-window dither, N(0, dither^2) added to every sample before the DC removal -
 // the reference's default (dither = 1.0, shennong/processor/base.py:122).  The stream is the one of
 // fbank512_kernel (same key per frame, same generator: bit-identical features from either kernel); the key

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Tallies the instructions of one kernel of a gfx950 assembly listing (hipcc -S --cuda-device-only) by
-issue class: what the 512-point kernels' time is made of.
+issue class: what the 512-point kernels' time is made of (profiles/NOTEBOOK.md 4.1b).
 
     python tools/count_isa.py listing.s <substring of the mangled kernel name> [...] [-v]
 """

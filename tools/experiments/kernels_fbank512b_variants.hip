@@ -1,5 +1,5 @@
 // SNAPSHOT of the round-3 experiment build of fbank512b_kernel (not compiled into the library).
-// Every variant DESIGN.md 4.1 quotes a number for is a bit of the template parameter V (1: split real /
+// Every variant profiles/NOTEBOOK.md 4.1 quotes a number for is a bit of the template parameter V (1: split real /
 // imaginary exchange tile, 2 / 4: late / early request of the next set's samples, 8: one 16_16_16_16
 // typed load per element, 16: compiler-scheduled LDS waits, 32 / 64: L2 touch-ahead, 128: plain dword
 // loads, 256: MFMA weights from global memory, 512: one buffer store per set), the occupancy
