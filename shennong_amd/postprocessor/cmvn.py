@@ -31,168 +31,113 @@ def _fake_stats_for_dims(stats, skip_dims):
     return stats
 
 
+def _require(ok, message, *values):
+    """Argument checks of this module: the reference's ValueError texts (its tests match on them,
+    test/postprocessor/test_cmvn.py), written once each as a format string"""
+    if not ok:
+        raise ValueError(message.format(*values))
+
+
+_MESSAGES = {
+    'dim': 'dimension must be a strictly positive integer, it is {}',
+    'stats': 'stats must be an array of shape {}, but is shaped as {}',
+    'weights_ndim': 'weights must have a single dimension but have {}',
+    'weights_len': 'there is {} weights but {} feature frames, must be equal',
+    'features_dim': 'features dimension is {} but CMVN dimension is {}',
+    'count': 'insufficient accumulation of stats for CMVN, must be >= 1.0 but is {}',
+    'skip': 'skipped dimensions must be in [0, {}[ but are in [{}, {}[',
+    'collection_dims': 'features in the collection must have consistent dimensions but dimensions are: {}',
+    'keys': 'keys differ for weights and features collection',
+    'skip_collection': 'out of bounds dimensions in skip_dims, must be in [0, {}] but are in [{}, {}]',
+}
+
+
 class CmvnPostProcessor(FeaturesPostProcessor):
-    """Computes CMVN statistics on speech features
+    """CMVN statistics of speech features and their application (reference cmvn.py:83-282)
 
-    Parameters
-    ----------
-    dim : int
-        The features dimension, must be strictly positive
-    stats : array, shape = [2, dim+1]
-        Preaccumulated CMVN statistics
+    `dim` is the features dimension (a strictly positive int, else ValueError); `stats`, when given,
+    are pre-accumulated statistics of shape [2, dim + 1]."""
+    name = property(lambda self: 'cmvn')
+    dim = property(lambda self: self._dim, doc='The dimension of features on which to compute CMVN')
+    ndims = property(lambda self: self._dim)
+    stats = property(lambda self: self._stats, doc=(
+        'The accumulated CMVN statistics, shape [2, dim+1]: row 0 the sums (last: the weighted frame '
+        'count), row 1 the sums of squares (last: unused)'))
+    count = property(lambda self: self._stats[0, -1],
+                     doc='The weighted total count of accumulated features frames')
 
-    Raises
-    ------
-    ValueError
-        If ``dim`` is not a strictly positive integer
-    """
     def __init__(self, dim, stats=None):
         super().__init__()
-        if not isinstance(dim, int) or dim <= 0:
-            raise ValueError(
-                'dimension must be a strictly positive integer, it is {}'
-                .format(dim))
+        _require(isinstance(dim, int) and dim > 0, _MESSAGES['dim'], dim)
         self._dim = dim
-        self._stats = np.zeros((2, dim + 1), dtype=np.float64)
+        shape = (2, dim + 1)
+        self._stats = np.zeros(shape, dtype=np.float64)
         if stats is not None:
-            stats = np.asarray(stats)
-            if stats.shape != (2, self.dim + 1):
-                raise ValueError(
-                    'stats must be an array of shape {}, but is shaped as {}'
-                    .format((2, self.dim + 1), stats.shape))
-            self._stats[...] = stats
-
-    @property
-    def name(self):
-        return 'cmvn'
-
-    @property
-    def dim(self):
-        """The dimension of features on which to compute CMVN"""
-        return self._dim
-
-    @property
-    def stats(self):
-        """The accumulated CMVN statistics, shape [2, dim+1]: row 0 the sums (last: the
-        weighted frame count), row 1 the sums of squares (last: unused)"""
-        return self._stats
-
-    @property
-    def count(self):
-        """The weighted total count of accumulated features frames"""
-        return self.stats[0, -1]
-
-    @property
-    def ndims(self):
-        return self.dim
+            given = np.asarray(stats)
+            _require(given.shape == shape, _MESSAGES['stats'], shape, given.shape)
+            self._stats[...] = given
 
     def get_properties(self, features):
         properties = super().get_properties(features)
         properties[self.name]['stats'] = self.stats
         return properties
 
-    def accumulate(self, features, weights=None):
-        """Accumulates the CMVN statistics of `features` (optionally frame-weighted)
+    def _as_batch(self, stats):
+        return stats.reshape((1, 2, self._dim + 1))
 
-        Raises
-        ------
-        ValueError
-            If ``weights`` have more than one dimension or if ``weights`` length does not
-            fit ``features`` dimension.
-        """
+    def accumulate(self, features, weights=None):
+        """Adds the statistics of `features` (one weight per frame when `weights` is given) to `stats`;
+        ValueError for weights that are not a vector of one value per frame, or features of another dimension"""
         if weights is not None:
-            if weights.ndim != 1:
-                raise ValueError(
-                    'weights must have a single dimension but have {}'
-                    .format(weights.ndim))
-            if weights.shape[0] != features.nframes:
-                raise ValueError(
-                    'there is {} weights but {} feature frames, must be equal'
-                    .format(weights.shape[0], features.nframes))
-        if features.ndims != self.dim:
-            raise ValueError(
-                'features dimension is {} but CMVN dimension is {}'.format(
-                    features.ndims, self.dim))
+            _require(weights.ndim == 1, _MESSAGES['weights_ndim'], weights.ndim)
+            _require(weights.shape[0] == features.nframes, _MESSAGES['weights_len'],
+                     weights.shape[0], features.nframes)
+        _require(features.ndims == self._dim, _MESSAGES['features_dim'], features.ndims, self._dim)
         _cmvn_plan().cmvn_accumulate(
-            [np.asarray(features.data, dtype=np.float32)],
-            self._stats.reshape((1, 2, self.dim + 1)),
+            [np.asarray(features.data, dtype=np.float32)], self._as_batch(self._stats),
             weights=None if weights is None else [weights])
 
     def process(self, features, norm_vars=True, skip_dims=None, reverse=False):
-        """Applies the accumulated CMVN statistics to the given ``features``
-
-        Raises
-        ------
-        ValueError
-            If no stats have been accumulated
-        """
-        if self.count < 1.0:
-            raise ValueError(
-                'insufficient accumulation of stats for CMVN, '
-                'must be >= 1.0 but is {}'.format(self.count))
+        """`features` normalised with the accumulated statistics (mean only when `norm_vars` is false; the
+        dimensions of `skip_dims` untouched; `reverse` undoes a normalisation); ValueError before any
+        statistics were accumulated"""
+        _require(self.count >= 1.0, _MESSAGES['count'], self.count)
         stats = self._stats
         if skip_dims:
-            dmin, dmax = min(skip_dims), max(skip_dims)
-            if dmin < 0 or dmax >= features.ndims:
-                raise ValueError(
-                    'skipped dimensions must be in [0, {}[ but are in [{}, {}['
-                    .format(features.ndims, dmin, dmax))
+            first, last = min(skip_dims), max(skip_dims)
+            _require(first >= 0 and last < features.ndims, _MESSAGES['skip'], features.ndims, first, last)
             stats = _fake_stats_for_dims(stats, skip_dims)
-        data = _cmvn_plan().cmvn_apply(
-            [np.asarray(features.data, dtype=np.float32)],
-            stats.reshape((1, 2, self.dim + 1)),
+        normalised = _cmvn_plan().cmvn_apply(
+            [np.asarray(features.data, dtype=np.float32)], self._as_batch(stats),
             norm_vars=norm_vars, reverse=reverse)[0]
-        return Features(
-            data, features.times, properties=self.get_properties(features))
+        return Features(normalised, features.times, properties=self.get_properties(features))
 
 
 def apply_cmvn(feats_collection, by_collection=True, norm_vars=True,
                weights=None, skip_dims=None):
     """CMVN normalization of a collection of features, over the whole collection
-    (`by_collection`) or independently for each item.  One statistics launch and one apply
-    launch cover the whole collection.
-
-    Raises
-    ------
-    ValueError
-        If something goes wrong during CMVN processing.
-    """
-    dim = set(f.ndims for f in feats_collection.values())
-    if not len(dim) == 1:
-        raise ValueError(
-            'features in the collection must have consistent dimensions '
-            'but dimensions are: {}'.format(sorted(dim)))
-    dim = list(dim)[0]
-
-    if weights is not None and weights.keys() != feats_collection.keys():
-        raise ValueError('keys differ for weights and features collection')
-
-    if skip_dims is not None:
-        sdmin, sdmax = min(skip_dims), max(skip_dims)
-        if sdmin < 0 or sdmax >= dim:
-            raise ValueError(
-                'out of bounds dimensions in skip_dims, must be in [0, {}] '
-                'but are in [{}, {}]'.format(dim - 1, sdmin, sdmax))
-
+    (`by_collection`) or independently for each item (reference cmvn.py:285-390).  One statistics
+    launch and one apply launch cover the whole collection.  ValueError for inconsistent dimensions,
+    weights whose keys or lengths do not fit, skipped dimensions out of range, or an empty count."""
     keys = list(feats_collection.keys())
     feats = [feats_collection[k] for k in keys]
+    dims = sorted(set(f.ndims for f in feats))
+    _require(len(dims) == 1, _MESSAGES['collection_dims'], dims)
+    dim = dims[0]
+    _require(weights is None or weights.keys() == feats_collection.keys(), _MESSAGES['keys'])
+    if skip_dims is not None:
+        first, last = min(skip_dims), max(skip_dims)
+        _require(first >= 0 and last < dim, _MESSAGES['skip_collection'], dim - 1, first, last)
     if weights is not None and all(weights[k] is None for k in keys):
         weights = None
     if weights is not None:
-        weights = {
-            k: (np.ones(f.nframes, dtype=np.float32) if weights[k] is None
-                else np.asarray(weights[k]))
-            for k, f in zip(keys, feats)}
+        filled = {}
         for k, f in zip(keys, feats):
-            w = weights[k]
-            if w.ndim != 1:
-                raise ValueError(
-                    'weights must have a single dimension but have {}'
-                    .format(w.ndim))
-            if w.shape[0] != f.nframes:
-                raise ValueError(
-                    'there is {} weights but {} feature frames, must be equal'
-                    .format(w.shape[0], f.nframes))
+            w = np.ones(f.nframes, dtype=np.float32) if weights[k] is None else np.asarray(weights[k])
+            _require(w.ndim == 1, _MESSAGES['weights_ndim'], w.ndim)
+            _require(w.shape[0] == f.nframes, _MESSAGES['weights_len'], w.shape[0], f.nframes)
+            filled[k] = w
+        weights = filled
     n = len(feats)
     if n == 0:
         return FeaturesCollection()
@@ -205,10 +150,7 @@ def apply_cmvn(feats_collection, by_collection=True, norm_vars=True,
         mats, stats, groups=groups,
         weights=None if weights is None else [weights[k] for k in keys])
     for g in range(n_groups):
-        if stats[g, 0, -1] < 1.0:
-            raise ValueError(
-                'insufficient accumulation of stats for CMVN, '
-                'must be >= 1.0 but is {}'.format(stats[g, 0, -1]))
+        _require(stats[g, 0, -1] >= 1.0, _MESSAGES['count'], stats[g, 0, -1])
     applied = stats
     if skip_dims:
         applied = np.stack(
