@@ -339,14 +339,18 @@ class Plan:
         return wrap(res)
 
     def _clones(self, count):
-        """`count` private plans with this plan's options on its device (own stream, own offset tables): the
-        pieces of a large batch run through them side by side (a plan keeps ONE pair of offset tables in HBM
-        and a call that changes them waits for its stream first)"""
+        """(lock, `count` private plans with this plan's options on its device): the pieces of a large batch run
+        through them side by side (a plan keeps ONE pair of offset tables in HBM, which a piece that is still in
+        flight may be reading).  The caller holds the lock from its first enqueue until its streams are
+        synchronised: a second large call with the same options - another thread of a joblib-style caller - would
+        otherwise rewrite the tables under the first one's kernels.  Such calls are bound by the link, which
+        they would share anyway; calls with other options run side by side."""
+        key = (_abi.options_key(self.opts), self.device)
         with _LOCK:
-            clones = _CLONES.setdefault((_abi.options_key(self.opts), self.device), [])
+            lock, clones = _CLONES.setdefault(key, (threading.Lock(), []))
             while len(clones) < count:
                 clones.append(Plan(self.opts, self.device))
-            return clones[:count]
+            return lock, clones[:count]
 
     def run_pinned(self, corpus, vtln_warps=None, check_finite=False, wrap=None):
         """`run` over every utterance of a :class:`PinnedCorpus`, uploaded straight from its page-locked block"""
@@ -415,7 +419,7 @@ class Plan:
             # side: a stream per thread carrying upload -> kernel -> download of its pieces in turn 24.9 ms - the
             # next upload queues behind the last download -, a stream per piece 28.3 ms.)  Every piece has a plan
             # clone of its own: a clone keeps ONE pair of offset tables, which a piece in flight may be reading.
-            clones = self._clones(pieces)
+            clone_lock, clones = self._clones(pieces)
             if _COPY_POOL is None:
                 from concurrent.futures import ThreadPoolExecutor
                 with _LOCK:
@@ -464,6 +468,7 @@ class Plan:
 
             from concurrent.futures import wait
             futures = []
+            clone_lock.acquire()
             try:
                 if pinned is None:
                     futures = [_COPY_POOL.submit(run, w) for w in range(threads)]
@@ -485,6 +490,7 @@ class Plan:
                 wait(futures)
                 L.snf_stream_synchronize(C.c_void_p(up))
                 L.snf_stream_synchronize(C.c_void_p(down))
+                clone_lock.release()
                 for ev in events:
                     L.snf_event_destroy(ev)
             for future in futures:

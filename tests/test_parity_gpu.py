@@ -1054,6 +1054,35 @@ def test_large_batches_and_pinned_utterances(gpu, wav_file):
     assert all(got[k] == want[k] for k in 'abc')
 
 
+def test_large_batches_from_several_threads(gpu):
+    """the large-batch path runs its pieces through clones of the plan on two shared streams: concurrent calls
+    with the same options (they take turns on the clones) and with different options (side by side) return what
+    a sequential call returns"""
+    from concurrent.futures import ThreadPoolExecutor
+    from shennong_amd import Utterances
+    rng = np.random.default_rng(5)
+    corpora = []
+    for c in range(3):
+        lengths = [int(x) for x in rng.integers(20000, 70000, 500)]
+        waves = [synth.utterances(1000 * c + i, 1, n)[0] for i, n in enumerate(lengths)]
+        assert sum(lengths) * 2 > _backend._LARGE_BATCH_BYTES
+        corpora.append(Utterances([(f'c{c}u{i:03d}', Audio(w, 16000, validate=False)) for i, w in enumerate(waves)]))
+    procs = [FilterbankProcessor(num_bins=40, dither=0), MfccProcessor(dither=0)]
+    want = {(p, c): procs[p].process_all(corpora[c]) for p in range(2) for c in range(3)}
+    jobs = [(p, c) for c in range(3) for p in range(2)] * 3
+
+    def work(job):
+        p, c = job
+        return procs[p].process_all(corpora[c] if (p + c) % 2 else corpora[c].pin())
+    with ThreadPoolExecutor(6) as pool:
+        got = list(pool.map(work, jobs))
+    for job, coll in zip(jobs, got):
+        ref = want[job]
+        assert list(coll.keys()) == list(ref.keys())
+        for name in list(ref.keys())[::7]:
+            assert np.array_equal(coll[name].data, ref[name].data), (job, name)
+
+
 def test_threaded_callers(gpu, synth_waves):
     """the reference's callers are joblib THREADS (processor/base.py:104-107, pipeline.py:545-565):
     concurrent `process` / `process_all` calls on one shared plan and on different plans return what
