@@ -348,20 +348,21 @@ def main():
                 # peer computed - its first rows, sent over the rendezvous sockets, compared on the root
                 mine = np.empty((2, 40), dtype=np.float32)
                 d_out.download(mine)
-                heads = comm.all_gather_object(mine) if world > 1 else [mine]
+                # (plain lists of Python floats: the rendezvous sockets accept plain data only)
+                heads = comm.all_gather_object(mine.tolist()) if world > 1 else [mine.tolist()]
                 got_all = np.empty((sum(counts) // 40, 40), dtype=np.float32)
                 d_all.download(got_all)
                 ok, pos = True, 0
                 for r in range(world):
-                    ok = ok and bool(np.array_equal(got_all[pos:pos + 2], heads[r]))
+                    ok = ok and bool(np.array_equal(got_all[pos:pos + 2], np.asarray(heads[r], dtype=np.float32)))
                     pos += counts[r] // 40
                 gathered['gathered_blocks_ok'] = ok
             elif world > 1:
                 mine = np.empty((2, 40), dtype=np.float32)
                 d_out.download(mine)
-                comm.all_gather_object(mine)
-        except RuntimeError as exc:   # (the compute-only value must not be lost with it)
-            gathered = {'error': str(exc)}
+                comm.all_gather_object(mine.tolist())
+        except Exception as exc:   # (whatever goes wrong here, the compute-only value must not be lost with it)
+            gathered = {'error': '%s: %s' % (type(exc).__name__, exc)}
         if d_all is not None:
             d_all.free()
 
