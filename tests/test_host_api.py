@@ -498,3 +498,39 @@ def test_option_descriptors():
     with pytest.raises(ValueError, match=r'proportion_threshold must be in \]0, 1\['):
         vad.proportion_threshold = 1.5
     assert vad.proportion_threshold == np.float32(0.6)
+
+
+def test_paused_gc_restores_the_collector():
+    """batched calls pause the cyclic collector while they make their objects (shennong_amd.utils.paused_gc):
+    it comes back as it was, also when the body raises and when calls nest or the collector was off"""
+    import gc
+    from shennong_amd.utils import paused_gc
+    assert gc.isenabled()
+    with paused_gc():
+        assert not gc.isenabled()
+        with paused_gc():
+            assert not gc.isenabled()
+        assert not gc.isenabled()
+    assert gc.isenabled()
+    with pytest.raises(KeyError):
+        with paused_gc():
+            raise KeyError('x')
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with paused_gc():
+            pass
+        assert not gc.isenabled()
+    finally:
+        gc.enable()
+
+
+def test_streamed_batch_default_without_a_device():
+    """the streamed pipeline's default batch is derived from the free HBM; without a device (host-logic tests)
+    it is the four hours measured best on a 288 GB GPU"""
+    from shennong_amd import _backend, pipeline
+    if _backend.device_count() < 1:
+        assert pipeline.default_batch_duration(1) == 14400.0
+        assert pipeline.default_batch_duration(8) == 14400.0
+    else:
+        assert 600.0 <= pipeline.default_batch_duration(8) <= pipeline.default_batch_duration(1) <= 14400.0
