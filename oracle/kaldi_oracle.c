@@ -24,6 +24,14 @@
  * (tests/golden/make_golden_plp.py: glue pinned, primitives are stand-ins).  The float32 round-off of
  * Kaldi's own kernels remains unpinned.
  *
+ * THIRD-PARTY PIN (round 5): tests/test_third_party_pin.py compares this file's fbank / spectrogram / MFCC (18
+ * cases: 23 / 40 / 80 bins, four windows, with and without pre-emphasis and DC removal, band limits, linear and
+ * magnitude banks, 8 kHz, other frame lengths, DCT +- lifter) with HuggingFace transformers' numpy restatement of
+ * Kaldi's front end (transformers.audio_utils 5.15.0, the stand-in of torchaudio.compliance.kaldi.fbank in its
+ * feature extractors) + scipy's orthonormal DCT-II, at 1e-4: an implementation by other authors, tested upstream
+ * against torchaudio (itself tested against Kaldi's binaries).  Not Kaldi, not the reference; PLP, pitch, delta,
+ * energies, VTLN and centred frames have no such counterpart.
+ *
  * HOW TO PIN IT (round 5): tests/golden/make_golden_kaldi.py, run where bootphon/shennong and its pykaldi are
  * installed (never here, never on the GPU box), writes tests/golden/reference_kaldi.npz - the reference's
  * own outputs for 30 cases on tests/golden/test.wav / test.8k.wav (spectrogram, fbank-23/40, MFCC, PLP
