@@ -278,10 +278,10 @@ def main():
                 L.snf_event_destroy(a)
                 L.snf_event_destroy(b)
 
-    def timed_region(p, d_dst, gather=None):
-        """K steps of `inner` passes of plan `p` between two synchronisations -> (seconds, kernel ms of every
-        pass); `gather(d_dst)` is enqueued on the same stream behind every pass when given"""
-        marks = Marks(args.steps * inner)
+    def timed_region(p, d_dst, gather=None, passes=None):
+        """K steps of `passes` (default `inner`) passes of plan `p` between two synchronisations -> (seconds,
+        kernel ms of every pass); `gather(d_dst)` is enqueued on the same stream behind every pass when given"""
+        marks = Marks(args.steps * (passes or inner))
         sync_all()
         t0 = time.perf_counter()
         for a, b in marks.pairs:
@@ -333,13 +333,28 @@ def main():
             comm.gatherv_device(d_src.ptr, total_frames * 40, d_all.ptr if d_all else None, counts, 0,
                                 stream=stream.value)
         try:
-            for _ in range(args.warmup):
-                step()
-                gather(d_out)
-            g_elapsed, g_kernel_ms = timed_region(plan, d_out, gather=gather)
-            gathered = {'value': job_frames * inner * args.steps / g_elapsed,
+            # passes per step of THIS region: as many as the compute-only region when the exchange is cheap, fewer
+            # when it is not (a gather of 7 x 477 MB per pass at a fraction of the xGMI rate must not turn the run
+            # into minutes): two probe passes, the slowest rank's time, a region of about three seconds
+            def passes_with_gather(count):
+                for _ in range(count):
+                    plan.run_device(d_wave.ptr, soff, foff, d_out.ptr, stream=stream.value)
+                    gather(d_out)
+                _backend.check(L.snf_stream_synchronize(stream))
+            passes_with_gather(1)
+            sync_all()
+            t0 = time.perf_counter()
+            passes_with_gather(2)
+            probe = (time.perf_counter() - t0) / 2
+            probe = float(comm.allreduce(np.array([probe]), 'max')[0])
+            g_inner = int(max(1, min(inner, 3.0 / (args.steps * max(probe, 1e-6)))))
+            for _ in range(min(args.warmup, 2)):
+                passes_with_gather(min(g_inner, 8))
+            g_elapsed, g_kernel_ms = timed_region(plan, d_out, gather=gather, passes=g_inner)
+            gathered = {'value': job_frames * g_inner * args.steps / g_elapsed,
                         'ms_per_step': g_elapsed / args.steps * 1e3,
-                        'ms_per_pass': g_elapsed / args.steps / inner * 1e3,
+                        'ms_per_pass': g_elapsed / args.steps / g_inner * 1e3,
+                        'passes_per_step': g_inner, 'probe_ms_per_pass': probe * 1e3,
                         'gather_bytes_per_pass_at_root': int(sum(counts) - counts[0]) * 4,
                         'kernel_ms': float(np.mean(g_kernel_ms)),
                         'rccl_ranks_seen': comm.ranks_seen()}
