@@ -18,8 +18,9 @@ snf_comm_*), device pointers in and out.  `--scaling weak` (default): every GPU 
 `--scaling strong`: ONE 10 000-utterance corpus is dealt over the ranks by `shard_utterances`.  Two values:
 `value` (compute only, as in earlier rounds) and `value_with_gather`: a second timed region of the same K
 steps in which EVERY pass is followed, on the compute stream, by the `snf_comm_gatherv` of every rank's
-[frames, 40] block to rank 0 - the whole job including its one collective; `rccl_ranks_seen` is what the
-RCCL communicator itself reports (ncclCommCount).
+[frames, 40] block to rank 0 - the whole job including its one collective (its passes per step are sized from
+two probe passes so that the region lasts about three seconds whatever the exchange costs:
+`with_gather.passes_per_step`); `rccl_ranks_seen` is what the RCCL communicator itself reports (ncclCommCount).
 
 Rank 0 prints ONE JSON line.  `value` = frames of all ranks per second of the slowest rank.
 `roofline` prices the dominant kernel against the 8 TB/s HBM peak with the algorithmic bytes of
