@@ -1092,6 +1092,254 @@ __device__ void viterbi_forward_team(const PitchDevTables& t, const float* __res
   __syncthreads();
 }
 
+
+// ---- 4c. the same forward pass with a lane per CANDIDATE (round 5) ------------------------------------------
+// The search above gives a lane to every STATE and lets it scan its window, which is as long as the backpointer
+// function is steep there: windows of 1 to 100+ candidates side by side in one wave, hence the scan loops, the
+// queue of long windows, the 8-lane teams and five levels of set-up - 3 070 instructions per frame and wave
+// of which the candidate arithmetic is a sixth (profiles/r05_pmc_pitch10k_before_summary.txt,
+// tools/pitch_search_replay.py).  Here every lane owns seven consecutive CANDIDATES j = 7 lane + k.  Per level
+// (the multiples of 128 exactly, then of 32, 8, 4, then every state - the same five levels):
+//   * the backpointers of the known states are counted into marks[j]; a prefix sum over j (six adds per lane, one
+//     scan over the lanes) tells every candidate between which two known states' backpointers it lies: its gap;
+//   * a candidate strictly inside a gap offers its cost to the (one or three) new states of that gap with ONE LDS
+//     instruction each: an atomic minimum on the 64-bit key (cost bits << 32 | j) - costs are non-negative
+//     floats, so the unsigned order of the keys is "lower cost first, lower index on ties", Kaldi's rule;
+//   * the two ends of a window (candidates that ARE a known backpointer belong to two windows) are offered by the
+//     new state itself, which thereby also initialises its key.
+// No loop depends on the data, there is no long-window case, and a jump of the backpointer function costs what
+// its candidates cost, once per level.  Same candidates per state, same arithmetic (d = j - i exact in float,
+// fl(fl(d d) f) + fwd[j] without contraction), same tie-break: bit-identical to viterbi_forward.
+// MEASURED (10 000 x 3 s, same box): 2 530 instructions per frame and wave against 3 070 (1 855 vector, 513
+// scalar, 159 LDS), and 15.2 ms against 14.0 for the whole pitch call: an LDS atomic costs ~0.6 clocks per
+// active LANE (one per candidate: 35 ms; one per run of a lane's candidates that share a gap: 16.0; level 1
+// through DPP instead of four 64-lane atomics on one key: 15.2), the LDS is busy 1 100 clocks per frame and wave
+// and the waves wait for it.  Not the default (SNF_PITCH_FLAT=1 selects it); what it would need next is a
+// cross-lane reduction of the runs that continue into the neighbouring lane at the coarse levels, where every
+// lane's last run hits one of 3 - 13 keys.
+constexpr int kFlatCand = 7;               // candidates per lane: 7 x 64 = 448 states at most
+constexpr int kFlatSlots = 448 + 128;      // keys: a last partial gap names states up to S - 1 + 127
+constexpr int kFlatWaveBytes = kFlatSlots * 8 + (448 + kFwdPad) * 4 + 448 * 4;   // keys, forward costs, marks of a wave
+
+struct FlatShared {
+  float* fwd;                   // [448 + kFwdPad]  normalised forward costs of the previous frame (FLT_MAX behind S)
+  unsigned long long* slots;    // [kFlatSlots]     key of every state: cost bits << 32 | backpointer
+  unsigned* marks;              // [448]            number of known states whose backpointer is j
+};
+
+// exclusive prefix sum over the 64 lanes (DPP inside the 16-lane rows, the three row totals through v_readlane)
+__device__ __forceinline__ int wave_exclusive_sum(int v, int lane) {
+  int t = v;
+  t += __builtin_amdgcn_update_dpp(0, t, 0x111, 0xf, 0xf, true);   // row_shr:1
+  t += __builtin_amdgcn_update_dpp(0, t, 0x112, 0xf, 0xf, true);   // row_shr:2
+  t += __builtin_amdgcn_update_dpp(0, t, 0x114, 0xf, 0xf, true);   // row_shr:4
+  t += __builtin_amdgcn_update_dpp(0, t, 0x118, 0xf, 0xf, true);   // row_shr:8
+  const int r0 = __builtin_amdgcn_readlane(t, 15), r1 = __builtin_amdgcn_readlane(t, 31),
+            r2 = __builtin_amdgcn_readlane(t, 47);
+  int base = lane >= 16 ? r0 : 0;
+  base += lane >= 32 ? r1 : 0;
+  base += lane >= 48 ? r2 : 0;
+  return t + base - v;
+}
+
+__device__ __forceinline__ unsigned long long flat_key(float cost, int j) {
+  return (static_cast<unsigned long long>(__builtin_bit_cast(unsigned, cost)) << 32) | static_cast<unsigned>(j);
+}
+
+// one level: the states u = g KNOWN + (s + 1) NEW (s < KNOWN / NEW - 1) of every gap g between the known states
+// g KNOWN and (g + 1) KNOWN
+template <int KNOWN, int NEW>
+__device__ __forceinline__ void flat_level(const FlatShared& sh, const int S, const float factor, const int lane,
+                                           const float (&fj)[kFlatCand], const float jf0) {
+  constexpr int M = KNOWN / NEW - 1;
+  static_assert(M == 1 || M == 3, "one or three new states per gap");
+  const int n_known = (S + KNOWN - 1) / KNOWN;
+  const int n_gaps = S > NEW ? (S - NEW - 1) / KNOWN + 1 : 0;   // gaps that hold a new state below S
+  // ---- marks ---------------------------------------------------------------------------------------------
+  unsigned* __restrict__ mk_lane = sh.marks + kFlatCand * lane;
+#pragma unroll
+  for (int k = 0; k < kFlatCand; ++k) mk_lane[k] = 0u;
+  wave_sync();
+  for (int t0 = 0; t0 < n_known; t0 += 64) {
+    const int t = t0 + lane;
+    if (t < n_known) {
+      const unsigned b = static_cast<unsigned>(sh.slots[t * KNOWN]);
+      atomicAdd(&sh.marks[b], 1u);
+    }
+  }
+  wave_sync();
+  int mk[kFlatCand], gap[kFlatCand];
+  int total = 0;
+#pragma unroll
+  for (int k = 0; k < kFlatCand; ++k) {
+    mk[k] = static_cast<int>(mk_lane[k]);
+    total += mk[k];
+  }
+  int count = wave_exclusive_sum(total, lane);   // known states with a backpointer below this lane's candidates
+#pragma unroll
+  for (int k = 0; k < kFlatCand; ++k) {
+    count += mk[k];
+    gap[k] = count - 1;                           // candidate j lies right of (or on) the backpointer of state gap
+  }
+  // ---- the ends of every window, by the new states themselves ------------------------------------------
+  const int n_new = n_gaps * M;
+  for (int t0 = 0; t0 < n_new; t0 += 64) {
+    const int t = t0 + lane;
+    const int g = M == 1 ? t : t / 3, sidx = M == 1 ? 0 : t - 3 * g;
+    const int u = g * KNOWN + (sidx + 1) * NEW;
+    if (t < n_new && u < S) {
+      const int above = (g + 1) * KNOWN;
+      const int lo = static_cast<int>(static_cast<unsigned>(sh.slots[g * KNOWN]));
+      const int hi = above < S ? static_cast<int>(static_cast<unsigned>(sh.slots[above])) : S - 1;
+      const float uf = static_cast<float>(u);
+      const float c_lo = trans_cost(lo, uf, factor, sh.fwd[lo]);
+      const float c_hi = trans_cost(hi, uf, factor, sh.fwd[hi]);
+      sh.slots[u] = c_hi < c_lo ? flat_key(c_hi, hi) : flat_key(c_lo, lo);   // (lo <= hi: the lower index on ties)
+    }
+  }
+  wave_sync();
+  // ---- the candidates strictly inside a window ---------------------------------------------------------
+  // An LDS atomic costs ~0.6 clocks per LANE whatever the addresses (measured: one atomic per candidate and
+  // state, 4 400 lane operations per frame, was 2 500 LDS clocks per frame and wave - three times the whole
+  // lane-per-state search).  The seven candidates of a lane are consecutive, so they fall into runs that share a
+  // gap: the lane keeps the best of the run in registers (ascending j, strict <: the lower index on ties) and
+  // offers it once, when the gap changes or its candidates end - 1 300 lane operations per frame.
+  float bc[M];
+  int bj[M];
+#pragma unroll
+  for (int sidx = 0; sidx < M; ++sidx) {
+    bc[sidx] = FLT_MAX;
+    bj[sidx] = -1;
+  }
+#pragma unroll
+  for (int k = 0; k < kFlatCand; ++k) {
+    const int j = kFlatCand * lane + k;
+    const bool in_gap = gap[k] >= 0 && gap[k] < n_gaps;
+    const bool inside = j < S && mk[k] == 0 && in_gap;
+    // (a candidate that is not inside a window offers FLT_MAX: x + FLT_MAX = FLT_MAX for these x, never < best)
+    const float fjm = inside ? fj[k] : FLT_MAX;
+    const int ub = gap[k] * KNOWN;
+    const float e = (jf0 + static_cast<float>(k)) - static_cast<float>(ub);   // j - g KNOWN: exact
+#pragma unroll
+    for (int sidx = 0; sidx < M; ++sidx) {
+      const float d = e - static_cast<float>((sidx + 1) * NEW);
+      const float c = __fadd_rn(__fmul_rn(d * d, factor), fjm);
+      const bool better = c < bc[sidx];
+      bj[sidx] = better ? j : bj[sidx];
+      bc[sidx] = better ? c : bc[sidx];
+    }
+    const bool last_of_run = k == kFlatCand - 1 || gap[k + (k < kFlatCand - 1 ? 1 : 0)] != gap[k];
+    if (last_of_run && bj[0] >= 0) {   // (the states of a gap see the same candidates: bj[0] >= 0 <=> any)
+#pragma unroll
+      for (int sidx = 0; sidx < M; ++sidx) atomicMin(&sh.slots[ub + (sidx + 1) * NEW], flat_key(bc[sidx], bj[sidx]));
+    }
+    if (last_of_run) {
+#pragma unroll
+      for (int sidx = 0; sidx < M; ++sidx) {
+        bc[sidx] = FLT_MAX;
+        bj[sidx] = -1;
+      }
+    }
+  }
+  wave_sync();
+}
+
+// one forward pass over all frames (S <= 448); returns with sh.fwd = final normalised forward cost
+__device__ void viterbi_forward_flat(const PitchDevTables& t, const float* __restrict__ res,
+                                     const float* __restrict__ anp, int64_t T, int64_t T1, bool rescale,
+                                     float old_b1, float old_b2, float new_ballast, int16_t* __restrict__ bp,
+                                     const FlatShared& sh, const float* __restrict__ st_lag, const int lane) {
+  constexpr int NK = 7;
+  const int S = t.num_states;
+  for (int s = lane; s < S; s += 64) sh.fwd[s] = 0.0f;
+  for (int s = S + lane; s < 448 + kFwdPad; s += 64) sh.fwd[s] = FLT_MAX;
+  const float factor = t.inter_frame_factor;
+  float ahead[NK], soft_lag[NK];
+  int col[NK], bpv[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    col[k] = lane + 64 * k < S ? lane + 64 * k : S - 1;
+    ahead[k] = T > 0 ? res[col[k]] : 0.0f;
+    soft_lag[k] = t.soft_min_f0 * st_lag[col[k]];
+    bpv[k] = 0;
+  }
+  const float jf0 = static_cast<float>(kFlatCand * lane);
+  const float* __restrict__ fwd_lane = sh.fwd + kFlatCand * lane;
+  for (int64_t frame = 0; frame < T; ++frame) {
+    float scale = 1.0f;
+    if (rescale) {
+      const float old_ballast = frame < T1 ? old_b1 : old_b2, a = anp[frame];
+      scale = sqrtf((old_ballast + a) / (new_ballast + a));
+    }
+    const float* __restrict__ row = res + frame * static_cast<int64_t>(S);
+    // local costs (kept in registers until the end of the frame), the backpointers of the previous frame, the
+    // row of the next one: as in viterbi_forward (see there for the order of the memory operations)
+    float local[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      float v = ahead[k];
+      if (rescale) v *= scale;
+      local[k] = 1.0f - v;
+      local[k] += soft_lag[k] * v;
+    }
+    if (frame > 0) {
+      int16_t* __restrict__ bp_row = bp + (frame - 1) * S;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) bp_row[col[k]] = static_cast<int16_t>(bpv[k]);
+    }
+    const float* __restrict__ nrow = frame + 1 < T ? row + S : row;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) ahead[k] = nrow[col[k]];
+    // ---- the lane's seven candidates ----------------------------------------------------------------------
+    wave_sync();
+    float fj[kFlatCand];
+#pragma unroll
+    for (int k = 0; k < kFlatCand; ++k) fj[k] = fwd_lane[k];
+    // ---- level 1: the states 0, 128, 256, 384 against every candidate: each lane reduces its seven in
+    // registers (ascending j, strict <: the lower index on ties), the 64 lanes through DPP (an atomic minimum of
+    // 64 lanes on ONE key costs the LDS ~130 clocks: four of them were a third of the kernel's LDS time) ----------
+    for (int u = 0; u < S; u += 128) {
+      const float e = jf0 - static_cast<float>(u);
+      float bc = FLT_MAX;
+      int bj = 0x7fffffff;
+#pragma unroll
+      for (int k = 0; k < kFlatCand; ++k) {
+        const float d = e + static_cast<float>(k);
+        const float c = __fadd_rn(__fmul_rn(d * d, factor), fj[k]);
+        const bool better = c < bc;
+        bj = better ? kFlatCand * lane + k : bj;
+        bc = better ? c : bc;
+      }
+      wave_argmin(bc, bj);
+      if (lane == 0) sh.slots[u] = flat_key(bc, bj);
+    }
+    wave_sync();
+    flat_level<128, 32>(sh, S, factor, lane, fj, jf0);
+    flat_level<32, 8>(sh, S, factor, lane, fj, jf0);
+    flat_level<8, 4>(sh, S, factor, lane, fj, jf0);
+    flat_level<4, 1>(sh, S, factor, lane, fj, jf0);
+    // ---- new forward costs: best + local cost, minus their minimum ----------------------------------------
+    float nx[NK], lane_min = FLT_MAX;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const unsigned long long key = sh.slots[col[k]];
+      bpv[k] = static_cast<int>(static_cast<unsigned>(key));
+      nx[k] = __builtin_bit_cast(float, static_cast<unsigned>(key >> 32)) + local[k];
+      lane_min = fminf(lane_min, nx[k]);
+    }
+    const float mn = wave_min_f(lane_min);
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < NK; ++k) sh.fwd[col[k]] = nx[k] + (-mn);
+  }
+  if (T > 0) {
+    int16_t* __restrict__ bp_row = bp + (T - 1) * S;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) bp_row[col[k]] = static_cast<int16_t>(bpv[k]);
+  }
+  wave_sync();
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(kVitWaves * 64, 4) void pitch_viterbi_kernel(
@@ -1134,6 +1382,48 @@ __global__ __launch_bounds__(kVitWaves * 64, 4) void pitch_viterbi_kernel(
   else if (S <= 512) viterbi_forward<8>(t, res, anp + f0, T, T1, recompute, ob1, ob2, nb, bp, sh, st_lag, lane);
   else viterbi_forward<0>(t, res, anp + f0, T, T1, recompute, ob1, ob2, nb, bp, sh, st_lag, lane);
 
+  viterbi_traceback(S, T, f0, bp, states, sh, lane);
+  wave_sync();
+  __threadfence_block();
+  pitch_output_rows(t, L, T, f0, states, pov_nccf, out, lane, 64);
+}
+
+// one wavefront per utterance with the lane-per-candidate search (viterbi_forward_flat): 129 .. 448 states
+__global__ __launch_bounds__(kVitWaves * 64, 4) void pitch_viterbi_flat_kernel(
+    const PitchDevTables t, const PitchBatch b, const float* __restrict__ nccf_res,
+    const float* __restrict__ anp, const float* __restrict__ ub, int16_t* __restrict__ backptr,
+    int32_t* __restrict__ states, const float* __restrict__ pov_all, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int S = t.num_states, L = t.num_lags, S4 = (S + 3) & ~3;
+  float* st_lag = reinterpret_cast<float*>(smem);
+  for (int s = threadIdx.x; s < S; s += blockDim.x) st_lag[s] = t.lags[s];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t slot = static_cast<int64_t>(blockIdx.x) * kVitWaves + wid;
+  if (slot >= b.n_utts) return;
+  const int64_t u = b.order ? b.order[slot] : slot;
+  const int64_t f0 = b.frame_offsets[u], T = b.frame_offsets[u + 1] - f0;
+  if (T <= 0) return;
+  const int64_t T1 = b.frames_phase1[u];
+  // per wave: keys (8-byte aligned: first), forward costs, marks
+  char* mine = smem + ((S4 * 4 + 15) & ~15) + wid * kFlatWaveBytes;
+  FlatShared fs;
+  fs.slots = reinterpret_cast<unsigned long long*>(mine);
+  fs.fwd = reinterpret_cast<float*>(mine + kFlatSlots * 8);
+  fs.marks = reinterpret_cast<unsigned*>(mine + kFlatSlots * 8 + (448 + kFwdPad) * 4);
+  int16_t* __restrict__ bp = backptr + f0 * S;
+  const float* __restrict__ res = nccf_res + f0 * static_cast<int64_t>(S);
+  const float* __restrict__ pov_nccf = pov_all + f0 * L;
+  const float* __restrict__ o = ub + u * 6;
+  const bool recompute = (T < t.recompute_frame || T1 < t.recompute_frame) && o[5] != 0.0f;   // (see pitch_viterbi_kernel)
+  const float ob1 = recompute ? o[2] : 0.0f, ob2 = recompute ? o[3] : 0.0f, nb = recompute ? o[4] : 0.0f;
+  viterbi_forward_flat(t, res, anp + f0, T, T1, recompute, ob1, ob2, nb, bp, fs, st_lag, lane);
+  // traceback: its scratch (64 ints) goes where the marks were
+  VitShared sh;
+  sh.fwd = fs.fwd;
+  sh.nxt = reinterpret_cast<float*>(fs.marks);
+  sh.bpw = nullptr;
+  sh.queue = nullptr;
   viterbi_traceback(S, T, f0, bp, states, sh, lane);
   wave_sync();
   __threadfence_block();
@@ -1248,6 +1538,19 @@ int launch_pitch(const PitchDevTables& t, const PitchBatch& b, const PitchScratc
       const size_t lds = sizeof(float) * (4 * static_cast<size_t>(S4) + kFwdPad + team * (kQueueFloats + 1));
       auto kern = team == 4 ? pitch_viterbi_team_kernel<4> : pitch_viterbi_team_kernel<2>;
       hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(b.n_utts)), dim3(team * 64), lds, stream, t, b,
+                         w.nccf_res, w.anp, w.ub, w.backptr, w.states, w.pov_nccf, out);
+      SNF_HIP_CHECK(hipGetLastError());
+    } else if (S > 128 && S <= 448 && getenv("SNF_PITCH_FLAT") && getenv("SNF_PITCH_FLAT")[0] == '1') {
+      // the lane-per-candidate search (round 5): bit-identical, 18 % fewer instructions and 8 % SLOWER than the
+      // lane-per-state kernel (15.2 against 14.0 ms per 10 000 utterances: its LDS atomics), so it is opt-in -
+      // SNF_PITCH_FLAT=1 (tests/test_parity_gpu.py::test_pitch_flat_search, tools/experiments/README.md)
+      const size_t lds = ((static_cast<size_t>(S4) * 4 + 15) & ~static_cast<size_t>(15)) +
+                         static_cast<size_t>(kVitWaves) * kFlatWaveBytes;
+      if (lds > 64 * 1024)
+        SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pitch_viterbi_flat_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+      const unsigned blocks = static_cast<unsigned>((b.n_utts + kVitWaves - 1) / kVitWaves);
+      hipLaunchKernelGGL(pitch_viterbi_flat_kernel, dim3(blocks), dim3(kVitWaves * 64), lds, stream, t, b,
                          w.nccf_res, w.anp, w.ub, w.backptr, w.states, w.pov_nccf, out);
       SNF_HIP_CHECK(hipGetLastError());
     } else {

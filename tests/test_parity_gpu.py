@@ -1054,6 +1054,28 @@ def test_large_batches_and_pinned_utterances(gpu, wav_file):
     assert all(got[k] == want[k] for k in 'abc')
 
 
+def test_pitch_flat_search(gpu, monkeypatch):
+    """the lane-per-candidate Viterbi search (csrc/kernels_pitch.hip 4c, opt-in: SNF_PITCH_FLAT=1) returns the
+    bits of the shipped lane-per-state search and of the oracle: ragged utterances, some short enough for
+    RecomputeBacktraces, digital silence (every cost ties) and noise"""
+    monkeypatch.setenv('SNF_PITCH_TEAM', '1')      # one wave per utterance whatever the batch size
+    rng = np.random.default_rng(21)
+    waves = [synth.utterances(300 + i, 1, int(n))[0] for i, n in enumerate(rng.integers(12000, 90000, 60))]
+    waves[3] = np.zeros(40000, dtype=np.int16)
+    waves[4] = (rng.standard_normal(50000) * 200).astype(np.int16)
+    waves[5] = np.concatenate([waves[6][:9000] // 50, waves[6][:30000]])   # a quiet start: the ballast changes
+    audios = [Audio(w, 16000, validate=False) for w in waves]
+    proc = KaldiPitchProcessor()
+    monkeypatch.setenv('SNF_PITCH_FLAT', '0')
+    shipped = [f.data.copy() for f in proc._process_batch(audios)]
+    monkeypatch.setenv('SNF_PITCH_FLAT', '1')
+    flat = [f.data.copy() for f in proc._process_batch(audios)]
+    for i, (a, b) in enumerate(zip(shipped, flat)):
+        assert np.array_equal(a, b), i
+    for i in (0, 3, 4, 5, 17, 59):
+        np.testing.assert_array_equal(flat[i], orc.pitch(proc._options, waves[i]), err_msg=str(i))
+
+
 def test_large_batches_from_several_threads(gpu):
     """the large-batch path runs its pieces through clones of the plan on two shared streams: concurrent calls
     with the same options (they take turns on the clones) and with different options (side by side) return what
