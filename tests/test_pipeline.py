@@ -703,7 +703,9 @@ def test_result_blocks_and_pooled_buffers(gpu):
     finally:
         block_cls._FRESH = fresh
     del b
-    # device buffers: a freed buffer is handed out again for a request of similar size
+    # device buffers: a freed buffer is handed out again for a request of similar size (the pool is bounded - 8 GiB -
+    # and earlier tests of the session may have filled it: start from an empty one)
+    _backend.DEVICE_POOL.clear()
     d = _backend.DeviceBuffer(3 << 20)
     ptr = d.ptr
     d.free()
