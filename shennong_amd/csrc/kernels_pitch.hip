@@ -1110,13 +1110,13 @@ __device__ void viterbi_forward_team(const PitchDevTables& t, const float* __res
 // No loop depends on the data, there is no long-window case, and a jump of the backpointer function costs what
 // its candidates cost, once per level.  Same candidates per state, same arithmetic (d = j - i exact in float,
 // fl(fl(d d) f) + fwd[j] without contraction), same tie-break: bit-identical to viterbi_forward.
-// MEASURED (10 000 x 3 s, same box): 2 530 instructions per frame and wave against 3 070 (1 855 vector, 513
-// scalar, 159 LDS), and 15.2 ms against 14.0 for the whole pitch call: an LDS atomic costs ~0.6 clocks per
-// active LANE (one per candidate: 35 ms; one per run of a lane's candidates that share a gap: 16.0; level 1
-// through DPP instead of four 64-lane atomics on one key: 15.2), the LDS is busy 1 100 clocks per frame and wave
-// and the waves wait for it.  Not the default (SNF_PITCH_FLAT=1 selects it); what it would need next is a
-// cross-lane reduction of the runs that continue into the neighbouring lane at the coarse levels, where every
-// lane's last run hits one of 3 - 13 keys.
+// MEASURED (10 000 x 3 s, same box, whole pitch call; shipped kernel 14.1-14.2 ms, 3 070 instructions per frame
+// and wave): an LDS atomic costs ~0.6 clocks per active LANE - one per candidate: 35 ms; one per run of a lane's
+// candidates that share a gap: 16.0; level 1 through DPP instead of four 64-lane atomics on one key: 15.2; the two
+// coarse levels (13 states, windows hundreds of candidates wide, where every lane's last run hits one of 3 keys)
+// in the lane-per-state form of viterbi_forward: 13.8 ms with 2 370 instructions (1 823 vector, 368 scalar, 178
+// LDS) - 23 % fewer instructions for 3 % less time: the waves wait for the LDS (3.55 clocks per instruction
+// against 2.87).  Not the default (SNF_PITCH_FLAT=1 selects it).
 constexpr int kFlatCand = 7;               // candidates per lane: 7 x 64 = 448 states at most
 constexpr int kFlatSlots = 448 + 128;      // keys: a last partial gap names states up to S - 1 + 127
 constexpr int kFlatWaveBytes = kFlatSlots * 8 + (448 + kFwdPad) * 4 + 448 * 4;   // keys, forward costs, marks of a wave
@@ -1163,7 +1163,7 @@ __device__ __forceinline__ void flat_level(const FlatShared& sh, const int S, co
   for (int t0 = 0; t0 < n_known; t0 += 64) {
     const int t = t0 + lane;
     if (t < n_known) {
-      const unsigned b = static_cast<unsigned>(sh.slots[t * KNOWN]);
+      const unsigned b = reinterpret_cast<const unsigned*>(sh.slots)[2 * (t * KNOWN)];   // (the low word: the backpointer)
       atomicAdd(&sh.marks[b], 1u);
     }
   }
@@ -1189,8 +1189,9 @@ __device__ __forceinline__ void flat_level(const FlatShared& sh, const int S, co
     const int u = g * KNOWN + (sidx + 1) * NEW;
     if (t < n_new && u < S) {
       const int above = (g + 1) * KNOWN;
-      const int lo = static_cast<int>(static_cast<unsigned>(sh.slots[g * KNOWN]));
-      const int hi = above < S ? static_cast<int>(static_cast<unsigned>(sh.slots[above])) : S - 1;
+      const unsigned* __restrict__ bps = reinterpret_cast<const unsigned*>(sh.slots);   // (low words)
+      const int lo = static_cast<int>(bps[2 * (g * KNOWN)]);
+      const int hi = above < S ? static_cast<int>(bps[2 * above]) : S - 1;
       const float uf = static_cast<float>(u);
       const float c_lo = trans_cost(lo, uf, factor, sh.fwd[lo]);
       const float c_hi = trans_cost(hi, uf, factor, sh.fwd[hi]);
@@ -1214,8 +1215,9 @@ __device__ __forceinline__ void flat_level(const FlatShared& sh, const int S, co
 #pragma unroll
   for (int k = 0; k < kFlatCand; ++k) {
     const int j = kFlatCand * lane + k;
-    const bool in_gap = gap[k] >= 0 && gap[k] < n_gaps;
-    const bool inside = j < S && mk[k] == 0 && in_gap;
+    // (one unsigned comparison for 0 <= gap < n_gaps; candidates behind the last state need no test: their
+    // forward cost is the FLT_MAX padding)
+    const bool inside = mk[k] == 0 && static_cast<unsigned>(gap[k]) < static_cast<unsigned>(n_gaps);
     // (a candidate that is not inside a window offers FLT_MAX: x + FLT_MAX = FLT_MAX for these x, never < best)
     const float fjm = inside ? fj[k] : FLT_MAX;
     const int ub = gap[k] * KNOWN;
@@ -1224,9 +1226,8 @@ __device__ __forceinline__ void flat_level(const FlatShared& sh, const int S, co
     for (int sidx = 0; sidx < M; ++sidx) {
       const float d = e - static_cast<float>((sidx + 1) * NEW);
       const float c = __fadd_rn(__fmul_rn(d * d, factor), fjm);
-      const bool better = c < bc[sidx];
-      bj[sidx] = better ? j : bj[sidx];
-      bc[sidx] = better ? c : bc[sidx];
+      bj[sidx] = c < bc[sidx] ? j : bj[sidx];
+      bc[sidx] = fminf(bc[sidx], c);   // (costs are never NaN: the minimum IS the select)
     }
     const bool last_of_run = k == kFlatCand - 1 || gap[k + (k < kFlatCand - 1 ? 1 : 0)] != gap[k];
     if (last_of_run && bj[0] >= 0) {   // (the states of a gap see the same candidates: bj[0] >= 0 <=> any)
@@ -1295,26 +1296,72 @@ __device__ void viterbi_forward_flat(const PitchDevTables& t, const float* __res
     float fj[kFlatCand];
 #pragma unroll
     for (int k = 0; k < kFlatCand; ++k) fj[k] = fwd_lane[k];
-    // ---- level 1: the states 0, 128, 256, 384 against every candidate: each lane reduces its seven in
-    // registers (ascending j, strict <: the lower index on ties), the 64 lanes through DPP (an atomic minimum of
-    // 64 lanes on ONE key costs the LDS ~130 clocks: four of them were a third of the kernel's LDS time) ----------
-    for (int u = 0; u < S; u += 128) {
-      const float e = jf0 - static_cast<float>(u);
-      float bc = FLT_MAX;
-      int bj = 0x7fffffff;
-#pragma unroll
-      for (int k = 0; k < kFlatCand; ++k) {
-        const float d = e + static_cast<float>(k);
-        const float c = __fadd_rn(__fmul_rn(d * d, factor), fj[k]);
-        const bool better = c < bc;
-        bj = better ? kFlatCand * lane + k : bj;
-        bc = better ? c : bc;
+    // ---- levels 1 and 2 as in viterbi_forward (a 16-lane row per state of level 1 over all candidates, 4 lanes per
+    // state of level 2 over its window: 13 states whose windows are hundreds of candidates wide - the lane-per-
+    // candidate form pays for them with one DPP reduction per state or with 64 lanes on 3 keys), keys to `slots` --
+    {
+      const int n_super = (S + 127) >> 7, n_reps = (S + 31) >> 5;
+      for (int base = 0; base < n_super; base += 4) {
+        const int r = base + (lane >> 4), sub = lane & 15;
+        const int i_rep = r << 7;
+        float best = FLT_MAX;
+        int best_j = 0x7fffffff;
+        if (r < n_super) {
+          const float fi = static_cast<float>(i_rep);
+          float d = static_cast<float>(sub) - fi, bd = 1.0e9f;
+#pragma unroll 9
+          for (int j = sub; j < S; j += 16) {
+            const float c = __fadd_rn(__fmul_rn(d * d, factor), sh.fwd[j]);
+            bd = c < best ? d : bd;
+            best = fminf(best, c);
+            d += 16.0f;
+          }
+          best_j = static_cast<int>(fi + bd);
+        }
+        quad_argmin(best, best_j);
+        argmin_take(best, best_j, dpp_f<0x124>(best), dpp_i<0x124>(best_j));
+        argmin_take(best, best_j, dpp_f<0x128>(best), dpp_i<0x128>(best_j));
+        if (sub == 0 && r < n_super) {
+          if (best_j >= S) best_j = 0;
+          sh.slots[i_rep] = flat_key(best, best_j);
+        }
       }
-      wave_argmin(bc, bj);
-      if (lane == 0) sh.slots[u] = flat_key(bc, bj);
+      wave_sync();
+      for (int base = 0; base < n_reps; base += 16) {
+        const int k = base + (lane >> 2), sub = lane & 3;
+        const int m = k + k / 3 + 1;
+        const int i_rep = m << 5;
+        float best = FLT_MAX;
+        int best_j = 0x7fffffff;
+        if (i_rep < S) {
+          const int below = i_rep & ~127, above = below + 128;
+          const int lo = static_cast<int>(static_cast<unsigned>(sh.slots[below]));
+          const int hi = above < S ? static_cast<int>(static_cast<unsigned>(sh.slots[above])) : S - 1;
+          const float fi = static_cast<float>(i_rep);
+          float d = static_cast<float>(lo + sub) - fi, bd = d;
+          for (int j = lo + sub; j <= hi; j += 32) {
+            float ff[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) ff[w] = sh.fwd[j + 4 * w];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+              const float dw = d + static_cast<float>(4 * w);
+              const float c = __fadd_rn(__fmul_rn(dw * dw, factor), ff[w]);
+              bd = c < best ? dw : bd;
+              best = fminf(best, c);
+            }
+            d += 32.0f;
+          }
+          best_j = static_cast<int>(fi + bd);
+        }
+        quad_argmin(best, best_j);
+        if (sub == 0 && i_rep < S) {
+          if (best_j >= S) best_j = static_cast<int>(static_cast<unsigned>(sh.slots[i_rep & ~127]));
+          sh.slots[i_rep] = flat_key(best, best_j);
+        }
+      }
+      wave_sync();
     }
-    wave_sync();
-    flat_level<128, 32>(sh, S, factor, lane, fj, jf0);
     flat_level<32, 8>(sh, S, factor, lane, fj, jf0);
     flat_level<8, 4>(sh, S, factor, lane, fj, jf0);
     flat_level<4, 1>(sh, S, factor, lane, fj, jf0);
@@ -1541,9 +1588,10 @@ int launch_pitch(const PitchDevTables& t, const PitchBatch& b, const PitchScratc
                          w.nccf_res, w.anp, w.ub, w.backptr, w.states, w.pov_nccf, out);
       SNF_HIP_CHECK(hipGetLastError());
     } else if (S > 128 && S <= 448 && getenv("SNF_PITCH_FLAT") && getenv("SNF_PITCH_FLAT")[0] == '1') {
-      // the lane-per-candidate search (round 5): bit-identical, 18 % fewer instructions and 8 % SLOWER than the
-      // lane-per-state kernel (15.2 against 14.0 ms per 10 000 utterances: its LDS atomics), so it is opt-in -
-      // SNF_PITCH_FLAT=1 (tests/test_parity_gpu.py::test_pitch_flat_search, tools/experiments/README.md)
+      // the lane-per-candidate search (round 5): bit-identical, 23 % fewer instructions and 3 % faster than the
+      // lane-per-state kernel (13.8 against 14.1-14.2 ms per 10 000 utterances: its waves wait for the LDS): a gain
+      // inside the box-to-box spread, so it is opt-in - SNF_PITCH_FLAT=1
+      // (tests/test_parity_gpu.py::test_pitch_flat_search, tools/experiments/README.md)
       const size_t lds = ((static_cast<size_t>(S4) * 4 + 15) & ~static_cast<size_t>(15)) +
                          static_cast<size_t>(kVitWaves) * kFlatWaveBytes;
       if (lds > 64 * 1024)
