@@ -1110,13 +1110,13 @@ __device__ void viterbi_forward_team(const PitchDevTables& t, const float* __res
 // No loop depends on the data, there is no long-window case, and a jump of the backpointer function costs what
 // its candidates cost, once per level.  Same candidates per state, same arithmetic (d = j - i exact in float,
 // fl(fl(d d) f) + fwd[j] without contraction), same tie-break: bit-identical to viterbi_forward.
-// MEASURED (10 000 x 3 s, same box, whole pitch call; shipped kernel 14.1-14.2 ms, 3 070 instructions per frame
-// and wave): an LDS atomic costs ~0.6 clocks per active LANE - one per candidate: 35 ms; one per run of a lane's
-// candidates that share a gap: 16.0; level 1 through DPP instead of four 64-lane atomics on one key: 15.2; the two
-// coarse levels (13 states, windows hundreds of candidates wide, where every lane's last run hits one of 3 keys)
-// in the lane-per-state form of viterbi_forward: 13.8 ms with 2 370 instructions (1 823 vector, 368 scalar, 178
-// LDS) - 23 % fewer instructions for 3 % less time: the waves wait for the LDS (3.55 clocks per instruction
-// against 2.87).  Not the default (SNF_PITCH_FLAT=1 selects it).
+// MEASURED (10 000 x 3 s, same box, whole pitch call; lane-per-state kernel 14.1-14.3 ms, 3 070 instructions per
+// frame and wave).  An LDS atomic costs ~0.6 clocks per active LANE: one per candidate: 35 ms; one per run of a
+// lane's candidates that share a gap: 16.0; level 1 through DPP instead of four 64-lane atomics on one key: 15.2;
+// the two coarse levels (13 states, windows hundreds of candidates wide, where every lane's last run hits one of
+// 3 keys) in the lane-per-state form of viterbi_forward: 13.8; keys in four planes by state mod 4 (bank conflicts
+// 490 -> 320 clocks per frame): 13.6; window ends by a lane per gap instead of per new state: **13.1 ms**, 2 300
+// instructions per frame and wave.  The default since then (SNF_PITCH_FLAT=0: the lane-per-state kernel).
 constexpr int kFlatCand = 7;               // candidates per lane: 7 x 64 = 448 states at most
 constexpr int kFlatSlots = 448 + 128;      // keys: a last partial gap names states up to S - 1 + 127
 constexpr int kFlatWaveBytes = kFlatSlots * 8 + (448 + kFwdPad) * 4 + 448 * 4;   // keys, forward costs, marks of a wave
@@ -1142,6 +1142,13 @@ __device__ __forceinline__ int wave_exclusive_sum(int v, int lane) {
   return t + base - v;
 }
 
+// Where the key of state u lives: four planes by u mod 4, each indexed by u / 4.  At the last level the known
+// states (multiples of 4) and each of the three kinds of new states are then contiguous, at the level before the
+// known states are two entries apart: with the keys in state order every access of a level was 32 / 64 / 256
+// bytes apart - 4, 2 or 1 banks for the whole wave (SQ_LDS_BANK_CONFLICT 490 clocks per frame and wave).
+constexpr int kFlatPlane = kFlatSlots / 4;
+__device__ __forceinline__ int flat_slot(int u) { return (u & 3) * kFlatPlane + (u >> 2); }
+
 __device__ __forceinline__ unsigned long long flat_key(float cost, int j) {
   return (static_cast<unsigned long long>(__builtin_bit_cast(unsigned, cost)) << 32) | static_cast<unsigned>(j);
 }
@@ -1163,7 +1170,7 @@ __device__ __forceinline__ void flat_level(const FlatShared& sh, const int S, co
   for (int t0 = 0; t0 < n_known; t0 += 64) {
     const int t = t0 + lane;
     if (t < n_known) {
-      const unsigned b = reinterpret_cast<const unsigned*>(sh.slots)[2 * (t * KNOWN)];   // (the low word: the backpointer)
+      const unsigned b = reinterpret_cast<const unsigned*>(sh.slots)[2 * (t * (KNOWN / 4))];   // (plane 0; the low word: the backpointer)
       atomicAdd(&sh.marks[b], 1u);
     }
   }
@@ -1181,21 +1188,27 @@ __device__ __forceinline__ void flat_level(const FlatShared& sh, const int S, co
     count += mk[k];
     gap[k] = count - 1;                           // candidate j lies right of (or on) the backpointer of state gap
   }
-  // ---- the ends of every window, by the new states themselves ------------------------------------------
-  const int n_new = n_gaps * M;
-  for (int t0 = 0; t0 < n_new; t0 += 64) {
-    const int t = t0 + lane;
-    const int g = M == 1 ? t : t / 3, sidx = M == 1 ? 0 : t - 3 * g;
-    const int u = g * KNOWN + (sidx + 1) * NEW;
-    if (t < n_new && u < S) {
+  // ---- the ends of every window: a lane per GAP offers lo and hi to each of the gap's new states (the three
+  // states of a gap share the window: one pair of reads, keys written one entry or one plane apart) -----------
+  for (int g0 = 0; g0 < n_gaps; g0 += 64) {
+    const int g = g0 + lane;
+    if (g < n_gaps) {
+      const unsigned* __restrict__ bps = reinterpret_cast<const unsigned*>(sh.slots);   // (plane 0, low words)
       const int above = (g + 1) * KNOWN;
-      const unsigned* __restrict__ bps = reinterpret_cast<const unsigned*>(sh.slots);   // (low words)
-      const int lo = static_cast<int>(bps[2 * (g * KNOWN)]);
-      const int hi = above < S ? static_cast<int>(bps[2 * above]) : S - 1;
-      const float uf = static_cast<float>(u);
-      const float c_lo = trans_cost(lo, uf, factor, sh.fwd[lo]);
-      const float c_hi = trans_cost(hi, uf, factor, sh.fwd[hi]);
-      sh.slots[u] = c_hi < c_lo ? flat_key(c_hi, hi) : flat_key(c_lo, lo);   // (lo <= hi: the lower index on ties)
+      const int lo = static_cast<int>(bps[2 * (g * (KNOWN / 4))]);
+      const int hi = above < S ? static_cast<int>(bps[2 * (above / 4)]) : S - 1;
+      const float f_lo = sh.fwd[lo], f_hi = sh.fwd[hi];
+      const float e_lo = static_cast<float>(lo - g * KNOWN), e_hi = static_cast<float>(hi - g * KNOWN);
+      unsigned long long* __restrict__ first = sh.slots + g * (KNOWN / 4);
+#pragma unroll
+      for (int sidx = 0; sidx < M; ++sidx) {
+        // (a new state behind the last state of a partial gap gets a key nobody reads: the array has the room)
+        const float d_lo = e_lo - static_cast<float>((sidx + 1) * NEW), d_hi = e_hi - static_cast<float>((sidx + 1) * NEW);
+        const float c_lo = __fadd_rn(__fmul_rn(d_lo * d_lo, factor), f_lo);
+        const float c_hi = __fadd_rn(__fmul_rn(d_hi * d_hi, factor), f_hi);
+        first[NEW >= 4 ? (sidx + 1) * (NEW / 4) : (sidx + 1) * kFlatPlane] =
+            c_hi < c_lo ? flat_key(c_hi, hi) : flat_key(c_lo, lo);   // (lo <= hi: the lower index on ties)
+      }
     }
   }
   wave_sync();
@@ -1231,8 +1244,11 @@ __device__ __forceinline__ void flat_level(const FlatShared& sh, const int S, co
     }
     const bool last_of_run = k == kFlatCand - 1 || gap[k + (k < kFlatCand - 1 ? 1 : 0)] != gap[k];
     if (last_of_run && bj[0] >= 0) {   // (the states of a gap see the same candidates: bj[0] >= 0 <=> any)
+      // (ub is a multiple of 4: plane 0 at ub / 4; the new states are whole entries or whole planes further)
+      unsigned long long* __restrict__ first = sh.slots + (ub >> 2);
 #pragma unroll
-      for (int sidx = 0; sidx < M; ++sidx) atomicMin(&sh.slots[ub + (sidx + 1) * NEW], flat_key(bc[sidx], bj[sidx]));
+      for (int sidx = 0; sidx < M; ++sidx)
+        atomicMin(first + (NEW >= 4 ? (sidx + 1) * (NEW / 4) : (sidx + 1) * kFlatPlane), flat_key(bc[sidx], bj[sidx]));
     }
     if (last_of_run) {
 #pragma unroll
@@ -1323,7 +1339,7 @@ __device__ void viterbi_forward_flat(const PitchDevTables& t, const float* __res
         argmin_take(best, best_j, dpp_f<0x128>(best), dpp_i<0x128>(best_j));
         if (sub == 0 && r < n_super) {
           if (best_j >= S) best_j = 0;
-          sh.slots[i_rep] = flat_key(best, best_j);
+          sh.slots[flat_slot(i_rep)] = flat_key(best, best_j);
         }
       }
       wave_sync();
@@ -1335,8 +1351,8 @@ __device__ void viterbi_forward_flat(const PitchDevTables& t, const float* __res
         int best_j = 0x7fffffff;
         if (i_rep < S) {
           const int below = i_rep & ~127, above = below + 128;
-          const int lo = static_cast<int>(static_cast<unsigned>(sh.slots[below]));
-          const int hi = above < S ? static_cast<int>(static_cast<unsigned>(sh.slots[above])) : S - 1;
+          const int lo = static_cast<int>(static_cast<unsigned>(sh.slots[flat_slot(below)]));
+          const int hi = above < S ? static_cast<int>(static_cast<unsigned>(sh.slots[flat_slot(above)])) : S - 1;
           const float fi = static_cast<float>(i_rep);
           float d = static_cast<float>(lo + sub) - fi, bd = d;
           for (int j = lo + sub; j <= hi; j += 32) {
@@ -1356,8 +1372,8 @@ __device__ void viterbi_forward_flat(const PitchDevTables& t, const float* __res
         }
         quad_argmin(best, best_j);
         if (sub == 0 && i_rep < S) {
-          if (best_j >= S) best_j = static_cast<int>(static_cast<unsigned>(sh.slots[i_rep & ~127]));
-          sh.slots[i_rep] = flat_key(best, best_j);
+          if (best_j >= S) best_j = static_cast<int>(static_cast<unsigned>(sh.slots[flat_slot(i_rep & ~127)]));
+          sh.slots[flat_slot(i_rep)] = flat_key(best, best_j);
         }
       }
       wave_sync();
@@ -1369,7 +1385,7 @@ __device__ void viterbi_forward_flat(const PitchDevTables& t, const float* __res
     float nx[NK], lane_min = FLT_MAX;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-      const unsigned long long key = sh.slots[col[k]];
+      const unsigned long long key = sh.slots[flat_slot(col[k])];
       bpv[k] = static_cast<int>(static_cast<unsigned>(key));
       nx[k] = __builtin_bit_cast(float, static_cast<unsigned>(key >> 32)) + local[k];
       lane_min = fminf(lane_min, nx[k]);
@@ -1587,11 +1603,10 @@ int launch_pitch(const PitchDevTables& t, const PitchBatch& b, const PitchScratc
       hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(b.n_utts)), dim3(team * 64), lds, stream, t, b,
                          w.nccf_res, w.anp, w.ub, w.backptr, w.states, w.pov_nccf, out);
       SNF_HIP_CHECK(hipGetLastError());
-    } else if (S > 128 && S <= 448 && getenv("SNF_PITCH_FLAT") && getenv("SNF_PITCH_FLAT")[0] == '1') {
-      // the lane-per-candidate search (round 5): bit-identical, 23 % fewer instructions and 3 % faster than the
-      // lane-per-state kernel (13.8 against 14.1-14.2 ms per 10 000 utterances: its waves wait for the LDS): a gain
-      // inside the box-to-box spread, so it is opt-in - SNF_PITCH_FLAT=1
-      // (tests/test_parity_gpu.py::test_pitch_flat_search, tools/experiments/README.md)
+    } else if (S > 128 && S <= 448 && !(getenv("SNF_PITCH_FLAT") && getenv("SNF_PITCH_FLAT")[0] == '0')) {
+      // the lane-per-candidate search (round 5): bit-identical to the lane-per-state kernel, 25 % fewer
+      // instructions, 13.1 against 14.2 ms per 10 000 utterances; SNF_PITCH_FLAT=0 keeps the old kernel (A/B runs,
+      // tests/test_parity_gpu.py::test_pitch_flat_search)
       const size_t lds = ((static_cast<size_t>(S4) * 4 + 15) & ~static_cast<size_t>(15)) +
                          static_cast<size_t>(kVitWaves) * kFlatWaveBytes;
       if (lds > 64 * 1024)

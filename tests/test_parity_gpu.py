@@ -1055,9 +1055,9 @@ def test_large_batches_and_pinned_utterances(gpu, wav_file):
 
 
 def test_pitch_flat_search(gpu, monkeypatch):
-    """the lane-per-candidate Viterbi search (csrc/kernels_pitch.hip 4c, opt-in: SNF_PITCH_FLAT=1) returns the
-    bits of the shipped lane-per-state search and of the oracle: ragged utterances, some short enough for
-    RecomputeBacktraces, digital silence (every cost ties) and noise"""
+    """the lane-per-candidate Viterbi search (csrc/kernels_pitch.hip 4c, the default for large batches since round
+    5) returns the bits of the lane-per-state search (SNF_PITCH_FLAT=0) and of the oracle: ragged utterances, some
+    short enough for RecomputeBacktraces, digital silence (every cost ties) and noise"""
     monkeypatch.setenv('SNF_PITCH_TEAM', '1')      # one wave per utterance whatever the batch size
     rng = np.random.default_rng(21)
     waves = [synth.utterances(300 + i, 1, int(n))[0] for i, n in enumerate(rng.integers(12000, 90000, 60))]
