@@ -1149,6 +1149,13 @@ __device__ __forceinline__ int wave_exclusive_sum(int v, int lane) {
 constexpr int kFlatPlane = kFlatSlots / 4;
 __device__ __forceinline__ int flat_slot(int u) { return (u & 3) * kFlatPlane + (u >> 2); }
 
+// minimum of two floats that are never NaN: fminf() quiets its operands first (a v_max_f32 x, x per call)
+__device__ __forceinline__ float min_nonan(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ unsigned long long flat_key(float cost, int j) {
   return (static_cast<unsigned long long>(__builtin_bit_cast(unsigned, cost)) << 32) | static_cast<unsigned>(j);
 }
@@ -1218,16 +1225,20 @@ __device__ __forceinline__ void flat_level(const FlatShared& sh, const int S, co
   // lane-per-state search).  The seven candidates of a lane are consecutive, so they fall into runs that share a
   // gap: the lane keeps the best of the run in registers (ascending j, strict <: the lower index on ties) and
   // offers it once, when the gap changes or its candidates end - 1 300 lane operations per frame.
+  // A candidate that carries a mark (it IS a known backpointer) opens a new gap and is itself outside every
+  // window: the lane's running best restarts there (and at its first candidate); it is offered at the last
+  // candidate before the next mark (or at the lane's last one) if the run saw any candidate.
   float bc[M];
   int bj[M];
 #pragma unroll
   for (int sidx = 0; sidx < M; ++sidx) {
     bc[sidx] = FLT_MAX;
-    bj[sidx] = -1;
+    bj[sidx] = 0;
   }
 #pragma unroll
   for (int k = 0; k < kFlatCand; ++k) {
     const int j = kFlatCand * lane + k;
+    const bool restart = k == 0 || mk[k] != 0;
     // (one unsigned comparison for 0 <= gap < n_gaps; candidates behind the last state need no test: their
     // forward cost is the FLT_MAX padding)
     const bool inside = mk[k] == 0 && static_cast<unsigned>(gap[k]) < static_cast<unsigned>(n_gaps);
@@ -1239,23 +1250,16 @@ __device__ __forceinline__ void flat_level(const FlatShared& sh, const int S, co
     for (int sidx = 0; sidx < M; ++sidx) {
       const float d = e - static_cast<float>((sidx + 1) * NEW);
       const float c = __fadd_rn(__fmul_rn(d * d, factor), fjm);
-      bj[sidx] = c < bc[sidx] ? j : bj[sidx];
-      bc[sidx] = fminf(bc[sidx], c);   // (costs are never NaN: the minimum IS the select)
+      bj[sidx] = (restart || c < bc[sidx]) ? j : bj[sidx];
+      bc[sidx] = restart ? c : min_nonan(bc[sidx], c);
     }
-    const bool last_of_run = k == kFlatCand - 1 || gap[k + (k < kFlatCand - 1 ? 1 : 0)] != gap[k];
-    if (last_of_run && bj[0] >= 0) {   // (the states of a gap see the same candidates: bj[0] >= 0 <=> any)
+    const bool last_of_run = k == kFlatCand - 1 || mk[k + (k < kFlatCand - 1 ? 1 : 0)] != 0;
+    if (last_of_run && bc[0] < FLT_MAX) {   // (the states of a gap see the same candidates: one test for all)
       // (ub is a multiple of 4: plane 0 at ub / 4; the new states are whole entries or whole planes further)
       unsigned long long* __restrict__ first = sh.slots + (ub >> 2);
 #pragma unroll
       for (int sidx = 0; sidx < M; ++sidx)
         atomicMin(first + (NEW >= 4 ? (sidx + 1) * (NEW / 4) : (sidx + 1) * kFlatPlane), flat_key(bc[sidx], bj[sidx]));
-    }
-    if (last_of_run) {
-#pragma unroll
-      for (int sidx = 0; sidx < M; ++sidx) {
-        bc[sidx] = FLT_MAX;
-        bj[sidx] = -1;
-      }
     }
   }
   wave_sync();
