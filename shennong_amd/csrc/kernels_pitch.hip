@@ -1162,45 +1162,33 @@ __device__ __forceinline__ unsigned long long flat_key(float cost, int j) {
 
 // one level: the states u = g KNOWN + (s + 1) NEW (s < KNOWN / NEW - 1) of every gap g between the known states
 // g KNOWN and (g + 1) KNOWN
-template <int KNOWN, int NEW>
+// FRESH: the stride of the states that became known since the marks were last brought up to date (the marks are
+// cumulative over the levels of a frame: only the backpointers of those states are added)
+template <int KNOWN, int NEW, int FRESH_FROM>
 __device__ __forceinline__ void flat_level(const FlatShared& sh, const int S, const float factor, const int lane,
                                            const float (&fj)[kFlatCand], const float jf0) {
   constexpr int M = KNOWN / NEW - 1;
   static_assert(M == 1 || M == 3, "one or three new states per gap");
-  const int n_known = (S + KNOWN - 1) / KNOWN;
   const int n_gaps = S > NEW ? (S - NEW - 1) / KNOWN + 1 : 0;   // gaps that hold a new state below S
-  // ---- marks ---------------------------------------------------------------------------------------------
+  const unsigned* __restrict__ bps = reinterpret_cast<const unsigned*>(sh.slots);   // plane 0, low words: backpointers
   unsigned* __restrict__ mk_lane = sh.marks + kFlatCand * lane;
-#pragma unroll
-  for (int k = 0; k < kFlatCand; ++k) mk_lane[k] = 0u;
-  wave_sync();
-  for (int t0 = 0; t0 < n_known; t0 += 64) {
+  // The phases of a level are LDS round trips of one wave; what does not depend on each other is issued together:
+  // (1) the backpointers the marks still lack and the two ends of every window, (2) the marks' atomic adds and the
+  // forward costs at the window ends, (3) the lane's seven marks and the keys of the window ends.
+  // ---- marks: the states t FRESH (FRESH_FROM == 0: all known states; else those that are not multiples of
+  // FRESH_FROM) became known at the previous level
+  constexpr int FRESH = KNOWN;
+  const int n_fresh = (S + FRESH - 1) / FRESH;
+  for (int t0 = 0; t0 < n_fresh; t0 += 64) {
     const int t = t0 + lane;
-    if (t < n_known) {
-      const unsigned b = reinterpret_cast<const unsigned*>(sh.slots)[2 * (t * (KNOWN / 4))];   // (plane 0; the low word: the backpointer)
-      atomicAdd(&sh.marks[b], 1u);
-    }
-  }
-  wave_sync();
-  int mk[kFlatCand], gap[kFlatCand];
-  int total = 0;
-#pragma unroll
-  for (int k = 0; k < kFlatCand; ++k) {
-    mk[k] = static_cast<int>(mk_lane[k]);
-    total += mk[k];
-  }
-  int count = wave_exclusive_sum(total, lane);   // known states with a backpointer below this lane's candidates
-#pragma unroll
-  for (int k = 0; k < kFlatCand; ++k) {
-    count += mk[k];
-    gap[k] = count - 1;                           // candidate j lies right of (or on) the backpointer of state gap
+    const bool fresh = t < n_fresh && (FRESH_FROM == 0 || (t * FRESH) % FRESH_FROM != 0);
+    if (fresh) atomicAdd(&sh.marks[bps[2 * (t * (FRESH / 4))]], 1u);
   }
   // ---- the ends of every window: a lane per GAP offers lo and hi to each of the gap's new states (the three
   // states of a gap share the window: one pair of reads, keys written one entry or one plane apart) -----------
   for (int g0 = 0; g0 < n_gaps; g0 += 64) {
     const int g = g0 + lane;
     if (g < n_gaps) {
-      const unsigned* __restrict__ bps = reinterpret_cast<const unsigned*>(sh.slots);   // (plane 0, low words)
       const int above = (g + 1) * KNOWN;
       const int lo = static_cast<int>(bps[2 * (g * (KNOWN / 4))]);
       const int hi = above < S ? static_cast<int>(bps[2 * (above / 4)]) : S - 1;
@@ -1219,6 +1207,19 @@ __device__ __forceinline__ void flat_level(const FlatShared& sh, const int S, co
     }
   }
   wave_sync();
+  int mk[kFlatCand], gap[kFlatCand];
+  int total = 0;
+#pragma unroll
+  for (int k = 0; k < kFlatCand; ++k) {
+    mk[k] = static_cast<int>(mk_lane[k]);
+    total += mk[k];
+  }
+  int count = wave_exclusive_sum(total, lane);   // known states with a backpointer below this lane's candidates
+#pragma unroll
+  for (int k = 0; k < kFlatCand; ++k) {
+    count += mk[k];
+    gap[k] = count - 1;                           // candidate j lies right of (or on) the backpointer of state gap
+  }
   // ---- the candidates strictly inside a window ---------------------------------------------------------
   // An LDS atomic costs ~0.6 clocks per LANE whatever the addresses (measured: one atomic per candidate and
   // state, 4 400 lane operations per frame, was 2 500 LDS clocks per frame and wave - three times the whole
@@ -1316,6 +1317,12 @@ __device__ void viterbi_forward_flat(const PitchDevTables& t, const float* __res
     float fj[kFlatCand];
 #pragma unroll
     for (int k = 0; k < kFlatCand; ++k) fj[k] = fwd_lane[k];
+    {
+      // (the marks of a frame are cumulative over its levels: zeroed once, here)
+      unsigned* __restrict__ mk_lane = sh.marks + kFlatCand * lane;
+#pragma unroll
+      for (int k = 0; k < kFlatCand; ++k) mk_lane[k] = 0u;
+    }
     // ---- levels 1 and 2 as in viterbi_forward (a 16-lane row per state of level 1 over all candidates, 4 lanes per
     // state of level 2 over its window: 13 states whose windows are hundreds of candidates wide - the lane-per-
     // candidate form pays for them with one DPP reduction per state or with 64 lanes on 3 keys), keys to `slots` --
@@ -1382,9 +1389,9 @@ __device__ void viterbi_forward_flat(const PitchDevTables& t, const float* __res
       }
       wave_sync();
     }
-    flat_level<32, 8>(sh, S, factor, lane, fj, jf0);
-    flat_level<8, 4>(sh, S, factor, lane, fj, jf0);
-    flat_level<4, 1>(sh, S, factor, lane, fj, jf0);
+    flat_level<32, 8, 0>(sh, S, factor, lane, fj, jf0);
+    flat_level<8, 4, 32>(sh, S, factor, lane, fj, jf0);
+    flat_level<4, 1, 8>(sh, S, factor, lane, fj, jf0);
     // ---- new forward costs: best + local cost, minus their minimum ----------------------------------------
     float nx[NK], lane_min = FLT_MAX;
 #pragma unroll
