@@ -713,7 +713,7 @@ int run_pitch_device(snf_plan* plan, const int16_t* d_wave, const int64_t* sampl
   if ((rc = plan->s_mel.ensure(sizeof(float) * nf * plan->pd.num_lags))) return rc;
   if ((rc = plan->s_pres.ensure(sizeof(float) * nf * plan->pd.num_states))) return rc;
   if ((rc = plan->s_anp.ensure(sizeof(float) * nf))) return rc;
-  if ((rc = plan->s_futt.ensure(sizeof(int32_t) * nf))) return rc;
+  if ((rc = plan->s_futt.ensure(sizeof(int4) * nf))) return rc;
   SNF_HIP_CHECK(hipStreamSynchronize(s));  // host vectors above go out of scope after launch setup
   PitchBatch b{};
   b.wave = d_wave;
@@ -735,7 +735,7 @@ int run_pitch_device(snf_plan* plan, const int16_t* d_wave, const int64_t* sampl
   w.anp = plan->s_anp.as<float>();
   w.backptr = plan->s_bp.as<int16_t>();
   w.states = plan->s_states.as<int32_t>();
-  w.frame_utt = plan->s_futt.as<int32_t>();
+  w.frame_meta = plan->s_futt.as<int4>();
   return launch_pitch(plan->pd, b, w, d_out, s);
 }
 

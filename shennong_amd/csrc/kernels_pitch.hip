@@ -358,17 +358,34 @@ __host__ __device__ inline NccfLayout nccf_layout(int wl, int ln, int num_lags) 
 
 }  // namespace
 
-// one thread per frame: the utterance it belongs to (a binary search of dependent loads: microseconds
-// when a wave does it at the head of every frame set, nothing when a million threads do it at once)
-__global__ void pitch_frame_utt_kernel(const PitchBatch b, int32_t* __restrict__ frame_utt) {
+// one thread per frame: where its window starts in the resampled batch, which of the window's samples exist, and
+// the frame's NCCF ballast - 16 bytes that the NCCF kernel reads with ONE load per frame (it used to walk
+// frame -> utterance -> offsets -> samples: three dependent trips to HBM at the head of every set of frames,
+// half of its wave cycles, profiles/r05_pmc_pitch10k_after_summary.txt)
+__global__ void pitch_frame_meta_kernel(const PitchDevTables t, const PitchBatch b, const float* __restrict__ ub,
+                                        int4* __restrict__ frame_meta) {
   const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (g < b.total_frames) frame_utt[g] = static_cast<int32_t>(find_utt(b.frame_offsets, b.n_utts, g));
+  if (g >= b.total_frames) return;
+  const int64_t u = find_utt(b.frame_offsets, b.n_utts, g);
+  const int64_t frame = g - b.frame_offsets[u];
+  const int64_t d0 = b.down_offsets[u], nd = b.down_offsets[u + 1] - d0;
+  int64_t start;
+  if (t.snip_edges) start = frame * t.win_shift;
+  else start = static_cast<int64_t>((static_cast<double>(frame) + 0.5) * t.win_shift) - t.full_len / 2;
+  // window sample i is signal sample start + i: it exists for lo <= i < hi (everything else reads as zero)
+  const int64_t lo = start < 0 ? (-start < t.full_len ? -start : t.full_len) : 0;
+  const int64_t room = nd - start;
+  const int64_t hi = room < 0 ? 0 : (room < t.full_len ? room : t.full_len);
+  const int64_t first = d0 + start;   // (may lie in front of the batch for a centred first frame: masked by lo)
+  const float ballast = frame < b.frames_phase1[u] ? ub[u * 6 + 0] : ub[u * 6 + 1];
+  frame_meta[g] = make_int4(static_cast<int>(static_cast<uint32_t>(first)), static_cast<int>(first >> 32),
+                            static_cast<int>(lo | (hi << 16)), __builtin_bit_cast(int, ballast));
 }
 
 // ---- 3. NCCF at the integer lags, resampled to the lags of the Viterbi states ------------------------
 __global__ __launch_bounds__(kNccfWaves * 64, 6) void pitch_nccf_kernel(
     const PitchDevTables t, const PitchBatch b, const float* __restrict__ down,
-    const float* __restrict__ ub, const int32_t* __restrict__ frame_utt, float* __restrict__ nccf_res,
+    const int4* __restrict__ frame_meta, float* __restrict__ nccf_res,
     float* __restrict__ pov_nccf, float* __restrict__ anp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = t.num_states, L = t.num_lags, W = t.win_size;
@@ -396,20 +413,15 @@ __global__ __launch_bounds__(kNccfWaves * 64, 6) void pitch_nccf_kernel(
        set += static_cast<int64_t>(gridDim.x) * kNccfWaves) {
     const int64_t g = set * 4 + q;
     const bool valid = g < b.total_frames;
-    const int64_t gc = valid ? g : b.total_frames - 1;
-    const int64_t u = frame_utt[gc];
-    const int64_t frame = gc - b.frame_offsets[u];
-    const int64_t d0 = b.down_offsets[u], nd = b.down_offsets[u + 1] - d0;
-    const float* __restrict__ x = down + d0;
-    const float ballast = frame < b.frames_phase1[u] ? ub[u * 6 + 0] : ub[u * 6 + 1];
-    int64_t start;
-    if (t.snip_edges) start = frame * t.win_shift;
-    else start = static_cast<int64_t>((static_cast<double>(frame) + 0.5) * t.win_shift) - t.full_len / 2;
+    const int4 meta = frame_meta[valid ? g : b.total_frames - 1];
+    const float ballast = __builtin_bit_cast(float, meta.w);
     // ---- window (zero beyond the signal and in the read-ahead padding), mean removal, e1 -----------
     wave_sync();
-    for (int i = l; i < WL; i += 16) {
-      const int64_t k = start + i;
-      win[i] = (i < t.full_len && k >= 0 && k < nd) ? x[k] : 0.0f;
+    {
+      const float* __restrict__ x = down + ((static_cast<int64_t>(meta.y) << 32) | static_cast<uint32_t>(meta.x));
+      // (hi < lo never happens: both are clamped to [0, full_len]; hi == lo: no sample of the window exists)
+      const unsigned lo = static_cast<unsigned>(meta.z) & 0xffffu, span = (static_cast<unsigned>(meta.z) >> 16) - lo;
+      for (int i = l; i < WL; i += 16) win[i] = static_cast<unsigned>(i) - lo < span ? x[i] : 0.0f;
     }
     float part = 0.0f;
     for (int i = l; i < W; i += 16) part += win[i];
@@ -1580,8 +1592,9 @@ int launch_pitch(const PitchDevTables& t, const PitchBatch& b, const PitchScratc
   };
   if (stage_done("resample + stats", 1)) return SNF_OK;
   const int S = t.num_states, L = t.num_lags, S4 = (S + 3) & ~3;
-  hipLaunchKernelGGL(pitch_frame_utt_kernel, dim3(static_cast<unsigned>((b.total_frames + 255) / 256)),
-                     dim3(256), 0, stream, b, w.frame_utt);
+  if (t.full_len >= 65536) return set_error(SNF_E_RUNTIME, "pitch: a correlation window of more than 65535 samples");
+  hipLaunchKernelGGL(pitch_frame_meta_kernel, dim3(static_cast<unsigned>((b.total_frames + 255) / 256)),
+                     dim3(256), 0, stream, t, b, w.ub, w.frame_meta);
   SNF_HIP_CHECK(hipGetLastError());
   {
     const int WL = (t.full_len + 16 + 3) & ~3, LN = (L + t.ar_quad_taps + 3) & ~3;
@@ -1596,7 +1609,7 @@ int launch_pitch(const PitchDevTables& t, const PitchBatch& b, const PitchScratc
     int64_t blocks = (n_sets + kNccfWaves - 1) / kNccfWaves;
     if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride: the taps are staged once per workgroup
     hipLaunchKernelGGL(pitch_nccf_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kNccfWaves * 64), lds,
-                       stream, t, b, w.down, w.ub, w.frame_utt, w.nccf_res, w.pov_nccf, w.anp);
+                       stream, t, b, w.down, w.frame_meta, w.nccf_res, w.pov_nccf, w.anp);
     SNF_HIP_CHECK(hipGetLastError());
     if (stage_done("nccf", 2)) return SNF_OK;
   }

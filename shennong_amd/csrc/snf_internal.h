@@ -297,7 +297,7 @@ struct PitchScratch {
   float* anp;        // [total_frames]                average norm product (RecomputeBacktraces)
   int16_t* backptr;  // [total_frames][num_states]
   int32_t* states;   // [total_frames]                traceback
-  int32_t* frame_utt;  // [total_frames]              utterance of every frame
+  int4* frame_meta;  // [total_frames]                window start / existing samples / ballast of every frame
 };
 // resample -> signal statistics -> frame-parallel NCCF + lag resampling -> Viterbi per utterance ->
 // traceback + POV output
