@@ -1259,12 +1259,16 @@ __device__ __forceinline__ void flat_level(const FlatShared& sh, const int S, co
     const float fjm = inside ? fj[k] : FLT_MAX;
     const int ub = gap[k] * KNOWN;
     const float e = (jf0 + static_cast<float>(k)) - static_cast<float>(ub);   // j - g KNOWN: exact
+    // (a restart as arithmetic: best + inf = inf, which every cost is below - an add in place of two selects on
+    // a scalar mask per state; best + 0 = best exactly, the costs being >= +0)
+    const float reset = restart ? __builtin_inff() : 0.0f;
 #pragma unroll
     for (int sidx = 0; sidx < M; ++sidx) {
       const float d = e - static_cast<float>((sidx + 1) * NEW);
       const float c = __fadd_rn(__fmul_rn(d * d, factor), fjm);
-      bj[sidx] = (restart || c < bc[sidx]) ? j : bj[sidx];
-      bc[sidx] = restart ? c : min_nonan(bc[sidx], c);
+      const float kept = __fadd_rn(bc[sidx], reset);
+      bj[sidx] = c < kept ? j : bj[sidx];
+      bc[sidx] = min_nonan(kept, c);
     }
     const bool last_of_run = k == kFlatCand - 1 || mk[k + (k < kFlatCand - 1 ? 1 : 0)] != 0;
     if (last_of_run && bc[0] < FLT_MAX) {   // (the states of a gap see the same candidates: one test for all)
