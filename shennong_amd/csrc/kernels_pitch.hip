@@ -1130,7 +1130,10 @@ __device__ void viterbi_forward_team(const PitchDevTables& t, const float* __res
 // 490 -> 320 clocks per frame): 13.6; window ends by a lane per gap instead of per new state: **13.1 ms**, 2 300
 // instructions per frame and wave.  The default since then (SNF_PITCH_FLAT=0: the lane-per-state kernel).
 constexpr int kFlatCand = 7;               // candidates per lane: 7 x 64 = 448 states at most
-constexpr int kFlatSlots = 448 + 128;      // keys: a last partial gap names states up to S - 1 + 127
+constexpr int kFlatSlots = 448 + 32;       // keys: a last partial gap of the first candidate level names states up to S + 15
+constexpr int kFlatWaves = 8;              // utterances (= wavefronts) per workgroup: two workgroups per CU = 4 waves per SIMD
+// (10 waves per workgroup and 96 registers = 5 waves per SIMD: 36 spilled registers, 14 scratch accesses per frame,
+// 15.9 against 12.6 ms per 10 000 utterances)
 constexpr int kFlatWaveBytes = kFlatSlots * 8 + (448 + kFwdPad) * 4 + 448 * 4;   // keys, forward costs, marks of a wave
 
 struct FlatShared {
@@ -1479,7 +1482,7 @@ __global__ __launch_bounds__(kVitWaves * 64, 4) void pitch_viterbi_kernel(
 }
 
 // one wavefront per utterance with the lane-per-candidate search (viterbi_forward_flat): 129 .. 448 states
-__global__ __launch_bounds__(kVitWaves * 64, 4) void pitch_viterbi_flat_kernel(
+__global__ __launch_bounds__(kFlatWaves * 64, 4) void pitch_viterbi_flat_kernel(
     const PitchDevTables t, const PitchBatch b, const float* __restrict__ nccf_res,
     const float* __restrict__ anp, const float* __restrict__ ub, int16_t* __restrict__ backptr,
     int32_t* __restrict__ states, const float* __restrict__ pov_all, float* __restrict__ out) {
@@ -1489,7 +1492,7 @@ __global__ __launch_bounds__(kVitWaves * 64, 4) void pitch_viterbi_flat_kernel(
   for (int s = threadIdx.x; s < S; s += blockDim.x) st_lag[s] = t.lags[s];
   __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int64_t slot = static_cast<int64_t>(blockIdx.x) * kVitWaves + wid;
+  const int64_t slot = static_cast<int64_t>(blockIdx.x) * kFlatWaves + wid;
   if (slot >= b.n_utts) return;
   const int64_t u = b.order ? b.order[slot] : slot;
   const int64_t f0 = b.frame_offsets[u], T = b.frame_offsets[u + 1] - f0;
@@ -1636,12 +1639,12 @@ int launch_pitch(const PitchDevTables& t, const PitchBatch& b, const PitchScratc
       // instructions, 13.1 against 14.2 ms per 10 000 utterances; SNF_PITCH_FLAT=0 keeps the old kernel (A/B runs,
       // tests/test_parity_gpu.py::test_pitch_flat_search)
       const size_t lds = ((static_cast<size_t>(S4) * 4 + 15) & ~static_cast<size_t>(15)) +
-                         static_cast<size_t>(kVitWaves) * kFlatWaveBytes;
+                         static_cast<size_t>(kFlatWaves) * kFlatWaveBytes;
       if (lds > 64 * 1024)
         SNF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pitch_viterbi_flat_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-      const unsigned blocks = static_cast<unsigned>((b.n_utts + kVitWaves - 1) / kVitWaves);
-      hipLaunchKernelGGL(pitch_viterbi_flat_kernel, dim3(blocks), dim3(kVitWaves * 64), lds, stream, t, b,
+      const unsigned blocks = static_cast<unsigned>((b.n_utts + kFlatWaves - 1) / kFlatWaves);
+      hipLaunchKernelGGL(pitch_viterbi_flat_kernel, dim3(blocks), dim3(kFlatWaves * 64), lds, stream, t, b,
                          w.nccf_res, w.anp, w.ub, w.backptr, w.states, w.pov_nccf, out);
       SNF_HIP_CHECK(hipGetLastError());
     } else {
