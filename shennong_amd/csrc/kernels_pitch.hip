@@ -1175,6 +1175,17 @@ __device__ __forceinline__ unsigned long long flat_key(float cost, int j) {
   return (static_cast<unsigned long long>(__builtin_bit_cast(unsigned, cost)) << 32) | static_cast<unsigned>(j);
 }
 
+// one step of an argmin over lanes ON THE KEYS: the unsigned order of (cost bits, index) is "lower cost, then lower
+// index" for non-negative costs - two DPP moves, one 64-bit compare and two selects, where the same step on a
+// (float, int) pair compiles to four compares and two exec-masked blocks
+template <int CTRL>
+__device__ __forceinline__ unsigned long long key_min_step(unsigned long long key) {
+  const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(static_cast<unsigned>(key)), CTRL, 0xf, 0xf, true));
+  const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(static_cast<unsigned>(key >> 32)), CTRL, 0xf, 0xf, true));
+  const unsigned long long other = (static_cast<unsigned long long>(hi) << 32) | lo;
+  return other < key ? other : key;
+}
+
 // one level: the states u = g KNOWN + (s + 1) NEW (s < KNOWN / NEW - 1) of every gap g between the known states
 // g KNOWN and (g + 1) KNOWN
 // FRESH: the stride of the states that became known since the marks were last brought up to date (the marks are
@@ -1355,21 +1366,41 @@ __device__ void viterbi_forward_flat(const PitchDevTables& t, const float* __res
         if (r < n_super) {
           const float fi = static_cast<float>(i_rep);
           float d = static_cast<float>(sub) - fi, bd = 1.0e9f;
-#pragma unroll 9
-          for (int j = sub; j < S; j += 16) {
-            const float c = __fadd_rn(__fmul_rn(d * d, factor), sh.fwd[j]);
-            bd = c < best ? d : bd;
-            best = fminf(best, c);
-            d += 16.0f;
+          // (the same number of steps in every lane - a scalar loop, no exec mask: the reads behind S - 1 land in
+          // the FLT_MAX padding, whose cost FLT_MAX is below nothing)
+          // (three steps per trip, their reads first: at most 47 entries behind S - 1, inside the 448 + kFwdPad
+          // entries that hold FLT_MAX from S on for every S <= 448)
+          const int n_steps = (S + 15) >> 4;
+          const float* __restrict__ fw = sh.fwd + sub;
+          float f3[3], g3[3];
+#pragma unroll
+          for (int w = 0; w < 3; ++w) f3[w] = fw[16 * w];
+          for (int t = 0; t < n_steps; t += 3) {
+            if (t + 3 < n_steps) {   // (scalar branch: the next trip's reads run under this trip's arithmetic)
+#pragma unroll
+              for (int w = 0; w < 3; ++w) g3[w] = fw[16 * (t + 3 + w)];
+            }
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+              const float c = __fadd_rn(__fmul_rn(d * d, factor), f3[w]);
+              const bool better = c < best;   // (one compare, two selects on vcc: no minimum, no canonicalisation)
+              bd = better ? d : bd;
+              best = better ? c : best;
+              d += 16.0f;
+            }
+#pragma unroll
+            for (int w = 0; w < 3; ++w) f3[w] = g3[w];
           }
           best_j = static_cast<int>(fi + bd);
         }
-        quad_argmin(best, best_j);
-        argmin_take(best, best_j, dpp_f<0x124>(best), dpp_i<0x124>(best_j));
-        argmin_take(best, best_j, dpp_f<0x128>(best), dpp_i<0x128>(best_j));
+        unsigned long long key = flat_key(best, best_j);
+        key = key_min_step<0xB1>(key);    // quad_perm [1,0,3,2]
+        key = key_min_step<0x4E>(key);    // quad_perm [2,3,0,1]
+        key = key_min_step<0x124>(key);   // row_ror:4
+        key = key_min_step<0x128>(key);   // row_ror:8
         if (sub == 0 && r < n_super) {
-          if (best_j >= S) best_j = 0;
-          sh.slots[flat_slot(i_rep)] = flat_key(best, best_j);
+          if (static_cast<unsigned>(key) >= static_cast<unsigned>(S)) key &= 0xffffffff00000000ull;   // (index 0)
+          sh.slots[flat_slot(i_rep)] = key;
         }
       }
       wave_sync();
@@ -1400,10 +1431,13 @@ __device__ void viterbi_forward_flat(const PitchDevTables& t, const float* __res
           }
           best_j = static_cast<int>(fi + bd);
         }
-        quad_argmin(best, best_j);
+        unsigned long long key = flat_key(best, best_j);
+        key = key_min_step<0xB1>(key);
+        key = key_min_step<0x4E>(key);
         if (sub == 0 && i_rep < S) {
-          if (best_j >= S) best_j = static_cast<int>(static_cast<unsigned>(sh.slots[flat_slot(i_rep & ~127)]));
-          sh.slots[flat_slot(i_rep)] = flat_key(best, best_j);
+          if (static_cast<unsigned>(key) >= static_cast<unsigned>(S))
+            key = (key & 0xffffffff00000000ull) | static_cast<unsigned>(sh.slots[flat_slot(i_rep & ~127)]);
+          sh.slots[flat_slot(i_rep)] = key;
         }
       }
       wave_sync();
