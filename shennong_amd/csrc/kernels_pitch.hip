@@ -244,9 +244,15 @@ __device__ __forceinline__ float wave_min_f(float v) {
   v = fminf(v, dpp_f<0x128>(v));
   return fminf(fminf(lane_f(v, 0), lane_f(v, 16)), fminf(lane_f(v, 32), lane_f(v, 48)));
 }
-// (cost, index) argmin step: lower cost wins, lower index on ties
+// (cost, index) argmin step: lower cost wins, lower index on ties.  Costs are non-negative floats and indices
+// non-negative ints, so that is the unsigned order of (cost bits << 32 | index): one 64-bit compare and two selects
+// (the float / int form compiled to four compares and two exec-masked blocks per step)
 __device__ __forceinline__ void argmin_take(float& c, int& j, float oc, int oj) {
-  if (oc < c || (oc == c && oj < j)) { c = oc; j = oj; }
+  const unsigned long long mine = (static_cast<unsigned long long>(__builtin_bit_cast(unsigned, c)) << 32) | static_cast<unsigned>(j);
+  const unsigned long long other = (static_cast<unsigned long long>(__builtin_bit_cast(unsigned, oc)) << 32) | static_cast<unsigned>(oj);
+  const bool take = other < mine;
+  c = take ? oc : c;
+  j = take ? oj : j;
 }
 __device__ __forceinline__ void quad_argmin(float& c, int& j) {
   argmin_take(c, j, dpp_f<0xB1>(c), dpp_i<0xB1>(j));
