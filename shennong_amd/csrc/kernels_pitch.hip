@@ -1191,6 +1191,16 @@ __device__ __forceinline__ unsigned long long key_min_step(unsigned long long ke
   const unsigned long long other = (static_cast<unsigned long long>(hi) << 32) | lo;
   return other < key ? other : key;
 }
+// the same with the key of the lane `CTRL` names taken from `from` (row_shl:n: lane + n of the row; a lane whose
+// source lies outside its row keeps its own halves of `from`)
+template <int CTRL>
+__device__ __forceinline__ unsigned long long key_min_shl(unsigned long long key, unsigned long long from) {
+  const int flo = static_cast<int>(static_cast<unsigned>(from)), fhi = static_cast<int>(static_cast<unsigned>(from >> 32));
+  const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_update_dpp(flo, flo, CTRL, 0xf, 0xf, false));
+  const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_update_dpp(fhi, fhi, CTRL, 0xf, 0xf, false));
+  const unsigned long long other = (static_cast<unsigned long long>(hi) << 32) | lo;
+  return other < key ? other : key;
+}
 
 // one level: the states u = g KNOWN + (s + 1) NEW (s < KNOWN / NEW - 1) of every gap g between the known states
 // g KNOWN and (g + 1) KNOWN
@@ -1410,39 +1420,47 @@ __device__ void viterbi_forward_flat(const PitchDevTables& t, const float* __res
         }
       }
       wave_sync();
-      for (int base = 0; base < n_reps; base += 16) {
-        const int k = base + (lane >> 2), sub = lane & 3;
+      // (five lanes per state, three states per 16-lane row: up to twelve states per trip - the ten multiples
+      // of 32 below 448 that are not multiples of 128 - on 60 lanes; four lanes per state used 40 and took a
+      // third more trips of the candidate loop)
+      for (int base = 0; base < n_reps; base += 12) {
+        const int in_row = lane & 15, group = (in_row * 13) >> 6, sub = in_row - 5 * group;   // in_row / 5, % 5
+        const int k = base + 3 * (lane >> 4) + group;
         const int m = k + k / 3 + 1;
-        const int i_rep = m << 5;
+        const int i_rep = group < 3 ? m << 5 : S;   // (lane 15 of a row: idle)
         float best = FLT_MAX;
-        int best_j = 0x7fffffff;
+        int best_j = 0x7fffffff, lo = 0;
         if (i_rep < S) {
           const int below = i_rep & ~127, above = below + 128;
-          const int lo = static_cast<int>(static_cast<unsigned>(sh.slots[flat_slot(below)]));
+          lo = static_cast<int>(static_cast<unsigned>(sh.slots[flat_slot(below)]));
           const int hi = above < S ? static_cast<int>(static_cast<unsigned>(sh.slots[flat_slot(above)])) : S - 1;
           const float fi = static_cast<float>(i_rep);
           float d = static_cast<float>(lo + sub) - fi, bd = d;
-          for (int j = lo + sub; j <= hi; j += 32) {
+          // (reads up to 35 entries behind hi <= S - 1: inside the kFwdPad entries of FLT_MAX)
+          for (int j = lo + sub; j <= hi; j += 40) {
             float ff[8];
 #pragma unroll
-            for (int w = 0; w < 8; ++w) ff[w] = sh.fwd[j + 4 * w];
+            for (int w = 0; w < 8; ++w) ff[w] = sh.fwd[j + 5 * w];
 #pragma unroll
             for (int w = 0; w < 8; ++w) {
-              const float dw = d + static_cast<float>(4 * w);
+              const float dw = d + static_cast<float>(5 * w);
               const float c = __fadd_rn(__fmul_rn(dw * dw, factor), ff[w]);
               bd = c < best ? dw : bd;
               best = fminf(best, c);
             }
-            d += 32.0f;
+            d += 40.0f;
           }
           best_j = static_cast<int>(fi + bd);
         }
+        // the five keys of a state -> its lane sub == 0: neighbours (row_shl:1), pairs (row_shl:2), the fifth
         unsigned long long key = flat_key(best, best_j);
-        key = key_min_step<0xB1>(key);
-        key = key_min_step<0x4E>(key);
+        const unsigned long long own = key;
+        key = key_min_shl<0x101>(key, key);
+        key = key_min_shl<0x102>(key, key);
+        key = key_min_shl<0x104>(key, own);
         if (sub == 0 && i_rep < S) {
-          if (static_cast<unsigned>(key) >= static_cast<unsigned>(S))
-            key = (key & 0xffffffff00000000ull) | static_cast<unsigned>(sh.slots[flat_slot(i_rep & ~127)]);
+          // (only if every cost was NaN / inf: the lower end of the window, which lane sub == 0 still holds)
+          if (static_cast<unsigned>(key) >= static_cast<unsigned>(S)) key = (key & 0xffffffff00000000ull) | static_cast<unsigned>(lo);
           sh.slots[flat_slot(i_rep)] = key;
         }
       }
