@@ -225,6 +225,12 @@ template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
 }
+// a value every lane of the wave holds, moved to scalar registers
+__device__ __forceinline__ int64_t uniform_i64(int64_t v) {
+  const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(v))));
+  const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint64_t>(v) >> 32)));
+  return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
+}
 __device__ __forceinline__ float lane_f(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
@@ -1133,8 +1139,11 @@ __device__ void viterbi_forward_team(const PitchDevTables& t, const float* __res
 // lane's candidates that share a gap: 16.0; level 1 through DPP instead of four 64-lane atomics on one key: 15.2;
 // the two coarse levels (13 states, windows hundreds of candidates wide, where every lane's last run hits one of
 // 3 keys) in the lane-per-state form of viterbi_forward: 13.8; keys in four planes by state mod 4 (bank conflicts
-// 490 -> 320 clocks per frame): 13.6; window ends by a lane per gap instead of per new state: **13.1 ms**, 2 300
-// instructions per frame and wave.  The default since then (SNF_PITCH_FLAT=0: the lane-per-state kernel).
+// 490 -> 320 clocks per frame): 13.6; window ends by a lane per gap instead of per new state: 13.1; marks cumulative
+// over the levels of a frame: 13.0; a run's restart as arithmetic: 12.6; (cost, index) keys reduced over the lanes with
+// one 64-bit compare per step, level 1 as a scalar loop, level 2 on 60 lanes: **11.8-11.9 ms**, 2 050 instructions per
+// frame and wave (tools/experiments/README.md has the table).  The default since then (SNF_PITCH_FLAT=0: the
+// lane-per-state kernel).
 constexpr int kFlatCand = 7;               // candidates per lane: 7 x 64 = 448 states at most
 constexpr int kFlatSlots = 448 + 32;       // keys: a last partial gap of the first candidate level names states up to S + 15
 constexpr int kFlatWaves = 8;              // utterances (= wavefronts) per workgroup: two workgroups per CU = 4 waves per SIMD
@@ -1549,13 +1558,16 @@ __global__ __launch_bounds__(kFlatWaves * 64, 4) void pitch_viterbi_flat_kernel(
   float* st_lag = reinterpret_cast<float*>(smem);
   for (int s = threadIdx.x; s < S; s += blockDim.x) st_lag[s] = t.lags[s];
   __syncthreads();
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  // (the wave's index as a SCALAR: the utterance, its offsets and the row pointers derived from them then live in
+  // scalar registers - 128 -> 124 vector registers and no spill left in the kernel)
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int64_t slot = static_cast<int64_t>(blockIdx.x) * kFlatWaves + wid;
   if (slot >= b.n_utts) return;
-  const int64_t u = b.order ? b.order[slot] : slot;
-  const int64_t f0 = b.frame_offsets[u], T = b.frame_offsets[u + 1] - f0;
+  // (values loaded at a uniform address arrive in vector registers: back to scalars, see wid)
+  const int64_t u = uniform_i64(b.order ? b.order[slot] : slot);
+  const int64_t f0 = uniform_i64(b.frame_offsets[u]), T = uniform_i64(b.frame_offsets[u + 1]) - f0;
   if (T <= 0) return;
-  const int64_t T1 = b.frames_phase1[u];
+  const int64_t T1 = uniform_i64(b.frames_phase1[u]);
   // per wave: keys (8-byte aligned: first), forward costs, marks
   char* mine = smem + ((S4 * 4 + 15) & ~15) + wid * kFlatWaveBytes;
   FlatShared fs;
@@ -1694,7 +1706,7 @@ int launch_pitch(const PitchDevTables& t, const PitchBatch& b, const PitchScratc
       SNF_HIP_CHECK(hipGetLastError());
     } else if (S > 128 && S <= 448 && !(getenv("SNF_PITCH_FLAT") && getenv("SNF_PITCH_FLAT")[0] == '0')) {
       // the lane-per-candidate search (round 5): bit-identical to the lane-per-state kernel, 25 % fewer
-      // instructions, 13.1 against 14.2 ms per 10 000 utterances; SNF_PITCH_FLAT=0 keeps the old kernel (A/B runs,
+      // instructions, 11.8 against 14.2 ms per 10 000 utterances; SNF_PITCH_FLAT=0 keeps the old kernel (A/B runs,
       // tests/test_parity_gpu.py::test_pitch_flat_search)
       const size_t lds = ((static_cast<size_t>(S4) * 4 + 15) & ~static_cast<size_t>(15)) +
                          static_cast<size_t>(kFlatWaves) * kFlatWaveBytes;
