@@ -236,14 +236,19 @@ def pitch_num_frames(pitch_opts, nsamples):
 # ---- plans -------------------------------------------------------------------
 class Plan:
     """An immutable device-resident feature plan (window, mel banks, DCT... in HBM)"""
-    def __init__(self, opts, device=None):
+    def __init__(self, opts, device=None, quiet=False):
         self.opts = _abi.Options.from_buffer_copy(bytes(opts))
         self.device = _DEVICE if device is None else int(device)
         handle = C.c_void_p()
         check(lib().snf_plan_create(
             C.byref(self.opts), self.device, C.byref(handle)))
         self.handle = handle
-        if lib().snf_plan_fast_path(handle) == 0:
+        # the noise stream of a call (dither, delta-pitch noise) is numbered HERE, one number per call of this
+        # plan whichever way the call takes - a small batch, the pieces of a large one (which run on clones),
+        # a device-resident call - so that two calls never share a stream (see snf_set_noise_call)
+        self._noise_calls = 0
+        self._noise_lock = threading.Lock()
+        if not quiet and lib().snf_plan_fast_path(handle) == 0:
             from shennong_amd.logger import get_logger
             get_logger('backend', 'warning').warning(
                 'this option combination is not covered by the register-resident kernels (even frames '
@@ -259,6 +264,11 @@ class Plan:
             except Exception:  # pragma: nocover
                 pass
             self.handle = None
+
+    def _next_noise_call(self):
+        with self._noise_lock:
+            self._noise_calls += 1
+            return self._noise_calls
 
     @property
     def ndims(self):
@@ -315,6 +325,7 @@ class Plan:
         # cost more than the launch and both transfers together)
         out = result_array((int(foff[-1]), self.ndims), np.float32)
         try:
+            lib().snf_set_noise_call(self._next_noise_call())   # (thread-local, used up by the call below)
             check(lib().snf_plan_run_batch(
                 self.handle, wave.ctypes.data_as(C.POINTER(C.c_int16)),
                 soff.ctypes.data_as(C.POINTER(C.c_int64)), n,
@@ -347,9 +358,18 @@ class Plan:
         they would share anyway; calls with other options run side by side."""
         key = (_abi.options_key(self.opts), self.device)
         with _LOCK:
-            lock, clones = _CLONES.setdefault(key, (threading.Lock(), []))
-            while len(clones) < count:
-                clones.append(Plan(self.opts, self.device))
+            entry = _CLONES.get(key)
+            if entry is None:
+                while len(_CLONES) >= _MAX_CLONE_SETS:   # (oldest option set first; a set in use stays alive
+                    _CLONES.pop(next(iter(_CLONES)))     # through its caller's references until that call ends)
+                entry = _CLONES[key] = (threading.Lock(), [])
+            lock, clones = entry
+            missing = count - len(clones)
+        # (plan creation uploads tables: not under the process-wide lock, which get_plan and the shared streams
+        # of other threads need; the clones say nothing about the kernel they use - the parent already did)
+        fresh = [Plan(self.opts, self.device, quiet=True) for _ in range(max(missing, 0))]
+        with _LOCK:
+            clones.extend(fresh[:max(count - len(clones), 0)])
             return lock, clones[:count]
 
     def run_pinned(self, corpus, vtln_warps=None, check_finite=False, wrap=None):
@@ -428,6 +448,7 @@ class Plan:
             base_in, base_out = staged.ctypes.data, out.ctypes.data
             L = lib()
             up, down = _shared_stream(self.device, 0), _shared_stream(self.device, 1)
+            noise_call = self._next_noise_call()   # (ONE number for the call: every piece draws from its stream)
             events = []
             for _ in range(pieces):
                 ev = C.c_void_p()
@@ -450,7 +471,8 @@ class Plan:
                     if f1 > f0:
                         clones[k].run_device(d_wave.ptr + 2 * s0, soff[a:b + 1] - s0, foff[a:b + 1] - f0,
                                              d_out.ptr + 4 * ndims * f0,
-                                             vtln_warps=None if warp is None else warp[a:b], stream=down)
+                                             vtln_warps=None if warp is None else warp[a:b], stream=down,
+                                             noise_call=noise_call)
                         check(L.snf_memcpy_d2h_async(C.c_void_p(base_out + 4 * ndims * f0),
                                                      C.c_void_p(d_out.ptr + 4 * ndims * f0),
                                                      4 * ndims * (f1 - f0), C.c_void_p(down)))
@@ -633,9 +655,8 @@ class Plan:
         warp = None
         if vtln_warps is not None:
             warp = np.ascontiguousarray(vtln_warps, dtype=np.float32)
-        if noise_call:
-            lib().snf_set_noise_call(int(noise_call))  # (thread-local, used up by the call below)
-        check(lib().snf_plan_run_batch_device(
+        lib().snf_set_noise_call(int(noise_call) if noise_call else self._next_noise_call())  # (thread-local,
+        check(lib().snf_plan_run_batch_device(                                                 # used up below)
             self.handle, C.c_void_p(d_wave),
             soff.ctypes.data_as(C.POINTER(C.c_int64)), n,
             warp.ctypes.data_as(C.POINTER(C.c_float)) if warp is not None
@@ -860,6 +881,7 @@ def stage_rows(mats, dtype):
 
 _COPY_POOL = None
 _CLONES = {}   # (options, device) -> private plans of Plan._clones
+_MAX_CLONE_SETS = 8   # option sets whose clones (16 plans' tables each) are kept
 _LARGE_BATCH_BYTES = 32 << 20   # Plan.run: batches from this many bytes of audio take the overlapped path
 _COPY_PIECES = int(os.environ.get('SNF_COPY_PIECES', '4'))    # pieces of a large batch per copy thread
 _COPY_THREADS = int(os.environ.get('SNF_COPY_THREADS', '4'))  # (8 / 16 threads measured slower: 6.4 / 5.1 against 4.1 ms per 96 MB)

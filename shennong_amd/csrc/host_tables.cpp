@@ -329,6 +329,11 @@ int make_pitch_tables(const snf_pitch_options& o, PitchTablesHost* t) {
     return set_error(SNF_E_RUNTIME, "bad pitch extraction options");
   if (o.preemph_coeff != 0.0f)
     return set_error(SNF_E_RUNTIME, "pitch preemph_coeff != 0 is not supported");
+  // the Viterbi kernels order (cost, index) pairs by the bit pattern of the float cost, which is the float
+  // order for non-negative costs only; the costs they compare are fwd[j] >= 0 plus (j - k)^2 times a factor
+  // with the sign of penalty_factor (Kaldi's own bounded search also presumes a convex transition cost)
+  if (!(o.penalty_factor >= 0.0f))
+    return set_error(SNF_E_INVALID, "pitch penalty_factor must be >= 0");
   const double rf = o.resample_freq;
   const double pad = o.upsample_filter_width / (2.0 * rf);
   t->first_lag = static_cast<int>(std::ceil(rf * (1.0 / o.max_f0 - pad)));

@@ -71,6 +71,7 @@ class Features:
         """The times of the rows, [nframes, 2] or [nframes]"""
         if self._times is None:
             self._times = self._shared[0].copy()
+            self._shared = (None,) + self._shared[1:]
         return self._times
 
     @property
@@ -83,7 +84,19 @@ class Features:
             self._properties = copy_properties(shared)
             if self._shared[2]:
                 self._properties.update(copy_properties(self._shared[2]))
+            self._shared = (self._shared[0], None, None)   # (the batch's history is not kept alive by a read copy)
         return self._properties
+
+    def __getstate__(self):
+        """Pickling (the `.pkl` serializer, joblib / multiprocessing transport): the times and properties a
+        batched launch shares between utterances are made this utterance's own first - the shared history
+        holds closures and the whole batch's cache, neither of which can or should travel"""
+        return {'_data': self._data, '_times': self.times, '_properties': self.properties,
+                '_shared': None}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
     dtype = property(lambda self: self.data.dtype)
     shape = property(lambda self: self.data.shape)
     nframes = property(lambda self: self.shape[0])

@@ -2,6 +2,7 @@
 
 import copy
 import multiprocessing
+import threading
 
 import numpy as np
 
@@ -62,15 +63,31 @@ class paused_gc:
     Features per utterance, views, tuples): none of them is garbage, and with a large corpus index alive every
     generation-2 pass of the collector walks hundreds of thousands of objects - measured as 5-8 ms of a 36 ms
     `process_all` inside bench.py (150 000-utterance index alive) against none in a fresh process.  Reference
-    counting frees everything as before; the collector is re-enabled on exit if it was enabled."""
+    counting frees everything as before.
+
+    The collector is process-wide and the batches of a streamed corpus enter this from several threads at once:
+    a nesting count (under a lock) disables it with the first section to start and re-enables it - if it was
+    enabled then - with the LAST one to end, not the first.  While any section is open no thread of the process
+    collects cycles."""
+    _lock = threading.Lock()
+    _depth = 0
+    _was = False
+
     def __enter__(self):
         import gc
-        self._was = gc.isenabled()
-        gc.disable()
+        cls = paused_gc
+        with cls._lock:
+            if cls._depth == 0:
+                cls._was = gc.isenabled()
+                gc.disable()
+            cls._depth += 1
         return self
 
     def __exit__(self, *exc):
-        if self._was:
-            import gc
-            gc.enable()
+        cls = paused_gc
+        with cls._lock:
+            cls._depth -= 1
+            if cls._depth == 0 and cls._was:
+                import gc
+                gc.enable()
         return False

@@ -116,6 +116,28 @@ def test_features_of_a_batch_own_their_times_and_properties():
     assert Features._from_dict(b._to_dict()) == b
 
 
+def test_features_of_a_batch_pickle():
+    """pipeline output is built on a lazy history (pipeline._Meta) that holds closures and the
+    batch's cache; pickling a Features (the .pkl serializer, joblib transport) makes its own times and
+    properties first and sends only those"""
+    import pickle
+    from shennong_amd.pipeline import _Meta
+    times = np.arange(8, dtype=np.float64).reshape(4, 2)
+    cache = {}
+    root = _Meta({'mfcc': {'num_ceps': 13}, 'pipeline': [{'name': 'mfcc', 'columns': [0, 12]}]}, 2, 4, times, 'mfcc')
+    scale = 3.0
+    lazy = root.derive(cache, ('cmvn', 0), lambda m: dict(m.properties, cmvn={'stats': np.full(3, scale)}))
+    data = np.arange(8, dtype=np.float32).reshape(4, 2)
+    a = Features._of_batch(data, times, lazy, {'speaker': 'anna'})
+    b = Features._of_batch(data, times, lazy, {'speaker': 'anna'})
+    back = pickle.loads(pickle.dumps(a))            # (never read before pickling)
+    assert back == b and back.properties['cmvn']['stats'][0] == 3.0 and back._shared is None
+    col = FeaturesCollection(x=Features._of_batch(data, times, lazy, None))
+    again = pickle.loads(pickle.dumps(col))
+    assert again['x'] == col['x'] and type(again) is FeaturesCollection
+    assert a._shared == (None, None, None)           # (a Features that was read no longer holds the batch's history)
+
+
 def test_features_concatenate(mfcc, capsys):
     both = mfcc.concatenate(mfcc)
     assert both.nframes == mfcc.nframes and both.ndims == 2 * mfcc.ndims

@@ -523,6 +523,30 @@ def test_paused_gc_restores_the_collector():
         assert not gc.isenabled()
     finally:
         gc.enable()
+    # sections that overlap on several threads (the batches in flight of a streamed corpus): the
+    # first one to END must not switch the collector back on under the others
+    import threading
+    inside, leave_first, first_left = threading.Barrier(3), threading.Event(), threading.Event()
+    seen = []
+
+    def section(first):
+        with paused_gc():
+            inside.wait()
+            if not first:
+                first_left.wait()
+                seen.append(gc.isenabled())
+            else:
+                leave_first.wait()
+        if first:
+            first_left.set()
+    threads = [threading.Thread(target=section, args=(k == 0,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    inside.wait()
+    leave_first.set()
+    for t in threads:
+        t.join()
+    assert seen == [False] and gc.isenabled()
 
 
 def test_streamed_batch_default_without_a_device():

@@ -177,6 +177,14 @@ def test_pitch(gpu, audio, wave, opts, vit_team):
     _pitch_close(got.data, want)
 
 
+def test_pitch_negative_penalty_is_refused(gpu, audio):
+    """the searches order costs by their bit pattern (non-negative floats only): a transition cost
+    that could go negative is an error at plan creation, not a silently different track"""
+    with pytest.raises(ValueError, match='penalty_factor must be >= 0'):
+        KaldiPitchProcessor(penalty_factor=-0.1).process(audio)
+    assert KaldiPitchProcessor(penalty_factor=0.0).process(audio).shape[1] == 2
+
+
 @pytest.mark.parametrize('opts', [
     dict(min_f0=40),                   # 461 states (the 8-slice register form), 95 lags: two correlation
                                        # passes, NCCF beside the window instead of over it

@@ -290,6 +290,13 @@ def test_pipeline_full(gpu, tmp_path, capsys):
     assert feats['u1'].shape == (98, 42) and feats['u2'].shape == (18, 42)
     assert all(f.dtype == np.float32 and f.is_valid() for f in feats.values())
 
+    # the collection goes through pickle (the .pkl serializer, joblib transport) before anything
+    # has read the lazily made properties
+    from shennong_amd import FeaturesCollection
+    fresh = pipeline.extract_features(config, index, njobs=2, log=get_logger('test', 'error'))
+    fresh.save(str(tmp_path / 'feats.pkl'))
+    assert FeaturesCollection.load(str(tmp_path / 'feats.pkl')) == feats
+
     # the same thing, one processor at a time
     mfcc, pitch = {}, {}
     for u in index:
