@@ -12,15 +12,23 @@ counts every pass, `roofline.kernel_ms` is the mean HIP-event time of ONE launch
 region are enqueued on one stream through the asynchronous `*_device` entry points (a pair of `snf_event_*`
 marks around each) and the region ends with one synchronisation - the way a pipeline drives the path.
 With N > 1 (launched through torch.distributed.run, used as a process spawner only: torch is never
-imported) the utterances shard across ranks with no data-path collective; the barrier / max-over-ranks and
-the gather of the Features blocks to rank 0 go over RCCL through the C ABI (shennong_amd.comm.RcclComm ->
-snf_comm_*), device pointers in and out.  `--scaling weak` (default): every GPU owns 10 000 utterances;
-`--scaling strong`: ONE 10 000-utterance corpus is dealt over the ranks by `shard_utterances`.  Two values:
-`value` (compute only, as in earlier rounds) and `value_with_gather`: a second timed region of the same K
-steps in which EVERY pass is followed, on the compute stream, by the `snf_comm_gatherv` of every rank's
-[frames, 40] block to rank 0 - the whole job including its one collective (its passes per step are sized from
-two probe passes so that the region lasts about three seconds whatever the exchange costs:
-`with_gather.passes_per_step`); `rccl_ranks_seen` is what the RCCL communicator itself reports (ncclCommCount).
+imported) the utterances shard across ranks with no data-path collective.  `--scaling weak` (default): every
+GPU owns 10 000 utterances; `--scaling strong`: ONE 10 000-utterance corpus is dealt over the ranks by
+`shard_utterances`.  Two values: `value` (compute only) - its barriers and its max-over-ranks go over the
+job's rendezvous SOCKETS (shennong_amd.comm.RcclComm.host_barrier / host_allreduce), so nothing of it depends on
+the transport the second value measures - and `value_with_gather`: a second timed region of the same K steps in
+which EVERY pass is followed by the `snf_comm_gatherv` (RCCL: ncclSend / ncclRecv pairs, device pointers) of
+every rank's [frames, 40] block to rank 0, on a stream of its own with two output buffers, so that the exchange
+of pass k runs beside the kernel of pass k + 1 (its passes per step are sized from two probe passes so that the
+region lasts about three seconds whatever the exchange costs: `with_gather.passes_per_step`); every rank's
+block is verified on the root by digest; `rccl_ranks_seen` is what the RCCL communicator itself reports
+(ncclCommCount).  That leg runs LAST and under a watchdog (`--comm-timeout`): RCCL's bootstrap, every enqueue
+and the end of the region are bounded, and a transport that stalls costs `with_gather` (= {"error": ...}), not
+the line - the process then leaves through os._exit behind the printed line instead of waiting on a stream that
+will never drain.  `--transport stub` (a dress rehearsal, NEVER a measurement; the line says so): the ranks are
+processes that share GPU 0 and the exchange is the socket stand-in of tests/tools/fake_comm.py staged through
+host memory - everything around the collective (sharding, counts, double buffering, digests, this JSON line)
+then executes on a one-GPU box.
 
 Rank 0 prints ONE JSON line.  `value` = frames of all ranks per second of the slowest rank.
 `roofline` prices the dominant kernel against the 8 TB/s HBM peak with the algorithmic bytes of
@@ -64,6 +72,13 @@ def parse_args():
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
                     help='N > 1: weak = --utts utterances per GPU; strong = --utts utterances in all, dealt over '
                          'the ranks by shennong_amd.distributed.shard_utterances')
+    ap.add_argument('--transport', choices=('rccl', 'stub'), default='rccl',
+                    help='N > 1: rccl = one GPU per rank, RCCL over xGMI; stub = every rank on GPU 0, the exchange '
+                         'through tests/tools/fake_comm.py (rehearsal of the N > 1 code path on a one-GPU box; the '
+                         'line is labelled and is not a measurement)')
+    ap.add_argument('--comm-timeout', type=float, default=60.0,
+                    help='seconds any single wait on the transport may take (sockets, RCCL bootstrap, an enqueue); '
+                         'the gather region as a whole gets 30 s + twice its estimated duration')
     ap.add_argument('--stream-hours', type=float, default=125.0,
                     help='hours of audio of the streamed-pipeline leg (BASELINE config 5: 1 000 h / 8 GPUs = 125 h '
                          'per GPU; the 10 000 waves of the batch are reused round robin, 1 000 speakers)')
@@ -89,7 +104,7 @@ def make_batch(first_id, count, nsamples):
     import numpy as np
     from concurrent.futures import ProcessPoolExecutor
     from shennong_amd import synth
-    workers = max(1, min(effective_cores(), 16))
+    workers = max(1, min(effective_cores() // max(1, int(os.environ.get('WORLD_SIZE', '1'))), 16))
     chunk = (count + workers - 1) // workers
     jobs = [(first_id + i, min(chunk, count - i)) for i in range(0, count, chunk)]
     if workers == 1 or count < 64:
@@ -116,7 +131,7 @@ def make_batch_ids(ids, nsamples):
     """The utterances `ids` of the seeded corpus (a rank's shard of it), same generator as make_batch"""
     import numpy as np
     from concurrent.futures import ProcessPoolExecutor
-    workers = max(1, min(effective_cores(), 16))
+    workers = max(1, min(effective_cores() // max(1, int(os.environ.get('WORLD_SIZE', '1'))), 16))
     chunk = max(1, (len(ids) + workers - 1) // workers)
     jobs = [(list(ids[i:i + chunk]), nsamples) for i in range(0, len(ids), chunk)]
     if workers == 1 or len(ids) < 64:
@@ -199,6 +214,240 @@ def end_to_end(plan, waves, frames_per_utt, chunk=500, reps=3, n_streams=3):
                     'chunks overlap; PCIe-inclusive, never the headline value' % n_streams}
 
 
+# ---- N > 1: the one collective of the job, measured under a watchdog ------------------------------------------
+XGMI_LINK_GBPS = (153.0, 76.5)   # one xGMI link, GB/s: the figure quoted for MI355X (7 links x ~153 GB/s per GPU) and
+                                 # half of it (should that figure count both directions); the gather is priced at both
+
+
+class Watchdog:
+    """Calls that may depend on OTHER processes (RCCL's bootstrap, an enqueue into a transport whose peer died,
+    the end of a region with a collective in it) run on a thread that can be abandoned: ctypes releases the
+    interpreter lock, the caller waits `seconds` and no longer.  Once something has been abandoned the process
+    holds a thread - possibly a HIP stream - that will never finish: `stuck` tells the caller to leave through
+    os._exit when it has printed what it has."""
+    def __init__(self):
+        self.stuck = False
+
+    def call(self, fn, seconds, what):
+        import threading
+        box = {}
+
+        def target():
+            try:
+                box['value'] = fn()
+            except BaseException as exc:   # noqa: BLE001 (handed to the caller below)
+                box['error'] = exc
+        thread = threading.Thread(target=target, name='snf-bench-watch', daemon=True)
+        thread.start()
+        thread.join(seconds)
+        if thread.is_alive():
+            self.stuck = True
+            raise TimeoutError('%s did not finish within %.0f s' % (what, seconds))
+        if 'error' in box:
+            raise box['error']
+        return box.get('value')
+
+
+class Marks:
+    """pairs of HIP events (snf_event_*) around the passes of one timed region"""
+    def __init__(self, L, n):
+        import ctypes as C
+        from shennong_amd import _backend
+        self.L, self.pairs = L, []
+        for _ in range(n):
+            a, b = C.c_void_p(), C.c_void_p()
+            _backend.check(L.snf_event_create(C.byref(a)))
+            _backend.check(L.snf_event_create(C.byref(b)))
+            self.pairs.append((a, b))
+
+    def ms(self):
+        import ctypes as C
+        from shennong_amd import _backend
+        out, ms = [], C.c_float()
+        for a, b in self.pairs:
+            _backend.check(self.L.snf_event_elapsed_ms(a, b, C.byref(ms)))
+            out.append(float(ms.value))
+        return out
+
+    def free(self):
+        for a, b in self.pairs:
+            self.L.snf_event_destroy(a)
+            self.L.snf_event_destroy(b)
+
+
+def block_digest(block):
+    """(sum, xor) of the 32-bit patterns of a float32 block: what a rank says about the block it sent and what
+    the root finds where that block should have landed"""
+    import numpy as np
+    bits = np.ascontiguousarray(block).reshape(-1).view(np.uint32)
+    if bits.size == 0:
+        return [0, 0]
+    return [int(bits.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(bits))]
+
+
+def predicted_gather_ms(counts, kernel_ms, root=0):
+    """Per pass, from link arithmetic: every peer sends its block over its OWN xGMI link to the
+    root, the links run side by side, the exchange of pass k runs beside the kernel of pass k + 1 - a pass costs
+    max(kernel, largest peer block / link rate); the root's HBM takes the sum of the blocks at a small fraction
+    of its 8 TB/s.  One figure per assumed link rate."""
+    peer_bytes = max([4 * c for r, c in enumerate(counts) if r != root] or [0])
+    return {'%g_GBps_per_link' % bw: max(float(kernel_ms), peer_bytes / (bw * 1e9) * 1e3) for bw in XGMI_LINK_GBPS}
+
+
+def gather_leg(L, group, watch, run_pass, bufs, own_floats, stream, DeviceBuffer, steps, inner, warmup,
+               job_frames, kernel_ms, comm_timeout, download):
+    """`value_with_gather`: K steps in which every pass is followed by the gather of every rank's block to rank 0.
+
+    `group`: an RcclComm made with connect=False (its sockets are up); `run_pass(dst_ptr, stream)` enqueues one
+    pass of the hot path into a device block of `own_floats` floats; `bufs`: two such blocks (DeviceBuffer);
+    `download(DeviceBuffer, count) -> float32 array`.  Returns the `with_gather` object of the line: numbers, or
+    {'error': ...} - whatever happens in here (an exception, a transport that stalls: see Watchdog) the caller
+    keeps what it measured before."""
+    import ctypes as C
+    import numpy as np
+    from shennong_amd import _backend
+    rank, world = group.rank, group.world_size
+    check = _backend.check
+    d_all = cstream = None
+    events = []
+    try:
+        watch.call(group.connect, comm_timeout, 'RCCL bootstrap (ncclCommInitRank)')
+        counts = [int(c) for c in group.host_allreduce(
+            np.array([float(own_floats) if r == rank else 0.0 for r in range(world)]), 'sum')]
+        if rank == 0:
+            d_all = DeviceBuffer(max(sum(counts) * 4, 16))
+        cstream = C.c_void_p()
+        check(L.snf_stream_create(C.byref(cstream)))
+        for _ in range(4):
+            ev = C.c_void_p()
+            check(L.snf_event_create(C.byref(ev)))
+            events.append(ev)
+        ready, drained = events[:2], events[2:]
+        used = [False, False]
+
+        def enqueue(count, marks=None):
+            """`count` passes: kernel of pass k on the compute stream into buffer k mod 2 (once that buffer's last
+            exchange has drained), its exchange on the communication stream behind it - beside the next kernel"""
+            for k in range(count):
+                b = k & 1
+                if used[b]:
+                    check(L.snf_stream_wait_event(stream, drained[b]))
+                if marks is not None:
+                    L.snf_event_record(marks.pairs[k][0], stream)
+                run_pass(bufs[b].ptr, stream)
+                if marks is not None:
+                    L.snf_event_record(marks.pairs[k][1], stream)
+                check(L.snf_event_record(ready[b], stream))
+                check(L.snf_stream_wait_event(cstream, ready[b]))
+                group.gatherv_device(bufs[b].ptr, own_floats, d_all.ptr if d_all else None, counts, 0,
+                                     stream=cstream.value)
+                check(L.snf_event_record(drained[b], cstream))
+                used[b] = True
+
+        def drain(seconds, what):
+            """both streams empty, or TimeoutError: polled (snf_stream_query), never a blocking wait on work
+            that a peer may never complete"""
+            deadline = time.perf_counter() + seconds
+            for st in (stream, cstream):
+                while True:
+                    rc = L.snf_stream_query(st)
+                    if rc == 0:
+                        break
+                    if rc < 0:
+                        check(rc)
+                    if time.perf_counter() > deadline:
+                        watch.stuck = True
+                        raise TimeoutError('%s did not finish within %.0f s' % (what, seconds))
+                    time.sleep(0.0002)
+
+        def barrier():
+            check(L.snf_device_synchronize())
+            group.host_barrier()
+
+        # passes per step of THIS region: as many as the compute-only region when the exchange is cheap, fewer
+        # when it is not (7 x 477 MB per pass must not turn the run into minutes): two probe passes, the slowest
+        # rank's time, a region of about three seconds
+        def probe():
+            enqueue(1)
+            drain(comm_timeout, 'the first gather')
+            barrier()
+            t0 = time.perf_counter()
+            enqueue(2)
+            drain(comm_timeout, 'the probe gathers')
+            return (time.perf_counter() - t0) / 2
+        probe_s = watch.call(probe, 3 * comm_timeout, 'the probe passes of the gather')
+        probe_s = float(group.host_allreduce(np.array([probe_s]), 'max')[0])
+        g_inner = int(max(1, min(inner, 3.0 / (steps * max(probe_s, 1e-6)))))
+        budget = 30.0 + 2.0 * probe_s * g_inner * (steps + min(warmup, 2))
+
+        def region():
+            for _ in range(min(warmup, 2)):
+                enqueue(min(g_inner, 8))
+            drain(budget, 'the warm-up of the gather region')
+            marks = Marks(L, steps * g_inner)
+            barrier()
+            t0 = time.perf_counter()
+            enqueue(steps * g_inner, marks)
+            drain(budget, 'the gather region')
+            dt = time.perf_counter() - t0
+            ms = marks.ms()
+            marks.free()
+            return dt, ms
+        g_elapsed, g_kernel_ms = watch.call(region, budget + 10.0, 'the gather region')
+        g_elapsed = float(group.host_allreduce(np.array([g_elapsed]), 'max')[0])
+        out = {'value': job_frames * g_inner * steps / g_elapsed,
+               'ms_per_step': g_elapsed / steps * 1e3,
+               'ms_per_pass': g_elapsed / steps / g_inner * 1e3,
+               'passes_per_step': g_inner, 'probe_ms_per_pass': probe_s * 1e3,
+               'gather_bytes_per_pass_at_root': int(sum(counts) - counts[0]) * 4,
+               'kernel_ms': float(np.mean(g_kernel_ms)),
+               'predicted_ms': predicted_gather_ms(counts, kernel_ms),
+               'overlap': 'the exchange of pass k (own stream, two output buffers) runs beside the kernel of pass k + 1',
+               'rccl_ranks_seen': group.ranks_seen()}
+        # what arrived: EVERY rank's block, whole - each rank digests the block it sent (the two buffers hold the
+        # same features), the root digests what lies where that block should have landed
+        digests = group.all_gather_object(block_digest(download(bufs[(steps * g_inner - 1) & 1], own_floats)))
+        if rank == 0:
+            got = download(d_all, sum(counts))
+            found, pos = [], 0
+            for r in range(world):
+                found.append(block_digest(got[pos:pos + counts[r]]))
+                pos += counts[r]
+            out['gathered_blocks_ok'] = bool(found == [list(d) for d in digests])
+            out['gathered_blocks_checked'] = world
+        return out
+    except BaseException as exc:   # noqa: BLE001 (the compute-only value must not be lost with the collective)
+        if isinstance(exc, (KeyboardInterrupt, SystemExit)):
+            raise
+        return {'error': '%s: %s' % (type(exc).__name__, exc), 'watchdog_abandoned_a_call': watch.stuck}
+    finally:
+        if not watch.stuck:   # (a stream that never drains is not waited for, its buffers are not given back)
+            for ev in events:
+                L.snf_event_destroy(ev)
+            if cstream is not None:
+                L.snf_stream_destroy(cstream)
+            if d_all is not None:
+                d_all.free()
+
+
+def finish(line, watch, comm):
+    """Rank 0 prints THE line; then every rank leaves - orderly when nothing was abandoned, through os._exit
+    when the watchdog gave up on a call into the transport: a thread, possibly a HIP stream, of this process
+    will then never finish, and neither would the interpreter's or the HIP runtime's shutdown behind it"""
+    if line is not None:
+        print(json.dumps(line), flush=True)
+    if watch.stuck:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
+    if comm is not None:
+        try:
+            comm.host_barrier()   # (nobody closes the sockets under a peer that is still reading them)
+        except Exception:  # noqa: BLE001 (a peer that left through the watchdog's exit)
+            pass
+        comm.close()
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -212,11 +461,19 @@ def main():
 
     if _backend.device_count() < 1:
         raise SystemExit('bench.py needs an MI355X: no HIP device visible')
-    _backend.set_device(local_rank)
+    stub = args.transport == 'stub'
+    device = 0 if stub else local_rank   # (stub: a rehearsal, every rank is a process on GPU 0)
+    _backend.set_device(device)
     comm = None
+    watch = Watchdog()
     if world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ:  # launched by torch.distributed.run
+        if stub:
+            sys.path.insert(0, os.path.join(ROOT, 'tests', 'tools'))
+            import fake_comm
+            fake_comm.install(device=True)
         from shennong_amd.comm import RcclComm
-        comm = RcclComm.from_env(device=local_rank)
+        # the sockets only: RCCL itself is brought up by the gather leg, last and under the watchdog
+        comm = RcclComm.from_env(device=device, connect=False, timeout=args.comm_timeout)
 
     nsamples = int(args.seconds * 16000)
     if args.scaling == 'strong' and world > 1:
@@ -242,9 +499,10 @@ def main():
     d_out = _backend.DeviceBuffer(total_frames * 40 * 4)
 
     def sync_all():
+        # (the barrier goes over the rendezvous sockets, not over RCCL: see the module docstring)
         _backend.check(_backend.lib().snf_device_synchronize())
         if comm is not None:
-            comm.barrier()
+            comm.host_barrier()
             _backend.check(_backend.lib().snf_device_synchronize())
 
     inner = max(1, args.inner)
@@ -257,44 +515,20 @@ def main():
     stream = C.c_void_p()
     _backend.check(L.snf_stream_create(C.byref(stream)))
 
-    class Marks:
-        """pairs of HIP events (snf_event_*) around the passes of one timed region"""
-        def __init__(self, n):
-            self.pairs = []
-            for _ in range(n):
-                a, b = C.c_void_p(), C.c_void_p()
-                _backend.check(L.snf_event_create(C.byref(a)))
-                _backend.check(L.snf_event_create(C.byref(b)))
-                self.pairs.append((a, b))
-
-        def ms(self):
-            out, ms = [], C.c_float()
-            for a, b in self.pairs:
-                _backend.check(L.snf_event_elapsed_ms(a, b, C.byref(ms)))
-                out.append(float(ms.value))
-            return out
-
-        def free(self):
-            for a, b in self.pairs:
-                L.snf_event_destroy(a)
-                L.snf_event_destroy(b)
-
-    def timed_region(p, d_dst, gather=None, passes=None):
-        """K steps of `passes` (default `inner`) passes of plan `p` between two synchronisations -> (seconds,
-        kernel ms of every pass); `gather(d_dst)` is enqueued on the same stream behind every pass when given"""
-        marks = Marks(args.steps * (passes or inner))
+    def timed_region(p, d_dst):
+        """K steps of `inner` passes of plan `p` between two barriers + synchronisations -> (seconds of the
+        slowest rank, kernel ms of every pass)"""
+        marks = Marks(L, args.steps * inner)
         sync_all()
         t0 = time.perf_counter()
         for a, b in marks.pairs:
             L.snf_event_record(a, stream)
             p.run_device(d_wave.ptr, soff, foff, d_dst.ptr, stream=stream.value)
             L.snf_event_record(b, stream)
-            if gather is not None:
-                gather(d_dst)
         _backend.check(L.snf_stream_synchronize(stream))
         dt = time.perf_counter() - t0
         if comm is not None:
-            dt = float(comm.allreduce(np.array([dt]), 'max')[0])
+            dt = float(comm.host_allreduce(np.array([dt]), 'max')[0])
         sync_all()
         ms = marks.ms()
         marks.free()
@@ -317,70 +551,9 @@ def main():
     # frames of the whole job per pass: N x 10 000 utterances (weak) or the one corpus (strong)
     job_frames = total_frames * world
     if comm is not None and world > 1:
-        job_frames = int(comm.allreduce(np.array([float(total_frames)]), 'sum')[0])
+        job_frames = int(comm.host_allreduce(np.array([float(total_frames)]), 'sum')[0])
     value = job_frames * inner * args.steps / elapsed
     kms = float(np.mean(kernel_ms))
-
-    # ---- the same K steps with the job's ONE collective inside the timed region:
-    # behind every pass, on the compute stream, the gather of every rank's [frames, 40] block to rank 0
-    # (snf_comm_gatherv: ncclSend / ncclRecv pairs, every peer over its own xGMI link) ----
-    gathered = None
-    if comm is not None:
-        counts = [int(c) for c in comm.allreduce(
-            np.array([float(total_frames * 40) if r == rank else 0.0 for r in range(world)]), 'sum')]
-        d_all = _backend.DeviceBuffer(max(sum(counts) * 4, 16)) if rank == 0 else None
-
-        def gather(d_src):
-            comm.gatherv_device(d_src.ptr, total_frames * 40, d_all.ptr if d_all else None, counts, 0,
-                                stream=stream.value)
-        try:
-            # passes per step of THIS region: as many as the compute-only region when the exchange is cheap, fewer
-            # when it is not (a gather of 7 x 477 MB per pass at a fraction of the xGMI rate must not turn the run
-            # into minutes): two probe passes, the slowest rank's time, a region of about three seconds
-            def passes_with_gather(count):
-                for _ in range(count):
-                    plan.run_device(d_wave.ptr, soff, foff, d_out.ptr, stream=stream.value)
-                    gather(d_out)
-                _backend.check(L.snf_stream_synchronize(stream))
-            passes_with_gather(1)
-            sync_all()
-            t0 = time.perf_counter()
-            passes_with_gather(2)
-            probe = (time.perf_counter() - t0) / 2
-            probe = float(comm.allreduce(np.array([probe]), 'max')[0])
-            g_inner = int(max(1, min(inner, 3.0 / (args.steps * max(probe, 1e-6)))))
-            for _ in range(min(args.warmup, 2)):
-                passes_with_gather(min(g_inner, 8))
-            g_elapsed, g_kernel_ms = timed_region(plan, d_out, gather=gather, passes=g_inner)
-            gathered = {'value': job_frames * g_inner * args.steps / g_elapsed,
-                        'ms_per_step': g_elapsed / args.steps * 1e3,
-                        'ms_per_pass': g_elapsed / args.steps / g_inner * 1e3,
-                        'passes_per_step': g_inner, 'probe_ms_per_pass': probe * 1e3,
-                        'gather_bytes_per_pass_at_root': int(sum(counts) - counts[0]) * 4,
-                        'kernel_ms': float(np.mean(g_kernel_ms)),
-                        'rccl_ranks_seen': comm.ranks_seen()}
-            if d_all is not None:
-                # what arrived: the root's own block unchanged, and (N > 1) the last peer's block is what that
-                # peer computed - its first rows, sent over the rendezvous sockets, compared on the root
-                mine = np.empty((2, 40), dtype=np.float32)
-                d_out.download(mine)
-                # (plain lists of Python floats: the rendezvous sockets accept plain data only)
-                heads = comm.all_gather_object(mine.tolist()) if world > 1 else [mine.tolist()]
-                got_all = np.empty((sum(counts) // 40, 40), dtype=np.float32)
-                d_all.download(got_all)
-                ok, pos = True, 0
-                for r in range(world):
-                    ok = ok and bool(np.array_equal(got_all[pos:pos + 2], np.asarray(heads[r], dtype=np.float32)))
-                    pos += counts[r] // 40
-                gathered['gathered_blocks_ok'] = ok
-            elif world > 1:
-                mine = np.empty((2, 40), dtype=np.float32)
-                d_out.download(mine)
-                comm.all_gather_object(mine.tolist())
-        except Exception as exc:   # (whatever goes wrong here, the compute-only value must not be lost with it)
-            gathered = {'error': '%s: %s' % (type(exc).__name__, exc)}
-        if d_all is not None:
-            d_all.free()
 
     # ---- the other half of the metric: MfccProcessor() (13 cepstra) over the same batch, timed the same
     # way right behind the fbank-40 steps (the same K steps between the same barriers) -----------------
@@ -703,6 +876,25 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
 
+    # ---- the same K steps with the job's ONE collective inside the timed region: behind every pass the gather
+    # of every rank's [frames, 40] block to rank 0 (snf_comm_gatherv: ncclSend / ncclRecv pairs, every peer over
+    # its own xGMI link).  LAST, under the watchdog: nothing above depends on the transport ----
+    gathered = None
+    if comm is not None:
+        d_out2 = _backend.DeviceBuffer(total_frames * 40 * 4)
+
+        def download(buf, count):
+            host = np.empty(int(count), dtype=np.float32)
+            if host.size:
+                buf.download(host)
+            return host
+        gathered = gather_leg(
+            L, comm, watch, lambda dst, st: plan.run_device(d_wave.ptr, soff, foff, dst, stream=st.value),
+            [d_out, d_out2], total_frames * 40, stream, _backend.DeviceBuffer, args.steps, inner, args.warmup,
+            job_frames, kms, args.comm_timeout, download)
+        if stub:
+            gathered['transport'] = 'stub'
+
     if rank == 0:
         line = {
             'metric': METRIC, 'value': value, 'value_mfcc13': value_mfcc13, 'unit': 'frames/s', 'n_gpus': world,
@@ -725,8 +917,8 @@ def main():
                             '*_device calls), one synchronisation at its end; a pair of HIP events around '
                             'every pass gives roofline.kernel_ms' % inner,
                 'parallelism': 'utterance-sharded x%d, no data-path collective in `value`; `value_with_gather` '
-                               'adds the gather of every Features block to rank 0 behind every pass' % world,
-                'device': _backend.device_name(local_rank)},
+                               'adds the gather of every Features block to rank 0 behind every pass (own stream, two buffers)' % world,
+                'device': _backend.device_name(device)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_note': traffic_note, 'valu': valu,
@@ -740,10 +932,12 @@ def main():
                 'algorithmic_bytes_per_frame': BYTES_PER_FRAME['mfcc13']},
             'cpu_baseline': cpu,
             'extra': extra}
-        print(json.dumps(line))
-    if comm is not None:
-        comm.barrier()
-        comm.close()
+        if stub:
+            # a dress rehearsal: N processes time-slice ONE GPU and the exchange crosses PCIe twice and a socket
+            line['transport'] = ('stub: %d processes share GPU 0, snf_comm_* replaced by the host-staged socket '
+                                 'stand-in of tests/tools/fake_comm.py' % world)
+            line['not_a_measurement'] = True
+    finish(line if rank == 0 else None, watch, comm)
 
 
 if __name__ == '__main__':

@@ -350,6 +350,11 @@ int snf_memset(void* dst, int value, uint64_t bytes);  /* complete when it retur
 int snf_stream_create(void** stream);
 int snf_stream_destroy(void* stream);
 int snf_stream_synchronize(void* stream);
+/* 0 = everything enqueued on `stream` has completed, 1 = not yet (hipStreamQuery; never waits), < 0 = error.
+   A host that must not wait for ever on work that depends on OTHER processes - the exchange steps below: a
+   peer that died or stalled never completes them - polls this against a deadline instead of synchronising
+   (bench.py's watchdog).  No counterpart in the reference (its pool is one process). */
+int snf_stream_query(void* stream);
 int snf_memcpy_h2d_async(void* dst, const void* src, uint64_t bytes, void* stream);
 int snf_memcpy_d2h_async(void* dst, const void* src, uint64_t bytes, void* stream);
 /* Timing marks on a caller's stream (hipEvent_t behind a plain pointer): a caller that enqueues several

@@ -39,7 +39,7 @@ EXPORTS = [
     'snf_comm_destroy', 'snf_comm_gatherv', 'snf_comm_allreduce_f64',
     'snf_plan_last_kernel_ms', 'snf_plan_kernel_name', 'snf_set_oom_hook',
     'snf_event_create', 'snf_event_destroy', 'snf_event_record', 'snf_event_elapsed_ms', 'snf_mem_info',
-    'snf_stream_wait_event']
+    'snf_stream_wait_event', 'snf_stream_query']
 
 
 _OOM_HOOK_TYPE = C.CFUNCTYPE(None)
@@ -127,6 +127,7 @@ def lib():
         L.snf_stream_create.argtypes = [C.POINTER(vp)]
         L.snf_stream_destroy.argtypes = [vp]
         L.snf_stream_synchronize.argtypes = [vp]
+        L.snf_stream_query.argtypes = [vp]
         L.snf_memcpy_h2d_async.argtypes = [vp, vp, C.c_uint64, vp]
         L.snf_event_create.argtypes = [C.POINTER(vp)]
         L.snf_event_destroy.argtypes = [vp]

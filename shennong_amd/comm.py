@@ -105,7 +105,13 @@ def _loads(payload):
 
 class RcclComm:
     """Communicator of `world_size` processes, one GPU each"""
-    def __init__(self, rank, world_size, device=None, addr='127.0.0.1', port=29500, timeout=120.0):
+    def __init__(self, rank, world_size, device=None, addr='127.0.0.1', port=29500, timeout=120.0,
+                 connect=True):
+        """`timeout` bounds every wait on the rendezvous sockets (a peer that died shows up as an error after
+        that long, not as a hang).  With `connect` false only the sockets are opened - the host-side collectives
+        (:func:`all_gather_object`, :func:`host_allreduce`, :func:`host_barrier`) work, the RCCL communicator is
+        made later by :func:`connect` - so that a caller can bound the time RCCL's own bootstrap may take and
+        still hold results that never needed it (bench.py)."""
         self.rank, self.world_size = int(rank), int(world_size)
         self.device = _backend.get_device() if device is None else int(device)
         self._peers = {}     # rank 0: rank -> socket; others: {0: socket}
@@ -114,7 +120,8 @@ class RcclComm:
         lib = _backend.lib()
         ident = (C.c_char * 128)()
         if self.rank == 0:
-            _backend.check(lib.snf_comm_unique_id(ident))
+            if connect:
+                _backend.check(lib.snf_comm_unique_id(ident))
             if self.world_size > 1:
                 server = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
                 server.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
@@ -139,8 +146,9 @@ class RcclComm:
                         continue
                     self._peers[peer] = conn
                 server.close()
-                for conn in self._peers.values():
-                    _send_msg(conn, bytes(ident), self._key)
+                if connect:
+                    for conn in self._peers.values():
+                        _send_msg(conn, bytes(ident), self._key)
         else:
             deadline = time.time() + timeout
             while True:
@@ -153,20 +161,40 @@ class RcclComm:
                     time.sleep(0.05)
             conn.settimeout(timeout)
             _send_msg(conn, _HELLO.pack(_MAGIC, self.rank), self._key)
-            C.memmove(ident, _recv_msg(conn, self._key, limit=128), 128)
+            if connect:
+                C.memmove(ident, _recv_msg(conn, self._key, limit=128), 128)
             self._peers[0] = conn
+        if connect:
+            _backend.check(lib.snf_comm_init(ident, self.world_size, self.rank, self.device,
+                                             C.byref(self._handle)))
+
+    def connect(self):
+        """Makes the RCCL communicator of a ``connect=False`` instance: rank 0 draws the unique id, the sockets
+        carry it to the peers, every rank joins (ncclCommInitRank blocks until all have; a caller that must not
+        wait for ever runs this on a thread it can abandon)"""
+        if self._handle:
+            return self
+        lib = _backend.lib()
+        ident = (C.c_char * 128)()
+        if self.rank == 0:
+            _backend.check(lib.snf_comm_unique_id(ident))
+            for conn in self._peers.values():
+                _send_msg(conn, bytes(ident), self._key)
+        else:
+            C.memmove(ident, _recv_msg(self._peers[0], self._key, limit=128), 128)
         _backend.check(lib.snf_comm_init(ident, self.world_size, self.rank, self.device,
                                          C.byref(self._handle)))
+        return self
 
     @classmethod
-    def from_env(cls, device=None):
+    def from_env(cls, device=None, **kwargs):
         """Communicator described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT"""
         rank = int(os.environ.get('RANK', '0'))
         local = int(os.environ.get('LOCAL_RANK', str(rank)))
         return cls(rank, int(os.environ.get('WORLD_SIZE', '1')),
                    device=local if device is None else device,
                    addr=os.environ.get('MASTER_ADDR', '127.0.0.1'),
-                   port=rendezvous_port(int(os.environ.get('MASTER_PORT', '29500'))))
+                   port=rendezvous_port(int(os.environ.get('MASTER_PORT', '29500'))), **kwargs)
 
     def close(self):
         if self._handle:
@@ -197,6 +225,21 @@ class RcclComm:
             return objs
         _send_msg(self._peers[0], pickle.dumps(obj), self._key)
         return _loads(_recv_msg(self._peers[0], self._key))
+
+    def host_allreduce(self, array, op='sum'):
+        """:func:`allreduce` over the rendezvous sockets instead of RCCL, applied in rank order: the barrier
+        and the max-over-ranks of a timed region that must not depend on the transport it is about to measure
+        (a stalled RCCL then costs the exchange's numbers, not the compute-only ones)"""
+        host = np.ascontiguousarray(array, dtype=np.float64)
+        parts = self.all_gather_object(host.tolist())
+        total = np.asarray(parts[0], dtype=np.float64)
+        for part in parts[1:]:
+            part = np.asarray(part, dtype=np.float64)
+            total = total + part if op == 'sum' else np.maximum(total, part)
+        return total.reshape(host.shape)
+
+    def host_barrier(self):
+        self.all_gather_object(None)
 
     # ---- device data over RCCL -------------------------------------------------------------------------
     def gatherv_device(self, d_send, send_count, d_recv, recv_counts, root=0, stream=None):

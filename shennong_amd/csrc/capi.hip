@@ -1637,6 +1637,15 @@ int snf_stream_synchronize(void* stream) {
   SNF_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   return SNF_OK;
 }
+int snf_stream_query(void* stream) {
+  const hipError_t e = hipStreamQuery(static_cast<hipStream_t>(stream));
+  if (e == hipSuccess) return 0;
+  if (e == hipErrorNotReady) {
+    (void)hipGetLastError();   // (not an error: nothing to leave behind for the next call's check)
+    return 1;
+  }
+  return set_error(SNF_E_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+}
 int snf_event_create(void** event) {
   if (!event) return set_error(SNF_E_INVALID, "null pointer");
   hipEvent_t e;

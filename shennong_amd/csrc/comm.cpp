@@ -159,19 +159,27 @@ int snf_comm_gatherv(snf_comm* c, const float* d_send, int64_t send_count, float
     if (!recv_counts || (!d_recv && send_count > 0)) return snf::set_error(SNF_E_INVALID, "null receive buffer");
     if (recv_counts[root] != send_count)
       return snf::set_error(SNF_E_INVALID, "recv_counts[root] differs from the root's send_count");
+    for (int peer = 0; peer < c->world; ++peer)
+      if (recv_counts[peer] < 0) return snf::set_error(SNF_E_INVALID, "negative receive count");
+    // (no return between GroupStart and GroupEnd: a group left open would swallow every later call on this
+    // thread; the first failure is kept and reported after the group has been closed)
     int64_t offset = 0;
+    ncclResult_t failed = ncclSuccess;
+    const char* where = "ncclRecv";
     SNF_NCCL_CHECK(r->GroupStart());
-    for (int peer = 0; peer < c->world; ++peer) {
+    for (int peer = 0; peer < c->world && failed == ncclSuccess; ++peer) {
       const int64_t n = recv_counts[peer];
-      if (n < 0) {
-        (void)r->GroupEnd();
-        return snf::set_error(SNF_E_INVALID, "negative receive count");
-      }
       if (peer != root && n > 0)
-        SNF_NCCL_CHECK(r->Recv(d_recv + offset, static_cast<size_t>(n), ncclFloat32, peer, c->comm, s));
+        failed = r->Recv(d_recv + offset, static_cast<size_t>(n), ncclFloat32, peer, c->comm, s);
       offset += n;
     }
-    SNF_NCCL_CHECK(r->GroupEnd());
+    const ncclResult_t closed = r->GroupEnd();
+    if (failed == ncclSuccess && closed != ncclSuccess) {
+      failed = closed;
+      where = "ncclGroupEnd";
+    }
+    if (failed != ncclSuccess)
+      return snf::set_error(SNF_E_RUNTIME, std::string(where) + " (gather, root): " + r->GetErrorString(failed));
     int64_t own = 0;
     for (int peer = 0; peer < root; ++peer) own += recv_counts[peer];
     if (send_count > 0 && d_recv + own != d_send)
@@ -179,8 +187,15 @@ int snf_comm_gatherv(snf_comm* c, const float* d_send, int64_t send_count, float
                                    hipMemcpyDeviceToDevice, s));
   } else if (send_count > 0) {
     SNF_NCCL_CHECK(r->GroupStart());
-    SNF_NCCL_CHECK(r->Send(d_send, static_cast<size_t>(send_count), ncclFloat32, root, c->comm, s));
-    SNF_NCCL_CHECK(r->GroupEnd());
+    ncclResult_t failed = r->Send(d_send, static_cast<size_t>(send_count), ncclFloat32, root, c->comm, s);
+    const char* where = "ncclSend";
+    const ncclResult_t closed = r->GroupEnd();
+    if (failed == ncclSuccess && closed != ncclSuccess) {
+      failed = closed;
+      where = "ncclGroupEnd";
+    }
+    if (failed != ncclSuccess)
+      return snf::set_error(SNF_E_RUNTIME, std::string(where) + " (gather, peer): " + r->GetErrorString(failed));
   }
   if (!stream) SNF_HIP_CHECK(hipStreamSynchronize(s));
   return SNF_OK;

@@ -601,3 +601,86 @@ def test_rccl_two_ranks(tmp_path):
         p.join(240)
     assert [p.exitcode for p in procs] == [0, 0]
     assert [open(tmp_path / f'ok{r}').read() for r in range(2)] == ['1', '1']
+
+
+def _gather_leg_worker(kind, rank, world, port, tmpdir):
+    """one rank of bench.py's gather leg on CPU: the socket stand-in in host mode, a 'hot path' that fills its
+    block with rank-dependent numbers; kind 'hang': the second gather of rank 1 never returns"""
+    for path in (ROOT, TOOLS):
+        if path not in sys.path:
+            sys.path.insert(0, path)
+    import json
+    import ctypes as C
+    import numpy as np
+    import fake_comm
+    import bench
+    from shennong_amd import _backend
+    from shennong_amd.comm import RcclComm
+    lib = fake_comm.install(hang_after=1 if kind == 'hang' and rank == 1 else None)
+    sys.stdout = open(os.path.join(tmpdir, f'stdout{rank}'), 'w')
+    group = RcclComm(rank, world, device=0, port=port, timeout=4.0, connect=False)
+    own = 1000 + 24 * rank    # (ragged blocks, as under --scaling strong)
+    bufs = [_backend.DeviceBuffer(4 * own), _backend.DeviceBuffer(4 * own)]
+    block = (np.arange(own, dtype=np.float32) + 1000.0 * rank)
+
+    def run_pass(dst, stream):
+        C.memmove(dst, block.ctypes.data, block.nbytes)
+
+    def download(buf, count):
+        return np.frombuffer(C.string_at(buf.ptr, 4 * int(count)), dtype=np.float32).copy()
+    stream = C.c_void_p()
+    lib.snf_stream_create(C.byref(stream))
+    watch = bench.Watchdog()
+    out = bench.gather_leg(lib, group, watch, run_pass, bufs, own, stream, _backend.DeviceBuffer, steps=3, inner=4,
+                           warmup=1, job_frames=123456.0, kernel_ms=0.9, comm_timeout=1.5, download=download)
+    open(os.path.join(tmpdir, f'out{rank}'), 'w').write(json.dumps([out, watch.stuck]))
+    line = {'metric': 'x', 'value': 1.0, 'with_gather': out} if rank == 0 else None
+    bench.finish(line, watch, group)
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize('kind', ['fine', 'hang'])
+def test_bench_gather_leg_and_watchdog(tmp_path, kind):
+    """bench.py's gather leg (own stream, two buffers, counts over the sockets, EVERY rank's
+    block verified by digest) at world size 2 on CPU - and the same with a transport that stalls: the leg comes
+    back with an error inside its bound on both ranks, rank 0 still prints its line, and both processes exit
+    although each holds a thread that will never finish"""
+    import json
+    import time
+    t0 = time.time()
+    results = [json.loads(r) for r in _run_pair(_gather_leg_worker, kind, tmp_path)]
+    line = json.loads(open(tmp_path / 'stdout0').read())
+    assert open(tmp_path / 'stdout1').read() == ''
+    assert line['value'] == 1.0
+    if kind == 'fine':
+        for out, stuck in results:
+            assert not stuck and 'error' not in out, out
+            assert out['passes_per_step'] == 4 and out['rccl_ranks_seen'] == 2
+            assert out['gather_bytes_per_pass_at_root'] == 4 * 1024
+            assert set(out['predicted_ms']) == {'153_GBps_per_link', '76.5_GBps_per_link'}
+        assert results[0][0]['gathered_blocks_ok'] is True and results[0][0]['gathered_blocks_checked'] == 2
+        assert line['with_gather']['gathered_blocks_ok'] is True
+    else:
+        assert time.time() - t0 < 60
+        for out, stuck in results:
+            assert stuck and 'did not finish within' in out['error'], out
+        assert 'TimeoutError' in line['with_gather']['error']
+
+
+def test_bench_digest_and_prediction():
+    for path in (ROOT, TOOLS):
+        if path not in sys.path:
+            sys.path.insert(0, path)
+    import numpy as np
+    import bench
+    a = np.arange(12, dtype=np.float32)
+    assert bench.block_digest(a) == bench.block_digest(a.reshape(3, 4)) != bench.block_digest(a[::-1].copy())[:1] + [0]
+    assert bench.block_digest(a[:0]) == [0, 0]
+    b = a.copy()
+    b[5] = np.nextafter(b[5], np.float32(100))
+    assert bench.block_digest(a) != bench.block_digest(b)
+    # 8 ranks x 2 980 000 x 40 floats: 476.8 MB per peer = 3.12 ms at 153 GB/s, above the 0.93 ms kernel
+    counts = [2980000 * 40] * 8
+    pred = bench.predicted_gather_ms(counts, 0.93)
+    assert abs(pred['153_GBps_per_link'] - 3.116) < 0.01 and abs(pred['76.5_GBps_per_link'] - 6.233) < 0.01
+    assert bench.predicted_gather_ms([100, 100], 0.93)['153_GBps_per_link'] == 0.93

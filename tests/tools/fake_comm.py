@@ -3,7 +3,12 @@ and for ``_backend.DeviceBuffer``, so that the REAL ``shennong_amd.comm.RcclComm
 broadcast of the unique id, the object all-gather, ``gather_features`` with its counts and offsets, the
 float64 all-reduce, the barrier - runs in two or more processes on a box without GPUs.
 
-"Device" pointers are host addresses.  The exchange runs over TCP connections to rank 0 whose port travels
+"Device" pointers are host addresses - or, with ``install(device=True)`` on a box that HAS a GPU, real device
+pointers that the stand-in stages through host memory (snf_memcpy_*): bench.py's ``--transport stub`` runs 2 / 4 /
+8 ranks as processes that share ONE GPU this way, so that everything around the exchange - sharding, counts,
+offsets, double buffering, the JSON line - executes on hardware before a node with several GPUs is available.
+Never a measurement: the blocks cross PCIe twice and a socket in between.  ``hang_after`` (tests): the n-th gather
+of this process never returns - what a stalled peer looks like to the caller.  The exchange runs over TCP connections to rank 0 whose port travels
 INSIDE the 128-byte unique id: a rank can only join if the id that rank 0 made reached it through
 RcclComm's own rendezvous, as with ncclGetUniqueId / ncclCommInitRank.  The semantics restate
 shennong_amd/csrc/comm.cpp (argument checks, the root's receive offsets = prefix sums of recv_counts in
@@ -51,12 +56,41 @@ class _Comm:
 
 class FakeCommLib:
     """Wraps the loaded library: everything except the communicator entry points goes to the real one"""
-    def __init__(self, real):
+    def __init__(self, real, device=False, hang_after=None):
         self._real = real
+        self._device = bool(device)
+        self._hang_after = hang_after
+        self._gathers = 0
         self._server = None
         self._comms = {}
         self._error = b''
         self.calls = []     # (name, details): what the communicator class asked for, for assertions
+
+    # ---- where the blocks live ---------------------------------------------------------------------------
+    def _fetch(self, ptr, nbytes, stream=None):
+        """bytes of a block; device mode: behind everything enqueued on `stream` (the kernel that makes it)"""
+        if nbytes <= 0:
+            return b''
+        if not self._device:
+            return C.string_at(ptr, nbytes)
+        if stream is not None and _value(stream):
+            self._real.snf_stream_synchronize(C.c_void_p(_value(stream)))
+        else:
+            self._real.snf_device_synchronize()
+        host = np.empty(nbytes, dtype=np.uint8)
+        if self._real.snf_memcpy_d2h(C.c_void_p(host.ctypes.data), C.c_void_p(ptr), nbytes) != 0:
+            raise RuntimeError(self._real.snf_last_error().decode())
+        return host.tobytes()
+
+    def _store(self, ptr, data):
+        if not data:
+            return
+        if not self._device:
+            C.memmove(ptr, data, len(data))
+            return
+        host = np.frombuffer(data, dtype=np.uint8)
+        if self._real.snf_memcpy_h2d(C.c_void_p(ptr), C.c_void_p(host.ctypes.data), len(data)) != 0:
+            raise RuntimeError(self._real.snf_last_error().decode())
 
     def __getattr__(self, name):
         return getattr(self._real, name)
@@ -69,9 +103,41 @@ class FakeCommLib:
         return self._error or self._real.snf_last_error()
 
     def snf_device_synchronize(self):
-        return _abi.SNF_OK
+        return self._real.snf_device_synchronize() if self._device else _abi.SNF_OK
 
     def snf_set_device(self, device_id):
+        return self._real.snf_set_device(device_id) if self._device else _abi.SNF_OK
+
+    # ---- streams and events without a device (host mode): every enqueue of the stand-in completes before it
+    # returns, so a stream is always drained and an event has always happened ------------------------------------
+    def _handle_out(self, out):
+        self._handles = getattr(self, '_handles', 0) + 1
+        out._obj.value = 0x57AE0000 + self._handles
+        return _abi.SNF_OK
+
+    def snf_stream_create(self, out):
+        return self._real.snf_stream_create(out) if self._device else self._handle_out(out)
+
+    def snf_event_create(self, out):
+        return self._real.snf_event_create(out) if self._device else self._handle_out(out)
+
+    def _noop(name, result=_abi.SNF_OK):   # noqa: N805 (a method factory, evaluated in the class body)
+        def method(self, *args):
+            return getattr(self._real, name)(*args) if self._device else result
+        method.__name__ = name
+        return method
+    snf_stream_destroy = _noop('snf_stream_destroy')
+    snf_stream_synchronize = _noop('snf_stream_synchronize')
+    snf_stream_query = _noop('snf_stream_query', 0)
+    snf_stream_wait_event = _noop('snf_stream_wait_event')
+    snf_event_destroy = _noop('snf_event_destroy')
+    snf_event_record = _noop('snf_event_record')
+    del _noop
+
+    def snf_event_elapsed_ms(self, start, stop, ms):
+        if self._device:
+            return self._real.snf_event_elapsed_ms(start, stop, ms)
+        ms._obj.value = 0.0
         return _abi.SNF_OK
 
     # ---- the communicator ------------------------------------------------------------------------------
@@ -143,7 +209,11 @@ class FakeCommLib:
                 return self._fail(_abi.SNF_E_INVALID, "recv_counts[root] differs from the root's send_count")
             if any(n < 0 for n in counts):
                 return self._fail(_abi.SNF_E_INVALID, 'negative receive count')
-        mine = C.string_at(send, 4 * send_count) if send_count > 0 else b''
+        self._gathers += 1
+        if self._hang_after is not None and self._gathers > self._hang_after:
+            import threading
+            threading.Event().wait()   # (a stalled transport: this call never comes back)
+        mine = self._fetch(send, 4 * send_count, stream)
         # the sockets form a star around rank 0: blocks travel peer -> rank 0 (-> root)
         blocks = None
         if comm.rank == 0:
@@ -171,7 +241,7 @@ class FakeCommLib:
                     return self._fail(_abi.SNF_E_RUNTIME, 'peer %d sends %d floats, root expects %d'
                                       % (peer, len(blocks[peer]) // 4, n))
                 if n > 0 and not (peer == root and recv + 4 * offset == send):
-                    C.memmove(recv + 4 * offset, blocks[peer], 4 * n)
+                    self._store(recv + 4 * offset, blocks[peer])
                 offset += n
             self.calls.append(('gatherv', 'root', counts))
         else:
@@ -188,7 +258,7 @@ class FakeCommLib:
         if count == 0 or comm.world == 1:
             return _abi.SNF_OK
         buf = _value(d_buf)
-        mine = np.frombuffer(C.string_at(buf, 8 * count), dtype=np.float64).copy()
+        mine = np.frombuffer(self._fetch(buf, 8 * count, stream), dtype=np.float64).copy()
         if comm.rank == 0:
             total = mine
             for peer in range(1, comm.world):     # rank order: the result does not depend on arrival order
@@ -203,7 +273,7 @@ class FakeCommLib:
         else:
             comm.peers[0].sendall(struct.pack('<qi', count, op) + mine.tobytes())
             total = np.frombuffer(_read(comm.peers[0], 8 * count), dtype=np.float64)
-        C.memmove(buf, total.tobytes(), 8 * count)
+        self._store(buf, total.tobytes())
         return _abi.SNF_OK
 
 
@@ -227,11 +297,13 @@ class HostBuffer:
         self.ptr = None
 
 
-def install():
-    """Routes ``_backend.lib()`` through the stand-in and ``_backend.DeviceBuffer`` to host memory in THIS
-    process (a test worker); returns the FakeCommLib (its ``calls`` record what the communicator asked for)"""
+def install(device=False, hang_after=None):
+    """Routes ``_backend.lib()`` through the stand-in in THIS process (a test worker, a rank of bench.py
+    --transport stub) and, unless `device`, ``_backend.DeviceBuffer`` to host memory; returns the FakeCommLib (its
+    ``calls`` record what the communicator asked for)"""
     from shennong_amd import _backend
-    fake = FakeCommLib(_backend.lib())
+    fake = FakeCommLib(_backend.lib(), device=device, hang_after=hang_after)
     _backend._LIB = fake
-    _backend.DeviceBuffer = HostBuffer
+    if not device:
+        _backend.DeviceBuffer = HostBuffer
     return fake
