@@ -740,31 +740,65 @@ def main():
         audios = [Audio(waves[i], 16000, validate=False) for i in range(n_utts)]
         index2 = Utterances([(f'u{i:06d}', audios[i % n_utts], f's{i % 1000:04d}') for i in range(n5)])
         hours = n5 * args.seconds / 3600.0
-        pipeline.extract_features_streamed(cfg5, Utterances(list(index2)[:2400]), lambda f: None, log=quiet)
-        seen = {'utts': 0, 'batches': 0, 'peak_device': 0, 'frames': 0}
+        # the corpus loaded ONCE into one page-locked int16 block (Utterances.pin(): what a loader that decodes
+        # files does for free; 14.4 GB for 125 h, untimed like the file reads it stands for): batches go up from
+        # where they lie, the upload of batch k + 1 beside the kernels of batch k
+        t0 = time.perf_counter()
+        pinned5 = index2.pin()
+        pin_s = time.perf_counter() - t0
+        warm = Utterances(list(index2)[:min(n5, 2 * 4800)])   # (two batches of the default size: pools at size)
+        pipeline.extract_features_streamed(cfg5, warm.pin(), lambda f: None, log=quiet)
+        pipeline.extract_features_streamed(cfg5, warm, lambda f: None, log=quiet)
+        del warm
         _, hbm_total = _backend.mem_info()
 
-        def counting_sink(feats):
-            seen['utts'] += len(feats)
-            seen['batches'] += 1
-            seen['frames'] += sum(f.nframes for f in feats.values())
-            free, total = _backend.mem_info()
-            seen['peak_device'] = max(seen['peak_device'], total - free)
-        t0 = time.perf_counter()
-        written = pipeline.extract_features_streamed(cfg5, index2, counting_sink, log=quiet)
-        dt = time.perf_counter() - t0
+        def run_streamed(index, njobs):
+            seen = {'utts': 0, 'batches': 0, 'peak_device': 0, 'frames': 0}
+
+            def counting_sink(feats):
+                seen['utts'] += len(feats)
+                seen['batches'] += 1
+                seen['frames'] += sum(f.nframes for f in feats.values())
+                free, total = _backend.mem_info()
+                seen['peak_device'] = max(seen['peak_device'], total - free)
+            run_stats = pipeline.RunStats()
+            t0 = time.perf_counter()
+            written = pipeline.extract_features_streamed(cfg5, index, counting_sink, log=quiet, njobs=njobs,
+                                                         stats=run_stats)
+            return time.perf_counter() - t0, written, seen, run_stats.as_dict()
+        tried = {}
+        for njobs in (1, 2, 3):
+            tried[njobs] = run_streamed(pinned5, njobs)
+        best = min(tried, key=lambda k: tried[k][0])
+        dt, written, seen, cost = tried[best]
+        dt_page, _, _, cost_page = run_streamed(index2, 1)
+        link = 57e9   # bytes per second and direction the host link of this box family sustains (end_to_end above)
         extra['pipeline_streamed'] = {
             'hours_of_audio': hours, 'hours_of_audio_per_s': hours / dt, 'wall_s': dt,
-            'frames_per_s': seen['frames'] / dt,
+            'frames_per_s': seen['frames'] / dt, 'njobs': best,
+            'wall_s_by_njobs': {str(k): v[0] for k, v in tried.items()},
+            'gpu_s': cost['gpu_ms'] / 1e3,
+            'link_floor_s': {'overlapped': max(cost['bytes_up'], cost['bytes_down']) / link,
+                             'serial': (cost['bytes_up'] + cost['bytes_down']) / link,
+                             'bytes_up': cost['bytes_up'], 'bytes_down': cost['bytes_down'],
+                             'assumed_bytes_per_s_per_direction': link},
+            'upload_wait_s': cost['upload_wait_s'], 'download_wait_s': cost['download_wait_s'],
+            'audio': 'Utterances.pin(): one page-locked int16 block (%.1f GB, page-locked in %.1f s, untimed)' % (
+                n5 * nsamples * 2 / 1e9, pin_s),
+            'pageable_hours_of_audio_per_s': hours / dt_page, 'pageable_wall_s': dt_page,
+            'pageable_upload_wait_s': cost_page['upload_wait_s'],
             'utterances': n5, 'utterances_written': int(written), 'every_utterance_once': seen['utts'] == n5,
             'speakers': 1000, 'cmvn': 'by speaker, VAD-weighted (reference default)', 'columns': 123,
-            'batches': seen['batches'], 'batch_s': pipeline.default_batch_duration(1),
+            'batches': seen['batches'], 'batch_s': pipeline.default_batch_duration(best),
             'peak_device_bytes': int(seen['peak_device']), 'device_total_bytes': int(hbm_total),
             'host_max_rss_bytes': int(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss) * 1024,
             'passes': 2, 'audio_resident_between_passes': True,
-            'note': 'BASELINE config 5 at one GPU\'s share (1 000 h / 8); wall clock includes loading, the '
-                    'uploads, both passes, the downloads and the per-utterance Features objects'}
-        del index2, audios
+            'note': 'BASELINE config 5 at one GPU\'s share (1 000 h / 8); wall clock includes the uploads, both '
+                    'passes, the downloads and the per-utterance Features objects; `njobs` batches in flight '
+                    '(the reference\'s parameter; best of 1 / 2 / 3); `pageable_*`: the same corpus as 150 000 '
+                    'separate numpy arrays (gathered into staging memory batch by batch), njobs 1; `gpu_s`: HIP '
+                    'events of every plan call of the run'}
+        del index2, audios, pinned5
 
         # FeaturesProcessor.process_all on the 10 000 in-memory utterances (the north_star's API surface,
         # reference processor/base.py:56-107): wall clock from utterances to a FeaturesCollection, host to host:
@@ -776,9 +810,12 @@ def main():
         pa_index = Utterances([(f'u{i:05d}', Audio(waves[i], 16000, validate=False)) for i in range(n_utts)])
 
         def time_process_all(index, reps=7):
-            fbank.process_all(index)
+            import gc
+            coll = fbank.process_all(index)
             walls = []
             for _ in range(reps):
+                del coll       # (giving back the previous result - 10 000 Features, a 477 MB page-locked block - is
+                gc.collect(0)  # not part of making the next one; the collector's young pass over them neither)
                 t0 = time.perf_counter()
                 coll = fbank.process_all(index)
                 walls.append(time.perf_counter() - t0)

@@ -1097,6 +1097,15 @@ class DeviceBuffer:
             array.nbytes))
         return array
 
+    def upload_async(self, array):
+        """Starts the copy of `array` (contiguous; page-locked for the copy to be asynchronous) into this block
+        on the calling thread's copy stream and returns a callable that waits for it (from any thread)"""
+        bind_device(self.device)
+        stream = _copy_stream(self.device)
+        check(lib().snf_memcpy_h2d_async(C.c_void_p(self.ptr), array.ctypes.data_as(C.c_void_p),
+                                         array.nbytes, C.c_void_p(stream)))
+        return lambda: check(lib().snf_stream_synchronize(C.c_void_p(stream)))
+
     def download_async(self, array):
         """Starts the copy into `array` on this thread's copy stream and returns a callable that waits for
         it: the caller does its host-side bookkeeping in between (the copy only overlaps when `array` is

@@ -82,8 +82,11 @@ class Features:
             if type(shared) is not dict:   # (a pipeline history that makes its dictionary when first asked)
                 shared = shared.properties
             self._properties = copy_properties(shared)
-            if self._shared[2]:
-                self._properties.update(copy_properties(self._shared[2]))
+            extra = self._shared[2]
+            if type(extra) is tuple:   # (function, arguments): this utterance's own entries, made when asked for
+                self._properties.update(extra[0](*extra[1:]))
+            elif extra:
+                self._properties.update(copy_properties(extra))
             self._shared = (self._shared[0], None, None)   # (the batch's history is not kept alive by a read copy)
         return self._properties
 

@@ -15,6 +15,7 @@ configuration entry; precomputed `warps` are supported), CREPE pitch, bottleneck
 
 import os
 import threading
+import time
 
 import numpy as np
 import yaml
@@ -309,7 +310,36 @@ def extract_features(configuration, utterances, warps=None, njobs=1,
              utterances.format(type=str))
     if warps:
         warps = _init_warps(warps, config, utterances, log)
-    return _extract_features(config, utterances, warps, log)
+    return _extract_features(config, _view_of(utterances), warps, log)
+
+
+def _view_of(utterances):
+    """`utterances` itself, or - for a pinned index (``Utterances.pin()``) - the view that tells the pipeline
+    where its audio lies in the page-locked block"""
+    pinned = getattr(utterances, '_pinned', None)
+    if pinned is None:
+        return utterances
+    return _BatchView(list(utterances), utterances.has_speakers(), pinned=pinned, first=0)
+
+
+def extract_features_warp(configuration, utterances, warp, log=get_logger('pipeline', 'warning'), njobs=1):
+    """Speech features extraction pipeline when all features are warped by the same factor
+
+    What the reference's VTLN trainer calls between its iterations (reference pipeline.py:650-696): the main
+    features of every utterance with ``vtln_warp=warp`` and, when the configuration has a 'delta' entry, their
+    deltas - no pitch, no CMVN, and properties without the per-utterance 'audio' / 'speaker' entries, exactly
+    what ``delta.process(features.process(audio, vtln_warp=warp))`` returns.  One batched launch per stage
+    instead of a thread pool; `njobs` is validated like the reference's.
+
+    Raises ValueError for an invalid configuration and for spectrogram features (no VTLN there)."""
+    get_njobs(njobs, log=log)
+    config = _init_config(configuration, log=log)
+    features = [k for k in config.keys() if k in valid_features()][0]
+    if features == 'spectrogram':
+        raise ValueError(f'{features} features do not support VTLN')
+    warps = {utt.name: float(warp) for utt in utterances}
+    return _extract_features(config, _view_of(utterances), warps, log, stages=('delta',),
+                             utterance_properties=False)
 
 
 def _batches(utterances, max_duration):
@@ -389,7 +419,7 @@ def default_batch_duration(depth=1):
 def extract_features_streamed(configuration, utterances, sink, warps=None,
                               max_batch_duration=None, njobs=1, stats_reduce=None,
                               resident_bytes=16 << 30,
-                              log=get_logger('pipeline', 'warning')):
+                              log=get_logger('pipeline', 'warning'), stats=None):
     """:func:`extract_features` for a corpus that must not sit in memory at once (BASELINE config 5)
 
     The utterances are processed in consecutive batches of at most `max_batch_duration` seconds of
@@ -417,8 +447,12 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
     `stats_reduce(names, stats) -> stats` sums the speakers' statistics across processes when the
     corpus is sharded (see shennong_amd.distributed.extract_features_streamed_sharded).
 
+    A pinned index (``utterances.pin()``: the audio loaded once into ONE page-locked int16 block) is taken
+    straight from that block: a batch is a stretch of it, uploaded from where it lies - no per-utterance load,
+    conversion, check or gather (what bounded this function before round 6: the host, not the link).
+    `stats` (a :class:`RunStats`): link bytes, transfer waits and kernel milliseconds summed over the run.
+
     Returns the number of utterances written."""
-    from shennong_amd.utterances import Utterances
     depth = min(get_njobs(njobs, log=log), 8)
     config = _init_config(configuration, log=log)
     if max_batch_duration is not None and not max_batch_duration > 0:
@@ -433,46 +467,84 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
     utts = list(utterances)
     if max_batch_duration is None:
         max_batch_duration = default_batch_duration(depth)
+    has_speakers, pinned = utterances.has_speakers(), getattr(utterances, '_pinned', None)
+
+    def views():
+        """the batches, in order; the audio of a pinned batch that is not in HBM from an earlier pass is sent
+        ahead: started when the batch BEFORE it is handed out, so that it crosses the link beside that one's
+        kernels"""
+        def view_of(batch, first, b):
+            view = _BatchView(batch, has_speakers, pinned=pinned, first=first)
+            if pinned is not None and not (resident is not None and resident.holds((b, pinned.sample_rate))):
+                view.prefetch = _Prefetch(view)
+            return view
+        batches = _batches(utts, max_batch_duration)
+        ahead = first = None
+        try:
+            batch, first, b = next(batches, None), 0, 0
+            ahead = view_of(batch, first, b) if batch is not None else None
+            while ahead is not None:
+                current, ahead = ahead, None
+                first, b = first + len(current), b + 1
+                batch = next(batches, None)
+                if batch is not None:
+                    ahead = view_of(batch, first, b)
+                yield current
+        finally:
+            if ahead is not None and ahead.prefetch is not None:   # (the run ended before this batch was handed out)
+                ahead.prefetch.cancel()
 
     def sub(batch):
         return {u.name: warps[u.name] for u in batch} if warps else None
 
     hook = None
     resident = _ResidentWaves(resident_bytes) if by_speaker and resident_bytes > 0 else None
+    # The cyclic collector stays paused for the whole run, not only inside the batches: re-enabled after a batch,
+    # its first pass walks the ~100 000 objects that batch just made - all alive: 5-11 ms per batch, inside
+    # whatever allocates next (the sink).  The batch's objects go when the sink has returned (reference counts);
+    # every eighth batch the young generations are collected by hand, so that cyclic garbage of the sink's own
+    # making does not pile up over a long corpus.
+    from shennong_amd.utils import paused_gc
+    gc_pause = paused_gc().__enter__()
     running = None   # the generator of the batches in flight: closed (its threads joined) before the audio
                      # buffers are released, whatever ends the pass - the end of the corpus, an error in a
                      # batch, an exception from `sink`
     try:
         if by_speaker:
-            total = {}
+            number, table = {}, [None]   # speaker -> row of table[0], float64 [speakers, 2, dim + 1]
 
             def first_pass(b, batch):
-                return _extract_features(config, Utterances(batch), sub(batch), log, stats_only=True,
-                                         resident=resident, batch_id=b)
+                return _extract_features(config, batch, sub(batch), log, stats_only=True,
+                                         resident=resident, batch_id=b, stats=stats)
 
-            running = _in_flight(_batches(utts, max_batch_duration), first_pass, depth)
+            running = _in_flight(views(), first_pass, depth)
             for speakers, per_utt in running:
-                for speaker, stats in zip(speakers, per_utt):
-                    if speaker in total:
-                        total[speaker] += stats
-                    else:
-                        total[speaker] = stats.copy()
+                # (summed in utterance order like the one-shot pipeline: np.add.at adds row after row)
+                for speaker in speakers:
+                    if speaker not in number:
+                        number[speaker] = len(number)
+                per_utt = np.asarray(per_utt)
+                if table[0] is None or len(number) > table[0].shape[0]:
+                    grown = np.zeros((max(2 * len(number), 64),) + per_utt.shape[1:], dtype=np.float64)
+                    if table[0] is not None:
+                        grown[:table[0].shape[0]] = table[0]
+                    table[0] = grown
+                np.add.at(table[0], np.fromiter((number[s] for s in speakers), np.int64, len(speakers)), per_utt)
             running = None
+            names = list(number)
+            total_of = table[0][:len(names)] if names else np.zeros((0, 2, 1), dtype=np.float64)
             if stats_reduce is not None:
-                names = list(total)
-                reduced = stats_reduce(names, np.stack([total[k] for k in names]) if names
-                                       else np.zeros((0, 2, 1), dtype=np.float64))
-                total = dict(zip(names, reduced))
+                total_of = np.asarray(stats_reduce(names, np.ascontiguousarray(total_of)))
 
-            def hook(names, _partial):
-                return np.stack([total[k] for k in names])
+            def hook(batch_names, _partial):
+                return total_of[np.fromiter((number[k] for k in batch_names), np.int64, len(batch_names))]
 
         def second_pass(b, batch):
-            return _extract_features(config, Utterances(batch), sub(batch), log, stats_hook=hook,
-                                     resident=resident, batch_id=b)
+            return _extract_features(config, batch, sub(batch), log, stats_hook=hook,
+                                     resident=resident, batch_id=b, stats=stats)
 
-        count = 0
-        batches = running = _in_flight(_batches(utts, max_batch_duration), second_pass, depth)
+        count = handed = 0
+        batches = running = _in_flight(views(), second_pass, depth)
         while True:
             # (nothing of batch k is referenced here while batch k + 1 is made: its page-locked result block
             # is back in the pool by then, see _backend.result_array)
@@ -482,12 +554,18 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
             sink(features)
             count += len(features)
             del features
+            handed += 1
+            if handed % 8 == 0:
+                gc_pause.collect_young()
         return count
     finally:
-        if running is not None:
-            running.close()   # (GeneratorExit inside _in_flight: pending batches cancelled, its pool joined)
-        if resident is not None:
-            resident.clear()
+        try:
+            if running is not None:
+                running.close()   # (GeneratorExit inside _in_flight: pending batches cancelled, its pool joined)
+            if resident is not None:
+                resident.clear()
+        finally:
+            gc_pause.__exit__(None, None, None)
 
 
 # The device-resident pipeline draws its random terms (dither, delta-pitch noise) from ONE named noise call
@@ -559,6 +637,10 @@ class _ResidentWaves:
             self.held += d_wave.nbytes
             return True
 
+    def holds(self, key):
+        with self._lock:
+            return key in self._items
+
     def take(self, key):
         with self._lock:
             item = self._items.pop(key, None)
@@ -575,209 +657,452 @@ class _ResidentWaves:
             d_wave.free(synced=True)
 
 
+class _BatchView:
+    """A run of utterances of an index as the device pipeline needs it: iteration, `has_speakers`, `duration`
+    - what ``Utterances(batch)`` gave, minus its validation (names, formats, duplicates: the index went through
+    it when it was made; 4 us per utterance and batch) - plus, when the index was pinned (``Utterances.pin()``),
+    WHERE the audio of the run lies in the page-locked block: utterances `first` ... `first + len` of `pinned`."""
+    def __init__(self, utts, has_speakers, pinned=None, first=0):
+        self._utts = utts
+        self._has_speakers = bool(has_speakers)
+        self.pinned, self.first = pinned, int(first)
+        self.prefetch = None   # a _Prefetch when the audio of the run was sent ahead
+
+    def __iter__(self):
+        return iter(self._utts)
+
+    def __len__(self):
+        return len(self._utts)
+
+    def has_speakers(self):
+        return self._has_speakers
+
+    def duration(self):
+        return sum(u.duration for u in self._utts)
+
+
+class _Prefetch:
+    """The audio of a pinned view on its way to HBM before its batch starts: the upload of batch k + 1 runs
+    beside the kernels of batch k (the 'double-buffered chunks' of SURVEY.md 8d, config 5).  Started on the
+    thread that walks the batches, taken (waited for) by the thread that runs the batch."""
+    def __init__(self, view):
+        pinned, a, n = view.pinned, view.first, len(view)
+        s0, s1 = int(pinned.soff[a]), int(pinned.soff[a + n])
+        self.soff = pinned.soff[a:a + n + 1] - s0
+        self.nbytes = 2 * (s1 - s0)
+        self.block = _backend.DeviceBuffer(max(self.nbytes, 16))
+        try:
+            self._wait = self.block.upload_async(pinned.block[s0:s1])
+        except BaseException:
+            self.block.free()
+            raise
+
+    def take(self):
+        """(block, sample offsets); the caller owns the block"""
+        block, self.block = self.block, None
+        try:
+            self._wait()
+        except BaseException:
+            block.free()
+            raise
+        return block, self.soff
+
+    def cancel(self):
+        if self.block is not None:
+            block, self.block = self.block, None
+            try:
+                self._wait()
+            finally:
+                block.free()
+
+    def __del__(self):   # (a view that was handed out and never ran: an error ended its pass)
+        try:
+            self.cancel()
+        except Exception:  # pragma: nocover
+            pass
+
+
+class RunStats:
+    """What a pipeline run cost, summed over its batches and threads (pass one as ``stats=`` to
+    :func:`extract_features_streamed`): bytes over the host link in each direction, seconds this process
+    waited for uploads / downloads, milliseconds of kernels (HIP events of every plan call).  bench.py prints
+    them beside the wall clock: the link floor and the GPU time of BASELINE config 5."""
+    _FIELDS = ('bytes_up', 'bytes_down', 'upload_wait_s', 'download_wait_s', 'gpu_ms', 'batches', 'utterances')
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        for name in self._FIELDS:
+            setattr(self, name, 0)
+
+    def add(self, **amounts):
+        with self._lock:
+            for name, value in amounts.items():
+                setattr(self, name, getattr(self, name) + value)
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name in self._FIELDS}
+
+
+def _utterance_properties(utt, sample_rate):
+    """The entries of an utterance's properties that are its own (reference pipeline.py:598-611), made when the
+    properties are first read (Features._of_batch)"""
+    audio = {'file': (os.path.abspath(utt.audio_file) if isinstance(utt.audio_file, str) else None),
+             'sample_rate': sample_rate}
+    if utt.tstart is not None:
+        audio['tstart'] = utt.tstart
+        audio['tstop'] = utt.tstop
+    audio['duration'] = utt.duration
+    return {'audio': audio, 'speaker': utt.speaker} if utt.speaker else {'audio': audio}
+
+
+class _Group:
+    """The utterances of one sample rate of a batch and the device blocks they own while they go through the
+    stages.  A block has ONE owner at any time - this table, the tracker's thread, or the _ResidentWaves - and
+    one place where it is given back: `swap` / `drop` (the launches that used it have been waited for: no device
+    wait), or `abort` (an error: something may still be enqueued, plain free() waits for the device)."""
+    def __init__(self, rate, idx):
+        self.rate, self.idx = rate, idx
+        self.blocks = {}
+        self.soff = self.foff = self.pfoff = None
+        self.dim = self.pdim = 0
+        self.pitch_job = None
+
+    def hold(self, name, block):
+        assert name not in self.blocks
+        self.blocks[name] = block
+        return block
+
+    def ptr(self, name):
+        return self.blocks[name].ptr
+
+    def swap(self, name, block):
+        """`block` takes the place of the block held under `name`, which is given back"""
+        self.blocks.pop(name).free(synced=True)
+        self.blocks[name] = block
+
+    def drop(self, name):
+        self.blocks.pop(name).free(synced=True)
+
+    def give(self, name):
+        """hands the block to another owner"""
+        return self.blocks.pop(name)
+
+    def abort(self):
+        if self.pitch_job is not None:   # (the tracker reads the audio: first let it end, whatever its outcome)
+            job, self.pitch_job = self.pitch_job, None
+            try:
+                self.blocks['pitch'] = job.result()
+            except BaseException:   # noqa: BLE001 (its own blocks were released by the job)
+                pass
+        for name in list(self.blocks):
+            self.blocks.pop(name).free()
+
+
+def _offsets(counts):
+    off = np.zeros(len(counts) + 1, dtype=np.int64)
+    np.cumsum(counts, out=off[1:])
+    return off
+
+
+def _classes_of(*keys):
+    """(representatives, class of every element): the distinct combinations of the integer arrays `keys` in order
+    of first appearance are NOT needed, only a dense numbering - np.unique over a mixed-radix code"""
+    code = np.zeros(keys[0].shape[0], dtype=np.int64)
+    for key in keys:
+        key = np.asarray(key, dtype=np.int64)
+        code = code * (int(key.max()) + 1 if key.size else 1) + key
+    uniq, first, inverse = np.unique(code, return_index=True, return_inverse=True)
+    return first, inverse
+
+
 def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=None,
-                      stats_only=False, resident=None, batch_id=None, device_out=None):
+                      stats_only=False, resident=None, batch_id=None, device_out=None, stats=None,
+                      stages=None, utterance_properties=True):
     from shennong_amd.utils import paused_gc
     with paused_gc():   # (thousands of small objects per batch, none of them garbage: see utils.paused_gc)
-        return _extract_features_body(config, utterances, warps, log, tolerance, stats_hook, stats_only,
-                                      resident, batch_id, device_out)
+        run = _PipelineRun(config, utterances, warps, log, tolerance, resident, batch_id, stats, stages,
+                           utterance_properties)
+        try:
+            return run.execute(stats_hook, stats_only, device_out)
+        except BaseException:
+            run.abort()
+            raise
 
 
-def _extract_features_body(config, utterances, warps, log, tolerance=2, stats_hook=None,
-                           stats_only=False, resident=None, batch_id=None, device_out=None):
-    """The whole pipeline with the intermediate features resident in HBM: the waveforms go up once,
-    every stage is one batched launch on device buffers (features, energy -> VAD, CMVN statistics and
-    apply, delta, pitch and its post-processing, column concatenation), the final matrices come down
-    once.  Stage order, arithmetic and properties are those of reference pipeline.py:525-643.
+class _PipelineRun:
+    """One batch through the whole pipeline with the intermediate features resident in HBM: the waveforms go up
+    once, every stage is one batched launch on device blocks (features, energy -> VAD, CMVN statistics and
+    apply, delta, pitch and its post-processing, column concatenation), the final matrices come down once.
+    Stage order, arithmetic and properties are those of reference pipeline.py:525-643; one method per stage:
 
-    `stats_only` (first pass of :func:`extract_features_streamed`): stop after the CMVN accumulation
-    and return ``(group name of every utterance, per-utterance statistics [n, 2, dim + 1])``; the
-    pitch stage, which the statistics do not depend on, is skipped.  `resident` (a _ResidentWaves) keeps
-    the uploaded waveforms of batch `batch_id` in HBM after that pass and hands them to the next one.
-    `device_out` (a list; :func:`shennong_amd.distributed.extract_features_sharded`): the final matrices
-    STAY in HBM - one ``(DeviceBuffer [rows, ndims], names in row order, ndims)`` per sample rate is appended
-    and the caller owns the buffers; the returned Features carry times and properties over data that were
-    never downloaded (untouched host pages)."""
-    features_name = [k for k in config.keys() if k in valid_features()][0]
-    with_cmvn = 'cmvn' in config
-    if with_cmvn and config['cmvn']['by_speaker'] and not utterances.has_speakers():
-        raise ValueError(
-            'cmvn normalization by speaker requested '
-            'but no speaker information provided')
+        audio -> [pitch, started on a side thread] -> features -> [vad] -> cmvn -> delta -> join
 
-    from shennong_amd.audio import Audio
-    utts = list(utterances)
-    n = len(utts)
-    metadata = {}
-    for utt in utts:
-        key = utt.audio_file if isinstance(utt.audio_file, str) else id(utt.audio_file)
-        if key not in metadata:
-            metadata[key] = Audio.scan(utt.audio_file)
-    meta_of = [metadata[u.audio_file if isinstance(u.audio_file, str) else id(u.audio_file)]
-               for u in utts]
-    speakers = ('' if not utterances.has_speakers() else ' from {} speakers'.format(
-        len(set(u.speaker for u in utts))))
-    import datetime
-    log.info('get %s utterances%s in %s audio files, total duration: %s',
-             len(utts), speakers, len(metadata),
-             datetime.timedelta(seconds=utterances.duration()))
-    if not all(m.nchannels == 1 for m in meta_of):
-        raise ValueError('all audio files are not mono')
-    samplerates = sorted(set(m.sample_rate for m in meta_of))
-    if len(samplerates) > 1:
-        log.warning(
-            'several sample rates found in audio files: %s, features '
-            'extraction pipeline will work but this may not be a good '
-            'idea to work on heterogeneous data',
-            ', '.join(str(s) + 'Hz' for s in samplerates))
+    `stats_only` (first pass of :func:`extract_features_streamed`): stop after the CMVN accumulation and return
+    ``(group name of every utterance, per-utterance statistics [n, 2, dim + 1])``; the pitch stage, which the
+    statistics do not depend on, is skipped.  `resident` (a _ResidentWaves) keeps the uploaded waveforms of batch
+    `batch_id` in HBM after that pass and hands them to the next one.  `device_out` (a list;
+    :func:`shennong_amd.distributed.extract_features_sharded`): the final matrices STAY in HBM - one
+    ``(DeviceBuffer [rows, ndims], names in row order, ndims)`` per sample rate is appended and the caller owns
+    the blocks; the returned Features carry times and properties over data that were never downloaded.
+    `stages`: None = what the configuration names; a subset (``extract_features_warp``: features and delta
+    only).  Every launch goes through an entry point that synchronises its stream before it returns and the one
+    asynchronous copy is waited for before its block is released: blocks are given back without the device-wide
+    wait DeviceBuffer.free() otherwise makes (see _Group)."""
+    def __init__(self, config, utterances, warps, log, tolerance, resident, batch_id, stats, stages,
+                 utterance_properties):
+        self.config, self.warps, self.log, self.tolerance = config, warps, log, tolerance
+        self.resident, self.batch_id, self.stats = resident, batch_id, stats
+        self.utterance_properties = utterance_properties
+        self.features_name = [k for k in config.keys() if k in valid_features()][0]
+        enabled = (lambda name: name in config) if stages is None else \
+            (lambda name: name in config and name in stages)
+        self.with_cmvn, self.with_delta, self.with_pitch = enabled('cmvn'), enabled('delta'), enabled('pitch')
+        if self.with_cmvn and config['cmvn']['by_speaker'] and not utterances.has_speakers():
+            raise ValueError(
+                'cmvn normalization by speaker requested '
+                'but no speaker information provided')
+        self.view = utterances
+        self.utts = list(utterances)
+        self.n = len(self.utts)
+        self.cache = {}       # properties per processing history (see _Meta)
+        self.groups = []      # one _Group per sample rate
+        self.classes = []     # the distinct _Meta of the main features ...
+        self.cls_of = np.zeros(self.n, dtype=np.int64)   # ... and which of them every utterance has
+        self.pclasses, self.pcls_of = [], np.zeros(self.n, dtype=np.int64)   # the same for the pitch features
+        self.rate_of = [None] * self.n
+        self.frame_length = self.frame_shift = None
 
-    from shennong_amd.processor.base import check_signal
-    # (every launch below goes through an entry point that synchronises its stream before it returns, and the
-    # one asynchronous copy is waited for before its buffer is released: the buffers are given back with
-    # synced=True, without the device-wide wait DeviceBuffer.free() otherwise makes - which would stall this
-    # thread behind the pitch tracker of the side thread)
-    DB = _backend.DeviceBuffer
-    frame_length = frame_shift = None
-    cache = {}          # properties per processing history (see _Meta)
-    groups_state = []   # per sample rate: buffers and tables of its utterances
-    meta = [None] * n   # _Meta of the main features
-    pmeta = [None] * n  # _Meta of the pitch features
+    def abort(self):
+        for group in self.groups:
+            group.abort()
 
-    def offsets(counts):
-        off = np.zeros(len(counts) + 1, dtype=np.int64)
-        np.cumsum(counts, out=off[1:])
-        return off
+    def _count(self, **amounts):
+        if self.stats is not None:
+            self.stats.add(**amounts)
 
-    # ---- pass one: features, (energy -> VAD), pitch ---------------------------------------------------
-    for rate in samplerates:
-        idx = [i for i in range(n) if meta_of[i].sample_rate == rate]
-        proc = _processor_class(features_name)(**config[features_name])
-        proc.sample_rate = rate
-        if frame_length is None:
-            frame_length, frame_shift = proc.frame_length, proc.frame_shift
-        held = resident.take((batch_id, rate)) if resident is not None else None
-        if held is not None:
-            d_wave, soff = held
-        else:
+    def execute(self, stats_hook, stats_only, device_out):
+        self.stage_audio()
+        for group in self.groups:
+            proc = _processor_class(self.features_name)(**self.config[self.features_name])
+            proc.sample_rate = group.rate
+            if self.frame_length is None:
+                self.frame_length, self.frame_shift = proc.frame_length, proc.frame_shift
+            if self.with_pitch and not stats_only:
+                self.stage_pitch_start(group)
+            self.stage_features(group, proc)
+            if self.with_cmvn and self.config['cmvn']['with_vad']:
+                self.stage_vad(group)
+            if group.pitch_job is not None:
+                pass   # (the tracker still reads the audio: released where it is waited for, stage_join)
+            elif stats_only and self.resident is not None and self.resident.offer(
+                    (self.batch_id, group.rate), group.blocks['wave'], group.soff):
+                group.give('wave')
+            else:
+                group.drop('wave')
+        if self.with_cmvn:
+            found = self.stage_cmvn(stats_hook, stats_only)
+            if stats_only:
+                return found
+        if self.with_delta:
+            self.stage_delta()
+        return self.stage_join(device_out)
+
+    # ---- audio: one int16 block per sample rate in HBM ------------------------------------------------------
+    def stage_audio(self):
+        from shennong_amd.audio import Audio
+        from shennong_amd.processor.base import check_signal
+        utts, n, log = self.utts, self.n, self.log
+        pinned = getattr(self.view, 'pinned', None)
+        if pinned is not None:
+            # the run's audio is one stretch of a page-locked block that was checked when it was made (mono,
+            # one rate, int16): it goes up from where it is
+            import logging
+            if log.isEnabledFor(logging.INFO):
+                self._log_summary(1)
+            a = self.view.first
+            group = _Group(pinned.sample_rate, np.arange(n))
+            self.rate_of = [pinned.sample_rate] * n
+            self.groups.append(group)
+            held = self.resident.take((self.batch_id, group.rate)) if self.resident is not None else None
+            if held is not None:
+                block, group.soff = held
+                group.hold('wave', block)
+                if self.view.prefetch is not None:
+                    self.view.prefetch.cancel()
+                return
+            t0 = time.perf_counter()
+            ahead, self.view.prefetch = self.view.prefetch or _Prefetch(self.view), None
+            block, group.soff = ahead.take()
+            group.hold('wave', block)
+            self._count(bytes_up=ahead.nbytes, upload_wait_s=time.perf_counter() - t0)
+            return
+        metadata = {}
+        meta_of = []
+        for utt in utts:
+            key = utt.audio_file if isinstance(utt.audio_file, str) else id(utt.audio_file)
+            found = metadata.get(key)
+            if found is None:
+                found = metadata[key] = Audio.scan(utt.audio_file)
+            meta_of.append(found)
+        self._log_summary(len(metadata))
+        if not all(m.nchannels == 1 for m in meta_of):
+            raise ValueError('all audio files are not mono')
+        self.rate_of = [m.sample_rate for m in meta_of]
+        samplerates = sorted(set(self.rate_of))
+        if len(samplerates) > 1:
+            log.warning(
+                'several sample rates found in audio files: %s, features '
+                'extraction pipeline will work but this may not be a good '
+                'idea to work on heterogeneous data',
+                ', '.join(str(s) + 'Hz' for s in samplerates))
+        for rate in samplerates:
+            idx = np.asarray([i for i in range(n) if self.rate_of[i] == rate], dtype=np.int64)
+            group = _Group(rate, idx)
+            self.groups.append(group)
+            held = self.resident.take((self.batch_id, rate)) if self.resident is not None else None
+            if held is not None:
+                block, group.soff = held
+                group.hold('wave', block)
+                continue
+            proc = _processor_class(self.features_name)(**self.config[self.features_name])
+            proc.sample_rate = rate
             waves, checked = [], set()
-            for i in idx:
+            for i in idx.tolist():
                 audio = utts[i].load_audio()
                 if (audio.nchannels, audio.sample_rate) not in checked:  # (one check per kind of signal)
                     check_signal(proc, audio)
                     checked.add((audio.nchannels, audio.sample_rate))
                 waves.append(audio.astype(np.int16).data)
-            soff = offsets([w.shape[0] for w in waves])
-            d_wave = _backend.upload_rows(waves, np.int16)  # (page-locked staging: full link rate)
-            del waves
+            group.soff = _offsets([w.shape[0] for w in waves])
+            t0 = time.perf_counter()
+            group.hold('wave', _backend.upload_rows(waves, np.int16))  # (page-locked staging: full link rate)
+            self._count(bytes_up=2 * int(group.soff[-1]), upload_wait_s=time.perf_counter() - t0)
+
+    def _log_summary(self, nfiles):
+        import datetime
+        utts = self.utts
+        speakers = ('' if not self.view.has_speakers() else ' from {} speakers'.format(
+            len(set(u.speaker for u in utts))))
+        self.log.info('get %s utterances%s in %s audio files, total duration: %s',
+                      len(utts), speakers, nfiles, datetime.timedelta(seconds=self.view.duration()))
+
+    @staticmethod
+    def _frame_offsets(plan, soff):
         lengths = np.diff(soff)
+        uniq, inverse = np.unique(lengths, return_inverse=True)
+        frames = np.asarray([plan.num_frames(x) for x in uniq.tolist()], dtype=np.int64)
+        return _offsets(frames[inverse])
 
-        def frame_offsets(a_plan):
-            frames_of = {x: a_plan.num_frames(x) for x in np.unique(lengths).tolist()}
-            return offsets([frames_of[x] for x in lengths.tolist()])
-        st = {'idx': idx, 'soff': soff, 'd_wave': d_wave}
+    # ---- pitch: needs nothing but the audio, runs on a side thread (its own streams) while this one takes the
+    # audio through the features, VAD, CMVN and delta; waited for where the columns are joined ------------------
+    def stage_pitch_start(self, group):
+        config, rate, cache = self.config, group.rate, self.cache
+        DB = _backend.DeviceBuffer
+        params = {k: v for k, v in config['pitch'].items() if k not in ('processor', 'postprocessing')}
+        params['sample_rate'] = rate
+        params['frame_shift'] = self.frame_shift
+        params['frame_length'] = self.frame_length
+        pproc = _processor_class('kaldi_pitch')(**params)
+        post = _processor_class('kaldi_pitch_post')(**config['pitch']['postprocessing'])
+        pplan = _backend.get_plan(pproc._build_options())
+        pfoff = self._frame_offsets(pplan, group.soff)
+        qplan = _backend.get_plan(post._build_options())
+        pdim = qplan.post_ndims(2)
+        d_wave, soff, count = group.ptr('wave'), group.soff, self._count
 
-        if 'pitch' in config and not stats_only:
-            params = {k: v for k, v in config['pitch'].items()
-                      if k not in ('processor', 'postprocessing')}
-            params['sample_rate'] = rate
-            params['frame_shift'] = frame_shift
-            params['frame_length'] = frame_length
-            pproc = _processor_class('kaldi_pitch')(**params)
-            post = _processor_class('kaldi_pitch_post')(**config['pitch']['postprocessing'])
-            pplan = _backend.get_plan(pproc._build_options())
-            pfoff = frame_offsets(pplan)
-            qplan = _backend.get_plan(post._build_options())
-            pdim = qplan.post_ndims(2)
+        def track():
+            d_raw = d_pitch = None
+            try:
+                d_raw = DB(max(int(pfoff[-1]) * 2 * 4, 16))
+                pplan.run_device(d_wave, soff, pfoff, d_raw.ptr)
+                d_pitch = DB(max(int(pfoff[-1]) * pdim * 4, 16))
+                qplan.run_post_device(d_raw.ptr, 2, pfoff, d_pitch.ptr, noise_call=_NOISE_CALL)
+                count(gpu_ms=pplan.last_kernel_ms(0) + qplan.last_kernel_ms(0))
+            except BaseException:
+                # a call that failed half way may have kernels enqueued that still write these blocks:
+                # the plain free() waits for the device before the pool can hand them to another thread
+                for block in (d_pitch, d_raw):
+                    if block is not None:
+                        block.free()
+                raise
+            d_raw.free(synced=True)   # (both calls returned: their streams are synchronised)
+            return d_pitch
 
-            def track(d_wave=d_wave, soff=soff, pfoff=pfoff, pplan=pplan, qplan=qplan, pdim=pdim):
-                # the tracker needs nothing but the audio: it runs on a side thread (its own stream) while
-                # this one takes the audio through the features, VAD, CMVN and delta, and is waited for where
-                # the columns are joined (the audio buffer is released there, after its last reader)
-                d_raw = d_pitch = None
-                try:
-                    d_raw = DB(max(int(pfoff[-1]) * 2 * 4, 16))
-                    pplan.run_device(d_wave.ptr, soff, pfoff, d_raw.ptr)
-                    d_pitch = DB(max(int(pfoff[-1]) * pdim * 4, 16))
-                    qplan.run_post_device(d_raw.ptr, 2, pfoff, d_pitch.ptr, noise_call=_NOISE_CALL)
-                except BaseException:
-                    # a call that failed half way may have kernels enqueued that still write these blocks:
-                    # the plain free() waits for the device before the pool can hand them to another thread
-                    for block in (d_pitch, d_raw):
-                        if block is not None:
-                            block.free()
-                    raise
-                d_raw.free(synced=True)   # (both calls returned: their streams are synchronised)
-                return d_pitch
+        group.pfoff, group.pdim = pfoff, pdim
+        group.pitch_job = _backend.side_pool().submit(track)
+        key = ('pitch', rate)
+        if key not in cache:
+            cache[key] = pproc.get_properties()
+        counts = np.diff(pfoff)
+        uniq, inverse = np.unique(counts, return_inverse=True)
+        base = len(self.pclasses)
+        for t in uniq.tolist():
+            tkey = ('times', 'pitch', rate, t)
+            if tkey not in cache:
+                cache[tkey] = pproc.times(t)
+            self.pclasses.append(_Meta(cache[key], 2, t, cache[tkey], key).derive(
+                cache, 'post', post.get_properties, ndims=pdim))
+        self.pcls_of[group.idx] = base + inverse
 
-            st.update(pfoff=pfoff, pdim=pdim, pitch_job=_backend.side_pool().submit(track))
-            step = {}
-            for i, t in zip(idx, np.diff(pfoff).tolist()):
-                found = step.get(t)
-                if found is None:
-                    key = ('pitch', rate)
-                    if key not in cache:
-                        cache[key] = pproc.get_properties()
-                    tkey = ('times', 'pitch', rate, t)
-                    if tkey not in cache:
-                        cache[tkey] = pproc.times(t)
-                    found = step[t] = _Meta(cache[key], 2, t, cache[tkey], key).derive(
-                        cache, 'post', post.get_properties, ndims=pdim)
-                pmeta[i] = found
-
-        opts = proc._build_options()
-        plan = _backend.get_plan(opts)
-        dim = plan.ndims
-        foff = frame_offsets(plan)
-        d_feat = DB(max(int(foff[-1]) * dim * 4, 16))
+    # ---- the main features ------------------------------------------------------------------------------------
+    def stage_features(self, group, proc):
+        features_name, rate, cache, utts = self.features_name, group.rate, self.cache, self.utts
+        plan = _backend.get_plan(proc._build_options())
+        group.dim = dim = plan.ndims
+        group.foff = foff = self._frame_offsets(plan, group.soff)
+        group.hold('feat', _backend.DeviceBuffer(max(int(foff[-1]) * dim * 4, 16)))
         vt = wlist = None
-        if warps and features_name != 'spectrogram':
-            wlist = [warps[utts[i].name] for i in idx]
-            vt = np.asarray(wlist, dtype=np.float32)
-        log.debug('extract %s on %d utterances at %d Hz', features_name, len(idx), rate)
-        plan.run_device(d_wave.ptr, soff, foff, d_feat.ptr, vtln_warps=vt, noise_call=_NOISE_CALL)
-        st.update(foff=foff, dim=dim, d_feat=d_feat)
-        step = {}
-        for k, (i, t) in enumerate(zip(idx, np.diff(foff).tolist())):
-            warp = None if features_name == 'spectrogram' else wlist[k] if wlist is not None else 1.0
-            found = step.get((warp, t))
-            if found is None:
-                key = (features_name, rate, warp)
-                if key not in cache:
-                    cache[key] = proc.get_properties(**({} if warp is None else {'vtln_warp': warp}))
-                tkey = ('times', features_name, rate, t)
-                if tkey not in cache:
-                    cache[tkey] = proc.times(t)
-                found = step[(warp, t)] = _Meta(cache[key], dim, t, cache[tkey], key)
-            meta[i] = found
+        if self.warps and features_name != 'spectrogram':
+            wlist = np.asarray([self.warps[utts[i].name] for i in group.idx.tolist()], dtype=np.float64)
+            vt = wlist.astype(np.float32)
+        self.log.debug('extract %s on %d utterances at %d Hz', features_name, len(group.idx), rate)
+        plan.run_device(group.ptr('wave'), group.soff, foff, group.ptr('feat'), vtln_warps=vt,
+                        noise_call=_NOISE_CALL)
+        self._count(gpu_ms=plan.last_kernel_ms(0))
+        # one _Meta per distinct (warp, frame count)
+        counts = np.diff(foff)
+        if wlist is None:
+            first, inverse = _classes_of(counts)
+        else:   # (classes by the caller's floats, which the properties record - not by their float32 images)
+            first, inverse = _classes_of(np.unique(wlist, return_inverse=True)[1], counts)
+        base = len(self.classes)
+        for k in first.tolist():
+            t = int(counts[k])
+            warp = None if features_name == 'spectrogram' else float(wlist[k]) if wlist is not None else 1.0
+            key = (features_name, rate, warp)
+            if key not in cache:
+                cache[key] = proc.get_properties(**({} if warp is None else {'vtln_warp': warp}))
+            tkey = ('times', features_name, rate, t)
+            if tkey not in cache:
+                cache[tkey] = proc.times(t)
+            self.classes.append(_Meta(cache[key], dim, t, cache[tkey], key))
+        self.cls_of[group.idx] = base + inverse
 
-        if with_cmvn and config['cmvn']['with_vad']:
-            energy = _processor_class('energy')()
-            energy.frame_length = frame_length
-            energy.frame_shift = frame_shift
-            energy.sample_rate = rate
-            eplan = _backend.get_plan(energy._build_options())
-            efoff = frame_offsets(eplan)
-            if not np.array_equal(efoff, foff):
-                raise ValueError('energy and features differ in number of frames')
-            d_energy = DB(max(int(foff[-1]) * 4, 16))
-            eplan.run_device(d_wave.ptr, soff, foff, d_energy.ptr, noise_call=_NOISE_CALL)
-            vad = _processor_class('vad')(**config['cmvn']['vad'])
-            d_vad = DB(max(int(foff[-1]) * 4, 16))
-            _backend.get_plan(vad._build_options()).run_post_device(
-                d_energy.ptr, 1, foff, d_vad.ptr)
-            d_energy.free(synced=True)
-            st['d_vad'] = d_vad
+    # ---- energy -> VAD: the weights of the CMVN statistics --------------------------------------------------
+    def stage_vad(self, group):
+        DB = _backend.DeviceBuffer
+        energy = _processor_class('energy')()
+        energy.frame_length = self.frame_length
+        energy.frame_shift = self.frame_shift
+        energy.sample_rate = group.rate
+        eplan = _backend.get_plan(energy._build_options())
+        foff = group.foff
+        if not np.array_equal(self._frame_offsets(eplan, group.soff), foff):
+            raise ValueError('energy and features differ in number of frames')
+        group.hold('energy', DB(max(int(foff[-1]) * 4, 16)))
+        eplan.run_device(group.ptr('wave'), group.soff, foff, group.ptr('energy'), noise_call=_NOISE_CALL)
+        vad = _processor_class('vad')(**self.config['cmvn']['vad'])
+        vplan = _backend.get_plan(vad._build_options())
+        group.hold('vad', DB(max(int(foff[-1]) * 4, 16)))
+        vplan.run_post_device(group.ptr('energy'), 1, foff, group.ptr('vad'))
+        self._count(gpu_ms=eplan.last_kernel_ms(0) + vplan.last_kernel_ms(0))
+        group.drop('energy')
 
-        if 'pitch_job' in st:
-            pass  # (the tracker still reads the audio: released where it is waited for)
-        elif not (stats_only and resident is not None and resident.offer((batch_id, rate), d_wave, soff)):
-            d_wave.free(synced=True)
-        groups_state.append(st)
-
-    # ---- CMVN: statistics of every utterance in one launch per sample rate, summed per speaker (or
-    # kept per utterance) on the host in utterance order; one apply launch per sample rate -----------
-    if with_cmvn:
-        dims = set(st['dim'] for st in groups_state)
+    # ---- CMVN: statistics of every utterance in one launch per sample rate, summed per speaker (or kept per
+    # utterance) on the host in utterance order; one apply launch per sample rate ------------------------------
+    def stage_cmvn(self, stats_hook, stats_only):
+        config, utts, n, cache = self.config, self.utts, self.n, self.cache
+        dims = set(group.dim for group in self.groups)
         if len(dims) != 1:  # pragma: nocover (one processor, one dimension)
             raise ValueError('features have inconsistent dimensions')
         dim = dims.pop()
@@ -790,145 +1115,151 @@ def _extract_features_body(config, utterances, warps, log, tolerance=2, stats_ho
             group_of = np.arange(n, dtype=np.int32)
         cplan = _backend.get_plan(_abi.default_options(_abi.KIND_CMVN))
         per_utt = np.zeros((n, 2, dim + 1), dtype=np.float64)
-        for st in groups_state:
-            local = np.zeros((len(st['idx']), 2, dim + 1), dtype=np.float64)
+        for group in self.groups:
+            local = np.zeros((len(group.idx), 2, dim + 1), dtype=np.float64)
             cplan.cmvn_accumulate_device(
-                st['d_feat'].ptr, dim, st['foff'], local,
-                d_weights=st['d_vad'].ptr if 'd_vad' in st else None,
-                groups=np.arange(len(st['idx']), dtype=np.int32))
-            per_utt[st['idx']] = local
-            if 'd_vad' in st:
-                st['d_vad'].free(synced=True)
+                group.ptr('feat'), dim, group.foff, local,
+                d_weights=group.ptr('vad') if 'vad' in group.blocks else None,
+                groups=np.arange(len(group.idx), dtype=np.int32))
+            per_utt[group.idx] = local
+            if 'vad' in group.blocks:
+                group.drop('vad')
         if stats_only:
-            for st in groups_state:
-                st['d_feat'].free(synced=True)
-            return [names[g] for g in group_of], per_utt
+            for group in self.groups:
+                group.drop('feat')
+            return [names[g] for g in group_of.tolist()], per_utt
+        # (utterance order, like the reference's accumulate loop: np.add.at adds the rows one after the other)
         stats = np.zeros((len(names), 2, dim + 1), dtype=np.float64)
-        for i in range(n):
-            stats[group_of[i]] += per_utt[i]
+        np.add.at(stats, group_of, per_utt)
         if stats_hook is not None:
             # several processes share the utterances of a speaker: their partial statistics are
             # summed here (shennong_amd.distributed.extract_features_sharded)
             stats = stats_hook(names, stats)
-        for g in range(len(names)):
-            if stats[g, 0, -1] < 1.0:
-                raise ValueError(
-                    'insufficient accumulation of stats for CMVN, '
-                    'must be >= 1.0 but is {}'.format(stats[g, 0, -1]))
-        for st in groups_state:
-            d_out = DB(max(int(st['foff'][-1]) * dim * 4, 16))
+        low = np.flatnonzero(stats[:, 0, -1] < 1.0)
+        if low.size:
+            raise ValueError(
+                'insufficient accumulation of stats for CMVN, '
+                'must be >= 1.0 but is {}'.format(stats[low[0], 0, -1]))
+        for group in self.groups:
+            d_out = _backend.DeviceBuffer(max(int(group.foff[-1]) * dim * 4, 16))
             cplan.cmvn_apply_device(
-                st['d_feat'].ptr, dim, st['foff'], stats, d_out.ptr,
-                groups=group_of[st['idx']], norm_vars=True)
-            st['d_feat'].free(synced=True)
-            st['d_feat'] = d_out
-        step = {}  # (the utterances of a group that share a _Meta take this step once)
-        for i, g in enumerate(group_of.tolist()):
-            m = step.get((meta[i], g))
-            if m is None:
-                m = step[(meta[i], g)] = meta[i].derive(
-                    cache, ('cmvn', g),
-                    lambda m, g=g: CmvnPostProcessor(dim, stats=stats[g]).get_properties(m))
-            meta[i] = m
+                group.ptr('feat'), dim, group.foff, stats, d_out.ptr,
+                groups=group_of[group.idx], norm_vars=True)
+            group.swap('feat', d_out)
+        # (the utterances of a CMVN group that share a _Meta take this step once)
+        first, inverse = _classes_of(self.cls_of, group_of)
+        classes = []
+        for k in first.tolist():
+            g = int(group_of[k])
+            classes.append(self.classes[int(self.cls_of[k])].derive(
+                cache, ('cmvn', g),
+                lambda m, g=g: CmvnPostProcessor(dim, stats=stats[g]).get_properties(m)))
+        self.classes, self.cls_of = classes, inverse
 
-    # ---- delta ----------------------------------------------------------------------------------------
-    if 'delta' in config:
-        delta = _processor_class('delta')(**config['delta'])
+    # ---- delta --------------------------------------------------------------------------------------------
+    def stage_delta(self):
+        delta = _processor_class('delta')(**self.config['delta'])
         dplan = _backend.get_plan(delta._build_options())
-        for st in groups_state:
-            odim = dplan.post_ndims(st['dim'])
-            d_out = DB(max(int(st['foff'][-1]) * odim * 4, 16))
-            dplan.run_post_device(st['d_feat'].ptr, st['dim'], st['foff'], d_out.ptr)
-            st['d_feat'].free(synced=True)
-            st['d_feat'], st['dim'] = d_out, odim
-            step = {}
-            for i in st['idx']:
-                m = step.get(meta[i])
-                if m is None:
-                    m = step[meta[i]] = meta[i].derive(cache, 'delta', delta.get_properties, ndims=odim)
-                meta[i] = m
+        odim = None
+        for group in self.groups:
+            odim = dplan.post_ndims(group.dim)
+            d_out = _backend.DeviceBuffer(max(int(group.foff[-1]) * odim * 4, 16))
+            dplan.run_post_device(group.ptr('feat'), group.dim, group.foff, d_out.ptr)
+            self._count(gpu_ms=dplan.last_kernel_ms(0))
+            group.swap('feat', d_out)
+            group.dim = odim
+        self.classes = [m.derive(self.cache, 'delta', delta.get_properties, ndims=odim) for m in self.classes]
 
-    # ---- pitch columns (the number of frames can differ by a few because of the downsampling in the
-    # pitch tracker: same tolerance as Kaldi's paste-feats), then the only device -> host copy -----------
-    out = FeaturesCollection()
-    results = [None] * n
-    pending = []
-    for st in groups_state:
-        idx = st['idx']
-        if 'pitch_job' in st:
-            try:
-                st['d_pitch'] = st.pop('pitch_job').result()
-            except BaseException:
-                st['d_wave'].free()   # (a tracker that failed half way may still have readers enqueued)
-                raise
-            st['d_wave'].free(synced=True)
-            rows, step, trims = [], {}, {}
-            for i in idx:
-                hit = step.get((meta[i], pmeta[i]))
-                if hit is None:  # (same frame counts, times and histories: trimmed and merged once)
-                    # (the trimmed frame count and times depend on the two time axes only: one comparison per
-                    # pair of axes, not one per speaker)
-                    tkey = (meta[i].nframes, id(meta[i].times), pmeta[i].nframes, id(pmeta[i].times))
+    # ---- join: pitch columns (the number of frames can differ by a few because of the downsampling in the
+    # pitch tracker: same tolerance as Kaldi's paste-feats), then the only device -> host copy ------------------
+    def stage_join(self, device_out):
+        utts, n, cache, log, tolerance = self.utts, self.n, self.cache, self.log, self.tolerance
+        results = [None] * n
+        pending = []
+        for group in self.groups:
+            idx = group.idx
+            if group.pitch_job is not None:
+                job, group.pitch_job = group.pitch_job, None
+                try:
+                    group.hold('pitch', job.result())
+                except BaseException:
+                    group.blocks.pop('wave').free()   # (a tracker that failed half way may still have readers enqueued)
+                    raise
+                group.drop('wave')
+                # one trim / merge per pair of (features history, pitch history): same frame counts, times and
+                # histories; the trimmed frame count and times depend on the two time axes only
+                first, inverse = _classes_of(self.cls_of[idx], self.pcls_of[idx])
+                rows_of, classes, trims = [], [], {}
+                for k in first.tolist():
+                    m, o = self.classes[int(self.cls_of[idx[k]])], self.pclasses[int(self.pcls_of[idx[k]])]
+                    tkey = (m.nframes, id(m.times), o.nframes, id(o.times))
                     trim = trims.get(tkey)
                     if trim is None:
                         trim = trims[tkey] = Features._concatenate_meta(
-                            meta[i].nframes, meta[i].ndims, meta[i].times, {},
-                            pmeta[i].nframes, pmeta[i].times, {}, tolerance, log)[:2]
+                            m.nframes, m.ndims, m.times, {}, o.nframes, o.times, {}, tolerance, log)[:2]
                     r, times = trim
-                    hit = step[(meta[i], pmeta[i])] = (r, meta[i].derive(
-                        cache, ('concat', pmeta[i].key),
-                        lambda m, o=pmeta[i]: Features._concatenate_meta(
+                    rows_of.append(r)
+                    classes.append(m.derive(
+                        cache, ('concat', o.key),
+                        lambda m, o=o: Features._concatenate_meta(
                             1, m.ndims, m.times[:1], m.properties, 1, m.times[:1], o.properties,
                             tolerance, log)[2],
-                        ndims=meta[i].ndims + pmeta[i].ndims, nframes=r, times=times))
-                rows.append(hit[0])
-                meta[i] = hit[1]
-            ooff = offsets(rows)
-            odim = st['dim'] + st['pdim']
-            d_out = DB(max(int(ooff[-1]) * odim * 4, 16))
-            _backend.concat_columns_device(
-                st['d_feat'].ptr, st['dim'], st['foff'], st['d_pitch'].ptr, st['pdim'],
-                st['pfoff'], d_out.ptr, ooff)
-            st['d_feat'].free(synced=True)
-            st['d_pitch'].free(synced=True)
-            st['d_feat'], st['dim'], st['foff'] = d_out, odim, ooff
-        if device_out is not None:
-            host = np.empty((int(st['foff'][-1]), st['dim']), dtype=np.float32)   # (never written, never read)
-            if host.size:
-                _backend.check_finite_device(st['d_feat'].ptr, host.size)
-            device_out.append((st['d_feat'], [utts[i].name for i in idx], st['dim']))
+                        ndims=m.ndims + o.ndims, nframes=r, times=times))
+                base = len(self.classes)
+                self.classes = self.classes + classes
+                self.cls_of[idx] = base + inverse
+                ooff = _offsets(np.asarray(rows_of, dtype=np.int64)[inverse])
+                odim = group.dim + group.pdim
+                d_out = _backend.DeviceBuffer(max(int(ooff[-1]) * odim * 4, 16))
+                _backend.concat_columns_device(
+                    group.ptr('feat'), group.dim, group.foff, group.ptr('pitch'), group.pdim,
+                    group.pfoff, d_out.ptr, ooff)
+                group.drop('pitch')
+                group.swap('feat', d_out)
+                group.dim, group.foff = odim, ooff
+            rows = int(group.foff[-1])
+            if device_out is not None:
+                host = np.empty((rows, group.dim), dtype=np.float32)   # (never written, never read)
+                if host.size:
+                    _backend.check_finite_device(group.ptr('feat'), host.size)
+                device_out.append((group.give('feat'), [utts[i].name for i in idx.tolist()], group.dim))
+            else:
+                host = _backend.result_array((rows, group.dim), np.float32)
+                if host.size:
+                    # (Features.validate's data check, once for the batch and before it leaves HBM; the copy
+                    # then runs while the per-utterance objects below are made - they only need to know WHERE
+                    # their rows will be)
+                    _backend.check_finite_device(group.ptr('feat'), host.size)
+                    pending.append((group.blocks['feat'].download_async(host), group, host.nbytes))
+                else:
+                    group.drop('feat')
+            cuts = group.foff.tolist()
+            if len(self.groups) == 1:   # (views of the one downloaded array)
+                results = [host[a:b] for a, b in zip(cuts, cuts[1:])]
+            else:
+                for i, a, b in zip(idx.tolist(), cuts, cuts[1:]):
+                    results[i] = host[a:b]
+        # what is this utterance's own (its audio, its speaker) is made when its properties are first read; the
+        # processors' part of the properties and the times are shared by every utterance with the same history /
+        # frame count and copied when first read (Features._of_batch).  Times are generated, hence sorted; the
+        # data were checked above: no per-utterance validate
+        classes = self.classes
+        metas = [classes[c] for c in self.cls_of.tolist()]
+        of_batch = Features._of_batch
+        if self.utterance_properties:
+            out = FeaturesCollection(
+                (utt.name, of_batch(data, m.times, m, (_utterance_properties, utt, rate)))
+                for utt, data, m, rate in zip(utts, results, metas, self.rate_of))
         else:
-            host = _backend.result_array((int(st['foff'][-1]), st['dim']), np.float32)
-        if device_out is not None:
-            pass
-        elif host.size:
-            # (Features.validate's data check, once for the batch and before it leaves HBM; the copy then
-            # runs while the per-utterance objects below are made - they only need to know WHERE their rows
-            # will be)
-            _backend.check_finite_device(st['d_feat'].ptr, host.size)
-            pending.append((st['d_feat'].download_async(host), st['d_feat']))
-        else:
-            st['d_feat'].free(synced=True)
-        cuts = st['foff'].tolist()
-        for k, i in enumerate(idx):
-            results[i] = host[cuts[k]:cuts[k + 1]]  # views of the one downloaded array
-    of_batch = Features._of_batch
-    for i, utt in enumerate(utts):
-        # what is this utterance's own; the processors' part of the properties and the times are shared by
-        # every utterance with the same history / frame count and copied when first read (Features._of_batch)
-        audio = {'file': (os.path.abspath(utt.audio_file) if isinstance(utt.audio_file, str) else None),
-                 'sample_rate': meta_of[i].sample_rate}
-        if utt.tstart is not None:
-            audio['tstart'] = utt.tstart
-            audio['tstop'] = utt.tstop
-        audio['duration'] = utt.duration
-        extra = {'audio': audio, 'speaker': utt.speaker} if utt.speaker else {'audio': audio}
-        # (times are generated, hence sorted; the data were checked above: no per-utterance validate)
-        out[utt.name] = of_batch(results[i], meta[i].times, meta[i], extra)
-    for wait, d_feat in pending:
-        wait()
-        d_feat.free(synced=True)
-    return out
+            out = FeaturesCollection(
+                (utt.name, of_batch(data, m.times, m, None)) for utt, data, m in zip(utts, results, metas))
+        t0 = time.perf_counter()
+        for wait, group, nbytes in pending:
+            wait()
+            group.drop('feat')
+            self._count(bytes_down=nbytes)
+        self._count(download_wait_s=time.perf_counter() - t0, batches=1, utterances=n)
+        return out
 
 
 def _extract_features_by_stage(config, utterances, warps, log, tolerance=2):

@@ -324,6 +324,68 @@ def test_pipeline_warps(gpu, utterances):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('features', ['mfcc', 'filterbank', 'plp'])
+def test_extract_features_warp(gpu, utterances, features):
+    """reference pipeline.py:650-696 (what the VTLN trainer calls between its iterations; the reference has no
+    test of its own for it): every utterance warped by ONE factor, deltas when configured, nothing else - the
+    result is the chain delta.process(features.process(audio, vtln_warp=warp)), properties included"""
+    from shennong_amd import processor
+    from shennong_amd.postprocessor import DeltaPostProcessor
+    config = pipeline.get_default_config(features, with_pitch='kaldi', with_cmvn=True, with_delta=True)
+    config[features]['dither'] = 0
+    got = pipeline.extract_features_warp(config, utterances, 1.1, get_logger('test', 'error'), njobs=2)
+    cls = {'mfcc': processor.MfccProcessor, 'filterbank': processor.FilterbankProcessor,
+           'plp': processor.PlpProcessor}[features]
+    proc = cls(**config[features])
+    assert list(got.keys()) == ['utt1', 'utt2']
+    for utt in utterances:
+        want = DeltaPostProcessor(**config['delta']).process(proc.process(utt.load_audio(), vtln_warp=1.1))
+        assert got[utt.name] == want           # data, times and properties (no 'audio' / 'speaker' / pitch / cmvn)
+        assert got[utt.name].properties[features]['vtln_warp'] == 1.1
+    del config['delta']
+    plain = pipeline.extract_features_warp(config, utterances, 0.9, get_logger('test', 'error'))
+    assert plain['utt1'] == proc.process(utterances['utt1'].load_audio(), vtln_warp=0.9)
+    with pytest.raises(ValueError, match='do not support VTLN'):
+        pipeline.extract_features_warp(pipeline.get_default_config('spectrogram'), utterances, 1.1)
+    with pytest.raises(ValueError, match='must be strictly positive'):
+        pipeline.extract_features_warp(config, utterances, 1.1, njobs=0)
+
+
+@pytest.mark.gpu
+def test_pipeline_pinned_index(gpu):
+    """a pinned index (Utterances.pin(): the audio in ONE page-locked block) goes through the pipeline from where
+    it lies - one-shot and streamed in several batches, 1 and 3 batches in flight: the same features, bit for
+    bit, as the same utterances given as separate arrays"""
+    from shennong_amd import synth
+    waves = synth.utterances(7, 40, 16000)
+    rng = np.random.RandomState(3)
+    cuts = rng.randint(6000, 16000, size=40)
+    index = Utterances([(f'u{i:02d}', Audio(waves[i, :cuts[i]].copy(), 16000, validate=False), f's{i % 3}')
+                        for i in range(40)])
+    config = pipeline.get_default_config('filterbank', with_pitch='kaldi', with_cmvn=True, with_delta=True)
+    config['filterbank']['dither'] = 0
+    config['pitch']['postprocessing']['delta_pitch_noise_stddev'] = 0
+    want = pipeline.extract_features(config, index)
+    pinned = index.pin()
+    got = pipeline.extract_features(config, pinned)
+    assert list(got) == list(want)
+    for name in want:
+        assert np.array_equal(got[name].data, want[name].data) and np.array_equal(got[name].times, want[name].times)
+        assert got[name].properties['speaker'] == want[name].properties['speaker']
+        assert got[name].properties['pipeline'] == want[name].properties['pipeline']
+    for njobs in (1, 3):
+        out, stats = {}, pipeline.RunStats()
+        count = pipeline.extract_features_streamed(config, pinned, out.update, max_batch_duration=6.0, njobs=njobs,
+                                                   stats=stats)
+        assert count == 40 and list(out) == list(want)
+        assert all(np.array_equal(out[name].data, want[name].data) for name in want)
+        seen = stats.as_dict()
+        assert seen['utterances'] == 40 and seen['batches'] > 3 and seen['gpu_ms'] > 0
+        assert seen['bytes_up'] == 2 * int(cuts.sum())     # (every sample crossed the link once: the second
+        assert seen['bytes_down'] == sum(f.data.nbytes for f in want.values())   # pass reads the resident audio)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('features', ['mfcc', 'filterbank', 'plp', 'spectrogram'])
 def test_pipeline_resident_equals_by_stage(gpu, tmp_path, features):
     """the device-resident pipeline (one upload, one download) returns exactly what the chain of
