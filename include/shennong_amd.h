@@ -366,6 +366,10 @@ int snf_memcpy_d2h_async(void* dst, const void* src, uint64_t bytes, void* strea
 int snf_event_create(void** event);
 int snf_event_destroy(void* event);
 int snf_event_record(void* event, void* stream);
+/* The host waits until `event` has happened (hipEventSynchronize): ONE copy of a stream that already carries the
+   next one - the streamed pipeline sends the audio of batch k + 1 ahead on the stream that carried batch k's
+   (shennong_amd/pipeline.py _Prefetch). */
+int snf_event_synchronize(void* event);
 /* Work enqueued on `stream` after this call starts only when `event` (recorded on another stream) has happened:
    the upload stream of a large batch runs ahead of the stream that launches the kernels and downloads the rows
    (shennong_amd/_backend.py Plan._run_large).  hipStreamWaitEvent; the host does not wait. */

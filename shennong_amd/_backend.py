@@ -39,7 +39,7 @@ EXPORTS = [
     'snf_comm_destroy', 'snf_comm_gatherv', 'snf_comm_allreduce_f64',
     'snf_plan_last_kernel_ms', 'snf_plan_kernel_name', 'snf_set_oom_hook',
     'snf_event_create', 'snf_event_destroy', 'snf_event_record', 'snf_event_elapsed_ms', 'snf_mem_info',
-    'snf_stream_wait_event', 'snf_stream_query']
+    'snf_stream_wait_event', 'snf_stream_query', 'snf_event_synchronize']
 
 
 _OOM_HOOK_TYPE = C.CFUNCTYPE(None)
@@ -133,6 +133,7 @@ def lib():
         L.snf_event_destroy.argtypes = [vp]
         L.snf_event_record.argtypes = [vp, vp]
         L.snf_stream_wait_event.argtypes = [vp, vp]
+        L.snf_event_synchronize.argtypes = [vp]
         L.snf_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
         L.snf_memcpy_d2h_async.argtypes = [vp, vp, C.c_uint64, vp]
         L.snf_comm_unique_id.argtypes = [vp]
@@ -845,6 +846,10 @@ class PinnedCorpus:
         self.views = [self.block[self.soff[k]:self.soff[k + 1]] for k in range(n)]
 
 
+RESULT_KINDS = {'page_locked': 0, 'plain': 0}   # batch results by kind of host memory (diagnostics: a corpus run
+                                                # whose results land in plain memory downloads at half the rate)
+
+
 def result_array(shape, dtype):
     """Uninitialised host array for the one device -> host copy of a batch: pooled page-locked memory
     (no page faults, no munmap per batch, twice the link rate of pageable memory).  Page-locking fresh memory
@@ -857,8 +862,10 @@ def result_array(shape, dtype):
     with _ResultBlock._lock:
         held = _ResultBlock._held
     if held + nbytes > _ResultBlock._LIMIT or nbytes < _Staging._MIN_BYTES:
+        RESULT_KINDS['plain'] += nbytes >= _Staging._MIN_BYTES
         return np.empty(shape, dtype=dtype)
     array, token = STAGING.array(shape, dtype, allocate=held + nbytes <= _ResultBlock._FRESH)
+    RESULT_KINDS['plain' if token is None else 'page_locked'] += 1
     if token is None:
         return array
     block = _ResultBlock(shape, dtype, token, token[1])
@@ -1017,15 +1024,20 @@ def side_pool():
 
 class _DevicePool:
     """Freed device buffers kept for the next batch (hipMalloc / hipFree synchronise the device and cost
-    0.1-0.4 ms each; a pipeline call makes twenty of them).  Bounded by SNF_DEVICE_POOL_BYTES (default
-    8 GiB of the 288 GB); a buffer is reused for a request of at least half its size."""
+    0.1-0.4 ms each and more for large blocks; a pipeline call makes twenty of them).  Bounded by
+    SNF_DEVICE_POOL_BYTES (default 16 GiB of the 288 GB); a buffer is reused for a request of at least half its
+    size.  When a block does not fit under the bound, the blocks that were parked LONGEST AGO are released to make
+    room: the pool follows the workload (round 6: after the benchmark's other legs had filled it with their block
+    sizes, every buffer of the streamed pipeline and of `process_all` went to hipMalloc and back to hipFree -
+    25 against 20 ms per `process_all` call)."""
     def __init__(self):
-        self.limit = int(os.environ.get('SNF_DEVICE_POOL_BYTES', 8 << 30))
+        self.limit = int(os.environ.get('SNF_DEVICE_POOL_BYTES', 16 << 30))
         # tests: a reused buffer is filled with NaN bit patterns before it is handed out, so that a kernel
         # that relies on what a fresh allocation happens to contain shows up
         self.poison = bool(int(os.environ.get('SNF_DEVICE_POOL_POISON', '0')))
-        self._free = {}  # device -> list of (capacity, pointer)
+        self._free = {}  # device -> list of (capacity, pointer, stamp)
         self._bytes = 0
+        self._stamp = 0
         self._lock = threading.Lock()
 
     def take(self, device, nbytes):
@@ -1037,16 +1049,32 @@ class _DevicePool:
                     block = min(fits)
                     blocks.remove(block)
                     self._bytes -= block[0]
-                    return block
+                    return block[:2]
         return None
 
     def give(self, device, block):
+        """parks `block` (capacity, pointer); -> False when it alone exceeds the bound (the caller releases it)"""
+        evicted = []
         with self._lock:
-            if self._bytes + block[0] > self.limit:
+            if block[0] > self.limit:
                 return False
-            self._free.setdefault(device, []).append(block)
+            while self._bytes + block[0] > self.limit:
+                oldest = min(((b[2], d, b) for d, bs in self._free.items() for b in bs), default=None)
+                if oldest is None:
+                    break
+                _, d, b = oldest
+                self._free[d].remove(b)
+                self._bytes -= b[0]
+                evicted.append((d, b))
+            self._stamp += 1
+            self._free.setdefault(device, []).append((block[0], block[1], self._stamp))
             self._bytes += block[0]
-            return True
+        for d, b in evicted:   # (the caller has just waited for the device or says it is idle: see DeviceBuffer.free)
+            bind_device(d)
+            lib().snf_free(C.c_void_p(b[1]))
+        if evicted:
+            bind_device(device)
+        return True
 
     def clear(self):
         with self._lock:
@@ -1102,9 +1130,21 @@ class DeviceBuffer:
         on the calling thread's copy stream and returns a callable that waits for it (from any thread)"""
         bind_device(self.device)
         stream = _copy_stream(self.device)
-        check(lib().snf_memcpy_h2d_async(C.c_void_p(self.ptr), array.ctypes.data_as(C.c_void_p),
-                                         array.nbytes, C.c_void_p(stream)))
-        return lambda: check(lib().snf_stream_synchronize(C.c_void_p(stream)))
+        L = lib()
+        check(L.snf_memcpy_h2d_async(C.c_void_p(self.ptr), array.ctypes.data_as(C.c_void_p),
+                                     array.nbytes, C.c_void_p(stream)))
+        done = C.c_void_p()
+        check(L.snf_event_create(C.byref(done)))
+        check(L.snf_event_record(done, C.c_void_p(stream)))
+
+        def wait():   # (THIS copy, not whatever was enqueued on the stream behind it; a second call is a no-op)
+            if done.value:
+                try:
+                    check(L.snf_event_synchronize(done))
+                finally:
+                    L.snf_event_destroy(done)
+                    done.value = None
+        return wait
 
     def download_async(self, array):
         """Starts the copy into `array` on this thread's copy stream and returns a callable that waits for

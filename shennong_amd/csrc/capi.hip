@@ -1662,6 +1662,11 @@ int snf_event_record(void* event, void* stream) {
   SNF_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)));
   return SNF_OK;
 }
+int snf_event_synchronize(void* event) {
+  if (!event) return set_error(SNF_E_INVALID, "null event");
+  SNF_HIP_CHECK(hipEventSynchronize(static_cast<hipEvent_t>(event)));
+  return SNF_OK;
+}
 int snf_stream_wait_event(void* stream, void* event) {
   if (!event) return set_error(SNF_E_INVALID, "null event");
   SNF_HIP_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(event), 0));

@@ -45,6 +45,9 @@ def _invalid(features):
 
 class Features:
     """Features data with attached timestamps and properties"""
+    # (no per-instance dictionary: a corpus run makes one of these per utterance)
+    __slots__ = ('_data', '_times', '_properties', '_shared')
+
     def __init__(self, data, times, properties=None, validate=True):
         self._data, self._times = data, times
         self._properties = {} if properties is None else properties
@@ -98,7 +101,8 @@ class Features:
                 '_shared': None}
 
     def __setstate__(self, state):
-        self.__dict__.update(state)
+        for name, value in state.items():
+            setattr(self, name, value)
 
     dtype = property(lambda self: self.data.dtype)
     shape = property(lambda self: self.data.shape)

@@ -468,13 +468,16 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
     if max_batch_duration is None:
         max_batch_duration = default_batch_duration(depth)
     has_speakers, pinned = utterances.has_speakers(), getattr(utterances, '_pinned', None)
+    all_names, all_speakers = [u.name for u in utts], [u.speaker for u in utts]
 
     def views():
         """the batches, in order; the audio of a pinned batch that is not in HBM from an earlier pass is sent
         ahead: started when the batch BEFORE it is handed out, so that it crosses the link beside that one's
         kernels"""
         def view_of(batch, first, b):
-            view = _BatchView(batch, has_speakers, pinned=pinned, first=first)
+            last = first + len(batch)
+            view = _BatchView(batch, has_speakers, pinned=pinned, first=first, names=all_names[first:last],
+                              speakers=all_speakers[first:last])
             if pinned is not None and not (resident is not None and resident.holds((b, pinned.sample_rate))):
                 view.prefetch = _Prefetch(view)
             return view
@@ -538,6 +541,7 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
 
             def hook(batch_names, _partial):
                 return total_of[np.fromiter((number[k] for k in batch_names), np.int64, len(batch_names))]
+            hook.replaces = True   # (the batch's own partial sums are not looked at: not made either)
 
         def second_pass(b, batch):
             return _extract_features(config, batch, sub(batch), log, stats_hook=hook,
@@ -662,11 +666,14 @@ class _BatchView:
     - what ``Utterances(batch)`` gave, minus its validation (names, formats, duplicates: the index went through
     it when it was made; 4 us per utterance and batch) - plus, when the index was pinned (``Utterances.pin()``),
     WHERE the audio of the run lies in the page-locked block: utterances `first` ... `first + len` of `pinned`."""
-    def __init__(self, utts, has_speakers, pinned=None, first=0):
+    def __init__(self, utts, has_speakers, pinned=None, first=0, names=None, speakers=None):
         self._utts = utts
         self._has_speakers = bool(has_speakers)
         self.pinned, self.first = pinned, int(first)
         self.prefetch = None   # a _Prefetch when the audio of the run was sent ahead
+        # (read once per corpus instead of once per utterance, batch and pass)
+        self.names = names if names is not None else [u.name for u in utts]
+        self.speakers = speakers if speakers is not None else [u.speaker for u in utts]
 
     def __iter__(self):
         return iter(self._utts)
@@ -864,6 +871,8 @@ class _PipelineRun:
         self.view = utterances
         self.utts = list(utterances)
         self.n = len(self.utts)
+        self.names = getattr(utterances, 'names', None) or [u.name for u in self.utts]
+        self.speakers = getattr(utterances, 'speakers', None) or [u.speaker for u in self.utts]
         self.cache = {}       # properties per processing history (see _Meta)
         self.groups = []      # one _Group per sample rate
         self.classes = []     # the distinct _Meta of the main features ...
@@ -1107,11 +1116,11 @@ class _PipelineRun:
             raise ValueError('features have inconsistent dimensions')
         dim = dims.pop()
         if config['cmvn']['by_speaker']:
-            names = list(dict.fromkeys(u.speaker for u in utts))
+            names = list(dict.fromkeys(self.speakers))
             number = {name: g for g, name in enumerate(names)}
-            group_of = np.asarray([number[u.speaker] for u in utts], dtype=np.int32)
+            group_of = np.fromiter(map(number.__getitem__, self.speakers), np.int32, n)
         else:
-            names = [u.name for u in utts]
+            names = self.names
             group_of = np.arange(n, dtype=np.int32)
         cplan = _backend.get_plan(_abi.default_options(_abi.KIND_CMVN))
         per_utt = np.zeros((n, 2, dim + 1), dtype=np.float64)
@@ -1128,9 +1137,11 @@ class _PipelineRun:
             for group in self.groups:
                 group.drop('feat')
             return [names[g] for g in group_of.tolist()], per_utt
-        # (utterance order, like the reference's accumulate loop: np.add.at adds the rows one after the other)
+        # (utterance order, like the reference's accumulate loop: np.add.at adds the rows one after the other; a
+        # hook that brings the statistics of the whole corpus - second pass of the streamed pipeline - needs none)
         stats = np.zeros((len(names), 2, dim + 1), dtype=np.float64)
-        np.add.at(stats, group_of, per_utt)
+        if not getattr(stats_hook, 'replaces', False):
+            np.add.at(stats, group_of, per_utt)
         if stats_hook is not None:
             # several processes share the utterances of a speaker: their partial statistics are
             # summed here (shennong_amd.distributed.extract_features_sharded)
@@ -1243,16 +1254,13 @@ class _PipelineRun:
         # processors' part of the properties and the times are shared by every utterance with the same history /
         # frame count and copied when first read (Features._of_batch).  Times are generated, hence sorted; the
         # data were checked above: no per-utterance validate
-        classes = self.classes
-        metas = [classes[c] for c in self.cls_of.tolist()]
-        of_batch = Features._of_batch
-        if self.utterance_properties:
-            out = FeaturesCollection(
-                (utt.name, of_batch(data, m.times, m, (_utterance_properties, utt, rate)))
-                for utt, data, m, rate in zip(utts, results, metas, self.rate_of))
-        else:
-            out = FeaturesCollection(
-                (utt.name, of_batch(data, m.times, m, None)) for utt, data, m in zip(utts, results, metas))
+        from itertools import repeat
+        from operator import attrgetter
+        metas = list(map(self.classes.__getitem__, self.cls_of.tolist()))
+        times = map(attrgetter('times'), metas)
+        extras = zip(repeat(_utterance_properties), utts, self.rate_of) if self.utterance_properties \
+            else repeat(None)
+        out = FeaturesCollection(zip(self.names, map(Features._of_batch, results, times, metas, extras)))
         t0 = time.perf_counter()
         for wait, group, nbytes in pending:
             wait()

@@ -558,3 +558,32 @@ def test_streamed_batch_default_without_a_device():
         assert pipeline.default_batch_duration(8) == 14400.0
     else:
         assert 600.0 <= pipeline.default_batch_duration(8) <= pipeline.default_batch_duration(1) <= 14400.0
+
+
+def test_device_pool_follows_the_workload(monkeypatch):
+    """round 6: a pool that is full of one leg's block sizes makes room for the next leg's by releasing what was
+    parked longest ago (it used to refuse: every buffer of the next leg then went through hipMalloc / hipFree)"""
+    from shennong_amd import _backend
+    freed = []
+
+    class Lib:
+        def snf_free(self, ptr):
+            freed.append(ptr.value)
+            return 0
+
+        def snf_set_device(self, device):
+            return 0
+    monkeypatch.setattr(_backend, 'lib', lambda: Lib())
+    pool = _backend._DevicePool()
+    M = 1 << 20
+    pool.limit = 1000 * M
+    assert pool.give(0, (400 * M, 1)) and pool.give(0, (400 * M, 2)) and pool._bytes == 800 * M and not freed
+    assert pool.take(0, 150 * M) is None and pool.take(0, 300 * M) == (400 * M, 1)   # (at most twice the request)
+    assert pool.give(0, (400 * M, 1)) and pool._bytes == 800 * M
+    assert pool.give(0, (500 * M, 3)) and freed == [2] and pool._bytes == 900 * M   # 2 was parked longest ago
+    assert pool.give(1, (900 * M, 4)) and sorted(freed) == [1, 2, 3] and pool._bytes == 900 * M
+    assert not pool.give(0, (1001 * M, 5)) and pool._bytes == 900 * M               # larger than the whole pool
+    assert pool.take(1, 900 * M) == (900 * M, 4) and pool._bytes == 0
+    pool.give(0, (10 * M, 6))
+    pool.clear()
+    assert freed[-1] == 6 and pool._bytes == 0

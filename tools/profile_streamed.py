@@ -41,8 +41,11 @@ def sink(feats):
     seen.append(sum(f.nframes for f in feats.values()))
 
 
+only = os.environ.get('ONLY')
 for name, idx in (('pageable', index), ('pinned', pinned)):
-    for njobs in (1, 2, 3, 4):
+    if only and name != only:
+        continue
+    for njobs in ((1, 2, 3, 4) if not only else (1, 2)):
         best = None
         for rep in range(3):
             st = pipeline.RunStats()
@@ -55,6 +58,8 @@ for name, idx in (('pageable', index), ('pinned', pinned)):
               'wait %.3f s, gpu %.3f s' % (name, njobs, best, hours / best, best / n * 1e6, d['bytes_up'] / 1e9,
                                            d['upload_wait_s'], d['bytes_down'] / 1e9, d['download_wait_s'],
                                            d['gpu_ms'] / 1e3), flush=True)
+        from shennong_amd import _backend
+        print('   result blocks:', _backend.RESULT_KINDS, 'held', _backend._ResultBlock._held, 'pool', [b[0] >> 20 for b in _backend.STAGING._free], flush=True)
 if what != 'none':
     idx = pinned if what == 'pin' else index
     prof = cProfile.Profile()
