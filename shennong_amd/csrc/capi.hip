@@ -71,6 +71,28 @@ struct DevBuf {
 
 constexpr int kMaxSlots = 6;
 
+// Scratch and a stream of its own for the plan-less device helpers (snf_concat_columns_device,
+// snf_count_nonfinite_device), per calling thread and device: no hipMalloc / hipFree per call (both wait for the
+// whole device) and no device-wide wait at the end - the batches a pipeline keeps in flight on other threads, and
+// the pitch tracker beside this thread, go on undisturbed.  Lives as long as the thread.
+struct ThreadScratch {
+  hipStream_t stream = nullptr;
+  DevBuf buf;
+};
+ThreadScratch* thread_scratch(int device_id) {
+  thread_local std::vector<std::pair<int, ThreadScratch*>> mine;
+  for (auto& e : mine)
+    if (e.first == device_id) return e.second;
+  ThreadScratch* t = new ThreadScratch;
+  if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete t;
+    snf::set_error(SNF_E_HIP, "hipStreamCreate failed");
+    return nullptr;
+  }
+  mine.emplace_back(device_id, t);
+  return t;
+}
+
 }  // namespace
 
 struct snf_plan {
@@ -1558,20 +1580,21 @@ int snf_concat_columns_device(int device_id, const float* d_a, int32_t cols_a,
   if (total == 0) return SNF_OK;
   if (!d_a || !d_b || !d_out) return set_error(SNF_E_INVALID, "null buffer");
   SNF_HIP_CHECK(hipSetDevice(device_id));
-  int64_t* d_off;
-  SNF_HIP_CHECK(hipMalloc(&d_off, sizeof(int64_t) * 3 * (n_utts + 1)));
-  int rc = SNF_OK;
-  if (hipMemcpy(d_off, offsets_a, sizeof(int64_t) * (n_utts + 1), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(d_off + (n_utts + 1), offsets_b, sizeof(int64_t) * (n_utts + 1),
-                hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(d_off + 2 * (n_utts + 1), offsets_out, sizeof(int64_t) * (n_utts + 1),
-                hipMemcpyHostToDevice) != hipSuccess)
-    rc = set_error(SNF_E_HIP, "offset upload failed");
-  if (!rc)
-    rc = launch_concat_columns(d_a, cols_a, d_off, d_b, cols_b, d_off + (n_utts + 1), n_utts, d_out,
-                               d_off + 2 * (n_utts + 1), total, nullptr);
-  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = set_error(SNF_E_HIP, "concat kernel failed");
-  (void)hipFree(d_off);
+  ThreadScratch* t = thread_scratch(device_id);
+  if (!t) return SNF_E_HIP;
+  int rc = t->buf.ensure(sizeof(int64_t) * 3 * (n_utts + 1));
+  if (rc) return rc;
+  int64_t* d_off = t->buf.as<int64_t>();
+  // (pageable sources: each copy has read its source when it returns; everything on the thread's own stream,
+  // waited for alone - a device-wide wait would also wait for the tracker and the copies of other batches)
+  SNF_HIP_CHECK(hipMemcpyAsync(d_off, offsets_a, sizeof(int64_t) * (n_utts + 1), hipMemcpyHostToDevice, t->stream));
+  SNF_HIP_CHECK(hipMemcpyAsync(d_off + (n_utts + 1), offsets_b, sizeof(int64_t) * (n_utts + 1),
+                               hipMemcpyHostToDevice, t->stream));
+  SNF_HIP_CHECK(hipMemcpyAsync(d_off + 2 * (n_utts + 1), offsets_out, sizeof(int64_t) * (n_utts + 1),
+                               hipMemcpyHostToDevice, t->stream));
+  rc = launch_concat_columns(d_a, cols_a, d_off, d_b, cols_b, d_off + (n_utts + 1), n_utts, d_out,
+                             d_off + 2 * (n_utts + 1), total, t->stream);
+  if (hipStreamSynchronize(t->stream) != hipSuccess && !rc) rc = set_error(SNF_E_HIP, "concat kernel failed");
   return rc;
 }
 
@@ -1582,15 +1605,17 @@ int snf_count_nonfinite_device(int device_id, const float* d_data, uint64_t n, u
   if (!d_data) return set_error(SNF_E_INVALID, "null buffer");
   if (reinterpret_cast<uintptr_t>(d_data) & 15) return set_error(SNF_E_INVALID, "buffer is not 16-byte aligned");
   SNF_HIP_CHECK(hipSetDevice(device_id));
-  unsigned long long* d_count;
-  SNF_HIP_CHECK(hipMalloc(&d_count, sizeof(unsigned long long)));
-  int rc = SNF_OK;
+  ThreadScratch* t = thread_scratch(device_id);
+  if (!t) return SNF_E_HIP;
+  int rc = t->buf.ensure(sizeof(unsigned long long));
+  if (rc) return rc;
+  unsigned long long* d_count = t->buf.as<unsigned long long>();
   unsigned long long host = 0;
-  if (hipMemset(d_count, 0, sizeof(unsigned long long)) != hipSuccess) rc = set_error(SNF_E_HIP, "memset failed");
-  if (!rc) rc = launch_count_nonfinite(d_data, n, d_count, nullptr);
-  if (!rc && hipMemcpy(&host, d_count, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess)
+  SNF_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), t->stream));
+  rc = launch_count_nonfinite(d_data, n, d_count, t->stream);
+  if (!rc && (hipMemcpyAsync(&host, d_count, sizeof(host), hipMemcpyDeviceToHost, t->stream) != hipSuccess ||
+              hipStreamSynchronize(t->stream) != hipSuccess))
     rc = set_error(SNF_E_HIP, "non-finite count kernel failed");
-  (void)hipFree(d_count);
   *count = host;
   return rc;
 }

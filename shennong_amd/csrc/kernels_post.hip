@@ -1271,29 +1271,42 @@ int launch_sliding_cmvn(const snf_sliding_cmvn_options& o, const float* in, int 
 
 // Column-wise concatenation of two feature blocks per utterance (reference Features.concatenate,
 // features.py:386-437: the longer side is trimmed to the shorter one within the caller's tolerance):
-// out[u][t] = [a[u][t], b[u][t]] for t < rows_out(u).  One thread per output element.
-__global__ void concat_columns_kernel(const float* __restrict__ a, const int ca,
-                                      const int64_t* __restrict__ off_a, const float* __restrict__ bm,
-                                      const int cb, const int64_t* __restrict__ off_b,
-                                      const int64_t n_utts, float* __restrict__ out,
-                                      const int64_t* __restrict__ off_o, const int64_t total_rows) {
+// out[u][t] = [a[u][t], b[u][t]] for t < rows_out(u).  A workgroup owns kConcatRows consecutive output rows: one
+// lane per row finds the row's utterance (the only search; it used to be one per ELEMENT) and leaves where the row
+// starts in `a` and `b` in LDS; then the 256 lanes walk the rows' elements in output order - coalesced stores, and
+// loads that are contiguous wherever consecutive rows belong to one utterance.  HBM-bound by design:
+// 4 (ca + cb) bytes read + as many written per row.
+constexpr int kConcatRows = 32;
+__global__ __launch_bounds__(256) void concat_columns_kernel(
+    const float* __restrict__ a, const int ca, const int64_t* __restrict__ off_a, const float* __restrict__ bm,
+    const int cb, const int64_t* __restrict__ off_b, const int64_t n_utts, float* __restrict__ out,
+    const int64_t* __restrict__ off_o, const int64_t total_rows) {
+  __shared__ int64_t row_a[kConcatRows], row_b[kConcatRows];
   const int co = ca + cb;
-  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (idx >= total_rows * co) return;
-  const int64_t g = idx / co;
-  const int c = static_cast<int>(idx - g * co);
-  const int64_t u = find_utt(off_o, n_utts, g);
-  const int64_t t = g - off_o[u];
-  out[idx] = c < ca ? a[(off_a[u] + t) * ca + c] : bm[(off_b[u] + t) * cb + (c - ca)];
+  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kConcatRows;
+  const int rows = static_cast<int>(total_rows - row0 < kConcatRows ? total_rows - row0 : kConcatRows);
+  if (static_cast<int>(threadIdx.x) < rows) {
+    const int64_t g = row0 + threadIdx.x;
+    const int64_t u = find_utt(off_o, n_utts, g);
+    const int64_t t = g - off_o[u];
+    row_a[threadIdx.x] = (off_a[u] + t) * ca;
+    row_b[threadIdx.x] = (off_b[u] + t) * cb - ca;   // (indexed with the output column)
+  }
+  __syncthreads();
+  float* __restrict__ dst = out + row0 * co;
+  const int count = rows * co;
+  for (int i = threadIdx.x; i < count; i += 256) {
+    const int r = i / co, c = i - r * co;
+    dst[i] = c < ca ? a[row_a[r] + c] : bm[row_b[r] + c];
+  }
 }
 
 int launch_concat_columns(const float* a, int cols_a, const int64_t* d_off_a, const float* b, int cols_b,
                           const int64_t* d_off_b, int64_t n_utts, float* out, const int64_t* d_off_out,
                           int64_t total_rows, hipStream_t stream) {
-  const int64_t total = total_rows * (cols_a + cols_b);
-  if (total <= 0) return SNF_OK;
-  hipLaunchKernelGGL(concat_columns_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256),
-                     0, stream, a, cols_a, d_off_a, b, cols_b, d_off_b, n_utts, out, d_off_out,
+  if (total_rows <= 0) return SNF_OK;
+  hipLaunchKernelGGL(concat_columns_kernel, dim3(static_cast<unsigned>((total_rows + kConcatRows - 1) / kConcatRows)),
+                     dim3(256), 0, stream, a, cols_a, d_off_a, b, cols_b, d_off_b, n_utts, out, d_off_out,
                      total_rows);
   SNF_HIP_CHECK(hipGetLastError());
   return SNF_OK;

@@ -470,6 +470,8 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
     has_speakers, pinned = utterances.has_speakers(), getattr(utterances, '_pinned', None)
     all_names, all_speakers = [u.name for u in utts], [u.speaker for u in utts]
 
+    all_batches = list(_batches(utts, max_batch_duration))   # (the same cuts in both passes: made once)
+
     def views():
         """the batches, in order; the audio of a pinned batch that is not in HBM from an earlier pass is sent
         ahead: started when the batch BEFORE it is handed out, so that it crosses the link beside that one's
@@ -481,7 +483,7 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
             if pinned is not None and not (resident is not None and resident.holds((b, pinned.sample_rate))):
                 view.prefetch = _Prefetch(view)
             return view
-        batches = _batches(utts, max_batch_duration)
+        batches = iter(all_batches)
         ahead = first = None
         try:
             batch, first, b = next(batches, None), 0, 0
@@ -583,8 +585,11 @@ class _Meta:
     """What the post-processors' `get_properties` need to know about features that live in HBM.
     The properties of a stage are the same for every utterance that went through the same processors
     with the same per-utterance arguments (warp factor, CMVN group): `key` names that history and
-    `cache` holds one properties dictionary per history, copied once per utterance at the end."""
-    __slots__ = ('_properties', '_source', 'ndims', 'nframes', 'times', 'key', '_derived')
+    `cache` holds one properties dictionary per history, copied once per utterance at the end.
+    A _Meta points to its parent only (no table of children: parent and child would form a reference cycle,
+    and the 3 000 of them a by-speaker batch makes would wait for the cyclic collector instead of going with
+    the batch)."""
+    __slots__ = ('_properties', '_source', 'ndims', 'nframes', 'times', 'key')
 
     def __init__(self, properties, ndims, nframes, times, key=None, source=None):
         self._properties = properties
@@ -593,7 +598,6 @@ class _Meta:
         self.nframes = nframes
         self.times = times
         self.key = key
-        self._derived = {}
 
     @property
     def properties(self):
@@ -609,18 +613,12 @@ class _Meta:
         return self._properties
 
     def derive(self, cache, tag, make_properties, ndims=None, nframes=None, times=None):
-        """The _Meta after one more stage.  Utterances with the same history and frame count share one
-        _Meta object, so the second utterance to take the same step finds the result here."""
-        memo = (tag, ndims, nframes, id(times))
-        found = self._derived.get(memo)
-        if found is not None:
-            return found
+        """The _Meta after one more stage (the stages call this once per distinct history and frame count,
+        see _classes_of)"""
         key = (self.key, tag)
-        found = self._derived[memo] = _Meta(
-            cache.get(key), self.ndims if ndims is None else ndims,
-            self.nframes if nframes is None else nframes,
-            self.times if times is None else times, key, source=(cache, self, make_properties))
-        return found
+        return _Meta(cache.get(key), self.ndims if ndims is None else ndims,
+                     self.nframes if nframes is None else nframes,
+                     self.times if times is None else times, key, source=(cache, self, make_properties))
 
 
 class _ResidentWaves:
