@@ -47,6 +47,73 @@ def _pool_map(fn, jobs):
         return list(pool.map(fn, jobs))
 
 
+def _oracle_pipeline_check(config, index, kept, wave_of, what):
+    """the composed pipeline against the ORACLE, not against itself.  For the utterances in
+    `kept` ({name: Features [frames, 123]}, all the utterances of their speakers) the expected columns are built
+    from oracle calls only (reference shennong/pipeline.py:570-644, postprocessor/cmvn.py:180-282):
+
+        fbank-40 (orc.compute) -> VAD weights (orc.vad_energy of the oracle's log-energy) -> statistics per
+        speaker (orc.cmvn_accumulate over ALL the speaker's utterances) -> orc.cmvn_apply -> orc.deltas ->
+        | orc.pitch -> orc.process_pitch | joined with the paste-feats tolerance of 2 frames
+
+    The reference dithers the energy the VAD looks at (EnergyProcessor's default dither = 1, drawn from a
+    generator the oracle cannot replay), so a handful of frames next to the threshold may be weighted the other
+    way: (a) the statistics the pipeline recorded in the properties agree with the oracle's to that extent -
+    frame counts within 0.2 %, sums within 2e-3 relative -, (b) the final columns agree with the all-oracle chain
+    at 5e-3 absolute (normalised units), and (c) with the oracle chain run on the pipeline's OWN recorded
+    statistics - which removes the dither from the comparison - at the parity tolerance, every column family."""
+    from shennong_amd.processor import EnergyProcessor, FilterbankProcessor
+    fopts = FilterbankProcessor(**config['filterbank'])._build_options()
+    eopts = EnergyProcessor(dither=0)._build_options()
+    pproc = KaldiPitchProcessor(**{k: v for k, v in config['pitch'].items()
+                                   if k not in ('processor', 'postprocessing')})
+    post = KaldiPitchPostProcessor(**config['pitch']['postprocessing'])
+    per_wave = {}
+
+    def oracle_of(wave_id):
+        if wave_id not in per_wave:
+            wave = wave_of(wave_id)
+            fbank = orc.compute(fopts, wave)
+            weights = orc.vad_energy(orc.compute(eopts, wave), **config['cmvn']['vad'])
+            pitch = orc.process_pitch(post._options, orc.pitch(pproc._options, wave))
+            per_wave[wave_id] = (fbank, weights, pitch)
+        return per_wave[wave_id]
+    by_speaker = {}
+    for name in kept:
+        by_speaker.setdefault(index.by_name()[name].speaker, []).append(name)
+    checked = 0
+    for speaker, names in by_speaker.items():
+        assert len(names) == sum(1 for u in index if u.speaker == speaker)   # (all of the speaker's utterances)
+        want_stats = np.zeros((2, 41))
+        for name in sorted(names):
+            fbank, weights, _ = oracle_of(index.by_name()[name]._wave_id)
+            orc.cmvn_accumulate(fbank, weights=weights, stats=want_stats)
+        got_stats = kept[names[0]].properties['cmvn']['stats']
+        assert got_stats.shape == (2, 41)
+        assert abs(got_stats[0, -1] - want_stats[0, -1]) <= 2e-3 * want_stats[0, -1], (what, speaker)
+        np.testing.assert_allclose(got_stats, want_stats, rtol=2e-3, err_msg=f'{what}: statistics of {speaker}')
+        for name in names:
+            fbank, _, pitch = oracle_of(index.by_name()[name]._wave_id)
+            got = kept[name].data
+            rows = min(fbank.shape[0], pitch.shape[0])
+            assert abs(fbank.shape[0] - pitch.shape[0]) <= 2 and got.shape == (rows, 123)
+            for stats, atol in ((want_stats, 5e-3), (got_stats, None)):
+                normed = orc.cmvn_apply(fbank, stats)
+                want = np.hstack((orc.deltas(normed, 2, 2)[:rows], pitch[:rows]))
+                assert want.shape == got.shape and want.dtype == np.float32
+                if atol is not None:   # (b) all-oracle: within the VAD's dither
+                    np.testing.assert_allclose(got[:, :120], want[:, :120], rtol=1e-4, atol=atol,
+                                               err_msg=f'{what}: {name} vs the all-oracle chain')
+                else:                  # (c) the oracle chain on the recorded statistics: the parity tolerance
+                    assert_close(got[:, :40], want[:, :40], rtol=1e-4, atol=1e-4, what=f'{what} cmvn(fbank) {name}')
+                    assert_close(got[:, 40:120], want[:, 40:120], rtol=1e-4, atol=1e-4,
+                                 what=f'{what} delta columns {name}')
+                    assert_close(got[:, 120:], want[:, 120:], rtol=1e-4, family='pitch_post',
+                                 what=f'{what} pitch columns {name}')
+            checked += 1
+    return checked
+
+
 def test_config4_one_shard(gpu):
     n = 12500
     waves = [w for part in _pool_map(_ragged, [(i, min(500, n - i)) for i in range(0, n, 500)]) for w in part]
@@ -124,6 +191,8 @@ def test_config5_per_gpu_share_streamed(gpu):
     waves = np.concatenate(_pool_map(_uniform, [(i, 100, nsamples) for i in range(0, unique, 100)]))
     index = Utterances([(f'u{i:06d}', Audio(waves[i % unique], 16000, validate=False), f's{i % speakers:04d}')
                         for i in range(n)])
+    for i, utt in enumerate(index):
+        utt._wave_id = i % unique
     assert abs(sum(u.duration for u in index) / 3600.0 - 125.0) < 1e-6
     config = pipeline.get_default_config('filterbank', with_pitch='kaldi', with_cmvn=True, with_delta=True)
     config['filterbank']['num_bins'] = 40
@@ -165,3 +234,16 @@ def test_config5_per_gpu_share_streamed(gpu):
     assert sorted(whole.keys()) == sorted(kept)
     for name, f in kept.items():
         assert f == whole[name], name
+    # ... and against the oracle: the 450 utterances of the three speakers, every column family
+    assert _oracle_pipeline_check(config, index, kept, lambda k: waves[k], 'config 5, 125 h streamed') == 450
+    # the same corpus from ONE page-locked block (Utterances.pin(), two batches in flight): the same bits
+    pinned_kept = {}
+
+    def pinned_sink(feats):
+        for name, f in feats.items():
+            if name in kept:
+                pinned_kept[name] = f.copy()
+    assert pipeline.extract_features_streamed(config, index.pin(), pinned_sink, njobs=2, log=quiet) == n
+    assert sorted(pinned_kept) == sorted(kept)
+    for name, f in kept.items():
+        assert np.array_equal(pinned_kept[name].data, f.data), name

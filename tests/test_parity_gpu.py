@@ -272,18 +272,28 @@ def _synth_job(args):
     return synth.utterances(*args)
 
 
-@pytest.mark.parametrize('kind', ['fbank40', 'mfcc13', 'mfcc13_delta', 'plp13'])
+@pytest.mark.parametrize('kind', ['fbank40', 'mfcc13', 'mfcc13_delta', 'plp13', 'spectrogram257'])
 def test_full_workload_every_frame(gpu, full_workload, kind):
     """The whole bench workload (2.98 M frames), EVERY frame against the oracle, through the same
     batched entry point the bench times; then order independence: the batch reversed gives the same
-    rows bit for bit."""
+    rows bit for bit.  `spectrogram257` (the other half of BASELINE config 2; 3.06 GB of output) is compared
+    500 utterances at a time."""
     waves = full_workload
     proc = (FilterbankProcessor(num_bins=40, dither=0) if kind == 'fbank40'
-            else PlpProcessor(dither=0) if kind == 'plp13' else MfccProcessor(dither=0))
+            else PlpProcessor(dither=0) if kind == 'plp13'
+            else SpectrogramProcessor(dither=0) if kind == 'spectrogram257' else MfccProcessor(dither=0))
     opts = proc._build_options()
     plan = _backend.get_plan(opts)
     got = plan.run(list(waves))
     assert len(got) == 10000 and all(g.shape == (298, plan.ndims) for g in got[::997])
+    if kind == 'spectrogram257':
+        assert plan.ndims == 257
+        for a in range(0, 10000, 500):
+            want = orc.compute_batch(opts, waves[a:a + 500], os.cpu_count() or 1)
+            assert_close(np.concatenate(got[a:a + 500]), want, what=f'spectrogram utterances {a}..{a + 499}')
+        rev = plan.run(list(waves[:2000][::-1]))[::-1]   # (order independence on a fifth of it)
+        assert all(np.array_equal(r, g) for r, g in zip(rev, got[:2000]))
+        return
     got = np.concatenate(got)
     want = orc.compute_batch(opts, waves, os.cpu_count() or 1)
     if kind == 'mfcc13_delta':

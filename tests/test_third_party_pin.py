@@ -75,3 +75,148 @@ def test_hip_path_against_third_party(gpu, name):
     proc = CLASSES[case['processor']](**case['params'])
     rate = case['params'].get('sample_rate', 16000)
     _check(name, proc.process(Audio(_wave(case['wav']), rate)).data)
+
+
+# ---- round 6: post-processing families against third-party code of the build image (scipy, scikit-learn) ----------
+# Float64 libraries by other authors, no code in common with oracle/kaldi_oracle.c or oracle/spec_f64.py; each
+# states a textbook operation that Kaldi's routine equals by definition (reference file:line beside each).
+def _matrix(seed, frames, dim, scale=8.0):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((frames, dim)) * scale + rng.uniform(-20, 20, size=dim)).astype(np.float32)
+
+
+def _delta_by_scipy(x, order, window):
+    """Kaldi ComputeDeltas (reference postprocessor/delta.py:129-131) as ONE correlation per
+    order with edge replication: `scipy.ndimage.correlate1d(mode='nearest')` clamps t + j to [0, T - 1]"""
+    from scipy.ndimage import correlate1d
+    base = np.arange(-window, window + 1, dtype=np.float64)
+    base /= np.sum(base ** 2)
+    kernel, blocks = np.ones(1), []
+    for _ in range(order + 1):
+        blocks.append(correlate1d(x.astype(np.float64), kernel, axis=0, mode='nearest') if kernel.size > 1
+                      else x.astype(np.float64))
+        kernel = np.convolve(kernel, base)
+    return np.hstack(blocks)
+
+
+DELTA_CASES = [(1, 2), (2, 2), (2, 3), (3, 1), (2, 5)]
+
+
+@pytest.mark.parametrize('order, window', DELTA_CASES)
+def test_oracle_delta_against_scipy(order, window):
+    for frames in (1, 3, 9, 140):      # (shorter than the kernel: the clamped edges overlap)
+        x = _matrix(order * 10 + window + frames, frames, 13)
+        got = orc.deltas(x, order, window)
+        assert_close(got, _delta_by_scipy(x, order, window).astype(np.float32), rtol=1e-5, what='delta vs scipy')
+
+
+def _cmvn_by_sklearn(xs, weights=None):
+    """Kaldi's CMVN with variance normalisation (reference postprocessor/cmvn.py:180-282: mean and population
+    variance of the accumulated frames, weighted) is scikit-learn's StandardScaler with `sample_weight`"""
+    from sklearn.preprocessing import StandardScaler
+    scaler = StandardScaler()
+    stacked = np.concatenate(xs).astype(np.float64)
+    scaler.fit(stacked, sample_weight=None if weights is None else np.concatenate(weights).astype(np.float64))
+    return [scaler.transform(x.astype(np.float64)) for x in xs], scaler
+
+
+def test_oracle_cmvn_against_sklearn():
+    pytest.importorskip('sklearn')
+    xs = [_matrix(5, 140, 13), _matrix(6, 77, 13), _matrix(7, 1, 13)]
+    rng = np.random.default_rng(8)
+    for weights in (None, [(rng.random(x.shape[0]) > 0.4).astype(np.float32) for x in xs]):
+        stats = np.zeros((2, 14))
+        for k, x in enumerate(xs):
+            orc.cmvn_accumulate(x, weights=None if weights is None else weights[k], stats=stats)
+        want, scaler = _cmvn_by_sklearn(xs, weights)
+        count = sum(x.shape[0] for x in xs) if weights is None else float(sum(w.sum() for w in weights))
+        assert stats[0, -1] == pytest.approx(count)
+        np.testing.assert_allclose(stats[0, :-1] / stats[0, -1], scaler.mean_, rtol=1e-9)
+        for x, w in zip(xs, want):
+            np.testing.assert_allclose(orc.cmvn_apply(x, stats), w, rtol=1e-4, atol=2e-5)
+
+
+def _sliding_by_scipy(x, window, normalize_variance):
+    """interior frames of Kaldi's centred SlidingWindowCmn (reference postprocessor/cmvn.py:382-470: the mean - and
+    the variance - of the `window` frames around t, t - window / 2 ... t + window / 2 - 1) as a moving average:
+    `scipy.ndimage.uniform_filter1d` with its origin moved so that the window starts at t - window / 2"""
+    from scipy.ndimage import uniform_filter1d
+    x = x.astype(np.float64)
+    # (scipy's window of an even size is t - size / 2 ... t + size / 2 - 1 and of an odd size t -+ size // 2: Kaldi's)
+    mean = uniform_filter1d(x, size=window, axis=0, mode='nearest')
+    out = x - mean
+    if normalize_variance:
+        var = uniform_filter1d(x * x, size=window, axis=0, mode='nearest') - mean ** 2
+        out = out / np.sqrt(np.maximum(var, 1e-10))
+    half = window // 2
+    return out, slice(half, x.shape[0] - (window - half) + 1)
+
+
+@pytest.mark.parametrize('window, normalize_variance', [(60, False), (60, True), (101, False)])
+def test_oracle_sliding_cmvn_against_scipy(window, normalize_variance):
+    x = _matrix(21, 400, 13)
+    got = orc.sliding_cmn(x, center=True, cmn_window=window, min_window=20, normalize_variance=normalize_variance)
+    want, interior = _sliding_by_scipy(x, window, normalize_variance)
+    assert interior.stop - interior.start > 250
+    np.testing.assert_allclose(got[interior], want[interior], rtol=1e-4, atol=2e-4)
+
+
+def _rasta_by_scipy(x):
+    """the RASTA filter of a log-domain trajectory [frames, bands] (reference processor/plp.py:100-168, whose
+    own test replays rasta_py's lfilter form, test/processor/test_plp.py:94-124): numerator 0.2, 0.1, 0, -0.1,
+    -0.2, one pole at 0.94; the first four outputs are zero while the FIR part charges from a state that
+    `lfilter_zi` scales by the first frame, the pole takes part from the fifth frame on"""
+    import scipy.signal
+    numer = np.array([0.2, 0.1, 0.0, -0.1, -0.2])
+    out = np.zeros_like(x, dtype=np.float64)
+    for band in range(x.shape[1]):
+        column = x[:, band].astype(np.float64)
+        state = scipy.signal.lfilter_zi(numer, [1.0]) * column[0]
+        _, state = scipy.signal.lfilter(numer, [1.0], column[:4], zi=state)
+        out[4:, band], _ = scipy.signal.lfilter(numer, [1.0, -0.94], column[4:], zi=state)
+    return out
+
+
+def test_oracle_rasta_against_scipy():
+    frames = 80
+    t = np.arange(frames)
+    x = np.stack([np.sin(2 * np.pi * t / 16.0), np.random.default_rng(2).random(frames),
+                  (t == 0).astype(np.float64), np.linspace(-3, 5, frames)], axis=1).astype(np.float32)
+    got = orc.rasta(x, do_log=False)
+    np.testing.assert_allclose(got, _rasta_by_scipy(x), rtol=1e-5, atol=1e-6)
+    assert np.all(got[:4] == 0)
+
+
+@pytest.mark.gpu
+def test_hip_post_processing_against_third_parties(gpu):
+    """the same third-party statements against the HIP path (delta, CMVN +- weights, sliding CMVN kernels through
+    the post-processor classes)"""
+    pytest.importorskip('sklearn')
+    from shennong_amd import Features
+    from shennong_amd.postprocessor import (
+        CmvnPostProcessor, DeltaPostProcessor, SlidingWindowCmvnPostProcessor)
+
+    def feats(x):
+        return Features(x, np.arange(x.shape[0], dtype=np.float64) * 0.01,
+                        properties={'pipeline': [{'name': 'mfcc', 'columns': [0, x.shape[1] - 1]}], 'mfcc': {}})
+    for order, window in DELTA_CASES:
+        for frames in (1, 3, 9, 140):
+            x = _matrix(order * 10 + window + frames, frames, 13)
+            got = DeltaPostProcessor(order=order, window=window).process(feats(x)).data
+            assert_close(got, _delta_by_scipy(x, order, window).astype(np.float32), rtol=1e-5, what='delta vs scipy')
+    xs = [_matrix(5, 140, 13), _matrix(6, 77, 13), _matrix(7, 1, 13)]
+    rng = np.random.default_rng(8)
+    for weights in (None, [(rng.random(x.shape[0]) > 0.4).astype(np.float32) for x in xs]):
+        cmvn = CmvnPostProcessor(13)
+        for k, x in enumerate(xs):
+            cmvn.accumulate(feats(x), weights=None if weights is None else weights[k])
+        want, scaler = _cmvn_by_sklearn(xs, weights)
+        np.testing.assert_allclose(cmvn.stats[0, :-1] / cmvn.count, scaler.mean_, rtol=1e-9)
+        for x, w in zip(xs, want):
+            np.testing.assert_allclose(cmvn.process(feats(x)).data, w, rtol=1e-4, atol=2e-5)
+    x = _matrix(21, 400, 13)
+    for window, normalize_variance in ((60, False), (60, True), (101, False)):
+        got = SlidingWindowCmvnPostProcessor(center=True, cmn_window=window, min_window=20,
+                                             normalize_variance=normalize_variance).process(feats(x)).data
+        want, interior = _sliding_by_scipy(x, window, normalize_variance)
+        np.testing.assert_allclose(got[interior], want[interior], rtol=1e-4, atol=2e-4)
