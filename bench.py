@@ -225,8 +225,9 @@ class Watchdog:
     interpreter lock, the caller waits `seconds` and no longer.  Once something has been abandoned the process
     holds a thread - possibly a HIP stream - that will never finish: `stuck` tells the caller to leave through
     os._exit when it has printed what it has."""
-    def __init__(self):
+    def __init__(self, bind=None):
         self.stuck = False
+        self.bind = bind   # called first on every such thread: hipSetDevice is per thread, a fresh one is on GPU 0
 
     def call(self, fn, seconds, what):
         import threading
@@ -234,6 +235,8 @@ class Watchdog:
 
         def target():
             try:
+                if self.bind is not None:
+                    self.bind()
                 box['value'] = fn()
             except BaseException as exc:   # noqa: BLE001 (handed to the caller below)
                 box['error'] = exc
@@ -465,7 +468,7 @@ def main():
     device = 0 if stub else local_rank   # (stub: a rehearsal, every rank is a process on GPU 0)
     _backend.set_device(device)
     comm = None
-    watch = Watchdog()
+    watch = Watchdog(bind=_backend.bind_device)
     if world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ:  # launched by torch.distributed.run
         if stub:
             sys.path.insert(0, os.path.join(ROOT, 'tests', 'tools'))
