@@ -323,6 +323,37 @@ __device__ __forceinline__ void fft16_lf(float2 (&v)[16]) {
   for (int q = 0; q < 4; ++q) dft4(v[q], v[q + 4], v[q + 8], v[q + 12], t[0][q], t[1][q], t[2][q], t[3][q]);
   fft16_layer2_lf(t, v);
 }
+// The same transform when only the first NZ inputs can be non-zero (a 25 ms frame at 44.1 / 48 kHz fills 9 / 10
+// of the 16 element rows of the 2048-point kernel: the rest is the zero padding of the power-of-two window).  The
+// first radix-4 layer drops the terms that are zero by construction - an exact zero added or subtracted changes
+// nothing but the sign of a zero - instead of adding them (IEEE addition of a constant 0.0f is not folded away).
+template <int NZ>
+__device__ __forceinline__ void fft16_lf_head(float2 (&v)[16]) {
+  float2 t[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q + 8 >= NZ) {          // a2 = a3 = 0: s0 = s1 = a0, s2 = a1, s3 = -i a1
+      const float2 a0 = v[q], a1 = (q + 4 < NZ) ? v[q + 4] : make_float2(0.0f, 0.0f), m1 = mul_mi(a1);
+      if (q + 4 < NZ) {
+        t[0][q] = cadd(a0, a1);
+        t[1][q] = cadd(a0, m1);
+        t[2][q] = csub(a0, a1);
+        t[3][q] = csub(a0, m1);
+      } else {
+        t[0][q] = t[1][q] = t[2][q] = t[3][q] = a0;
+      }
+    } else if (q + 12 >= NZ) {  // a3 = 0: s2 = a1, s3 = -i a1
+      const float2 s0 = cadd(v[q], v[q + 8]), s1 = csub(v[q], v[q + 8]), s2 = v[q + 4], s3 = mul_mi(v[q + 4]);
+      t[0][q] = cadd(s0, s2);
+      t[1][q] = cadd(s1, s3);
+      t[2][q] = csub(s0, s2);
+      t[3][q] = csub(s1, s3);
+    } else {
+      dft4(v[q], v[q + 4], v[q + 8], v[q + 12], t[0][q], t[1][q], t[2][q], t[3][q]);
+    }
+  }
+  fft16_layer2_lf(t, v);
+}
 // 16-point FFT of r[m] * W[m] with the input twiddles W[m] = c[m] (1 + i t[m]) given as (c, t) pairs
 // (W[0] = 1): the first radix-4 layer consumes them in its butterflies.  An exact -i is stored as
 // (2^-40, -2^40): the products are exact powers of two and the absorbed term is the one a true zero

@@ -250,7 +250,8 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- B: pass 1 (FFT over j), twiddle W1024^(L k1), transpose ---------------------------------------
-    fft16(z);
+    // (rows j >= NJ are the zero padding: the first layer skips them; butterflies with folded twiddles)
+    fft16_lf_head<NJ>(z);
     float4 tw4[8];
     read_quads_whole<8>(t_tw1, tw4);
     lds_wait();
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void fbank2048_kernel(
     lds_wait();
     wave_lds_sync();
     // ---- D: pass 3 (FFT over b): z[d] = Z[kappa + 64 d] ---------------------------------------------------
-    fft16(z);
+    fft16_lf(z);
     __builtin_amdgcn_sched_barrier(0);
     // ---- E: real-FFT unpack + power.  Partner of k = kappa + 64 d (d < 8) is 1024 - k: register 15 - d of
     // the lane with kappa' = 64 - kappa (own register 16 - d for kappa = 0) ---------------------------------
