@@ -475,8 +475,10 @@ def main():
             import fake_comm
             fake_comm.install(device=True)
         from shennong_amd.comm import RcclComm
-        # the sockets only: RCCL itself is brought up by the gather leg, last and under the watchdog
-        comm = RcclComm.from_env(device=device, connect=False, timeout=args.comm_timeout)
+        # the sockets only: RCCL itself is brought up by the gather leg, last and under the watchdog.  The sockets
+        # wait long (ranks reach a barrier tens of seconds apart when the host is busy generating 8 x 10 000
+        # utterances): what bounds a stalled TRANSPORT is the watchdog, not these timeouts
+        comm = RcclComm.from_env(device=device, connect=False, timeout=max(args.comm_timeout, 600.0))
 
     nsamples = int(args.seconds * 16000)
     if args.scaling == 'strong' and world > 1:
