@@ -473,7 +473,9 @@ def main():
         if stub:
             sys.path.insert(0, os.path.join(ROOT, 'tests', 'tools'))
             import fake_comm
-            fake_comm.install(device=True)
+            # (SNF_STUB_HANG_AFTER=n on rank 1: its n + 1-th gather never returns - the watchdog's rehearsal)
+            hang = os.environ.get('SNF_STUB_HANG_AFTER')
+            fake_comm.install(device=True, hang_after=int(hang) if hang and rank == 1 else None)
         from shennong_amd.comm import RcclComm
         # the sockets only: RCCL itself is brought up by the gather leg, last and under the watchdog.  The sockets
         # wait long (ranks reach a barrier tens of seconds apart when the host is busy generating 8 x 10 000
