@@ -727,6 +727,49 @@ class _Prefetch:
             pass
 
 
+class _Tracker:
+    """The pitch tracker (+ its post-processing) of one block of audio that is in HBM, started on a side thread:
+    it needs nothing but the audio and runs beside the features -> VAD -> CMVN -> delta chain of its batch.
+    `job.result()` is the device block of the post-processed pitch (the caller owns it); the audio block must
+    outlive the job.  (Round 6 also started the tracker of batch k + 1 of the second streamed pass when batch k
+    begins, its audio being resident: 1.158 against 1.179 s per 125 h - the per-batch chain is bound by the
+    download and the host work around it, not by the wait for the tracker; not kept.)"""
+    def __init__(self, config, rate, frame_shift, frame_length, d_wave, soff, stats=None):
+        DB = _backend.DeviceBuffer
+        params = {k: v for k, v in config['pitch'].items() if k not in ('processor', 'postprocessing')}
+        params['sample_rate'] = rate
+        params['frame_shift'] = frame_shift
+        params['frame_length'] = frame_length
+        self.rate, self.soff = rate, soff
+        self.pproc = pproc = _processor_class('kaldi_pitch')(**params)
+        self.post = post = _processor_class('kaldi_pitch_post')(**config['pitch']['postprocessing'])
+        pplan = _backend.get_plan(pproc._build_options())
+        self.pfoff = pfoff = _PipelineRun._frame_offsets(pplan, soff)
+        qplan = _backend.get_plan(post._build_options())
+        self.pdim = pdim = qplan.post_ndims(2)
+
+        def track():
+            d_raw = d_pitch = None
+            try:
+                d_raw = DB(max(int(pfoff[-1]) * 2 * 4, 16))
+                pplan.run_device(d_wave, soff, pfoff, d_raw.ptr)
+                d_pitch = DB(max(int(pfoff[-1]) * pdim * 4, 16))
+                qplan.run_post_device(d_raw.ptr, 2, pfoff, d_pitch.ptr, noise_call=_NOISE_CALL)
+                if stats is not None:
+                    stats.add(gpu_ms=_call_ms(pplan) + _call_ms(qplan))
+            except BaseException:
+                # a call that failed half way may have kernels enqueued that still write these blocks:
+                # the plain free() waits for the device before the pool can hand them to another thread
+                for block in (d_pitch, d_raw):
+                    if block is not None:
+                        block.free()
+                raise
+            d_raw.free(synced=True)   # (both calls returned: their streams are synchronised)
+            return d_pitch
+
+        self.job = _backend.side_pool().submit(track)
+
+
 class RunStats:
     """What a pipeline run cost, summed over its batches and threads (pass one as ``stats=`` to
     :func:`extract_features_streamed`): bytes over the host link in each direction, seconds this process
@@ -801,6 +844,13 @@ class _Group:
                 pass
         for name in list(self.blocks):
             self.blocks.pop(name).free()
+
+
+def _call_ms(plan):
+    """HIP-event time of the plan's last call for RunStats.  With several batches in flight on one cached plan the
+    marks may already belong to the next call when they are read (-1, or a partial time): the sum is an estimate
+    then, never negative"""
+    return max(plan.last_kernel_ms(0), 0.0)
 
 
 def _offsets(counts):
@@ -1003,40 +1053,11 @@ class _PipelineRun:
     # ---- pitch: needs nothing but the audio, runs on a side thread (its own streams) while this one takes the
     # audio through the features, VAD, CMVN and delta; waited for where the columns are joined ------------------
     def stage_pitch_start(self, group):
-        config, rate, cache = self.config, group.rate, self.cache
-        DB = _backend.DeviceBuffer
-        params = {k: v for k, v in config['pitch'].items() if k not in ('processor', 'postprocessing')}
-        params['sample_rate'] = rate
-        params['frame_shift'] = self.frame_shift
-        params['frame_length'] = self.frame_length
-        pproc = _processor_class('kaldi_pitch')(**params)
-        post = _processor_class('kaldi_pitch_post')(**config['pitch']['postprocessing'])
-        pplan = _backend.get_plan(pproc._build_options())
-        pfoff = self._frame_offsets(pplan, group.soff)
-        qplan = _backend.get_plan(post._build_options())
-        pdim = qplan.post_ndims(2)
-        d_wave, soff, count = group.ptr('wave'), group.soff, self._count
-
-        def track():
-            d_raw = d_pitch = None
-            try:
-                d_raw = DB(max(int(pfoff[-1]) * 2 * 4, 16))
-                pplan.run_device(d_wave, soff, pfoff, d_raw.ptr)
-                d_pitch = DB(max(int(pfoff[-1]) * pdim * 4, 16))
-                qplan.run_post_device(d_raw.ptr, 2, pfoff, d_pitch.ptr, noise_call=_NOISE_CALL)
-                count(gpu_ms=pplan.last_kernel_ms(0) + qplan.last_kernel_ms(0))
-            except BaseException:
-                # a call that failed half way may have kernels enqueued that still write these blocks:
-                # the plain free() waits for the device before the pool can hand them to another thread
-                for block in (d_pitch, d_raw):
-                    if block is not None:
-                        block.free()
-                raise
-            d_raw.free(synced=True)   # (both calls returned: their streams are synchronised)
-            return d_pitch
-
-        group.pfoff, group.pdim = pfoff, pdim
-        group.pitch_job = _backend.side_pool().submit(track)
+        cache, rate = self.cache, group.rate
+        tracker = _Tracker(self.config, rate, self.frame_shift, self.frame_length, group.ptr('wave'), group.soff,
+                           self.stats)
+        group.pfoff, group.pdim, group.pitch_job = tracker.pfoff, tracker.pdim, tracker.job
+        pproc, post, pfoff, pdim = tracker.pproc, tracker.post, tracker.pfoff, tracker.pdim
         key = ('pitch', rate)
         if key not in cache:
             cache[key] = pproc.get_properties()
@@ -1065,7 +1086,7 @@ class _PipelineRun:
         self.log.debug('extract %s on %d utterances at %d Hz', features_name, len(group.idx), rate)
         plan.run_device(group.ptr('wave'), group.soff, foff, group.ptr('feat'), vtln_warps=vt,
                         noise_call=_NOISE_CALL)
-        self._count(gpu_ms=plan.last_kernel_ms(0))
+        self._count(gpu_ms=_call_ms(plan))
         # one _Meta per distinct (warp, frame count)
         counts = np.diff(foff)
         if wlist is None:
@@ -1102,7 +1123,7 @@ class _PipelineRun:
         vplan = _backend.get_plan(vad._build_options())
         group.hold('vad', DB(max(int(foff[-1]) * 4, 16)))
         vplan.run_post_device(group.ptr('energy'), 1, foff, group.ptr('vad'))
-        self._count(gpu_ms=eplan.last_kernel_ms(0) + vplan.last_kernel_ms(0))
+        self._count(gpu_ms=_call_ms(eplan) + _call_ms(vplan))
         group.drop('energy')
 
     # ---- CMVN: statistics of every utterance in one launch per sample rate, summed per speaker (or kept per
@@ -1174,7 +1195,7 @@ class _PipelineRun:
             odim = dplan.post_ndims(group.dim)
             d_out = _backend.DeviceBuffer(max(int(group.foff[-1]) * odim * 4, 16))
             dplan.run_post_device(group.ptr('feat'), group.dim, group.foff, d_out.ptr)
-            self._count(gpu_ms=dplan.last_kernel_ms(0))
+            self._count(gpu_ms=_call_ms(dplan))
             group.swap('feat', d_out)
             group.dim = odim
         self.classes = [m.derive(self.cache, 'delta', delta.get_properties, ndims=odim) for m in self.classes]
