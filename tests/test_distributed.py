@@ -684,3 +684,97 @@ def test_bench_digest_and_prediction():
     pred = bench.predicted_gather_ms(counts, 0.93)
     assert abs(pred['153_GBps_per_link'] - 3.116) < 0.01 and abs(pred['76.5_GBps_per_link'] - 6.233) < 0.01
     assert bench.predicted_gather_ms([100, 100], 0.93)['153_GBps_per_link'] == 0.93
+
+
+def _sharded_on_gpu_worker(rank, port, tmpdir):
+    """one of two ranks that share GPU 0: the REAL device pipeline on this rank's shard, the exchange through the
+    device-mode socket stand-in of snf_comm_* (device pointers in and out, staged through host memory)"""
+    for path in (ROOT, TOOLS):
+        if path not in sys.path:
+            sys.path.insert(0, path)
+    import numpy as np
+    import fake_comm
+    from conftest import GOLDEN
+    from shennong_amd import Audio, Utterances, _backend, pipeline, synth
+    from shennong_amd.comm import RcclComm
+    from shennong_amd.distributed import (
+        extract_features_sharded, extract_features_streamed_sharded, process_all_sharded)
+    from shennong_amd.processor import MfccProcessor
+    os.environ['SNF_COMM_TOKEN'] = 'gpu-stub-%d' % port
+    _backend.set_device(0)
+    fake = fake_comm.install(device=True)
+    comm = RcclComm(rank, 2, device=0, port=port)
+    wav = os.path.join(GOLDEN, 'test.wav')
+    waves = synth.utterances(3, 6, 20000)
+    items = [(f'w{i}', wav, f's{i % 3}', 0.1 * (i % 4), 0.1 * (i % 4) + 0.4 + 0.1 * (i % 5)) for i in range(1, 8)]
+    index = Utterances(items)
+    memory = Utterances([(f'm{i}', Audio(waves[i, :12000 + 1500 * i].copy(), 16000, validate=False), f's{i % 2}')
+                         for i in range(6)])
+    config = pipeline.get_default_config('mfcc', with_pitch='kaldi', with_cmvn=True, with_delta=True)
+    config['mfcc']['dither'] = 0
+    config['pitch']['postprocessing']['delta_pitch_noise_stddev'] = 0
+    config['cmvn']['by_speaker'] = True
+    ok, why = True, []
+
+    def same(got, want, what, exact):
+        good = sorted(got) == sorted(want)
+        for k in want:
+            if good:
+                a, b = got[k].data, want[k].data
+                # (a speaker's statistics are the sum of per-RANK partial sums here and of per-utterance terms in
+                # the one-process run: float64 sums in another order, the normalised float32 within an ulp or two)
+                good = a.shape == b.shape and (np.array_equal(a, b) if exact else np.allclose(a, b, rtol=1e-5, atol=1e-5))
+                good = good and np.array_equal(got[k].times, want[k].times)
+        if not good:
+            why.append(what)
+        return good
+    for name, utts in (('files', index), ('memory', memory)):
+        got = extract_features_sharded(config, utts, dst=0, group=comm)
+        if rank == 0:
+            want = pipeline.extract_features(config, utts)
+            ok = same(got, want, 'sharded ' + name, False) and ok
+            ok = ok and all(got[k].properties['pipeline'] == want[k].properties['pipeline'] for k in want)
+        else:
+            ok = ok and got is None
+    # streamed: every rank streams its shard into its own sink; statistics summed over ranks and batches
+    out = {}
+    count = extract_features_streamed_sharded(config, memory, out.update, max_batch_duration=1.6, group=comm)
+    names = comm.all_gather_object(sorted(out))
+    ok = ok and count == len(out) and sorted(names[0] + names[1]) == sorted(u.name for u in memory)
+    whole = pipeline.extract_features(config, memory)
+    ok = same(out, {k: whole[k] for k in out}, 'streamed sharded', False) and ok
+    # process_all over the ranks (no statistics: bit for bit)
+    proc = MfccProcessor(dither=0)
+    got = process_all_sharded(proc, memory, dst=1, group=comm)
+    if rank == 1:
+        ok = same(got, proc.process_all(memory), 'process_all sharded', True) and ok
+    else:
+        ok = ok and got is None
+    calls = [c[0] for c in fake.calls]
+    ok = ok and 'gatherv' in calls and 'allreduce' in calls
+    comm.close()
+    open(os.path.join(tmpdir, f'ok{rank}'), 'w').write('1' if ok else '0 %s' % why)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_sharded_pipelines_two_ranks_on_one_gpu(gpu, tmp_path):
+    """extract_features_sharded / extract_features_streamed_sharded / process_all_sharded with TWO rank processes on
+    the one GPU of the test box: the real device pipeline per shard, device-resident blocks handed to the
+    communicator class, the by-speaker statistics reduced across ranks - everything but RCCL itself, which the
+    device-mode stand-in replaces (blocks staged through host memory).  Results equal the one-process pipeline."""
+    import multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=_sharded_on_gpu_worker, args=(r, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert [p.exitcode for p in procs] == [0, 0]
+    assert [open(tmp_path / f'ok{r}').read() for r in range(2)] == ['1', '1']
