@@ -720,17 +720,27 @@ def main():
         cfg['filterbank']['dither'] = 0
         cfg['cmvn']['with_vad'] = False
         quiet = get_logger('bench', 'error')
-        pipeline.extract_features(cfg, index, log=quiet)
-        walls = []
-        for _ in range(5):   # (one call is 13-15 ms of host and device work: the median of five)
-            t0 = time.perf_counter()
-            feats = pipeline.extract_features(cfg, index, log=quiet)
-            walls.append(time.perf_counter() - t0)
-        dt = float(np.median(walls))
+        def time_pipeline(idx):
+            pipeline.extract_features(cfg, idx, log=quiet)
+            walls = []
+            for _ in range(5):   # (one call is 8-14 ms of host and device work: the median of five)
+                t0 = time.perf_counter()
+                feats = pipeline.extract_features(cfg, idx, log=quiet)
+                walls.append(time.perf_counter() - t0)
+            return float(np.median(walls)), min(walls), feats
+        dt, dt_min, feats = time_pipeline(index)
+        dt_pin, dt_pin_min, _ = time_pipeline(index.pin())
         nfr = sum(f.nframes for f in feats.values())
+        cols = int(next(iter(feats.values())).ndims)
         extra['pipeline_fbank_pitch_delta_cmvn'] = {
-            'frames_per_s': nfr / dt, 'wall_s': dt, 'wall_s_min': min(walls), 'calls': len(walls),
-            'utterances': pn, 'columns': int(next(iter(feats.values())).ndims)}
+            'frames_per_s': nfr / dt, 'wall_s': dt, 'wall_s_min': dt_min, 'calls': 5,
+            'pinned_wall_s': dt_pin, 'pinned_wall_s_min': dt_pin_min, 'pinned_frames_per_s': nfr / dt_pin,
+            'link_floor_s': (pn * nsamples * 2 + nfr * cols * 4) / 57e9,
+            'utterances': pn, 'columns': cols,
+            'note': 'extract_features on 1 000 in-memory utterances, host to host; `pinned_*`: the same index after '
+                    'Utterances.pin(); the upload, the pitch tracker (~3 ms, the features beside it) and the '
+                    'download follow each other: `link_floor_s` is the two copies at 57 GB/s'}
+        del feats
 
         # the same pipeline streamed in bounded batches at ONE GPU's share of BASELINE config 5: 1 000 h / 8 =
         # 125 h = 150 000 utterances of 3 s (the 10 000 waves of the batch reused round robin: host synthesis

@@ -19,6 +19,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     log = get_logger('fuzz', 'error')
+    pinned_cases = [0]
     for case in range(n_cases):
         features = str(rng.choice(['mfcc', 'filterbank', 'plp', 'spectrogram']))
         with_cmvn, with_delta = bool(rng.integers(2)), bool(rng.integers(2))
@@ -72,7 +73,29 @@ def main():
         if list(got.keys()) != list(a.keys()) or any(not got[k] == a[k] for k in a):
             print('FAIL streamed != one shot', tag, [k for k in a if not got[k] == a[k]])
             return 1
-    print(f'{n_cases} random pipelines: resident == by stage == streamed (seed {seed})')
+        if len(rates) == 1 or len(set(it[1].sample_rate for it in items)) == 1:
+            # round 6: the same index from ONE page-locked block (Utterances.pin()): one shot, and streamed with
+            # 1 - 3 batches in flight (the audio of a batch sent ahead of it)
+            pinned = index.pin()
+            njobs = int(rng.integers(1, 4))
+            try:
+                c = pipeline.extract_features(config, pinned, warps=warps, log=log)
+                d = FeaturesCollection()
+                pipeline.extract_features_streamed(config, pinned, d.update, warps=warps, njobs=njobs,
+                                                   max_batch_duration=batch_s, log=log)
+            except Exception:
+                print('FAIL (exception, pinned)', tag, batch_s, njobs)
+                raise
+            for name, other in (('pinned one shot', c), ('pinned streamed njobs %d' % njobs, d)):
+                same = list(other.keys()) == list(a.keys()) and all(
+                    np.array_equal(other[k].data, a[k].data) and np.array_equal(other[k].times, a[k].times)
+                    and other[k].properties['pipeline'] == a[k].properties['pipeline'] for k in a)
+                if not same:
+                    print('FAIL %s != one shot' % name, tag)
+                    return 1
+            pinned_cases[0] += 1
+    print(f'{n_cases} random pipelines: resident == by stage == streamed (seed {seed}); '
+          f'{pinned_cases[0]} of them also from a pinned index, one shot and streamed with 1-3 batches in flight')
     return 0
 
 
