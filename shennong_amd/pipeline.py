@@ -947,7 +947,10 @@ class _PipelineRun:
             if self.with_pitch and not stats_only:
                 self.stage_pitch_start(group)
             self.stage_features(group, proc)
-            if self.with_cmvn and self.config['cmvn']['with_vad']:
+            # (a hook that brings the statistics of the whole corpus - the second pass of the streamed pipeline -
+            # makes this batch's own statistics, and the VAD weights that only they use, unnecessary)
+            own_stats = self.with_cmvn and not getattr(stats_hook, 'replaces', False)
+            if own_stats and self.config['cmvn']['with_vad']:
                 self.stage_vad(group)
             if group.pitch_job is not None:
                 pass   # (the tracker still reads the audio: released where it is waited for, stage_join)
@@ -1142,8 +1145,11 @@ class _PipelineRun:
             names = self.names
             group_of = np.arange(n, dtype=np.int32)
         cplan = _backend.get_plan(_abi.default_options(_abi.KIND_CMVN))
-        per_utt = np.zeros((n, 2, dim + 1), dtype=np.float64)
+        replaced = getattr(stats_hook, 'replaces', False) and not stats_only
+        per_utt = np.zeros((0 if replaced else n, 2, dim + 1), dtype=np.float64)
         for group in self.groups:
+            if replaced:
+                break
             local = np.zeros((len(group.idx), 2, dim + 1), dtype=np.float64)
             cplan.cmvn_accumulate_device(
                 group.ptr('feat'), dim, group.foff, local,
@@ -1159,7 +1165,7 @@ class _PipelineRun:
         # (utterance order, like the reference's accumulate loop: np.add.at adds the rows one after the other; a
         # hook that brings the statistics of the whole corpus - second pass of the streamed pipeline - needs none)
         stats = np.zeros((len(names), 2, dim + 1), dtype=np.float64)
-        if not getattr(stats_hook, 'replaces', False):
+        if not replaced:
             np.add.at(stats, group_of, per_utt)
         if stats_hook is not None:
             # several processes share the utterances of a speaker: their partial statistics are
