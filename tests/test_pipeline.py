@@ -383,6 +383,14 @@ def test_pipeline_pinned_index(gpu):
         assert seen['utterances'] == 40 and seen['batches'] > 3 and seen['gpu_ms'] > 0
         assert seen['bytes_up'] == 2 * int(cuts.sum())     # (every sample crossed the link once: the second
         assert seen['bytes_down'] == sum(f.data.nbytes for f in want.values())   # pass reads the resident audio)
+    # no room (or not enough) for the audio between the passes: the second pass sends its batches ahead again
+    for budget in (0, 150000):
+        out, stats = {}, pipeline.RunStats()
+        pipeline.extract_features_streamed(config, pinned, out.update, max_batch_duration=6.0, njobs=2,
+                                           resident_bytes=budget, stats=stats)
+        assert list(out) == list(want) and all(np.array_equal(out[name].data, want[name].data) for name in want)
+        up = stats.as_dict()['bytes_up']
+        assert (up == 4 * int(cuts.sum())) if budget == 0 else (2 * int(cuts.sum()) < up < 4 * int(cuts.sum()))
 
 
 @pytest.mark.gpu
