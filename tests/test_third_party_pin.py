@@ -220,3 +220,64 @@ def test_hip_post_processing_against_third_parties(gpu):
                                              normalize_variance=normalize_variance).process(feats(x)).data
         want, interior = _sliding_by_scipy(x, window, normalize_variance)
         np.testing.assert_allclose(got[interior], want[interior], rtol=1e-4, atol=2e-4)
+
+
+# ---- the PLP tail (reference processor/plp.py:548-626) from third-party primitives ---------------------------------
+# mel energies: the oracle's LINEAR filterbank outputs - the family the HuggingFace front end pins above - then, in
+# float64: equal loudness (a closed formula of the bins' centre frequencies), cube root (np.cbrt), autocorrelation =
+# the IDFT of the duplicated-edge spectrum = scipy's DCT-I / (2 (n - 1)), LPC = the solution of the Toeplitz normal
+# equations (scipy.linalg.solve_toeplitz instead of Kaldi's Durbin recursion), LPC -> cepstrum = the cepstrum of the
+# all-pole filter 1 / A(z) read off a 4096-point FFT of log(1 / A) (instead of the recursion of plp.py:149-168), lifter.
+def _plp_tail_by_scipy(mel, sample_rate, lpc_order, num_ceps, lifter, low_freq=20.0):
+    import scipy.fft
+    import scipy.linalg
+    nbins = mel.shape[1]
+    to_mel = lambda f: 1127.0 * np.log(1.0 + f / 700.0)   # noqa: E731
+    step = (to_mel(0.5 * sample_rate) - to_mel(low_freq)) / (nbins + 1)
+    centre = 700.0 * (np.exp((to_mel(low_freq) + step * np.arange(1, nbins + 1)) / 1127.0) - 1.0)
+    fsq = centre ** 2
+    loudness = (fsq / (fsq + 1.6e5)) ** 2 * ((fsq + 1.44e6) / (fsq + 9.61e6))
+    x = np.cbrt(mel.astype(np.float64) * loudness)
+    x = np.concatenate([x[:, :1], x, x[:, -1:]], axis=1)                      # first and last bins duplicated
+    autocorr = scipy.fft.dct(x, type=1, axis=1)[:, :lpc_order + 1] / (2.0 * (x.shape[1] - 1))
+    out = np.zeros((mel.shape[0], num_ceps))
+    for t, r in enumerate(autocorr):
+        a = scipy.linalg.solve_toeplitz(r[:lpc_order], -r[1:lpc_order + 1])   # R a = -r
+        residual = r[0] + a @ r[1:lpc_order + 1]
+        spectrum = np.fft.fft(np.concatenate([[1.0], a]), 4096)
+        cepstrum = np.real(np.fft.ifft(-np.log(spectrum)))                    # of 1 / A(z), minimum phase
+        out[t, 0] = max(np.log(residual), np.finfo(float).eps)
+        out[t, 1:] = cepstrum[1:num_ceps]
+    if lifter:
+        out *= 1.0 + 0.5 * lifter * np.sin(np.pi * np.arange(num_ceps) / lifter)
+    return out
+
+
+PLP_CASES = [dict(), dict(num_ceps=9, lpc_order=10), dict(cepstral_lifter=0), dict(num_bins=30, lpc_order=14)]
+
+
+def _plp_case(params, wave, compute_plp, compute_fbank):
+    from shennong_amd.processor import PlpProcessor
+    nbins = params.get('num_bins', 23)
+    plp = PlpProcessor(dither=0, use_energy=False, **params)
+    bank = FilterbankProcessor(dither=0, num_bins=nbins, use_log_fbank=False)
+    want = _plp_tail_by_scipy(compute_fbank(bank, wave), 16000, plp.lpc_order, plp.num_ceps, plp.cepstral_lifter)
+    got = compute_plp(plp, wave)
+    assert got.shape == want.shape
+    # (float32 Durbin on float32 mel energies against float64 linear algebra: the parity tolerance plus an absolute
+    # term for cepstra near a zero crossing - measured need 9.4e-6 on values up to 6, asserted at twice that)
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize('params', PLP_CASES)
+def test_oracle_plp_tail_against_scipy(params):
+    _plp_case(params, _wave('test.wav'), lambda p, w: orc.compute(p._build_options(), w),
+              lambda p, w: orc.compute(p._build_options(), w))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('params', PLP_CASES)
+def test_hip_plp_tail_against_scipy(gpu, params):
+    from shennong_amd import Audio
+    _plp_case(params, _wave('test.wav'), lambda p, w: p.process(Audio(w, 16000)).data,
+              lambda p, w: p.process(Audio(w, 16000)).data)
