@@ -860,13 +860,14 @@ def _offsets(counts):
 
 
 def _classes_of(*keys):
-    """(representatives, class of every element): the distinct combinations of the integer arrays `keys` in order
-    of first appearance are NOT needed, only a dense numbering - np.unique over a mixed-radix code"""
+    """Utterances that agree in all of the non-negative integer arrays `keys` form a class: returns (the index of
+    one member per class, the class number of every utterance) - np.unique over a mixed-radix code of the keys,
+    instead of a dictionary lookup per utterance"""
     code = np.zeros(keys[0].shape[0], dtype=np.int64)
     for key in keys:
         key = np.asarray(key, dtype=np.int64)
         code = code * (int(key.max()) + 1 if key.size else 1) + key
-    uniq, first, inverse = np.unique(code, return_index=True, return_inverse=True)
+    _, first, inverse = np.unique(code, return_index=True, return_inverse=True)
     return first, inverse
 
 
@@ -979,7 +980,6 @@ class _PipelineRun:
             import logging
             if log.isEnabledFor(logging.INFO):
                 self._log_summary(1)
-            a = self.view.first
             group = _Group(pinned.sample_rate, np.arange(n))
             self.rate_of = [pinned.sample_rate] * n
             self.groups.append(group)
@@ -1132,7 +1132,7 @@ class _PipelineRun:
     # ---- CMVN: statistics of every utterance in one launch per sample rate, summed per speaker (or kept per
     # utterance) on the host in utterance order; one apply launch per sample rate ------------------------------
     def stage_cmvn(self, stats_hook, stats_only):
-        config, utts, n, cache = self.config, self.utts, self.n, self.cache
+        config, n, cache = self.config, self.n, self.cache
         dims = set(group.dim for group in self.groups)
         if len(dims) != 1:  # pragma: nocover (one processor, one dimension)
             raise ValueError('features have inconsistent dimensions')
