@@ -589,7 +589,7 @@ class _Meta:
     A _Meta points to its parent only (no table of children: parent and child would form a reference cycle,
     and the 3 000 of them a by-speaker batch makes would wait for the cyclic collector instead of going with
     the batch)."""
-    __slots__ = ('_properties', '_source', 'ndims', 'nframes', 'times', 'key')
+    __slots__ = ('_properties', '_source', 'ndims', 'nframes', 'times', 'key', '_json')
 
     def __init__(self, properties, ndims, nframes, times, key=None, source=None):
         self._properties = properties
@@ -598,6 +598,13 @@ class _Meta:
         self.nframes = nframes
         self.times = times
         self.key = key
+        self._json = None
+
+    def json(self, dumps):
+        """`properties` as JSON text, encoded once (serializers: Features._json_properties)"""
+        if self._json is None:
+            self._json = dumps(self.properties)
+        return self._json
 
     @property
     def properties(self):

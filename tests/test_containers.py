@@ -138,6 +138,39 @@ def test_features_of_a_batch_pickle():
     assert a._shared == (None, None, None)           # (a Features that was read no longer holds the batch's history)
 
 
+def test_features_json_properties_of_a_batch(tmp_path):
+    """serializers write the properties of a pipeline batch without materialising them per utterance: the text
+    `Features._json_properties` splices (shared history encoded once + this utterance's own entries) is the JSON
+    of `properties`, and an archive written from such features reads back equal"""
+    import json
+    from shennong_amd import serializers
+    from shennong_amd.pipeline import _Meta, _utterance_properties
+    times = np.arange(8, dtype=np.float64).reshape(4, 2)
+    cache = {}
+    root = _Meta({'mfcc': {'num_ceps': 13}, 'pipeline': [{'name': 'mfcc', 'columns': [0, 12]}]}, 2, 4, times, 'mfcc')
+    lazy = root.derive(cache, ('cmvn', 0), lambda m: dict(m.properties, cmvn={'stats': np.arange(6.0).reshape(2, 3)}))
+
+    class Utt:
+        audio_file, tstart, tstop, duration, speaker = None, 0.5, 1.5, 1.0, 'anna'
+    data = np.arange(16, dtype=np.float32).reshape(8, 2)
+    a = Features._of_batch(data[:4], times, lazy, (_utterance_properties, Utt, 16000))
+    b = Features._of_batch(data[4:], times, lazy, None)
+    plain = Features(data[:4], times.copy(), properties={'x': {'y': np.float32(2.5)}})
+    empty = Features(data[:4], times.copy())
+    for feat in (a, b, plain, empty):
+        text = feat._json_properties(serializers._dumps)
+        assert json.loads(text, object_hook=serializers._decode_arrays).keys() == feat.properties.keys()
+        again = json.loads(serializers._dumps(feat.properties))
+        assert json.loads(text) == again
+    assert lazy._json is not None and a._json_properties(serializers._dumps).count('"speaker": "anna"') == 1
+    col = FeaturesCollection(a=Features._of_batch(data[:4], times, lazy, (_utterance_properties, Utt, 16000)),
+                             b=Features._of_batch(data[4:], times, lazy, None), c=plain, d=empty)
+    col.save(str(tmp_path / 'x.ark'))
+    back = FeaturesCollection.load(str(tmp_path / 'x.ark'))
+    assert back == col and back['a'].properties['audio']['tstop'] == 1.5
+    assert np.array_equal(back['a'].properties['cmvn']['stats'], np.arange(6.0).reshape(2, 3))
+
+
 def test_features_concatenate(mfcc, capsys):
     both = mfcc.concatenate(mfcc)
     assert both.nframes == mfcc.nframes and both.ndims == 2 * mfcc.ndims
