@@ -381,6 +381,20 @@ int snf_event_elapsed_ms(void* start, void* stop, float* ms);
    memory as far as the caller is concerned. */
 int snf_host_malloc(void** hptr, uint64_t bytes);
 int snf_host_free(void* hptr);
+/* ---- WAV ingest (host only) ---------------------------------------------------------
+   The reference decodes one file per job in Python (shennong/audio.py:243-286: scipy, sox for other containers)
+   and forces the signal to int16 before Kaldi sees it (processor/base.py:428).  These read RIFF / WAVE files
+   natively: snf_wav_scan is `Audio.scan` (channels, sample rate, samples per channel, bits, format tag: 1 = PCM,
+   3 = IEEE float); snf_wav_read_pcm16 copies samples [first_sample[i], first_sample[i] + n_samples[i]) of file i
+   to dst + dst_offsets[i] for n_files files on `threads` threads - straight into the (page-locked) block a batch
+   is uploaded from.  status[i]: 0 = read; 1 = not 16-bit mono PCM (the caller's general reader takes that file);
+   2 = I/O error; 3 = the file holds fewer samples than asked for.  The call itself fails only for bad arguments. */
+int snf_wav_scan(const char* path, int32_t* channels, int32_t* sample_rate, int64_t* nsamples, int32_t* bits,
+                 int32_t* format_tag);
+int snf_wav_read_pcm16(const char* const* paths, int64_t n_files, const int64_t* first_sample,
+                       const int64_t* n_samples, int16_t* dst, const int64_t* dst_offsets, int32_t threads,
+                       int32_t* status);
+
 /* ---- multi-GPU exchange steps (RCCL over xGMI; one process per GPU) --------------------------------
    The features path shards by utterance and needs no data-path collective; what crosses GPUs is (a)
    the final gather of the per-rank feature blocks to a root - the counterpart of the reference's

@@ -39,7 +39,7 @@ EXPORTS = [
     'snf_comm_destroy', 'snf_comm_gatherv', 'snf_comm_allreduce_f64',
     'snf_plan_last_kernel_ms', 'snf_plan_kernel_name', 'snf_set_oom_hook',
     'snf_event_create', 'snf_event_destroy', 'snf_event_record', 'snf_event_elapsed_ms', 'snf_mem_info',
-    'snf_stream_wait_event', 'snf_stream_query', 'snf_event_synchronize']
+    'snf_stream_wait_event', 'snf_stream_query', 'snf_event_synchronize', 'snf_wav_scan', 'snf_wav_read_pcm16']
 
 
 _OOM_HOOK_TYPE = C.CFUNCTYPE(None)
@@ -149,6 +149,8 @@ def lib():
         L.snf_plan_kernel_name.restype = C.c_char_p
         L.snf_set_oom_hook.argtypes = [_OOM_HOOK_TYPE]
         L.snf_mem_info.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.snf_wav_scan.argtypes = [C.c_char_p, pi32, pi32, pi64, pi32, pi32]
+        L.snf_wav_read_pcm16.argtypes = [C.POINTER(C.c_char_p), i64, pi64, pi64, pi16, pi64, i32, pi32]
         # the library's own allocations (plan scratch: ~19 GB for a 10 000-utterance pitch batch) reclaim
         # what DEVICE_POOL has parked before they give up
         L.snf_set_oom_hook(_OOM_HOOK)
@@ -833,21 +835,50 @@ class PinnedCorpus:
     made of these utterances in this order is uploaded straight from the block - no gather into a staging buffer
     (which is what bounds `process_all` on pageable arrays: the host's memory traffic, not the link) and no
     per-utterance checks: they were made when the block was built."""
-    def __init__(self, waves, sample_rate):
-        n = len(waves)
+    def __init__(self, waves, sample_rate, lengths=None, fill=None):
+        """`waves`: one int16 array per utterance - or None with `lengths` and ``fill(block, soff)``, which writes
+        the samples itself (the native WAV reader: files go straight into the block)"""
+        n = len(waves) if waves is not None else len(lengths)
         self.sample_rate = int(sample_rate)
         self.soff = np.zeros(n + 1, dtype=np.int64)
-        np.cumsum([w.shape[0] for w in waves], out=self.soff[1:])
+        np.cumsum([w.shape[0] for w in waves] if waves is not None else lengths, out=self.soff[1:])
         total = int(self.soff[-1])
         self.owner = _PinnedOwner((max(total, 8),), np.int16)
         self.block = np.asarray(self.owner)
-        for k, w in enumerate(waves):
-            self.block[self.soff[k]:self.soff[k + 1]] = w
+        if waves is not None:
+            for k, w in enumerate(waves):
+                self.block[self.soff[k]:self.soff[k + 1]] = w
+        else:
+            fill(self.block, self.soff)
         self.views = [self.block[self.soff[k]:self.soff[k + 1]] for k in range(n)]
 
 
 RESULT_KINDS = {'page_locked': 0, 'plain': 0}   # batch results by kind of host memory (diagnostics: a corpus run
                                                 # whose results land in plain memory downloads at half the rate)
+
+
+def read_wav_pcm16(paths, first_samples, n_samples, dst, dst_offsets, threads=None):
+    """Samples [first, first + n) of every file of `paths` (16-bit mono PCM WAV) into the int16 array `dst` at
+    `dst_offsets`, read natively on `threads` threads (snf_wav_read_pcm16; default: the cores this process may
+    use, at most 16).  Returns the per-file status (0 read, 1 not 16-bit mono PCM: the caller's general reader
+    takes it, 2 I/O error, 3 shorter than its header said)."""
+    n = len(paths)
+    status = np.zeros(n, dtype=np.int32)
+    if n == 0:
+        return status
+    if threads is None:
+        threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+    names = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    first = np.ascontiguousarray(first_samples, dtype=np.int64)
+    count = np.ascontiguousarray(n_samples, dtype=np.int64)
+    where = np.ascontiguousarray(dst_offsets, dtype=np.int64)
+    assert dst.dtype == np.int16 and dst.flags.c_contiguous
+    assert int((where + count).max()) <= dst.size
+    p64 = C.POINTER(C.c_int64)
+    check(lib().snf_wav_read_pcm16(names, n, first.ctypes.data_as(p64), count.ctypes.data_as(p64),
+                                   dst.ctypes.data_as(C.POINTER(C.c_int16)), where.ctypes.data_as(p64),
+                                   int(threads), status.ctypes.data_as(C.POINTER(C.c_int32))))
+    return status
 
 
 def result_array(shape, dtype):

@@ -40,6 +40,43 @@ def _read_wav(filename, what, **kwargs):
             f'decodes other formats with pydub/ffmpeg)') from None
 
 
+def sample_range(nsamples, sample_rate, tstart, tstop):
+    """(first sample, number of samples) of the (tstart, tstop) interval of a signal, in seconds - what
+    ``Utterance.load_audio`` cuts (`Audio.segment`: int(t * rate) on both ends, a Python slice: clipped to the
+    signal); the whole signal when neither bound is set"""
+    if not (tstart or tstop):
+        return 0, int(nsamples)
+    start = min(max(int(tstart * sample_rate), 0), nsamples) if tstart is not None else 0
+    stop = min(max(int(tstop * sample_rate), 0), nsamples) if tstop is not None else nsamples
+    return start, max(stop - start, 0)
+
+
+def load_int16_block(utterances, metadata, block, offsets, load=None):
+    """The int16 samples of file-based `utterances` (path, tstart, tstop; `metadata`: their header scans) written
+    to `block` at `offsets`: 16-bit mono PCM files by the native reader, side by side (snf_wav_read_pcm16), every
+    other sample type through ``load(utterance) -> Audio`` and `Audio.astype` (reference audio.py:469-518)"""
+    from shennong_amd import _backend
+    first, count = [], []
+    for utt, meta in zip(utterances, metadata):
+        a, c = sample_range(meta.nsamples, meta.sample_rate, utt.tstart, utt.tstop)
+        first.append(a)
+        count.append(c)
+    status = _backend.read_wav_pcm16([u.audio_file for u in utterances], first, count, block, offsets[:-1])
+    for k in np.flatnonzero(status).tolist():
+        utt = utterances[k]
+        if status[k] != 1:
+            raise ValueError(f'{utt.audio_file}: cannot read file' + (
+                ', it holds fewer samples than its header says' if status[k] == 3 else ''))
+        signal = (load or (lambda u: u.load_audio()))(utt)
+        if signal.nchannels != 1:
+            raise ValueError('signal must have one dimension, but it has {} ({})'.format(signal.nchannels, utt.name))
+        data = signal.astype(np.int16).data
+        if data.shape[0] != count[k]:   # pragma: nocover (the header scan and the decoder disagree)
+            raise ValueError(f'{utt.audio_file}: {data.shape[0]} samples decoded, {count[k]} expected')
+        block[offsets[k]:offsets[k + 1]] = data
+    return np.asarray(count, dtype=np.int64)
+
+
 class Audio:
     """An audio signal with the given `data` and `sample_rate`"""
     def __init__(self, data, sample_rate, validate=True):

@@ -1031,11 +1031,30 @@ class _PipelineRun:
                 block, group.soff = held
                 group.hold('wave', block)
                 continue
+            mine = [utts[i] for i in idx.tolist()]
+            if all(isinstance(u.audio_file, str) for u in mine):
+                # WAV files: read side by side straight into page-locked staging memory (16-bit mono PCM natively,
+                # other sample types through Audio.load + astype), uploaded from there
+                from shennong_amd.audio import load_int16_block, sample_range
+                metas = [meta_of[i] for i in idx.tolist()]
+                group.soff = _offsets([sample_range(m.nsamples, m.sample_rate, u.tstart, u.tstop)[1]
+                                       for u, m in zip(mine, metas)])
+                total = int(group.soff[-1])
+                staged, token = _backend.STAGING.array((max(total, 1),), np.int16)
+                try:
+                    load_int16_block(mine, metas, staged, group.soff)
+                    t0 = time.perf_counter()
+                    group.hold('wave', _backend.DeviceBuffer(max(2 * total, 16))).upload(staged[:total])
+                    self._count(bytes_up=2 * total, upload_wait_s=time.perf_counter() - t0)
+                finally:
+                    del staged
+                    _backend.STAGING.release(token)
+                continue
             proc = _processor_class(self.features_name)(**self.config[self.features_name])
             proc.sample_rate = rate
             waves, checked = [], set()
-            for i in idx.tolist():
-                audio = utts[i].load_audio()
+            for utt in mine:
+                audio = utt.load_audio()
                 if (audio.nchannels, audio.sample_rate) not in checked:  # (one check per kind of signal)
                     check_signal(proc, audio)
                     checked.add((audio.nchannels, audio.sample_rate))

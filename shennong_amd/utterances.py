@@ -199,17 +199,35 @@ class Utterances:
         has no device to feed.  Needs the HIP library (page-locked memory comes from it)."""
         import numpy as np
         from shennong_amd import _backend
+        from shennong_amd.audio import load_int16_block, sample_range
         utts = list(self)
-        signals = [u.load_audio() for u in utts]
-        rates = sorted(set(s.sample_rate for s in signals))
-        if len(rates) != 1:
-            raise ValueError('utterances to pin must share one sample rate, found ' +
-                             ', '.join('%dHz' % r for r in rates))
-        for utt, signal in zip(utts, signals):
-            if signal.nchannels != 1:
-                raise ValueError('signal must have one dimension, but it has {} ({})'.format(
-                    signal.nchannels, utt.name))
-        corpus = _backend.PinnedCorpus([s.astype(np.int16).data for s in signals], rates[0])
+        if all(isinstance(u.audio_file, str) for u in utts):
+            # WAV files: header scans, then the samples of all of them side by side straight into the block
+            # (16-bit mono PCM natively, snf_wav_read_pcm16; other sample types through Audio.load + astype)
+            scans = {}
+            metas = [scans.get(u.audio_file) or scans.setdefault(u.audio_file, Audio.scan(u.audio_file)) for u in utts]
+            rates = sorted(set(m.sample_rate for m in metas))
+            if len(rates) != 1:
+                raise ValueError('utterances to pin must share one sample rate, found ' +
+                                 ', '.join('%dHz' % r for r in rates))
+            for utt, meta in zip(utts, metas):
+                if meta.nchannels != 1:
+                    raise ValueError('signal must have one dimension, but it has {} ({})'.format(
+                        meta.nchannels, utt.name))
+            lengths = [sample_range(m.nsamples, m.sample_rate, u.tstart, u.tstop)[1] for u, m in zip(utts, metas)]
+            corpus = _backend.PinnedCorpus(None, rates[0], lengths=lengths,
+                                           fill=lambda block, soff: load_int16_block(utts, metas, block, soff))
+        else:
+            signals = [u.load_audio() for u in utts]
+            rates = sorted(set(s.sample_rate for s in signals))
+            if len(rates) != 1:
+                raise ValueError('utterances to pin must share one sample rate, found ' +
+                                 ', '.join('%dHz' % r for r in rates))
+            for utt, signal in zip(utts, signals):
+                if signal.nchannels != 1:
+                    raise ValueError('signal must have one dimension, but it has {} ({})'.format(
+                        signal.nchannels, utt.name))
+            corpus = _backend.PinnedCorpus([s.astype(np.int16).data for s in signals], rates[0])
         fields = (lambda u: (u.speaker,)) if self.has_speakers() else (lambda u: ())
         pinned = Utterances([(u.name, Audio(view, rates[0], validate=False)) + fields(u)
                              for u, view in zip(utts, corpus.views)])

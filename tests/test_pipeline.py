@@ -394,6 +394,37 @@ def test_pipeline_pinned_index(gpu):
 
 
 @pytest.mark.gpu
+def test_pipeline_from_wav_files_natively(gpu, tmp_path):
+    """a corpus of WAV files goes through the native reader (16-bit mono PCM side by side into page-locked memory,
+    other sample types through the Python reader): the pipeline, process_all and Utterances.pin() see the same
+    samples as utterances whose audio was loaded one by one"""
+    import scipy.io.wavfile
+    from shennong_amd.processor import MfccProcessor
+    audio = Audio.load(WAV)
+    wav_f32 = str(tmp_path / 'f32.wav')
+    scipy.io.wavfile.write(wav_f32, 16000, (audio.data / 2 ** 15).astype(np.float32))
+    items = [('a', WAV, 's1', 0, 1.0), ('b', WAV, 's2', 0.3, 1.3), ('c', wav_f32, 's1', 0.1, 0.9),
+             ('d', WAV, 's2', 0.0, 1.4195), ('e', WAV, 's1', 1.0, 1.4)]
+    with pytest.warns(UserWarning):
+        items.append(('f', WAV, 's2', 1.0, 3.0))      # (runs past the end of the file: cut there)
+        index = Utterances(items)
+    loaded = Utterances([(u.name, u.load_audio(), u.speaker) for u in index])
+    config = pipeline.get_default_config('mfcc', with_pitch='kaldi', with_cmvn=True, with_delta=True)
+    config['mfcc']['dither'] = 0
+    config['pitch']['postprocessing']['delta_pitch_noise_stddev'] = 0
+    want = pipeline.extract_features(config, loaded)
+    for name, got in (('files', pipeline.extract_features(config, index)),
+                      ('pinned files', pipeline.extract_features(config, index.pin()))):
+        assert sorted(got) == sorted(want), name
+        for key in want:
+            assert np.array_equal(got[key].data, want[key].data), (name, key)
+    assert pipeline.extract_features(config, index)['b'].properties['audio']['file'] == WAV
+    proc = MfccProcessor(dither=0)
+    a, b, c = proc.process_all(index), proc.process_all(loaded), proc.process_all(index.pin())
+    assert all(np.array_equal(a[k].data, b[k].data) and np.array_equal(c[k].data, b[k].data) for k in b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('features', ['mfcc', 'filterbank', 'plp', 'spectrogram'])
 def test_pipeline_resident_equals_by_stage(gpu, tmp_path, features):
     """the device-resident pipeline (one upload, one download) returns exactly what the chain of
