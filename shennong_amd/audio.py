@@ -77,6 +77,25 @@ def load_int16_block(utterances, metadata, block, offsets, load=None):
     return np.asarray(count, dtype=np.int64)
 
 
+def _scan_native(filename):
+    """Header scan by the library (snf_wav_scan: 2 us per file against 15 for a memory-mapped scipy read) for the
+    sample types it knows to describe exactly as scipy does - PCM of 16 or 32 bits, IEEE float of 32 or 64;
+    None for everything else (and when the library has not been built): the caller's scipy path decides"""
+    import ctypes as C
+    try:
+        from shennong_amd import _backend
+        lib = _backend.lib()
+    except (RuntimeError, OSError):
+        return None
+    channels, rate, nsamples, bits, tag = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int32(), C.c_int32()
+    if lib.snf_wav_scan(os.fsencode(str(filename)), C.byref(channels), C.byref(rate), C.byref(nsamples),
+                        C.byref(bits), C.byref(tag)) != 0:
+        return None
+    if (tag.value, bits.value) not in ((1, 16), (1, 32), (3, 32), (3, 64)) or rate.value <= 0:
+        return None
+    return _Metadata(channels.value, rate.value, nsamples.value, nsamples.value / rate.value)
+
+
 class Audio:
     """An audio signal with the given `data` and `sample_rate`"""
     def __init__(self, data, sample_rate, validate=True):
@@ -118,6 +137,9 @@ class Audio:
         if isinstance(filename, Audio):
             audio = filename
             return _Metadata(audio.nchannels, audio.sample_rate, audio.nsamples, audio.duration)
+        native = _scan_native(filename)
+        if native is not None:
+            return native
         sample_rate, data = _read_wav(filename, 'cannot scan audio file', mmap=True)
         return _Metadata(1 if data.ndim == 1 else data.shape[1], sample_rate, data.shape[0],
                          data.shape[0] / sample_rate)

@@ -1008,8 +1008,8 @@ class _PipelineRun:
         for utt in utts:
             key = utt.audio_file if isinstance(utt.audio_file, str) else id(utt.audio_file)
             found = metadata.get(key)
-            if found is None:
-                found = metadata[key] = Audio.scan(utt.audio_file)
+            if found is None:   # (the index scanned the header of every file when it was made)
+                found = metadata[key] = getattr(utt, '_scan', None) or Audio.scan(utt.audio_file)
             meta_of.append(found)
         self._log_summary(len(metadata))
         if not all(m.nchannels == 1 for m in meta_of):

@@ -116,6 +116,10 @@ class FeaturesProcessor(BaseProcessor, metaclass=abc.ABCMeta):
             per_utt = {k: [v[u.name] for u in utts] for k, v in kwargs.items()}
             feats = self._process_pinned(corpus, **per_utt)
             return FeaturesCollection(zip([u.name for u in utts], feats))
+        if utts and hasattr(self, '_process_pinned') and all(isinstance(u._audio, str) for u in utts):
+            feats = self._process_files(utts, kwargs)
+            if feats is not None:
+                return FeaturesCollection(zip([u.name for u in utts], feats))
         # (an utterance that is a whole in-memory Audio needs no call: load_audio is for files and segments)
         signals = [u._audio if type(u._audio) is Audio and not (u._tstart or u._tstop) else u.load_audio()
                    for u in utts]
@@ -123,6 +127,28 @@ class FeaturesProcessor(BaseProcessor, metaclass=abc.ABCMeta):
         feats = self._process_batch(signals, **per_utt)
         return FeaturesCollection(
             (u.name, f) for u, f in zip(utts, feats))
+
+
+    def _process_files(self, utts, kwargs):
+        """`process_all` of utterances that are WAV files (or intervals of them): the samples of all of them are
+        read side by side straight into pooled page-locked memory (shennong_amd.audio.load_int16_block: 16-bit mono
+        PCM natively, other sample types through the Python reader) and the batch is uploaded from there - no
+        Audio object, conversion or check per utterance.  None when the files are not one mono sample rate (the
+        general path then raises what the reference raises)."""
+        from shennong_amd.audio import load_int16_block, sample_range
+        scans = {}
+        metas = [scans.get(u._audio) or scans.setdefault(u._audio, getattr(u, '_scan', None) or Audio.scan(u._audio))
+                 for u in utts]
+        if any(m.nchannels != 1 or m.sample_rate != metas[0].sample_rate for m in metas):
+            return None
+        lengths = [sample_range(m.nsamples, m.sample_rate, u.tstart, u.tstop)[1] for u, m in zip(utts, metas)]
+        corpus = _backend.StagedCorpus(lengths, metas[0].sample_rate)
+        try:
+            load_int16_block(utts, metas, corpus.block, corpus.soff)
+            per_utt = {k: [v[u.name] for u in utts] for k, v in kwargs.items()}
+            return self._process_pinned(corpus, **per_utt)
+        finally:
+            corpus.release()
 
 
 class FramesProcessor(Configurable, FeaturesProcessor, metaclass=abc.ABCMeta):

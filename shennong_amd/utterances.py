@@ -50,7 +50,8 @@ class Utterance:
                 f'(tstart, tstop)=({self._tstart}, {self._tstop})')
         # the duration comes from the file itself (scanning raises if it is missing or not audio);
         # an interval that runs past the end of the file is cut there
-        self._duration = Audio.scan(self._audio).duration
+        self._scan = Audio.scan(self._audio)   # (kept: the pipeline sizes its batches from it without a second scan)
+        self._duration = self._scan.duration
         if self._tstart is not None:
             if self._tstop > self._duration:
                 warnings.warn(
@@ -205,7 +206,8 @@ class Utterances:
             # WAV files: header scans, then the samples of all of them side by side straight into the block
             # (16-bit mono PCM natively, snf_wav_read_pcm16; other sample types through Audio.load + astype)
             scans = {}
-            metas = [scans.get(u.audio_file) or scans.setdefault(u.audio_file, Audio.scan(u.audio_file)) for u in utts]
+            metas = [scans.get(u.audio_file) or scans.setdefault(
+                u.audio_file, getattr(u, '_scan', None) or Audio.scan(u.audio_file)) for u in utts]
             rates = sorted(set(m.sample_rate for m in metas))
             if len(rates) != 1:
                 raise ValueError('utterances to pin must share one sample rate, found ' +
