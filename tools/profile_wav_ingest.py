@@ -54,4 +54,14 @@ for njobs in (1, 4, 8):
 pinned = timed('Utterances.pin()', lambda: index.pin(), reps=2)
 timed('process_all from the pinned index', lambda: fbank.process_all(pinned))
 timed('extract_features from the pinned index', lambda: pipeline.extract_features(cfg, pinned, log=quiet))
+# the streamed pipeline (by-speaker CMVN: two passes, the audio of the first kept in HBM) straight from the files
+cfg5 = pipeline.get_default_config('filterbank', with_pitch='kaldi', with_cmvn=True, with_delta=True)
+cfg5['filterbank']['num_bins'] = 40
+cfg5['filterbank']['dither'] = 0
+cfg5['cmvn']['by_speaker'] = True
+for njobs in (1, 2):
+    timed('extract_features_streamed from files, njobs %d' % njobs,
+          lambda: pipeline.extract_features_streamed(cfg5, index, lambda f: None, njobs=njobs, log=quiet), reps=2)
+timed('extract_features_streamed from the pinned index',
+      lambda: pipeline.extract_features_streamed(cfg5, pinned, lambda f: None, log=quiet), reps=2)
 shutil.rmtree(where)
