@@ -64,4 +64,16 @@ for njobs in (1, 2):
           lambda: pipeline.extract_features_streamed(cfg5, index, lambda f: None, njobs=njobs, log=quiet), reps=2)
 timed('extract_features_streamed from the pinned index',
       lambda: pipeline.extract_features_streamed(cfg5, pinned, lambda f: None, log=quiet), reps=2)
+# files in, Kaldi archive out: the whole corpus run
+from shennong_amd.serializers import KaldiStreamWriter  # noqa: E402
+for double in (False, True):
+    def run():
+        out = tempfile.mkdtemp(dir=where)
+        with KaldiStreamWriter(os.path.join(out, 'corpus.ark'), double=double) as writer:
+            pipeline.extract_features_streamed(cfg5, index, writer.write, njobs=2, log=quiet)
+        size = os.path.getsize(os.path.join(out, 'corpus.ark')) / 1e9
+        shutil.rmtree(out)
+        return size
+    size = timed('WAV files -> pipeline -> %s archive' % ('double' if double else 'float'), run, reps=2)
+    print('   (%.2f GB of matrices)' % size)
 shutil.rmtree(where)
