@@ -17,7 +17,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def child(hours, njobs, tag, sync_dir):
+def child(hours, njobs, tag, sync_dir, ark=None):
     sys.path.insert(0, ROOT)
     from shennong_amd import Audio, Utterances, pipeline, synth
     from shennong_amd.logger import get_logger
@@ -40,8 +40,18 @@ def child(hours, njobs, tag, sync_dir):
     open(os.path.join(sync_dir, 'ready%s' % tag), 'w').close()
     while not os.path.exists(os.path.join(sync_dir, 'go')):
         time.sleep(0.001)
+    writer = None
+    if ark:   # every process writes its own shard (float matrices): separate files, separate locks
+        from shennong_amd.serializers import KaldiStreamWriter
+        writer = KaldiStreamWriter(os.path.join(ark, 'shard%s.ark' % tag), double=False)
+
+        def sink(feats, write=writer.write):   # noqa: F811
+            seen[0] += len(feats)
+            write(feats)
     t0 = time.perf_counter()
     pipeline.extract_features_streamed(cfg, index, sink, log=quiet, njobs=njobs)
+    if writer is not None:
+        writer.close()
     dt = time.perf_counter() - t0
     assert seen[0] == n
     print(json.dumps({'tag': tag, 'hours': hours, 'wall_s': dt}), flush=True)
@@ -49,13 +59,17 @@ def child(hours, njobs, tag, sync_dir):
 
 def main():
     total = float(sys.argv[1]) if len(sys.argv) > 1 else 125.0
+    ark = sys.argv[2] if len(sys.argv) > 2 else ''
     print('# processes x njobs: aggregate hours of audio per second = total hours / slowest process '
-          '(%.0f h in all, split evenly; pinned indexes; nproc %d)' % (total, os.cpu_count()))
-    for njobs in (1, 2):
+          '(%.0f h in all, split evenly; pinned indexes; nproc %d)%s' % (
+              total, os.cpu_count(), '; every process writes its shard to a Kaldi archive of float matrices under '
+              + ark if ark else ''))
+    for njobs in ((2,) if ark else (1, 2)):
         for procs in (1, 2, 4, 8):
-            with tempfile.TemporaryDirectory() as sync_dir:
+            with tempfile.TemporaryDirectory() as sync_dir, tempfile.TemporaryDirectory(dir=ark or None) as out:
                 kids = [subprocess.Popen([sys.executable, __file__, 'child', str(total / procs), str(njobs), str(k),
-                                          sync_dir], stdout=subprocess.PIPE, text=True) for k in range(procs)]
+                                          sync_dir, out if ark else ''], stdout=subprocess.PIPE, text=True)
+                        for k in range(procs)]
                 while sum(os.path.exists(os.path.join(sync_dir, 'ready%d' % k)) for k in range(procs)) < procs:
                     if any(kid.poll() not in (None, 0) for kid in kids):
                         raise SystemExit('a child failed')
@@ -68,6 +82,6 @@ def main():
 
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'child':
-        child(float(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5])
+        child(float(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6] if len(sys.argv) > 6 else None)
     else:
         main()
