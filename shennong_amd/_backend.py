@@ -423,6 +423,11 @@ class Plan:
             d_out = DeviceBuffer(max(total * ndims * 4, 16), self.device)
             out = result_array((total, ndims), np.float32)
             pieces = max(1, min(_COPY_PIECES * _COPY_THREADS, n, total_samples * 2 // (8 << 20)))
+            if self.opts.kind == _abi.KIND_PITCH:
+                # (the tracker's cost per utterance falls with the size of a call - 250 / 1 000 / 10 000 utterances:
+                # 8 / 3 / 1.2 us - : fewer, larger pieces, still enough of them to run the uploads beside the
+                # kernels.  10 000 x 3 s from pageable arrays: 16 pieces 59.6 ms, 8: 49.3, 4: 51.2, 2: 57.4, 1: 78.8)
+                pieces = max(1, min(pieces, int(os.environ.get('SNF_PITCH_PIECES', '8'))))
             # (round 5, measured and dropped: a small first piece per thread, so that the link starts after 0.7 ms
             # of gathering instead of 5 - 31-34 against 30-31 ms: the call is bound by the host's memory traffic
             # - 960 MB gathered, read again by the upload, 477 MB written by the download - not by its head)

@@ -206,6 +206,20 @@ class FramesProcessor(Configurable, FeaturesProcessor, metaclass=abc.ABCMeta):
             if signal._data.ndim != 1 or signal._sample_rate != rate:
                 check_signal(self, signal)
 
+    def _process_pinned(self, corpus):
+        """`_process_batch` over a page-locked corpus (``Utterances.pin()``, or the WAV files of an index read
+        into pooled staging memory: `_process_files`): uploaded from where it lies, no per-utterance conversion or
+        check (one sample rate and mono by construction)"""
+        if self.sample_rate != corpus.sample_rate:
+            raise ValueError(
+                'processor and signal mismatch in sample rates: '
+                '{} != {}'.format(self.sample_rate, corpus.sample_rate))
+        return _backend.get_plan(self._build_options()).run_pinned(
+            corpus, None, check_finite=True, wrap=self._wrap_pinned)
+
+    def _wrap_pinned(self, datas):
+        return batch_features(datas, self.times, lambda _: self.get_properties())
+
     def _run(self, opts, signals, vtln_warps=None, wrap=None):
         """One batched launch over `signals` (forced to 16 bits integers like the reference does
         before Kaldi, processor/base.py:428); the batch is validated once.  `wrap(matrices)` builds the

@@ -57,6 +57,11 @@ class EnergyProcessor(FramesProcessor):
         """Computes energy on the input `signal` -> Features [nframes, 1]"""
         return self._process_batch([signal])[0]
 
+    def _wrap_pinned(self, datas):
+        # (an utterance without frames comes back as Kaldi's (0, 0) matrix: one column here)
+        return batch_features([d if d.shape[0] else d.reshape((0, 1)) for d in datas],
+                              self.times, lambda _: self.get_properties())
+
     def _process_batch(self, signals):
         for signal in signals:
             check_signal(self, signal)

@@ -76,6 +76,16 @@ class KaldiPitchProcessor(Configurable, FeaturesProcessor):
         """Extracts the (NCCF, pitch) from a given speech `signal`"""
         return self._process_batch([signal])[0]
 
+    def _process_pinned(self, corpus):
+        """`_process_batch` over a page-locked corpus (Utterances.pin(), or WAV files read into staging memory)"""
+        if self.sample_rate != corpus.sample_rate:
+            raise ValueError(
+                'processor and signal mismatch in sample rates: '
+                '{} != {}'.format(self.sample_rate, corpus.sample_rate))
+        return _backend.get_plan(self._build_options()).run_pinned(
+            corpus, None, check_finite=True,
+            wrap=lambda datas: batch_features(datas, self.times, lambda _: self.get_properties()))
+
     def _process_batch(self, signals):
         for signal in signals:
             self._check(signal)

@@ -419,9 +419,15 @@ def test_pipeline_from_wav_files_natively(gpu, tmp_path):
         for key in want:
             assert np.array_equal(got[key].data, want[key].data), (name, key)
     assert pipeline.extract_features(config, index)['b'].properties['audio']['file'] == WAV
-    proc = MfccProcessor(dither=0)
-    a, b, c = proc.process_all(index), proc.process_all(loaded), proc.process_all(index.pin())
-    assert all(np.array_equal(a[k].data, b[k].data) and np.array_equal(c[k].data, b[k].data) for k in b)
+    from shennong_amd.processor import (
+        EnergyProcessor, KaldiPitchProcessor, PlpProcessor, SpectrogramProcessor)
+    for proc in (MfccProcessor(dither=0), KaldiPitchProcessor(), SpectrogramProcessor(dither=0),
+                 EnergyProcessor(dither=0), PlpProcessor(dither=0, rasta=True)):
+        a, b, c = proc.process_all(index), proc.process_all(loaded), proc.process_all(index.pin())
+        assert list(a) == list(b) == list(c), proc.name
+        assert all(a[k] == b[k] and np.array_equal(c[k].data, b[k].data) for k in b), proc.name
+    with pytest.raises(ValueError, match='mismatch in sample rates'):
+        KaldiPitchProcessor(sample_rate=8000).process_all(index)
 
 
 @pytest.mark.gpu
