@@ -821,6 +821,46 @@ def main():
                     'events of every plan call of the run'}
         del index2, audios, pinned5
 
+        # a corpus on DISK, in and out: 4 000 of the utterances written as 16-bit WAV files,
+        # read back natively (snf_wav_read_pcm16: side by side into page-locked memory) by process_all and by the
+        # streamed config-5 pipeline, whose batches go to a Kaldi archive of float matrices (KaldiStreamWriter)
+        import shutil
+        import tempfile
+        import scipy.io.wavfile
+        from shennong_amd.serializers import KaldiStreamWriter
+        nfiles = min(n_utts, 4000)
+        where = tempfile.mkdtemp(prefix='snf_bench_')
+        try:
+            for i in range(nfiles):
+                scipy.io.wavfile.write(os.path.join(where, 'u%05d.wav' % i), 16000, waves[i])
+            t0 = time.perf_counter()
+            on_disk = Utterances([('u%05d' % i, os.path.join(where, 'u%05d.wav' % i), 's%03d' % (i % 50))
+                                  for i in range(nfiles)])
+            index_s = time.perf_counter() - t0
+            fbank.process_all(on_disk)
+            walls = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                coll = fbank.process_all(on_disk)
+                walls.append(time.perf_counter() - t0)
+                del coll
+            t0 = time.perf_counter()
+            with KaldiStreamWriter(os.path.join(where, 'corpus.ark'), double=False) as writer:
+                written = pipeline.extract_features_streamed(cfg5, on_disk, writer.write, njobs=2, log=quiet)
+            corpus_s = time.perf_counter() - t0
+            hours_disk = nfiles * args.seconds / 3600.0
+            extra['corpus_on_disk'] = {
+                'files': nfiles, 'hours_of_audio': hours_disk, 'index_us_per_file': index_s / nfiles * 1e6,
+                'process_all_us_per_file': min(walls) / nfiles * 1e6,
+                'process_all_hours_of_audio_per_s': hours_disk / min(walls),
+                'wav_to_archive_s': corpus_s, 'wav_to_archive_hours_of_audio_per_s': hours_disk / corpus_s,
+                'archive_bytes': os.path.getsize(os.path.join(where, 'corpus.ark')), 'utterances_written': int(written),
+                'note': '16-bit mono WAV files (page cache warm) -> FilterbankProcessor.process_all; and -> the '
+                        'streamed config-5 pipeline (CMVN by speaker, two passes, two batches in flight) -> '
+                        'KaldiStreamWriter(double=False); directory: ' + tempfile.gettempdir()}
+        finally:
+            shutil.rmtree(where, ignore_errors=True)
+
         # FeaturesProcessor.process_all on the 10 000 in-memory utterances (the north_star's API surface,
         # reference processor/base.py:56-107): wall clock from utterances to a FeaturesCollection, host to host:
         # upload (960 MB: PCIe floor 22.4 ms at 42.8 GB/s) + kernel + download (477 MB) + one Features per
