@@ -322,6 +322,12 @@ class Plan:
                 warp = None
         if n == 0:
             return wrap([])
+        cuts = self._tracker_chunks(soff)
+        if cuts is not None:   # (a corpus whose tracker scratch would not fit: whole calls one after the other)
+            res = []
+            for a, b in zip(cuts, cuts[1:]):
+                res += self._run(waves[a:b], None, check_finite, lambda part: part)
+            return wrap(res)
         if int(soff[-1]) * 2 >= _LARGE_BATCH_BYTES and self.ndims > 0:
             return self._run_large(waves, soff, foff, nfr, warp, check_finite, wrap)
         wave, wave_token = stage_rows(waves, np.int16)
@@ -352,6 +358,22 @@ class Plan:
             del wave
             STAGING.release(wave_token)
         return wrap(res)
+
+    def _tracker_chunks(self, soff):
+        """Utterance cuts of a pitch batch that is too long for ONE call - the tracker keeps ~2.3 GB of scratch per
+        hour of audio (back pointers and the resampled NCCF of every frame: 19 GB per 10 000 x 3 s), per plan and
+        grow-only - or None when the batch fits `_MAX_TRACKER_HOURS` (or is not a pitch batch)"""
+        if self.opts.kind != _abi.KIND_PITCH:
+            return None
+        limit = int(_MAX_TRACKER_HOURS * 3600.0 * float(self.opts.pitch.samp_freq))
+        if int(soff[-1]) <= limit:
+            return None
+        cuts, n = [0], soff.shape[0] - 1
+        while cuts[-1] < n:
+            a = cuts[-1]
+            b = int(np.searchsorted(soff, soff[a] + limit, side='right')) - 1
+            cuts.append(min(max(b, a + 1), n))   # (an utterance longer than the limit is a call of its own)
+        return cuts if len(cuts) > 2 else None
 
     def _clones(self, count):
         """(lock, `count` private plans with this plan's options on its device): the pieces of a large batch run
@@ -395,6 +417,12 @@ class Plan:
         wrap = wrap or (lambda res: res)
         if n == 0:
             return wrap([])
+        cuts = self._tracker_chunks(soff)
+        if cuts is not None:
+            res = []
+            for a, b in zip(cuts, cuts[1:]):
+                res += self.run_pinned(_CorpusSlice(corpus, a, b), None, check_finite, lambda part: part)
+            return wrap(res)
         if self.ndims <= 0 or int(soff[-1]) * 2 < _LARGE_BATCH_BYTES:
             return self._run(corpus.views, vtln_warps, check_finite, wrap)
         return self._run_large(corpus.views, soff, foff, nfr, warp, check_finite, wrap, pinned=corpus)
@@ -834,6 +862,16 @@ class _PinnedOwner:
                 pass
 
 
+class _CorpusSlice:
+    """Utterances a .. b of a page-locked corpus, as a corpus (Plan.run_pinned of a stretch of it)"""
+    def __init__(self, corpus, a, b):
+        self.sample_rate = corpus.sample_rate
+        s0, s1 = int(corpus.soff[a]), int(corpus.soff[b])
+        self.soff = corpus.soff[a:b + 1] - s0
+        self.block = corpus.block[s0:s1]
+        self.views = corpus.views[a:b]
+
+
 class PinnedCorpus:
     """The int16 audio of a set of utterances in ONE page-locked block (``Utterances.pin()``): what the
     processors force every signal to before they run (reference processor/base.py:428), loaded once.  A batch
@@ -946,6 +984,7 @@ def stage_rows(mats, dtype):
 _COPY_POOL = None
 _CLONES = {}   # (options, device) -> private plans of Plan._clones
 _MAX_CLONE_SETS = 8   # option sets whose clones (16 plans' tables each) are kept
+_MAX_TRACKER_HOURS = float(os.environ.get('SNF_MAX_TRACKER_HOURS', '16'))   # audio per pitch call (~37 GB of scratch)
 _LARGE_BATCH_BYTES = 32 << 20   # Plan.run: batches from this many bytes of audio take the overlapped path
 _COPY_PIECES = int(os.environ.get('SNF_COPY_PIECES', '4'))    # pieces of a large batch per copy thread
 _COPY_THREADS = int(os.environ.get('SNF_COPY_THREADS', '4'))  # (8 / 16 threads measured slower: 6.4 / 5.1 against 4.1 ms per 96 MB)

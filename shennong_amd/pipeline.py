@@ -308,9 +308,29 @@ def extract_features(configuration, utterances, warps=None, njobs=1,
     config = _init_config(configuration, log=log)
     log.info('detected format for utterances index is: %s',
              utterances.format(type=str))
+    if _too_large_for_one_batch(utterances):
+        # the corpus in one launch per stage would not fit the HBM that is free (the pitch tracker alone keeps
+        # 2.3 GB of scratch per hour of audio): the same features - bit for bit, see extract_features_streamed -
+        # from bounded batches, collected here (the reference, on the CPU, takes a corpus of any size)
+        log.info('the corpus does not fit one device batch: extracting in batches')
+        collected = FeaturesCollection()
+        extract_features_streamed(config, utterances, collected.update, warps=warps, njobs=min(njobs, 2), log=log)
+        return collected
     if warps:
         warps = _init_warps(warps, config, utterances, log)
     return _extract_features(config, _view_of(utterances), warps, log)
+
+
+def _too_large_for_one_batch(utterances):
+    """True when one batch over all of `utterances` would need more than half of the HBM that is free
+    (_BATCH_BYTES_PER_HOUR per hour of audio while a batch is in flight)"""
+    if _backend.device_count() < 1:   # (host-logic tests with the device pipeline replaced by a stand-in)
+        return False
+    need = utterances.duration() / 3600.0 * _BATCH_BYTES_PER_HOUR
+    if need < (8 << 30):              # (no query for what certainly fits)
+        return False
+    free, _ = _backend.mem_info()
+    return need > free // 2
 
 
 def _view_of(utterances):

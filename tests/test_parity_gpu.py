@@ -177,6 +177,24 @@ def test_pitch(gpu, audio, wave, opts, vit_team):
     _pitch_close(got.data, want)
 
 
+def test_pitch_corpus_longer_than_one_call(gpu, synth_waves, monkeypatch):
+    """a pitch batch whose tracker scratch (2.3 GB per hour of audio, per plan) would not fit goes through whole
+    calls one after the other - here with the limit lowered to one second of audio: arrays and a pinned corpus,
+    utterances longer than the limit included; the rows are those of one call"""
+    from shennong_amd import Utterances
+    waves = list(synth_waves)          # six utterances of 0.3 .. 1.2 s
+    proc = KaldiPitchProcessor()
+    index = Utterances([(f'u{i}', Audio(w, 16000, validate=False)) for i, w in enumerate(waves)])
+    want = proc.process_all(index)
+    monkeypatch.setattr(_backend, '_MAX_TRACKER_HOURS', 1.0 / 3600.0)
+    plan = _backend.get_plan(proc._build_options())
+    cuts = plan._tracker_chunks(np.concatenate([[0], np.cumsum([w.shape[0] for w in waves])]).astype(np.int64))
+    assert cuts is not None and len(cuts) > 3 and cuts[0] == 0 and cuts[-1] == len(waves)
+    for got in (proc.process_all(index), proc.process_all(index.pin())):
+        assert list(got) == list(want)
+        assert all(np.array_equal(got[k].data, want[k].data) for k in want)
+
+
 def test_pitch_negative_penalty_is_refused(gpu, audio):
     """the searches order costs by their bit pattern (non-negative floats only): a transition cost
     that could go negative is an error at plan creation, not a silently different track"""

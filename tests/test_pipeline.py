@@ -394,6 +394,30 @@ def test_pipeline_pinned_index(gpu):
 
 
 @pytest.mark.gpu
+def test_extract_features_falls_back_to_batches_when_the_corpus_does_not_fit(gpu, monkeypatch):
+    """a corpus whose single batch would not fit the free HBM (2.3 GB of tracker scratch per hour of audio: 125 h
+    would ask for more than the device has) is extracted in bounded batches behind the same call: same keys, same
+    order, same bits"""
+    from shennong_amd import synth
+    waves = synth.utterances(11, 24, 16000)
+    index = Utterances([(f'u{i:02d}', Audio(waves[i, :9000 + 250 * i].copy(), 16000, validate=False), f's{i % 4}')
+                        for i in range(24)])
+    config = pipeline.get_default_config('filterbank', with_pitch='kaldi', with_cmvn=True, with_delta=True)
+    config['filterbank']['dither'] = 0
+    config['pitch']['postprocessing']['delta_pitch_noise_stddev'] = 0
+    want = pipeline.extract_features(config, index)
+    assert not pipeline._too_large_for_one_batch(index)
+    # (an hour of audio "needs" 2^50 bytes: nothing fits one batch; the streamed default is ten minutes then)
+    monkeypatch.setattr(pipeline, '_BATCH_BYTES_PER_HOUR', 1 << 50)
+    monkeypatch.setattr(pipeline, 'default_batch_duration', lambda depth=1: 5.0)
+    assert pipeline._too_large_for_one_batch(index)
+    got = pipeline.extract_features(config, index, njobs=2)
+    assert list(got) == list(want)
+    for name in want:
+        assert got[name] == want[name], name
+
+
+@pytest.mark.gpu
 def test_pipeline_from_wav_files_natively(gpu, tmp_path):
     """a corpus of WAV files goes through the native reader (16-bit mono PCM side by side into page-locked memory,
     other sample types through the Python reader): the pipeline, process_all and Utterances.pin() see the same
