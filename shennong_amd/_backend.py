@@ -1242,14 +1242,28 @@ class DeviceBuffer:
         return wait
 
     def download_async(self, array):
-        """Starts the copy into `array` on this thread's copy stream and returns a callable that waits for
-        it: the caller does its host-side bookkeeping in between (the copy only overlaps when `array` is
-        page-locked, :func:`result_array`; into plain memory it is done when this returns)"""
+        """Starts the copy into `array` on this thread's download stream (its own: an upload that is on its way
+        does not queue behind it, the link's two directions run side by side) and returns a callable that waits
+        for THIS copy, from any thread; the caller does its host-side bookkeeping - or the next batch's
+        launches - in between (the copy only overlaps when `array` is page-locked, :func:`result_array`; into
+        plain memory it is done when this returns)"""
         bind_device(self.device)
-        stream = _copy_stream(self.device)
-        check(lib().snf_memcpy_d2h_async(array.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
-                                         array.nbytes, C.c_void_p(stream)))
-        return lambda: check(lib().snf_stream_synchronize(C.c_void_p(stream)))
+        stream = _copy_stream(self.device, 1)
+        L = lib()
+        check(L.snf_memcpy_d2h_async(array.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
+                                     array.nbytes, C.c_void_p(stream)))
+        done = C.c_void_p()
+        check(L.snf_event_create(C.byref(done)))
+        check(L.snf_event_record(done, C.c_void_p(stream)))
+
+        def wait():   # (a second call is a no-op)
+            if done.value:
+                try:
+                    check(L.snf_event_synchronize(done))
+                finally:
+                    L.snf_event_destroy(done)
+                    done.value = None
+        return wait
 
     def free(self, synced=False):
         """Gives the block back (to the pool, or to the driver when the pool is full).  Like hipFree, which

@@ -393,31 +393,63 @@ def _batch_pool():
     return _BATCH_POOL
 
 
-def _in_flight(batches, work, depth):
+def _in_flight(batches, work, depth, deferred=False):
     """``work(b, batch)`` for every batch, results in order, at most `depth` batches started and not yet
     handed over.  With `depth` > 1 the batches run on threads: the staging copy, the transfers and the
     launches of one (all outside the interpreter lock) overlap the per-utterance bookkeeping of another.
+    `deferred`: `work` returns ``(result, finish)`` with the copy of the result still on its way
+    (:func:`_extract_features` with ``defer=True``); `finish()` is called here, as late as the order allows -
+    with one batch at a time, after the NEXT batch's work, so that the copy of batch k crosses the link beside
+    the launches and the bookkeeping of batch k + 1 instead of being waited for.
     Closing the generator early (an error in the consumer) cancels what has not started and WAITS for what
-    is running: nothing touches the caller's buffers after it returns."""
-    if depth <= 1:
-        for b, batch in enumerate(batches):
-            yield work(b, batch)
-        return
+    is running and for the copies on their way: nothing touches the caller's buffers after it returns."""
     from collections import deque
-    from concurrent.futures import wait
-    pending = deque()
-    pool = _batch_pool()
+    done = deque()       # deferred results whose copy has not been waited for
+
+    def hand_over(item):
+        if not deferred:
+            return item
+        result, finish = item
+        finish()
+        return result
+
     try:
-        for b, batch in enumerate(batches):
-            pending.append(pool.submit(work, b, batch))
-            if len(pending) >= depth:
-                yield pending.popleft().result()
-        while pending:
-            yield pending.popleft().result()
+        if depth <= 1:
+            for b, batch in enumerate(batches):
+                item = work(b, batch)
+                if not deferred:
+                    yield item
+                    continue
+                done.append(item)
+                if len(done) > 1:
+                    yield hand_over(done.popleft())
+            while done:
+                yield hand_over(done.popleft())
+            return
+        from concurrent.futures import wait
+        pending = deque()
+        pool = _batch_pool()
+        try:
+            for b, batch in enumerate(batches):
+                pending.append(pool.submit(work, b, batch))
+                if len(pending) >= depth:
+                    yield hand_over(pending.popleft().result())
+            while pending:
+                yield hand_over(pending.popleft().result())
+        finally:
+            for future in pending:
+                future.cancel()
+            wait(list(pending))
+            if deferred:
+                for future in pending:
+                    if not future.cancelled() and future.exception() is None:
+                        done.append(future.result())
     finally:
-        for future in pending:
-            future.cancel()
-        wait(list(pending))
+        while done:   # (the run ended early: the copies must have landed before their blocks go back to the pools)
+            try:
+                done.popleft()[1]()
+            except Exception:  # pragma: nocover
+                pass
 
 
 _BATCH_BYTES_PER_HOUR = 4 << 30   # HBM one hour of audio needs while its batch is in flight: 2.3 GB of pitch
@@ -567,10 +599,10 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
 
         def second_pass(b, batch):
             return _extract_features(config, batch, sub(batch), log, stats_hook=hook,
-                                     resident=resident, batch_id=b, stats=stats)
+                                     resident=resident, batch_id=b, stats=stats, defer=True)
 
         count = handed = 0
-        batches = running = _in_flight(views(), second_pass, depth)
+        batches = running = _in_flight(views(), second_pass, depth, deferred=True)
         while True:
             # (nothing of batch k is referenced here while batch k + 1 is made: its page-locked result block
             # is back in the pool by then, see _backend.result_array)
@@ -900,13 +932,16 @@ def _classes_of(*keys):
 
 def _extract_features(config, utterances, warps, log, tolerance=2, stats_hook=None,
                       stats_only=False, resident=None, batch_id=None, device_out=None, stats=None,
-                      stages=None, utterance_properties=True):
+                      stages=None, utterance_properties=True, defer=False):
+    """`defer`: return ``(features, finish)`` with the copy of the result block still on its way; `finish()`
+    waits for it and must be called before the data are read (extract_features_streamed: the copy of batch k
+    crosses the link beside the launches of batch k + 1)"""
     from shennong_amd.utils import paused_gc
     with paused_gc():   # (thousands of small objects per batch, none of them garbage: see utils.paused_gc)
         run = _PipelineRun(config, utterances, warps, log, tolerance, resident, batch_id, stats, stages,
                            utterance_properties)
         try:
-            return run.execute(stats_hook, stats_only, device_out)
+            return run.execute(stats_hook, stats_only, device_out, defer)
         except BaseException:
             run.abort()
             raise
@@ -965,7 +1000,7 @@ class _PipelineRun:
         if self.stats is not None:
             self.stats.add(**amounts)
 
-    def execute(self, stats_hook, stats_only, device_out):
+    def execute(self, stats_hook, stats_only, device_out, defer=False):
         self.stage_audio()
         for group in self.groups:
             proc = _processor_class(self.features_name)(**self.config[self.features_name])
@@ -993,7 +1028,7 @@ class _PipelineRun:
                 return found
         if self.with_delta:
             self.stage_delta()
-        return self.stage_join(device_out)
+        return self.stage_join(device_out, defer)
 
     # ---- audio: one int16 block per sample rate in HBM ------------------------------------------------------
     def stage_audio(self):
@@ -1254,7 +1289,7 @@ class _PipelineRun:
 
     # ---- join: pitch columns (the number of frames can differ by a few because of the downsampling in the
     # pitch tracker: same tolerance as Kaldi's paste-feats), then the only device -> host copy ------------------
-    def stage_join(self, device_out):
+    def stage_join(self, device_out, defer=False):
         utts, n, cache, log, tolerance = self.utts, self.n, self.cache, self.log, self.tolerance
         results = [None] * n
         pending = []
@@ -1332,12 +1367,23 @@ class _PipelineRun:
         extras = zip(repeat(_utterance_properties), utts, self.rate_of) if self.utterance_properties \
             else repeat(None)
         out = FeaturesCollection(zip(self.names, map(Features._of_batch, results, times, metas, extras)))
-        t0 = time.perf_counter()
-        for wait, group, nbytes in pending:
-            wait()
-            group.drop('feat')
-            self._count(bytes_down=nbytes)
-        self._count(download_wait_s=time.perf_counter() - t0, batches=1, utterances=n)
+        def finish():
+            """waits for the copies into the result block and gives the device blocks back (once)"""
+            t0 = time.perf_counter()
+            while pending:
+                wait, group, nbytes = pending.pop()
+                try:
+                    wait()
+                except BaseException:
+                    group.abort()   # (a copy that failed may still be writing: the plain free() waits)
+                    raise
+                group.drop('feat')
+                self._count(bytes_down=nbytes)
+            self._count(download_wait_s=time.perf_counter() - t0)
+        self._count(batches=1, utterances=n)
+        if defer:
+            return out, finish
+        finish()
         return out
 
 

@@ -216,7 +216,8 @@ def _streamed_worker(kind, rank, world, port, tmpdir):
             return [u.speaker for u in utts], per_utt
         names = list(dict.fromkeys(u.speaker for u in utts))
         stats = stats_hook(names, np.zeros((len(names), 2, 3)))
-        return {u.name: float(stats[names.index(u.speaker)][0, 0]) for u in utts}
+        out = {u.name: float(stats[names.index(u.speaker)][0, 0]) for u in utts}
+        return (out, lambda: None) if _resident.get('defer') else out
 
     pipeline._extract_features = fake
     config = pipeline.get_default_config('mfcc', with_cmvn=True)

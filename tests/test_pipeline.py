@@ -554,7 +554,8 @@ def test_streamed_driver_logic(monkeypatch):
                             for s in names])
         stats = stats_hook(names, partial) if stats_hook else partial
         calls.append(('apply', [u.name for u in utts]))
-        return {u.name: stats[names.index(u.speaker)][0, 0] for u in utts}
+        out = {u.name: stats[names.index(u.speaker)][0, 0] for u in utts}
+        return (out, lambda: None) if _resident.get('defer') else out
 
     monkeypatch.setattr(pipeline, '_extract_features', fake)
     config = pipeline.get_default_config('mfcc', with_cmvn=True)
@@ -666,6 +667,46 @@ def test_batches_in_flight(depth):
     assert list(pipeline._in_flight(iter([]), work, depth)) == []
     with pytest.raises(ValueError, match='batch 2'):
         list(pipeline._in_flight(iter(['a', 'b', 'bad', 'c', 'bad']), work, depth))
+
+
+@pytest.mark.parametrize('depth', [1, 2, 3])
+def test_batches_in_flight_deferred(depth):
+    """deferred results (the copy of a batch still on its way when its work returns): handed over in order, every
+    `finish` called exactly once and before its result is handed over; with one batch at a time the finish of
+    batch k comes AFTER the work of batch k + 1 (that is the overlap); a consumer that stops early, or a batch
+    that fails, still has every started copy waited for"""
+    events = []
+
+    def work(b, batch):
+        events.append(('work', b))
+        if batch == 'bad':
+            raise ValueError('batch %d' % b)
+        return (b, batch), (lambda b=b: events.append(('finish', b)))
+
+    batches = ['b%d' % i for i in range(7)]
+    handed = []
+    for b, batch in pipeline._in_flight(iter(batches), work, depth, deferred=True):
+        assert ('finish', b) in events
+        handed.append((b, batch))
+    assert handed == list(enumerate(batches))
+    assert sorted(e for e in events if e[0] == 'finish') == [('finish', b) for b in range(7)]
+    if depth == 1:
+        for b in range(6):
+            assert events.index(('work', b + 1)) < events.index(('finish', b))
+    assert list(pipeline._in_flight(iter([]), work, depth, deferred=True)) == []
+    # early close: the copies of what ran are waited for
+    del events[:]
+    gen = pipeline._in_flight(iter(batches), work, depth, deferred=True)
+    assert next(gen) == (0, 'b0')
+    gen.close()
+    started = sorted(b for kind, b in events if kind == 'work')
+    assert sorted(b for kind, b in events if kind == 'finish') == started
+    # a failing batch: the earlier results were either handed over or finished
+    del events[:]
+    with pytest.raises(ValueError, match='batch 2'):
+        list(pipeline._in_flight(iter(['a', 'b', 'bad', 'c']), work, depth, deferred=True))
+    finished = sorted(b for kind, b in events if kind == 'finish')
+    assert finished[:2] == [0, 1] and 2 not in finished
 
 
 def test_batches_in_flight_closed_early():
