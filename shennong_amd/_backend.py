@@ -256,9 +256,9 @@ class Plan:
             from shennong_amd.logger import get_logger
             get_logger('backend', 'warning').warning(
                 'this option combination is not covered by the register-resident kernels (even frames '
-                'that pad to 128 ... 512 samples with <= 64 mel bins, <= 16 cepstra and a power spectrum, '
-                'or to 1024 / 2048 samples with <= 128 mel bins): the generic wave-per-frame kernel is '
-                'used, 5 to 8 times slower per frame')
+                'that pad to 128 ... 512 samples with <= 64 mel bins, <= 16 cepstra and a power spectrum; '
+                'frames that pad to 1024 samples, or even ones that pad to 2048, with <= 128 mel bins): the '
+                'generic wave-per-frame kernel is used, 5 to 8 times slower per frame')
 
     def __del__(self):
         handle = getattr(self, 'handle', None)

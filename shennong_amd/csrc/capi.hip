@@ -125,6 +125,7 @@ struct snf_plan {
   bool fast_warps_ok = true;     // false: some warp's banks do not fit the fast kernel
   // register-resident 2048-point path (frames that pad to 2048 or 1024 samples)
   bool fast2048 = false;
+  bool pair1024 = false;      // frames that pad to 1024 samples: two per transform (kernels_fbank1024x2.hip)
   DevBuf d_long_tables;
 
   // delta (post-processor plans, and MFCC plans with append_deltas)
@@ -406,7 +407,12 @@ int build_mel_plan(snf_plan* plan) {
   if (want_fused && !plan->fast512)
     return set_error(SNF_E_INVALID, "append_deltas: this configuration is not covered by the register-resident "
                                     "512-point kernel (its tables do not fit); chain a delta plan");
-  if (!plan->fast512 && fbank2048_eligible(p)) {
+  if (!plan->fast512 && fbank1024x2_eligible(p)) {
+    std::vector<float> blob;
+    fbank1024x2_tables(p, window, &blob);
+    if ((rc = plan->d_long_tables.upload(blob, plan->stream))) return rc;
+    plan->pair1024 = true;
+  } else if (!plan->fast512 && fbank2048_eligible(p)) {
     std::vector<float> blob;
     fbank2048_tables(p, window, &blob);
     if ((rc = plan->d_long_tables.upload(blob, plan->stream))) return rc;
@@ -440,8 +446,8 @@ int sync_warp_tables(snf_plan* plan) {
   if ((rc = plan->d_mel_size.upload(size, plan->stream))) return rc;
   if ((rc = plan->d_mel_off.upload(off, plan->stream))) return rc;
   if ((rc = plan->d_mel_w.upload(w, plan->stream))) return rc;
-  if (plan->fast2048) {
-    // the long-frame kernel reads a filter in 32-tap slices of 16-byte vectors: a copy of the weights in
+  if (plan->fast2048 || plan->pair1024) {
+    // the long-frame kernels read a filter in 32-tap slices of 16-byte vectors: a copy of the weights in
     // which every filter is zero-padded to whole slices, behind one all-zero slice (for the lanes whose
     // filter has fewer slices than the widest one of their round)
     std::vector<float> w32(32, 0.0f);
@@ -916,7 +922,7 @@ int32_t snf_plan_fast_path(const snf_plan* plan) {
     case SNF_KIND_MFCC:
     case SNF_KIND_PLP:
     case SNF_KIND_ENERGY:
-      return (plan->fast512 || plan->fast2048) ? 1 : 0;
+      return (plan->fast512 || plan->fast2048 || plan->pair1024) ? 1 : 0;
     default:
       return 1;  // (no slower alternative exists for this kind)
   }
@@ -1020,7 +1026,7 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     if ((rc = plan->s_energy.ensure(sizeof(double) * static_cast<size_t>(total_frames)))) return rc;
   }
   bool use_fast = plan->fast512;
-  bool use_long = plan->fast2048;  // (per-utterance VTLN warps included: it reads the plan's bank tables)
+  bool use_long = plan->fast2048 || plan->pair1024;  // (per-utterance VTLN warps included: they read the plan's bank tables)
   if (use_fast && any_warp) {
     if ((rc = sync_fast_warp_tables(plan))) return rc;
     use_fast = plan->fast_warps_ok;
@@ -1075,7 +1081,8 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     b.n_blocks = static_cast<int64_t>(blk_utt.size());
   }
   BatchArgs b_dual = b;  // the arguments of the two-frame kernel (all utterances, or the unwarped ones)
-  if (use_fast && plan->fp.dual && (!any_warp || split_dual)) {
+  const bool use_pair = use_long && plan->pair1024;   // (every utterance, warped or not: fbank1024x2_kernel)
+  if ((use_fast && plan->fp.dual && (!any_warp || split_dual)) || use_pair) {
     // fbank256x2_kernel: frame pairs formed inside every utterance (PairRec), built once per offsets table
     // (a batch split by warp factor: pairs of the unwarped utterances only, rebuilt on every call)
     if (split_dual || any_short) plan->pairs_valid = false;
@@ -1100,7 +1107,7 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     b_dual.blk_utt = nullptr;
     b_dual.blk_set0 = nullptr;
     b_dual.n_blocks = 0;
-    b_dual.utt_warp = nullptr;
+    if (!use_pair) b_dual.utt_warp = nullptr;
   } else if (!(use_fast && (any_warp || fused)) && !plan->setidx_valid) {
     // frame -> first-sample index, edge marks and utterance index: built once per offsets table,
     // reused by later calls (fast kernel: bulk loads; generic kernel: no per-frame binary search)
@@ -1149,6 +1156,20 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     if (own_stream) mark_kernel(plan, fbank512b_eligible(fpx, b) ? "fbank512b_kernel" : "fbank512_kernel");
     return SNF_OK;
   };
+  // the long-frame family: one frame per wave (2048-sample frames), or a pair of frames (1024-sample frames)
+  auto run_long = [&](float* out, int cols, double* energy) -> int {
+    int rc2;
+    if (use_pair) {
+      BatchArgs bp = b_dual;
+      bp.utt_noise = b.utt_noise;
+      if ((rc2 = launch_fbank1024x2(plan->mp, bp, plan->d_long_tables.as<float>(), out, cols, energy, s))) return rc2;
+      if (own_stream) mark_kernel(plan, "fbank1024x2_kernel");
+      return SNF_OK;
+    }
+    if ((rc2 = launch_fbank2048(plan->mp, b, plan->d_long_tables.as<float>(), out, cols, energy, s))) return rc2;
+    if (own_stream) mark_kernel(plan, "fbank2048_kernel");
+    return SNF_OK;
+  };
   // utterances shorter than a window (snip_edges = false), after the register-resident kernels
   auto run_short = [&](float* out, int cols, double* energy) -> int {
     if (!any_short || !(use_fast || use_long)) return SNF_OK;
@@ -1165,10 +1186,7 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     if (use_fast) {
       if ((rc = run_fast(plan->s_mel.as<float>(), nb, plan->s_energy.as<double>()))) return rc;
     } else if (use_long) {
-      if ((rc = launch_fbank2048(plan->mp, b, plan->d_long_tables.as<float>(), plan->s_mel.as<float>(), nb,
-                                 plan->s_energy.as<double>(), s)))
-        return rc;
-      if (own_stream) mark_kernel(plan, "fbank2048_kernel");
+      if ((rc = run_long(plan->s_mel.as<float>(), nb, plan->s_energy.as<double>()))) return rc;
     } else {
       if ((rc = launch_mel_features(plan->mp, b, plan->s_mel.as<float>(), nb,
                                     plan->s_energy.as<double>(), s)))
@@ -1196,9 +1214,7 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     if (use_fast) {
       if ((rc = run_fast(feat_out, feat_cols, nullptr))) return rc;
     } else if (use_long) {
-      if ((rc = launch_fbank2048(plan->mp, b, plan->d_long_tables.as<float>(), feat_out, feat_cols, nullptr, s)))
-        return rc;
-      if (own_stream) mark_kernel(plan, "fbank2048_kernel");
+      if ((rc = run_long(feat_out, feat_cols, nullptr))) return rc;
     } else {
       if ((rc = launch_mel_features(plan->mp, b, feat_out, feat_cols, nullptr, s))) return rc;
       if (own_stream) mark_kernel(plan, "mel_features_generic_kernel");

@@ -133,7 +133,7 @@ struct BatchArgs {
   const uint8_t* utt_mask;        // [n_utts] generic kernel: when set, only the utterances marked 1 are computed
   const uint64_t* frame_noise;    // [total_frames] fbank512b_kernel with dither: wave_noise_id of every frame
   const uint32_t* utt_noise;      // [n_utts] dither: a hash of 64 samples spread over every utterance (per call)
-  const PairRec* pair_tab;        // [n_pairs] fbank256x2_kernel only
+  const PairRec* pair_tab;        // [n_pairs] fbank256x2_kernel / fbank1024x2_kernel only
   int64_t n_pairs;
   int64_t n_blocks;
   int64_t n_utts;
@@ -257,6 +257,13 @@ bool fbank2048_eligible(const MelParams& mp);
 void fbank2048_tables(const MelParams& mp, const std::vector<float>& window, std::vector<float>* blob);
 int launch_fbank2048(const MelParams& p, const BatchArgs& b, const float* tables, float* out, int out_cols,
                      double* energy_out, hipStream_t stream);
+
+// ---- two 1024-sample frames per complex transform (kernels_fbank1024x2.hip): 22.05 / 32 kHz frames; `b` carries
+// the pair table of launch_build_pair_table
+bool fbank1024x2_eligible(const MelParams& mp);
+void fbank1024x2_tables(const MelParams& mp, const std::vector<float>& window, std::vector<float>* blob);
+int launch_fbank1024x2(const MelParams& p, const BatchArgs& b, const float* tables, float* out, int out_cols,
+                       double* energy_out, hipStream_t stream);
 
 struct PitchDevTables {
   int first_lag, last_lag, num_lags, num_states, win_size, win_shift, full_len;

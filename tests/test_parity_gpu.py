@@ -774,7 +774,8 @@ def test_delta_pitch_noise_does_not_depend_on_the_batch(gpu):
 
 
 @pytest.mark.parametrize('cls, sample_rate', [(MfccProcessor, 8000), (PlpProcessor, 8000),
-                                              (FilterbankProcessor, 16000), (MfccProcessor, 44100)])
+                                              (FilterbankProcessor, 16000), (MfccProcessor, 44100),
+                                              (MfccProcessor, 32000), (FilterbankProcessor, 22050)])
 def test_features_do_not_depend_on_the_warps_of_the_batch(gpu, cls, sample_rate):
     """VTLN: an utterance runs on the same kernel, to the same bits, whatever the warp factors of the
     utterances around it (found by tools/fuzz_pipeline.py, seed 8 case 7: a streamed 8 kHz corpus whose
@@ -792,7 +793,8 @@ def test_features_do_not_depend_on_the_warps_of_the_batch(gpu, cls, sample_rate)
 
 
 @pytest.mark.parametrize('cls, sample_rate', [(MfccProcessor, 8000), (FilterbankProcessor, 16000),
-                                              (PlpProcessor, 8000), (FilterbankProcessor, 44100)])
+                                              (PlpProcessor, 8000), (FilterbankProcessor, 44100),
+                                              (FilterbankProcessor, 32000), (PlpProcessor, 22050)])
 def test_every_route_in_one_batch(gpu, cls, sample_rate):
     """snip_edges = False, VTLN warps and utterances shorter than a window together: warped / unwarped /
     sub-window utterances each take their own kernel inside one call (capi.hip: split_dual, run_short),
@@ -824,15 +826,24 @@ def test_every_route_in_one_batch(gpu, cls, sample_rate):
     (MfccProcessor, 48000, dict(use_energy=False)),           # 1200 samples -> 2048
     (PlpProcessor, 44100, dict()),
     (SpectrogramProcessor, 44100, dict()),
-    (SpectrogramProcessor, 32000, dict(raw_energy=False)),    # 800 samples -> 1024: zero-extended
+    (SpectrogramProcessor, 32000, dict(raw_energy=False)),    # 800 samples -> 1024: two frames per transform
     (MfccProcessor, 32000, dict()),
+    (FilterbankProcessor, 32000, dict(num_bins=40)),
+    (FilterbankProcessor, 32000, dict(num_bins=23, use_energy=True, raw_energy=False, htk_compat=True)),
+    (FilterbankProcessor, 32000, dict(use_energy=True, use_power=False, remove_dc_offset=False)),
+    (PlpProcessor, 32000, dict()),
+    (FilterbankProcessor, 22050, dict(num_bins=40)),           # 551 samples (odd) -> 1024
+    (MfccProcessor, 22050, dict(use_energy=False, window_type='hamming', preemph_coeff=0.0)),
+    (SpectrogramProcessor, 22050, dict()),
+    (PlpProcessor, 22050, dict(rasta=True)),
     (FilterbankProcessor, 16000, dict(frame_length=0.064, frame_shift=0.02, num_bins=40)),  # 1024 samples
     (FilterbankProcessor, 16000, dict(frame_length=0.1, frame_shift=0.03, num_bins=64)),    # 1600 -> 2048
 ])
 def test_fast_kernel_long_frames(gpu, cls, sample_rate, opts, snip_edges):
     """frames that pad to 2048 samples (44.1 / 48 kHz; the reference tests MFCC at 44.1 kHz,
-    test/processor/test_mfcc.py:129-137) and, zero-extended, to 1024 samples (32 kHz) run on the
-    register-resident 2048-point kernel, VTLN warps included"""
+    test/processor/test_mfcc.py:129-137) run on the register-resident 2048-point kernel, frames that pad to
+    1024 samples (22.05 / 32 kHz, odd window lengths included) two at a time on the same transform; VTLN warps
+    included"""
     n = int(0.35 * sample_rate)
     waves = [synth.utterances(21 + i, 1, n + 1013 * i, sample_rate)[0] for i in range(3)]
     proc = cls(sample_rate=sample_rate, dither=0, snip_edges=snip_edges, **opts)
@@ -840,7 +851,8 @@ def test_fast_kernel_long_frames(gpu, cls, sample_rate, opts, snip_edges):
     linear = opts.get('use_power', True) is False
     kw = dict(vtln_warp=[1.0, 1.0, 1.0]) if cls is not SpectrogramProcessor else {}
     feats = proc._process_batch([Audio(w, sample_rate) for w in waves], **kw)
-    assert plan.kernel_name(1) == 'fbank2048_kernel'
+    kernel = 'fbank1024x2_kernel' if proc.frame_length * sample_rate <= 1024 else 'fbank2048_kernel'
+    assert plan.kernel_name(1) == kernel
     for w, f in zip(waves, feats):
         want = _oracle(proc, w)
         assert f.shape == want.shape
@@ -850,9 +862,44 @@ def test_fast_kernel_long_frames(gpu, cls, sample_rate, opts, snip_edges):
         return
     warps = [0.9, 1.0, 1.15]
     feats = proc._process_batch([Audio(w, sample_rate) for w in waves], vtln_warp=warps)
-    assert plan.kernel_name(1) == 'fbank2048_kernel'
+    assert plan.kernel_name(1) == kernel
     for w, wf, f in zip(waves, warps, feats):
         assert_close(f.data, _oracle(proc, w, wf), rtol=1e-4, what=f'{proc.name} warp {wf} {opts}')
+
+
+@pytest.mark.parametrize('sample_rate', [32000, 22050])
+def test_paired_frames_of_unequal_energy(gpu, sample_rate):
+    """two frames per transform share their roundings, the louder frame sets the error floor of both: a quiet
+    frame beside an onset (digital silence beside a full-scale tone, a +-1 LSB murmur beside it, a 60 dB step)
+    must still match the oracle - such pairs are transformed one frame at a time (kernels_fbank1024x2.hip)"""
+    rng = np.random.default_rng(5)
+    n = sample_rate
+    t = np.arange(n) / sample_rate
+    # (a tone over a noise floor 36 dB below it: the bins of a PURE tone far from its frequency are float
+    # round-off in any transform, the oracle's included)
+    tone = (20000 * np.sin(2 * np.pi * 997.0 * t) + rng.integers(-300, 301, size=n)).astype(np.int16)
+    waves = []
+    for kind in range(4):
+        w = tone.copy()
+        quiet = slice(n // 4, n // 2 + 137 * kind)
+        if kind == 0:
+            w[quiet] = 0
+        elif kind == 1:
+            w[quiet] = rng.integers(-1, 2, size=w[quiet].shape)
+        elif kind == 2:
+            w[quiet] = rng.integers(-30, 31, size=w[quiet].shape)
+        else:
+            w[:n // 3] = 0
+            w[n // 3:] = rng.integers(-20000, 20000, size=n - n // 3)
+        waves.append(w)
+    for cls, opts in ((FilterbankProcessor, dict(num_bins=40)), (MfccProcessor, dict()),
+                      (SpectrogramProcessor, dict())):
+        proc = cls(sample_rate=sample_rate, dither=0, **opts)
+        feats = proc._process_batch([Audio(w, sample_rate) for w in waves])
+        plan = _backend.get_plan(proc._build_options())
+        assert plan.kernel_name(1) == 'fbank1024x2_kernel'
+        for k, (w, f) in enumerate(zip(waves, feats)):
+            assert_close(f.data, _oracle(proc, w), rtol=1e-4, what=f'{proc.name} {sample_rate} Hz, signal {k}')
 
 
 def test_long_frames_single_utterance_shorter_than_a_window(gpu):

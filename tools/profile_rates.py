@@ -1,5 +1,5 @@
-"""Dev helper: run the plans of the other sample rates (44.1 / 48 / 32 / 8 kHz: fbank2048_kernel,
-fbank256x2_kernel) and the delta plan a few times (for rocprofv3 --kernel-trace / --pmc); prints the
+"""Dev helper: run the plans of the other sample rates (44.1 / 48 / 32 / 22.05 / 8 kHz: fbank2048_kernel,
+fbank1024x2_kernel, fbank256x2_kernel) and the delta plan a few times (for rocprofv3 --kernel-trace / --pmc); prints the
 HIP-event kernel times next to the kernel names"""
 import os
 import sys
@@ -10,8 +10,11 @@ from shennong_amd.processor import FilterbankProcessor, MfccProcessor
 from shennong_amd.postprocessor import DeltaPostProcessor
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+only = int(sys.argv[2]) if len(sys.argv) > 2 else None   # (one sample rate only)
 # 596 000 frames at the long rates (2000 x 3 s), 1 192 000 at 8 kHz (4000 x 3 s)
-for sr, n_utts in ((44100, 2000), (48000, 2000), (32000, 2000), (8000, 4000)):
+for sr, n_utts in ((44100, 2000), (48000, 2000), (32000, 2000), (22050, 2000), (8000, 4000)):
+    if only is not None and sr != only:
+        continue
     ns = 3 * sr
     base = synth.utterances(0, 20, ns, sr)
     waves = np.ascontiguousarray(np.tile(base, (n_utts // 20, 1)))
@@ -34,6 +37,8 @@ for sr, n_utts in ((44100, 2000), (48000, 2000), (32000, 2000), (8000, 4000)):
             cls.__name__, sr, plan.kernel_name(1), fpu * n_utts, np.median(ks), np.min(ks)), flush=True)
         d_out.free()
     d_wave.free()
+if only is not None:
+    sys.exit(0)
 # delta 13 -> 39 on 2.98 M frames
 n_utts, fpu = 10000, 298
 x = np.random.default_rng(0).standard_normal((n_utts * fpu, 13)).astype(np.float32)
