@@ -927,6 +927,23 @@ def main():
         extra['fbank40_44khz']['kernel'] = p44.kernel_name(1)
         d_w44.free()
         d_o44.free()
+        # 32 kHz audio (800-sample frames, padded to 1024): two frames per 1024-point complex transform
+        # (fbank1024x2_kernel, round 6; until then the zero-extended 2048-point transform); 2000 x 3 s
+        sub32 = min(n_utts, 2000)
+        n32 = 96000
+        w32 = np.ascontiguousarray(waves.reshape(-1)[:sub32 * n32].reshape(sub32, n32))
+        d_w32 = _backend.DeviceBuffer(w32.nbytes)
+        d_w32.upload(w32)
+        p32 = _backend.get_plan(FilterbankProcessor(sample_rate=32000, num_bins=40, dither=0)._build_options())
+        f32 = p32.num_frames(n32)
+        soff32 = np.arange(sub32 + 1, dtype=np.int64) * n32
+        foff32 = np.arange(sub32 + 1, dtype=np.int64) * f32
+        d_o32 = _backend.DeviceBuffer(f32 * sub32 * 40 * 4)
+        extra['fbank40_32khz'] = time_plan(
+            p32, lambda: p32.run_device(d_w32.ptr, soff32, foff32, d_o32.ptr), f32 * sub32, 2 * 320 + 160)
+        extra['fbank40_32khz']['kernel'] = p32.kernel_name(1)
+        d_w32.free()
+        d_o32.free()
 
     d_mfcc.free()
     # ---- CPU baseline (rank 0, N = 1 only) -----------------------------------------------------------

@@ -70,6 +70,8 @@ struct DevBuf {
 };
 
 constexpr int kMaxSlots = 6;
+constexpr float kPairSplitRatio = 8.0f;   // fbank256x2_kernel: windowed-energy ratio beyond which a pair is redone
+                                          // one frame at a time (kernels_fbank1024x2.hip holds the same number)
 
 // Scratch and a stream of its own for the plan-less device helpers (snf_concat_columns_device,
 // snf_count_nonfinite_device), per calling thread and device: no hipMalloc / hipFree per call (both wait for the
@@ -146,7 +148,7 @@ struct snf_plan {
 
   // scratch (host-pointer entry points and intermediates)
   DevBuf s_wave, s_out, s_in, s_soff, s_foff, s_uwarp, s_mel, s_energy;
-  DevBuf s_down, s_stats, s_bp, s_doff, s_dp1, s_fp1, s_states, s_setidx, s_edge, s_futt, s_poff, s_pairs, s_umask;
+  DevBuf s_down, s_stats, s_bp, s_doff, s_dp1, s_fp1, s_states, s_setidx, s_edge, s_futt, s_poff, s_pairs, s_umask, s_fix, s_fixcount;
   DevBuf s_pres, s_anp;  // pitch: NCCF at the lag of every state [frames, states], norm average [frames]
   bool setidx_valid = false;
   bool pairs_valid = false;   // s_pairs / n_pairs describe the cached offsets tables
@@ -1104,6 +1106,20 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
     }
     b_dual.pair_tab = plan->s_pairs.as<PairRec>();
     b_dual.n_pairs = plan->n_pairs;
+    if (!use_pair && plan->n_pairs > 0 && !getenv("SNF_DUAL_NO_FIXUP")) {
+      // fbank256x2_kernel: pairs of very different energies are redone one frame at a time by a second launch
+      // (BatchArgs::fix_tab): room for every pair, the count zeroed in stream order
+      if ((rc = plan->s_fix.ensure(sizeof(PairRec) * 2 * static_cast<size_t>(plan->n_pairs)))) return rc;
+      if ((rc = plan->s_fixcount.ensure(sizeof(unsigned int)))) return rc;
+      SNF_HIP_CHECK(hipMemsetAsync(plan->s_fixcount.p, 0, sizeof(unsigned int), s));
+      b_dual.fix_tab = plan->s_fix.as<PairRec>();
+      b_dual.fix_count = plan->s_fixcount.as<unsigned int>();
+      static const float ratio = [] {
+        const char* e = getenv("SNF_PAIR_SPLIT_RATIO");   // (experiments: 0 redoes every pair)
+        return e ? static_cast<float>(atof(e)) : kPairSplitRatio;
+      }();
+      b_dual.split_ratio = ratio;
+    }
     b_dual.blk_utt = nullptr;
     b_dual.blk_set0 = nullptr;
     b_dual.n_blocks = 0;

@@ -396,27 +396,38 @@ __global__ __launch_bounds__(kPairWaves * 64) void fbank1024x2_kernel(
       // indices of the next round are requested a round ahead.
       const int* __restrict__ moff32 = p.mel_off32 + warp_id * nb;
       const int team = lane >> 3, tl = lane & 7;
+      const float* __restrict__ wz = p.mel_w32 + 4 * tl;
+      // the first two slices of a filter's weights: zero slices beyond its end
+      auto weights_of = [&](int first_, int size_, int woff_, f32x4_a4 (&w_)[2]) __attribute__((always_inline)) {
+        const int slices_ = (size_ + (first_ & 3) + 31) >> 5;
+        const float* __restrict__ wt_ = p.mel_w32 + woff_ + 4 * tl;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) w_[i] = *reinterpret_cast<const f32x4_a4*>(i < slices_ ? wt_ + 32 * i : wz);
+      };
+      // (bin indices two rounds ahead, weights one round ahead: a round waits for neither)
       bool active = team < nb;
       int first = active ? mfirst[team] : 0, size = active ? msize[team] : 0, woff = active ? moff32[team] : 0;
+      const bool active_1 = team + 8 < nb;
+      int first_n = active_1 ? mfirst[team + 8] : 0, size_n = active_1 ? msize[team + 8] : 0,
+          woff_n = active_1 ? moff32[team + 8] : 0;
+      f32x4_a4 w[2];
+      weights_of(first, size, woff, w);
       for (int m0 = 0; m0 < nb; m0 += 8) {
-        const int m = m0 + team, mn = m + 8;
-        const bool active_n = mn < nb;
-        const int first_n = active_n ? mfirst[mn] : 0, size_n = active_n ? msize[mn] : 0,
-                  woff_n = active_n ? moff32[mn] : 0;
+        const int m = m0 + team, mnn = m + 16;
+        const bool active_n = m + 8 < nb, active_nn = mnn < nb;
+        const int first_nn = active_nn ? mfirst[mnn] : 0, size_nn = active_nn ? msize[mnn] : 0,
+                  woff_nn = active_nn ? moff32[mnn] : 0;
+        f32x4_a4 w_n[2];
+        weights_of(first_n, size_n, woff_n, w_n);
         const int lead = first & 3, slices = (size + lead + 31) >> 5;
         const float* __restrict__ wt = p.mel_w32 + woff + 4 * tl;
-        const float* __restrict__ wz = p.mel_w32 + 4 * tl;
         const float* __restrict__ pb0 = ps + (first - lead) + 4 * tl;
         const int rot = team & 3;
         const float* __restrict__ pbr[4] = {pb0 + rot, pb0 + ((rot + 1) & 3), pb0 + ((rot + 2) & 3),
                                             pb0 + ((rot + 3) & 3)};
         float acc_a = 0.0f, acc_b = 0.0f;
-        for (int e0 = 0; __any(e0 < slices); e0 += 2) {
-          f32x4_a4 w[2];
+        for (int e0 = 0;;) {
           float pva[8], pvb[8];
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-            w[i] = *reinterpret_cast<const f32x4_a4*>(e0 + i < slices ? wt + 32 * (e0 + i) : wz);
 #pragma unroll
           for (int e = 0; e < 8; ++e) pva[e] = pbr[e & 3][32 * (e0 + (e >> 2))];
           if (two) {
@@ -432,6 +443,11 @@ __global__ __launch_bounds__(kPairWaves * 64) void fbank1024x2_kernel(
             acc_a += w[e >> 2][e & 3] * pva[e];
             acc_b += w[e >> 2][e & 3] * pvb[e];
           }
+          e0 += 2;
+          if (!__any(e0 < slices)) break;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)   // (a filter wider than two slices: its next two)
+            w[i] = *reinterpret_cast<const f32x4_a4*>(e0 + i < slices ? wt + 32 * (e0 + i) : wz);
         }
         acc_a += dpp_row_ror<0xB1>(acc_a);   // quad_perm [1,0,3,2]
         acc_b += dpp_row_ror<0xB1>(acc_b);
@@ -455,6 +471,11 @@ __global__ __launch_bounds__(kPairWaves * 64) void fbank1024x2_kernel(
         first = first_n;
         size = size_n;
         woff = woff_n;
+        first_n = first_nn;
+        size_n = size_nn;
+        woff_n = woff_nn;
+        w[0] = w_n[0];
+        w[1] = w_n[1];
       }
       if (KIND == SNF_KIND_FBANK && p.use_energy && lane == 0) {
         row_a[p.htk_compat ? nb : 0] = log_energy[0];

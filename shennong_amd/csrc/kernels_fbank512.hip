@@ -738,9 +738,11 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
 
   const float win_len_f = static_cast<float>(p.win_len), inv_win_len = 1.0f / win_len_f;
   const int n_waves = blockDim.x >> 6;
-  const int64_t n_sets = (b.n_pairs + 3) >> 2;
+  // (the fix-up launch walks a list whose length only the device knows: BatchArgs::n_pairs_dev)
+  const int64_t n_pairs = b.n_pairs_dev ? static_cast<int64_t>(*b.n_pairs_dev) : b.n_pairs;
+  const int64_t n_sets = (n_pairs + 3) >> 2;
   const int64_t set_stride = static_cast<int64_t>(gridDim.x) * n_waves;
-  const int64_t last_pair = b.n_pairs - 1;
+  const int64_t last_pair = n_pairs - 1;
   // a pair record as two 16-byte halves: {start_a, start_b} and {frame_a, utt1, flags}
   auto starts_of = [&](int64_t pi) -> longlong2 {
     return reinterpret_cast<const longlong2*>(b.pair_tab + (pi < last_pair ? pi : last_pair))[0];
@@ -908,18 +910,37 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
         const float ye = (ae - p.preemph * pa) * w.x;
         const float yo = (ao - p.preemph * pb) * w.y;
         z[j] = make_float2(ye, yo);
-        if (ENERGY == 2) {
-          ep_a += ye * ye;
-          ep_b += yo * yo;
-        }
+        ep_a += ye * ye;   // (the energies of the windowed frames: the pairing decision below, ENERGY == 2)
+        ep_b += yo * yo;
       } else {
         z[j] = make_float2(0.0f, 0.0f);
       }
     }
     float e_lin_a = 0.0f, e_lin_b = 0.0f;
-    if (ENERGY != 0) {
-      e_lin_a = row_sum16(ENERGY == 1 ? er_a : ep_a);
-      e_lin_b = row_sum16(ENERGY == 1 ? er_b : ep_b);
+    {
+      const float ew_a = row_sum16(ep_a), ew_b = row_sum16(ep_b);
+      if (ENERGY == 2) {
+        e_lin_a = ew_a;
+        e_lin_b = ew_b;
+      } else if (ENERGY == 1) {
+        e_lin_a = row_sum16(er_a);
+        e_lin_b = row_sum16(er_b);
+      }
+      // The two frames share the roundings of one transform.  A pair of very different energies (a quiet frame
+      // beside an onset, digital silence beside anything) is put down for the fix-up launch, which transforms
+      // each of its frames alone and rewrites the two rows (BatchArgs::fix_tab).
+      if (b.fix_tab != nullptr && valid_b && l == 0 &&
+          fmaxf(ew_a, ew_b) > b.split_ratio * fminf(ew_a, ew_b)) {
+        const longlong2 st = starts_of(set * 4 + q);
+        const unsigned at = atomicAdd(b.fix_count, 2u);
+        longlong2* rec = reinterpret_cast<longlong2*>(b.fix_tab + at);
+        int4* rec_meta = reinterpret_cast<int4*>(b.fix_tab + at);
+        rec[0] = make_longlong2(st.x, st.x);
+        rec_meta[1] = make_int4(meta.x, meta.y, meta.z, meta.w & 1);
+        const int64_t gb = ga + 1;
+        rec[2] = make_longlong2(st.y, st.y);
+        rec_meta[3] = make_int4(static_cast<int>(gb), static_cast<int>(gb >> 32), meta.z, (meta.w >> 1) & 1);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -1548,7 +1569,8 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
     int64_t blocks8 = (n_sets8 + n_waves - 1) / n_waves;
     const int64_t max_blocks8 = 256 * 4 * (kMaxWaves / n_waves);
     if (blocks8 > max_blocks8) blocks8 = max_blocks8;
-    const dim3 grid8(static_cast<unsigned>(blocks8)), block8(n_waves * 64);
+    const dim3 block8(n_waves * 64);
+    auto run_dual = [&](const BatchArgs& b, const dim3 grid8) -> int {
 #define SNF_DUAL5(NJ_, KIND_, EN_, DI_, SN_)                                                         \
   do {                                                                                              \
     if (lds > 64 * 1024)                                                                            \
@@ -1586,8 +1608,22 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
 #undef SNF_DUAL
 #undef SNF_DUAL3
 #undef SNF_DUAL5
-    SNF_HIP_CHECK(hipGetLastError());
-    return SNF_OK;
+      SNF_HIP_CHECK(hipGetLastError());
+      return SNF_OK;
+    };
+    int rc = run_dual(b, dim3(static_cast<unsigned>(blocks8)));
+    if (rc != SNF_OK || b.fix_tab == nullptr) return rc;
+    // the fix-up launch: the frames of the pairs the first launch put down (two records of one frame each), as
+    // many as `fix_count` says when the first launch is done - a grid sized for a twentieth of the pairs walks
+    // whatever the list holds
+    BatchArgs bf = b;
+    bf.pair_tab = b.fix_tab;
+    bf.n_pairs_dev = b.fix_count;
+    bf.fix_tab = nullptr;
+    bf.fix_count = nullptr;
+    int64_t blocks_fix = (blocks8 + 9) / 10;
+    if (blocks_fix < 16) blocks_fix = blocks8 < 16 ? blocks8 : 16;
+    return run_dual(bf, dim3(static_cast<unsigned>(blocks_fix)));
   }
   const int nj = (p.win_len + 31) / 32 == 13 ? 13 : 16;
   const int64_t n_sets = (b.total_frames + 3) / 4;

@@ -135,6 +135,14 @@ struct BatchArgs {
   const uint32_t* utt_noise;      // [n_utts] dither: a hash of 64 samples spread over every utterance (per call)
   const PairRec* pair_tab;        // [n_pairs] fbank256x2_kernel / fbank1024x2_kernel only
   int64_t n_pairs;
+  // fbank256x2_kernel: a pair of frames shares the roundings of ONE complex transform - the louder frame sets the
+  // error floor of both.  Pairs whose windowed energies differ by more than `split_ratio` are appended here, as two
+  // records of one frame each (a frame paired with itself), `fix_count` counting the records; a second launch
+  // of the kernel over that list (`n_pairs_dev` = the count, read on the device) rewrites their rows.
+  PairRec* fix_tab;
+  unsigned int* fix_count;
+  const unsigned int* n_pairs_dev;
+  float split_ratio;
   int64_t n_blocks;
   int64_t n_utts;
   int64_t total_frames;
