@@ -1516,3 +1516,20 @@ def test_plp_banks_are_built_when_a_frame_asks(gpu):
     with pytest.raises(RuntimeError, match='num_bins too large'):
         fb = FilterbankProcessor(**{k: v for k, v in opts.items() if k != 'num_ceps'})
         orc.compute(fb._build_options(), wave, 0.85)
+
+
+def test_adversarial_waveforms(gpu):
+    """digital silence, constants, full-scale squares, lone impulses, clipped noise, +-1 LSB noise, steps and
+    bursts at 8 / 16 / 22.05 / 32 / 44.1 kHz through every mel family (and the pitch tracker, bit for bit):
+    tools/adversarial_parity.py finds nothing outside the suite's tolerances but pure tones at their float32 floor"""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'adversarial_parity.py')
+    spec = importlib.util.spec_from_file_location('adversarial_parity', path)
+    module = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(module)
+    argv, sys_argv = ['adversarial_parity.py', '3'], __import__('sys').argv
+    __import__('sys').argv = argv
+    try:
+        assert module.main() == 0
+    finally:
+        __import__('sys').argv = sys_argv

@@ -1,0 +1,130 @@
+#!/usr/bin/env python
+"""Adversarial waveforms through every mel family and the pitch tracker at 8 / 16 / 22.05 / 32 / 44.1 kHz, HIP
+path against the oracle: digital silence, constants, full-scale square waves, the Nyquist alternation, lone
+impulses, clipped noise, +-1 LSB noise, steps between them at several alignments.  Prints the cases outside the
+suite's tolerances (tests/conftest.py; the filterbank's absolute term at 3e-5 here: these signals put log
+energies at zero crossings); exit status 1 if there are any.  The pure tones among the signals (a constant without
+DC removal, the Nyquist alternation) are listed apart and do not count: every bin but one lies 100+ dB under the
+frame's peak, which is round-off in ANY float32 transform - the float64 statement (oracle/spec_f64.py) disagrees
+with the oracle there by as much as the kernels do (bin 7 of fbank-40 at 16 kHz: 1.956 exact, 2.025 oracle, 1.941 HIP).
+
+    python tools/adversarial_parity.py [seed]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np  # noqa: E402
+from conftest import assert_close  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from shennong_amd import Audio, _backend  # noqa: E402
+from shennong_amd.processor import (FilterbankProcessor, MfccProcessor, PlpProcessor,  # noqa: E402
+                                    SpectrogramProcessor, EnergyProcessor, KaldiPitchProcessor)
+
+
+PURE_TONES = ('dc', 'min', 'nyquist')
+
+
+def signals(rate, rng):
+    n = int(0.5 * rate)
+    t = np.arange(n) / rate
+    noise = lambda a: rng.integers(-a, a + 1, size=n).astype(np.int16)  # noqa: E731
+    out = {}
+    out['zeros'] = np.zeros(n, np.int16)
+    out['dc'] = np.full(n, 12345, np.int16)
+    out['min'] = np.full(n, -32768, np.int16)
+    out['square100'] = np.where(np.sin(2 * np.pi * 100 * t) >= 0, 32767, -32768).astype(np.int16)
+    out['nyquist'] = np.where(np.arange(n) % 2 == 0, 32767, -32768).astype(np.int16)
+    imp = np.zeros(n, np.int16)
+    imp[n // 3] = 32767
+    out['impulse'] = imp
+    out['clipped'] = np.clip(rng.normal(0, 40000, size=n), -32768, 32767).astype(np.int16)
+    out['lsb'] = noise(1)
+    out['ramp'] = ((np.arange(n) * 977) % 65536 - 32768).astype(np.int16)
+    for k, cut in enumerate((n // 2, n // 2 + 37, n // 2 + int(0.0125 * rate))):
+        w = np.zeros(n, np.int16)
+        w[cut:] = noise(30000)[cut:]
+        out['step%d' % k] = w
+        w = noise(2)
+        w[cut:] = noise(30000)[cut:]
+        out['lsbstep%d' % k] = w
+        w = noise(30000)
+        w[cut:] = 0
+        out['fall%d' % k] = w
+    burst = noise(3)
+    for c in range(5):
+        a = n // 6 * (c + 1)
+        burst[a:a + int(0.004 * rate)] = noise(32000)[:int(0.004 * rate)]
+    out['bursts'] = burst
+    return out
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    rng = np.random.default_rng(seed)
+    bad = checked = pure = 0
+    kernels = {}
+    for rate in (8000, 16000, 22050, 32000, 44100):
+        sig = signals(rate, rng)
+        names = list(sig)
+        waves = [sig[k] for k in names]
+        for cls, opts in ((FilterbankProcessor, dict(num_bins=40 if rate > 8000 else 23)),
+                          (FilterbankProcessor, dict(use_energy=True, raw_energy=False, remove_dc_offset=False)),
+                          (MfccProcessor, dict()), (PlpProcessor, dict()), (SpectrogramProcessor, dict()),
+                          (EnergyProcessor, dict()), (FilterbankProcessor, dict(snip_edges=False))):
+            proc = cls(sample_rate=rate, dither=0, **opts)
+            plan = _backend.get_plan(proc._build_options())
+            # (a batch with a signal whose features are not finite is refused as a whole, like the reference's
+            # Features.validate: those signals go alone, and the oracle must not be finite for them either)
+            feats = []
+            for name, w in zip(names, waves):
+                try:
+                    feats.append(proc._process_batch([Audio(w, rate)])[0])
+                except ValueError as err:
+                    want = orc.compute(proc._build_options(), w, 1.0)
+                    if np.isfinite(want).all():
+                        bad += 1
+                        print('REFUSED %s %d Hz %s %s: %s (the oracle is finite)' % (proc.name, rate, opts, name, err))
+                    feats.append(None)
+            kernels[plan.kernel_name(1)] = kernels.get(plan.kernel_name(1), 0) + 1
+            for name, w, f in zip(names, waves, feats):
+                if f is None:
+                    continue
+                want = orc.compute(proc._build_options(), w, 1.0)
+                checked += 1
+                try:
+                    if cls is EnergyProcessor:
+                        np.testing.assert_allclose(f.data, want, rtol=1e-5, atol=1e-5)
+                    else:
+                        assert_close(f.data, want, rtol=1e-4, what='%s %d Hz %s %s' % (proc.name, rate, opts, name),
+                                     atol=3e-5 if cls is FilterbankProcessor else None)
+                except AssertionError as err:
+                    if name in PURE_TONES:
+                        pure += 1
+                        continue
+                    bad += 1
+                    d = np.abs(f.data.astype(np.float64) - want.astype(np.float64))
+                    print('OUTSIDE %-12s %6d Hz %-10s %-28s max abs %.3g at %s (got %.6g want %.6g) [%s]' % (
+                        proc.name, rate, name, opts, d.max(), np.unravel_index(d.argmax(), d.shape),
+                        f.data.flat[d.argmax()], want.flat[d.argmax()], plan.kernel_name(1)), flush=True)
+                    del err
+        if rate in (8000, 16000):
+            proc = KaldiPitchProcessor(sample_rate=rate)
+            feats = proc._process_batch([Audio(w, rate) for w in waves])
+            for name, w, f in zip(names, waves, feats):
+                want = orc.pitch(proc._options, w)
+                checked += 1
+                if not np.array_equal(f.data, want):
+                    bad += 1
+                    d = np.abs(f.data.astype(np.float64) - want.astype(np.float64))
+                    print('OUTSIDE pitch %6d Hz %-10s: %d of %d values differ, max %.3g' % (
+                        rate, name, int((f.data != want).sum()), want.size, np.nanmax(d)), flush=True)
+    print('%d cases, %d outside tolerance, %d pure-tone cases at their float32 floor (seed %d); kernels: %s' % (
+        checked, bad, pure, seed, kernels))
+    return 1 if bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
