@@ -680,6 +680,9 @@ class _Meta:
                      self.times if times is None else times, key, source=(cache, self, make_properties))
 
 
+_TRACK_IN_FIRST_PASS = os.environ.get('SNF_TRACK_IN_FIRST_PASS', '1') != '0'   # (developer knob: A/B runs)
+
+
 class _ResidentWaves:
     """Uploaded waveforms kept in HBM between the two passes of :func:`extract_features_streamed`
     (96 kB per 3 s utterance: 16 GiB hold 140 hours of 16 kHz audio), so that the second pass neither reads
@@ -688,6 +691,7 @@ class _ResidentWaves:
         self.budget = int(budget)
         self.held = 0
         self._items = {}
+        self._tracks = {}   # pitch trackers started on resident audio in the first pass (see offer_track)
         self._lock = threading.Lock()  # (the batches in flight run on threads)
 
     def offer(self, key, d_wave, soff):
@@ -709,11 +713,30 @@ class _ResidentWaves:
                 self.held -= item[0].nbytes
             return item
 
+    def offer_track(self, key, job):
+        """The pitch tracker of a resident batch, started in the FIRST pass - which is bound by the uploads and
+        leaves the GPU idle - so that the second pass, bound by the downloads, finds the pitch columns made
+        (3 floats per frame: 0.5 GB per 125 h, not counted against the budget).  `job.result()` is the device
+        block; the audio it reads is the resident block of the same key."""
+        with self._lock:
+            self._tracks[key] = job
+
+    def take_track(self, key):
+        with self._lock:
+            return self._tracks.pop(key, None)
+
     def clear(self):
         with self._lock:   # (a batch thread that is still running may offer / take meanwhile)
             items = list(self._items.values())
+            tracks = list(self._tracks.values())
             self._items.clear()
+            self._tracks.clear()
             self.held = 0
+        for job in tracks:   # (before the audio goes: a tracker that still runs reads it)
+            try:
+                job.result().free()
+            except BaseException:  # pragma: nocover  (the tracker failed: it gave its blocks back itself)
+                pass
         for d_wave, _ in items:
             d_wave.free(synced=True)
 
@@ -793,7 +816,7 @@ class _Tracker:
     outlive the job.  (Round 6 also started the tracker of batch k + 1 of the second streamed pass when batch k
     begins, its audio being resident: 1.158 against 1.179 s per 125 h - the per-batch chain is bound by the
     download and the host work around it, not by the wait for the tracker; not kept.)"""
-    def __init__(self, config, rate, frame_shift, frame_length, d_wave, soff, stats=None):
+    def __init__(self, config, rate, frame_shift, frame_length, d_wave, soff, stats=None, start=True):
         DB = _backend.DeviceBuffer
         params = {k: v for k, v in config['pitch'].items() if k not in ('processor', 'postprocessing')}
         params['sample_rate'] = rate
@@ -826,7 +849,7 @@ class _Tracker:
             d_raw.free(synced=True)   # (both calls returned: their streams are synchronised)
             return d_pitch
 
-        self.job = _backend.side_pool().submit(track)
+        self.job = _backend.side_pool().submit(track) if start else None   # (not started: the description only)
 
 
 class RunStats:
@@ -1019,7 +1042,14 @@ class _PipelineRun:
                 pass   # (the tracker still reads the audio: released where it is waited for, stage_join)
             elif stats_only and self.resident is not None and self.resident.offer(
                     (self.batch_id, group.rate), group.blocks['wave'], group.soff):
-                group.give('wave')
+                block = group.give('wave')
+                if self.with_pitch and _TRACK_IN_FIRST_PASS:
+                    # the tracker of this batch starts NOW, on the audio that stays in HBM: the first pass waits
+                    # for uploads, the second for downloads - the GPU is idle in the first
+                    self.resident.offer_track(
+                        (self.batch_id, group.rate),
+                        _Tracker(self.config, group.rate, self.frame_shift, self.frame_length, block.ptr,
+                                 group.soff, self.stats).job)
             else:
                 group.drop('wave')
         if self.with_cmvn:
@@ -1138,9 +1168,10 @@ class _PipelineRun:
     # audio through the features, VAD, CMVN and delta; waited for where the columns are joined ------------------
     def stage_pitch_start(self, group):
         cache, rate = self.cache, group.rate
+        made = self.resident.take_track((self.batch_id, rate)) if self.resident is not None else None
         tracker = _Tracker(self.config, rate, self.frame_shift, self.frame_length, group.ptr('wave'), group.soff,
-                           self.stats)
-        group.pfoff, group.pdim, group.pitch_job = tracker.pfoff, tracker.pdim, tracker.job
+                           self.stats, start=made is None)
+        group.pfoff, group.pdim, group.pitch_job = tracker.pfoff, tracker.pdim, made or tracker.job
         pproc, post, pfoff, pdim = tracker.pproc, tracker.post, tracker.pfoff, tracker.pdim
         key = ('pitch', rate)
         if key not in cache:

@@ -97,7 +97,7 @@ acc = collections.defaultdict(list)
 for name in sorted(glob.glob('gpurun_out/profiles/pmc_rates_group_*.csv')):
     for r in csv.DictReader(open(name)):
         k = r['Kernel_Name']
-        for tag in ('fbank2048_kernel<9, 1', 'fbank256x2_kernel<13, 1', 'delta_flat_o2w2_kernel<13'):
+        for tag in ('fbank2048_kernel<9, 1', 'fbank1024x2_kernel<13, 1', 'fbank256x2_kernel<13, 1', 'delta_flat_o2w2_kernel<13'):
             if tag in k:
                 acc[(tag, r['Counter_Name'])].append(float(r['Counter_Value']))
 for (tag, c), v in sorted(acc.items()):
