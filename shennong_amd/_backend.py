@@ -1120,13 +1120,18 @@ def side_pool():
 class _DevicePool:
     """Freed device buffers kept for the next batch (hipMalloc / hipFree synchronise the device and cost
     0.1-0.4 ms each and more for large blocks; a pipeline call makes twenty of them).  Bounded by
-    SNF_DEVICE_POOL_BYTES (default 16 GiB of the 288 GB); a buffer is reused for a request of at least half its
+    SNF_DEVICE_POOL_BYTES (default: a sixth of the device, at most 48 GiB of the 288 GB); a buffer is reused for a request of at least half its
     size.  When a block does not fit under the bound, the blocks that were parked LONGEST AGO are released to make
     room: the pool follows the workload (round 6: after the benchmark's other legs had filled it with their block
     sizes, every buffer of the streamed pipeline and of `process_all` went to hipMalloc and back to hipFree -
     25 against 20 ms per `process_all` call)."""
     def __init__(self):
-        self.limit = int(os.environ.get('SNF_DEVICE_POOL_BYTES', 16 << 30))
+        # (no bound named: a sixth of the device's memory, between 4 and 48 GiB, read when the first block comes
+        # back - 48 GiB of the 288 GB of an MI355X: the 14.4 GB of audio that a 125 h corpus keeps resident
+        # between its two passes come back to the pool block by block and used to push each other out through
+        # hipFree, 0.13 s per run)
+        limit = os.environ.get('SNF_DEVICE_POOL_BYTES')
+        self.limit = int(limit) if limit is not None else None
         # tests: a reused buffer is filled with NaN bit patterns before it is handed out, so that a kernel
         # that relies on what a fresh allocation happens to contain shows up
         self.poison = bool(int(os.environ.get('SNF_DEVICE_POOL_POISON', '0')))
@@ -1150,6 +1155,11 @@ class _DevicePool:
     def give(self, device, block):
         """parks `block` (capacity, pointer); -> False when it alone exceeds the bound (the caller releases it)"""
         evicted = []
+        if self.limit is None:
+            try:
+                self.limit = int(min(max(mem_info(device)[1] // 6, 4 << 30), 48 << 30))
+            except Exception:  # pragma: nocover
+                self.limit = 16 << 30
         with self._lock:
             if block[0] > self.limit:
                 return False
