@@ -381,6 +381,31 @@ def test_dither_is_gaussian(gpu):
     assert abs(power[0::2].mean() / power[1::2].mean() - 1.0) < 0.01
 
 
+@pytest.mark.parametrize('sample_rate, kernel', [(32000, 'fbank1024x2_kernel'), (22050, 'fbank1024x2_kernel'),
+                                                 (44100, 'fbank2048_kernel')])
+def test_dither_is_gaussian_long_frames(gpu, sample_rate, kernel):
+    """the same generator in the long-frame kernels (the 1024-sample kernel draws the normals of a frame pairwise
+    over its rows): unit variance, kurtosis 3, independent frames, a flat spectrum - and two frames of a pair
+    draw different noise"""
+    wave = np.zeros(sample_rate * 20, dtype=np.int16)
+    proc = SpectrogramProcessor(sample_rate=sample_rate, dither=1.0, window_type='rectangular', preemph_coeff=0.0,
+                                remove_dc_offset=False, raw_energy=True)
+    spec = proc.process(Audio(wave, sample_rate)).data
+    assert _backend.get_plan(proc._build_options()).kernel_name(1) == kernel
+    L = int(0.025 * sample_rate)
+    energy = np.exp(spec[:, 0].astype(np.float64))          # sum of L squared samples
+    assert abs(energy.mean() / L - 1.0) < 0.006, energy.mean() / L
+    kurt = energy.var() / L + 1.0
+    assert 2.7 < kurt < 3.3, kurt
+    assert abs(np.corrcoef(energy[:-1], energy[1:])[0, 1]) < 0.08
+    assert abs(np.corrcoef(energy[0:-1:2], energy[1::2])[0, 1]) < 0.1     # the two frames of a pair
+    power = np.exp(spec[:, 1:].astype(np.float64)).mean(axis=0)
+    assert np.abs(power / L - 1.0).max() < 0.12, (power.min() / L, power.max() / L)
+    half = power.shape[0] // 2
+    assert abs(power[:half].mean() / power[half:2 * half].mean() - 1.0) < 0.015
+    assert abs(power[0::2].mean() / power[1::2].mean() - 1.0) < 0.015
+
+
 # ---- SURVEY 8(f) rank 1: energy, VAD, CMVN, sliding-window CMVN -----------------------------------
 from shennong_amd import Features, FeaturesCollection  # noqa: E402
 from shennong_amd.processor import EnergyProcessor  # noqa: E402
@@ -687,6 +712,8 @@ def test_fast_kernel_short_frames(gpu, cls, sample_rate, opts, snip_edges):
     (MfccProcessor, 16000, dict(frame_length=0.016, frame_shift=0.005)),
     (FilterbankProcessor, 16000, dict()),                     # fbank512_kernel
     (MfccProcessor, 44100, dict()),                           # fbank2048_kernel
+    (FilterbankProcessor, 32000, dict()),                     # fbank1024x2_kernel: two frames per wave
+    (MfccProcessor, 22050, dict()),                           # ... an odd window length
 ])
 def test_features_do_not_depend_on_the_batch(gpu, cls, sample_rate, opts, snip_edges):
     """an utterance's features are the same bits whether it runs alone or inside any batch (the
@@ -717,6 +744,7 @@ def test_features_do_not_depend_on_the_batch(gpu, cls, sample_rate, opts, snip_e
     (FilterbankProcessor, 8000, dict()),                      # fbank256x2_kernel
     (FilterbankProcessor, 16000, dict()),                     # fbank512_kernel (dither keeps the round-2 form)
     (MfccProcessor, 44100, dict()),                           # fbank2048_kernel
+    (FilterbankProcessor, 32000, dict()),                     # fbank1024x2_kernel
     (FilterbankProcessor, 16000, dict(frame_length=0.019, frame_shift=0.007, use_power=False)),  # generic
 ])
 def test_default_dither_does_not_depend_on_the_batch(gpu, cls, sample_rate, opts, snip_edges):
