@@ -84,33 +84,46 @@ __global__ __launch_bounds__(kPairWaves * 64) void fbank1024x2_kernel(
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kPairWaves;
   int64_t g = static_cast<int64_t>(blockIdx.x) * kPairWaves + wid;
   const int64_t last_pair = b.n_pairs - 1;
-  const int nj_any = (L + 63) >> 6;   // element rows some lane of the wave holds (lane 0 holds the most)
   auto rec_of = [&](int64_t pi) -> const PairRec* { return b.pair_tab + (pi < last_pair ? pi : last_pair); };
-  // sample loads of one frame: SGPR base + lane offset + immediate 128 j.  Rows no lane needs are skipped
-  // (their registers keep finite stale values, the zero window weights cancel them: no load ever reaches
-  // beyond the window, i.e. beyond the utterance); a lane outside the window at the boundary row re-reads
-  // lane 0's element.
-#define SNF_LOAD_HALF(dst_, start_, njl_, lane_off_)                                                   \
-  do {                                                                                                 \
-    const char* __restrict__ wp_ = reinterpret_cast<const char*>(b.wave + uniform64(start_));          \
-    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                   \
-      if (j < nj_any) {                                                                                \
-        const unsigned off_ = j < (njl_) ? (lane_off_) : 0u;                                           \
-        dst_[j] = *reinterpret_cast<const short*>(wp_ + off_ + 128 * j);                               \
-      }                                                                                                \
-    }                                                                                                  \
+  // Sample ingest: a frame's samples come in as 16-byte pieces, lane l fetching pieces l and l + 64 (two wave
+  // instructions per frame: a 16-bit load per element would be 13 - the texture addresser takes a wave
+  // instruction per 64 addresses whatever their width, 0.26 of 1.11 ms by ablation), are laid down in the wave's
+  // LDS buffer at the top of the next trip (frame a at byte 0, frame b at byte 2048: the transposes need the
+  // buffer later) and read back element by element, lane L taking n = L + 64 j and its left neighbour n - 1.
+  // The pieces that would reach beyond the frame are not fetched whole: the last fb mod 16 bytes of a frame
+  // come through 16-bit loads of the first lanes - no load ever reaches beyond the window, i.e. beyond the
+  // utterance; lanes without a piece re-read piece 0.
+  typedef int int4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+  const int n_full = (2 * L) >> 4;            // whole 16-byte pieces of a frame (<= 128)
+  const int n_tail = ((2 * L) & 15) >> 1;     // samples behind them (< 8)
+  int4_a2 qa0 = {0, 0, 0, 0}, qa1 = {0, 0, 0, 0}, qb0 = {0, 0, 0, 0}, qb1 = {0, 0, 0, 0};
+  int tail_ab = 0;                            // tail samples: frame a in the low half, frame b in the high half
+#define SNF_LOAD_FRAMES(start_a_, start_b_, lane_)                                                           \
+  do {                                                                                                       \
+    const char* __restrict__ wa_ = reinterpret_cast<const char*>(b.wave + uniform64(start_a_));              \
+    const char* __restrict__ wb_ = reinterpret_cast<const char*>(b.wave + uniform64(start_b_));              \
+    const unsigned o0_ = (lane_) < n_full ? 16u * (lane_) : 0u;                                              \
+    const unsigned o1_ = (lane_) + 64 < n_full ? 16u * ((lane_) + 64) : 0u;                                  \
+    qa0 = *reinterpret_cast<const int4_a2*>(wa_ + o0_);                                                      \
+    qb0 = *reinterpret_cast<const int4_a2*>(wb_ + o0_);                                                      \
+    if (n_full > 64) {                                                                                       \
+      qa1 = *reinterpret_cast<const int4_a2*>(wa_ + o1_);                                                    \
+      qb1 = *reinterpret_cast<const int4_a2*>(wb_ + o1_);                                                    \
+    }                                                                                                        \
+    if (n_tail != 0) {                                                                                       \
+      const unsigned ot_ = 16u * n_full + ((lane_) < n_tail ? 2u * (lane_) : 0u);                            \
+      const unsigned lo_ = *reinterpret_cast<const unsigned short*>(wa_ + ot_);                              \
+      const unsigned hi_ = *reinterpret_cast<const unsigned short*>(wb_ + ot_);                              \
+      tail_ab = static_cast<int>(lo_ | (hi_ << 16));                                                         \
+    }                                                                                                        \
   } while (0)
-  int raw_a[NJ], raw_b[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) raw_a[j] = raw_b[j] = 0;
   int64_t frame_next = 0;
   int utt1_next = 1, flags_next = 0;
   longlong2 starts_now = make_longlong2(0, 0), starts_after = make_longlong2(0, 0);
   if (g <= last_pair) {
     const PairRec* r = rec_of(g);
     const longlong2 st = reinterpret_cast<const longlong2*>(r)[0];
-    SNF_LOAD_HALF(raw_a, st.x, (L - lane + 63) >> 6, 2u * lane);
-    SNF_LOAD_HALF(raw_b, st.y, (L - lane + 63) >> 6, 2u * lane);
+    SNF_LOAD_FRAMES(st.x, st.y, lane);
     starts_now = st;
     frame_next = r->frame_a;
     utt1_next = r->utt1;
@@ -135,6 +148,23 @@ __global__ __launch_bounds__(kPairWaves * 64) void fbank1024x2_kernel(
     const int kappa = kq + 16 * bq;              // lane holds Z[kappa + 64 d] after pass D
 
     auto in_window = [&](int j) -> bool { return j < njl; };
+    // the samples of this trip's two frames: registers -> LDS (whole pieces, then the tail)
+    {
+      char* sb_ = reinterpret_cast<char*>(buf);
+      if (lane_v < n_full) {
+        *reinterpret_cast<int4*>(sb_ + 16 * lane_v) = make_int4(qa0.x, qa0.y, qa0.z, qa0.w);
+        *reinterpret_cast<int4*>(sb_ + 2048 + 16 * lane_v) = make_int4(qb0.x, qb0.y, qb0.z, qb0.w);
+      }
+      if (lane_v + 64 < n_full) {
+        *reinterpret_cast<int4*>(sb_ + 16 * (lane_v + 64)) = make_int4(qa1.x, qa1.y, qa1.z, qa1.w);
+        *reinterpret_cast<int4*>(sb_ + 2048 + 16 * (lane_v + 64)) = make_int4(qb1.x, qb1.y, qb1.z, qb1.w);
+      }
+      if (lane_v < n_tail) {
+        *reinterpret_cast<short*>(sb_ + 16 * n_full + 2 * lane_v) = static_cast<short>(tail_ab & 0xffff);
+        *reinterpret_cast<short*>(sb_ + 2048 + 16 * n_full + 2 * lane_v) = static_cast<short>(tail_ab >> 16);
+      }
+      wave_lds_sync();
+    }
     const int64_t g_a = frame_next;
     const int64_t start_b = starts_now.y;
     const int64_t u = utt1_next - 1;
@@ -145,32 +175,35 @@ __global__ __launch_bounds__(kPairWaves * 64) void fbank1024x2_kernel(
     // ---- A: samples -> float, DC removal, pre-emphasis, window; one frame after the other ---------------
     // (frame f of the pair from its sample registers -> windowed frame, its energy as the options name it,
     // its windowed energy)
-    auto prepare = [&](const int (&raw)[NJ], const int f, float (&wf)[NJ], float& e_lin_f,
-                       float& e_win_f) __attribute__((always_inline)) {
-      float x[NJ];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) x[j] = static_cast<float>(raw[j]);
+    auto prepare = [&](const int f, float (&wf)[NJ], float& e_lin_f, float& e_win_f) __attribute__((always_inline)) {
+      short* __restrict__ sf = reinterpret_cast<short*>(reinterpret_cast<char*>(buf) + 2048 * f);
       if (!SNIP && (flags & (1 << f)) != 0) {
         // [KALDI-UPSTREAM] ExtractWindow, snip_edges = false: samples outside the utterance are reflected
         // (-k - 1 below the start, 2 n - 1 - k beyond the end); only the first and last frames of an
-        // utterance take this path, their prefetched samples came from a clamped window
+        // utterance take this path (their prefetched samples came from a clamped window): the frame's place
+        // in LDS is written again
         const int64_t s0 = b.sample_offsets[u], n = b.sample_offsets[u + 1] - s0;
         const int64_t gf = g_a + f;
         const int64_t rel = (gf - b.frame_offsets[u]) * p.win_shift + p.win_shift / 2 - p.win_len / 2;
         const int16_t* __restrict__ w0 = b.wave + s0;
-        float* xf = reinterpret_cast<float*>(buf);  // staged through the wave's buffer
+        wave_lds_sync();
         for (int i = lane_v; i < L; i += 64) {
           int64_t k = rel + i;
           while (k < 0 || k >= n) k = k < 0 ? -k - 1 : 2 * n - 1 - k;
-          xf[i] = static_cast<float>(w0[k]);
+          sf[i] = w0[k];
         }
         wave_lds_sync();
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          if (in_window(j)) x[j] = xf[lane_v + 64 * j];
-        lds_wait();
-        wave_lds_sync();
       }
+      // element j of the lane: sample n = lane + 64 j, and (no dither) its left neighbour n - 1 (n = 0: Kaldi's
+      // Preemphasize takes x[0] for x[-1])
+      float x[NJ], xl[NJ];
+      const short* __restrict__ sl = sf + (lane_v == 0 ? 0 : lane_v - 1);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        x[j] = static_cast<float>(sf[lane_v + 64 * j]);
+        if (!DITHER) xl[j] = static_cast<float>(j == 0 ? sl[0] : (sf - 1)[lane_v + 64 * j]);
+      }
+      lds_wait();
       if (DITHER) {  // Kaldi dithers before the DC removal
         const unsigned long long k = wave_noise_id(b, u, g_a + f - b.frame_offsets[u]) ^ p.seed;
         const unsigned dkey_lo = fmix32(static_cast<unsigned>(k));
@@ -196,10 +229,13 @@ __global__ __launch_bounds__(kPairWaves * 64) void fbank1024x2_kernel(
         }
         e_lin_f = wave_sum64(e_raw);
       }
-      // left neighbour x[n - 1]: the same row of lane L - 1, row j - 1 of lane 63 for lane 0
+      // left neighbour x[n - 1] of a dithered frame (the noise of a sample is drawn once): the same row of lane
+      // L - 1, row j - 1 of lane 63 for lane 0
       float rot[NJ];
+      if (DITHER) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) rot[j] = from_left_lane(x[j] + neg_mean, left_lane_bytes);
+        for (int j = 0; j < NJ; ++j) rot[j] = from_left_lane(x[j] + neg_mean, left_lane_bytes);
+      }
       float e_post = 0.0f;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {  // (window weights in two halves)
@@ -212,7 +248,8 @@ __global__ __launch_bounds__(kPairWaves * 64) void fbank1024x2_kernel(
             if (j < NJ) {
               const float a = x[j] + neg_mean;
               // lane 0, j = 0: x[-1] := x[0] (Kaldi Preemphasize)
-              const float ap = lane == 0 ? (j == 0 ? a : rot[j > 0 ? j - 1 : 0]) : rot[j];
+              const float ap = DITHER ? (lane == 0 ? (j == 0 ? a : rot[j > 0 ? j - 1 : 0]) : rot[j])
+                                      : xl[j] + neg_mean;
               const float w = (jj & 1) ? win4[jj >> 1].z : win4[jj >> 1].x;
               // (elements outside the window hold finite duplicates: their zero window weights make them 0)
               const float v = (a - p.preemph * ap) * w;
@@ -228,8 +265,8 @@ __global__ __launch_bounds__(kPairWaves * 64) void fbank1024x2_kernel(
     float wa[NJ], wb[NJ];          // windowed frames
     float e_lin[2] = {0.0f, 0.0f}; // frame energies (raw or windowed, whichever the options name)
     float e_win[2] = {0.0f, 0.0f}; // windowed energies (the pairing decision)
-    prepare(raw_a, 0, wa, e_lin[0], e_win[0]);
-    prepare(raw_b, 1, wb, e_lin[1], e_win[1]);
+    prepare(0, wa, e_lin[0], e_win[0]);
+    prepare(1, wb, e_lin[1], e_win[1]);
     // an odd last frame is transformed alone; a pair of very different energies as two single frames: this trip
     // takes frame a with a zero partner, the NEXT trip of the loop takes frame b the same way (its samples come
     // in again: the pair's record is replayed with frame b in the first seat, see the prefetch below)
@@ -338,8 +375,7 @@ __global__ __launch_bounds__(kPairWaves * 64) void fbank1024x2_kernel(
     // trip), the record of the pair after that
     {
       const int64_t ns_a = split ? start_b : starts_after.x, ns_b = split ? start_b : starts_after.y;
-      SNF_LOAD_HALF(raw_a, ns_a, njl, 2u * lane_v);
-      SNF_LOAD_HALF(raw_b, ns_b, njl, 2u * lane_v);
+      SNF_LOAD_FRAMES(ns_a, ns_b, lane_v);
       if (split) {
         frame_next = g_a + 1;
         flags_next = ((flags >> 1) & 1) | 8;
@@ -535,7 +571,7 @@ __global__ __launch_bounds__(kPairWaves * 64) void fbank1024x2_kernel(
     wave_lds_sync();  // the next trip reuses the buffer
     if (!split) g += stride;
   }
-#undef SNF_LOAD_HALF
+#undef SNF_LOAD_FRAMES
 }
 
 // ---------------------------------------------------------------------------------------------------
