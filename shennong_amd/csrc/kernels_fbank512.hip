@@ -756,23 +756,35 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
     if (NJ == 13) return j < NJ - 1 || in_last;
     return l + 16 * j < p.win_len;
   };
-  // element j of the lane: sample l + 16 j of frame a in the low half, of frame b in the high half
-  auto load_pair = [&](const int16_t* __restrict__ wa, const int16_t* __restrict__ wb, int j) -> int {
-    const bool in = (NJ == 13 && j < NJ - 1) || in_window(j);
-    const unsigned lo = *reinterpret_cast<const unsigned short*>(in ? wa + l + 16 * j : wa);
-    const int hi = *(in ? wb + l + 16 * j : wb);
-    return static_cast<int>(lo | (static_cast<unsigned>(hi) << 16));
+  // Sample ingest (round 6; first built for kernels_fbank1024x2.hip): the two frames of a pair lie in ONE span of
+  // the utterance - frame b starts `off_b` = start_b - start_a samples (0 ... the frame shift) behind frame a -
+  // which comes in as 16-byte pieces, lane l of the row fetching pieces l, l + 16, ... (3 wave instructions for a
+  // 25 ms / 10 ms pair at 8 kHz, where a 16-bit load per element and frame took 26: the texture addresser takes a
+  // wave instruction per 64 addresses whatever their width), is laid down in the row's LDS tile at the top of
+  // the next iteration and read back element by element.  The last bytes of a span that do not fill a piece come
+  // through one 16-bit load of the first lanes: no load reaches beyond the span, i.e. beyond the utterance.
+  typedef int int4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+  constexpr int NP = NJ == 13 ? 3 : 4;   // pieces per lane: spans of up to 384 / 512 samples (launch_fbank512)
+  int4_a2 qv[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) qv[i] = int4_a2{0, 0, 0, 0};
+  int tailv = 0, offb_next = 0;
+  auto load_span = [&](const longlong2 st) __attribute__((always_inline)) {
+    const char* __restrict__ pa = reinterpret_cast<const char*>(b.wave + st.x);
+    const int ob = static_cast<int>(st.y - st.x);
+    const int span_bytes = 2 * (ob + p.win_len);
+    const int nf = span_bytes >> 4, nt = (span_bytes & 15) >> 1;
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      qv[i] = *reinterpret_cast<const int4_a2*>(pa + (l + 16 * i < nf ? 16 * (l + 16 * i) : 0));
+    tailv = *reinterpret_cast<const short*>(pa + (l < nt ? 16 * nf + 2 * l : 0));
+    offb_next = ob;
   };
   int64_t set = static_cast<int64_t>(blockIdx.x) * n_waves + wid;
-  int raw[NJ];
   longlong2 next_starts = {0, 0};
   int4 meta_next = {0, 0, 0, 0};
   if (set < n_sets) {
-    const longlong2 st = starts_of(set * 4 + q);
-    const int16_t* __restrict__ wa = b.wave + st.x;
-    const int16_t* __restrict__ wb = b.wave + st.y;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) raw[j] = load_pair(wa, wb, j);
+    load_span(starts_of(set * 4 + q));
     next_starts = starts_of((set + set_stride) * 4 + q);
     meta_next = meta_of(set * 4 + q);
   }
@@ -783,7 +795,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
   // measured 5-10 % SLOWER, wherever the settle point was put, and was dropped there.)
   auto settle_prefetch = [&]() {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(raw[j]));
+    for (int i = 0; i < NP; ++i) asm volatile("" : "+v"(qv[i]));
+    asm volatile("" : "+v"(tailv), "+v"(offb_next));
     asm volatile("" : "+v"(next_starts.x), "+v"(next_starts.y));
     asm volatile("" : "+v"(meta_next.x), "+v"(meta_next.y), "+v"(meta_next.z), "+v"(meta_next.w));
   };
@@ -814,16 +827,37 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
     float part_a = 0.0f, part_b = 0.0f;
     constexpr bool kIntSum = !DITHER && SNIP;  // (integer sums are exact: see fbank512_kernel)
     int sum_a = 0, sum_b = 0;
+    {
+      // the span of this iteration's pair: registers -> the row's tile (whole pieces, then the tail), elements back
+      const int ob = offb_next;
+      const int span_bytes = 2 * (ob + p.win_len);
+      const int nf = span_bytes >> 4, nt = (span_bytes & 15) >> 1;
+      char* __restrict__ sb = reinterpret_cast<char*>(tile);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      xe[j] = static_cast<float>(static_cast<short>(raw[j] & 0xffff));
-      xo[j] = static_cast<float>(raw[j] >> 16);
-      if (kIntSum) {
-        const int ta = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, raw[j]), short2v{1, 0}, sum_a, false);
-        const int tb = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, raw[j]), short2v{0, 1}, sum_b, false);
-        sum_a = in_window(j) ? ta : sum_a;
-        sum_b = in_window(j) ? tb : sum_b;
+      for (int i = 0; i < NP; ++i)
+        if (l + 16 * i < nf)
+          *reinterpret_cast<int4*>(sb + 16 * (l + 16 * i)) = make_int4(qv[i].x, qv[i].y, qv[i].z, qv[i].w);
+      if (l < nt) *reinterpret_cast<short*>(sb + 16 * nf + 2 * l) = static_cast<short>(tailv);
+      wave_lds_sync();
+      const short* __restrict__ sa = reinterpret_cast<const short*>(tile) + l;
+      const short* __restrict__ sbb = sa + ob;
+      int va[NJ], vb[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        va[j] = sa[16 * j];
+        vb[j] = sbb[16 * j];
       }
+      lds_wait();
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        xe[j] = static_cast<float>(va[j]);
+        xo[j] = static_cast<float>(vb[j]);
+        if (kIntSum) {
+          sum_a += in_window(j) ? va[j] : 0;
+          sum_b += in_window(j) ? vb[j] : 0;
+        }
+      }
+      wave_lds_sync();
     }
     if (!SNIP && (edge_a | edge_b) != 0) {
       // [KALDI-UPSTREAM] ExtractWindow, snip_edges = false: reflected samples for the frames that reach
@@ -868,10 +902,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
     for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(xe[j]), "+v"(xo[j]) : : "memory");
     asm volatile("" : "+v"(part_a), "+v"(part_b) : : "memory");
     {  // prefetch: samples of the next set, start offsets of the set after it
-      const int16_t* __restrict__ wa = b.wave + next_starts.x;
-      const int16_t* __restrict__ wb = b.wave + next_starts.y;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) raw[j] = load_pair(wa, wb, j);
+      load_span(next_starts);
       next_starts = starts_of((set + 2 * set_stride) * 4 + q);
       meta_next = meta_of((set + set_stride) * 4 + q);
     }
@@ -1238,7 +1269,8 @@ bool fast512_eligible(const MelParams& mp, bool any_warp) {
 
 bool fast512_dual_eligible(const MelParams& mp) {
   if (getenv("SNF_DISABLE_DUAL256")) return false;
-  return fast512_eligible(mp, false) && mp.padded == 256 &&
+  // (a pair is fetched as one span of the utterance: at most 512 samples, kernels_fbank512.hip load_span)
+  return fast512_eligible(mp, false) && mp.padded == 256 && mp.win_len + mp.win_shift <= 512 &&
          (mp.kind == SNF_KIND_FBANK || mp.kind == SNF_KIND_MFCC || mp.kind == SNF_KIND_PLP);
 }
 
@@ -1596,7 +1628,8 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
     else if (energy == 1) SNF_DUAL3(NJ_, KIND_, 1);                                                 \
     else SNF_DUAL3(NJ_, KIND_, 2);                                                                  \
   } while (0)
-    if ((p.win_len + 15) / 16 == 13) {
+    // (the 13-row form fetches spans of up to 384 samples, the 16-row form of up to 512: fast512_dual_eligible)
+    if ((p.win_len + 15) / 16 == 13 && p.win_len + p.win_shift <= 384) {
       if (p.kind == SNF_KIND_FBANK) SNF_DUAL(13, SNF_KIND_FBANK);
       else if (p.kind == SNF_KIND_MFCC) SNF_DUAL(13, SNF_KIND_MFCC);
       else SNF_DUAL(13, SNF_KIND_PLP);
