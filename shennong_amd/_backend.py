@@ -817,9 +817,10 @@ class _ResultBlock:
     """Owner of one pooled page-locked buffer that holds the results of a batch.  The per-utterance
     matrices are numpy views of it (``np.asarray(block)``: numpy keeps the block as their base); the
     buffer goes back to the pool when the last of them is gone."""
-    _LIMIT = 4 << 30   # page-locked result memory handed out and not yet returned, at most
-    _FRESH = 2 << 30   # ... below which a result may page-lock a new buffer (see result_array; 1 GiB until the
-                       # streamed pipeline's four-hour batches: 0.7-1.5 GB of results per batch)
+    _LIMIT = 8 << 30   # page-locked result memory handed out and not yet returned, at most
+    _FRESH = 4 << 30   # ... below which a result may page-lock a new buffer (see result_array; 1 GiB until the
+                       # streamed pipeline's four-hour batches: 0.7-1.5 GB of results per batch; 2 GiB until
+                       # that pipeline kept the result block of batch k alive beside the one of batch k + 1)
     _held = 0
     _lock = threading.RLock()   # (re-entrant for the same reason as _Staging._lock)
 

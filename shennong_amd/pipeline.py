@@ -480,7 +480,7 @@ def extract_features_streamed(configuration, utterances, sink, warps=None,
     columns, 177 MB of float32 down and needs ~4 GB of HBM while in flight; four hours were measured on an 8 h corpus of 3 s utterances: 1 h batches 54-57 hours of
     audio per second, 2 h 54-65, 4 h 59-64, the whole 8 h in one batch 70 - the pitch tracker's cost per utterance
     halves between 1 000 and 4 000 utterances per call; the results of a batch must fit a pooled page-locked block
-    of at most 2 GiB (_backend._ResultBlock._FRESH): 4 h of 257 columns are 1.5 GB);
+    - two of them are alive at a time, 4 GiB in all (_backend._ResultBlock._FRESH): 4 h of 257 columns are 1.5 GB);
     each batch goes through the device-resident pipeline and its FeaturesCollection is
     handed to `sink` (a callable, e.g. ``KaldiStreamWriter.write``) and dropped.  The results are
     those of :func:`extract_features` on the whole corpus - bit for bit when no random term is
