@@ -55,9 +55,9 @@ __device__ __forceinline__ int64_t uniform64(int64_t v) {
   const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32));
   return static_cast<int64_t>((static_cast<unsigned long long>(hi) << 32) | lo);
 }
-__device__ __forceinline__ float from_left_lane(float v, int left_lane_bytes) {
-  return __builtin_bit_cast(float,
-                            __builtin_amdgcn_ds_bpermute(left_lane_bytes, __builtin_bit_cast(int, v)));
+// value of `v` in lane (lane - 1) mod 64 (a DPP move with wave_ror:1: kernels_fbank2048.hip)
+__device__ __forceinline__ float from_left_lane(float v, int) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xf, 0xf, false));
 }
 
 }  // namespace
