@@ -1050,6 +1050,26 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void fbank256x2_kernel(const Fas
     }
     float* __restrict__ row = out + ga * static_cast<int64_t>(p.out_cols);  // frame a; frame b: + out_cols
 
+    if (KIND == SNF_KIND_SPECTROGRAM) {
+      // the 129 log powers of each frame straight from the registers: lane l of the row holds bins l + 16 k1
+      // (16 lanes x 4 bytes per store), lane 0 bin 128 as well; column 0 is the log energy (Kaldi's
+      // SpectrogramComputer).  The powers above carry a factor 4 (see fbank512_kernel).
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        if (s2 ? valid_b : valid_a) {
+          float* __restrict__ r = row + s2 * p.out_cols;
+#pragma unroll
+          for (int k1 = 0; k1 < 8; ++k1) {
+            float v = fast_log(fmaxf(0.25f * (s2 ? pb[k1] : pa[k1]), FLT_EPSILON));
+            if (k1 == 0 && l == 0) v = log_e[s2];
+            r[l + 16 * k1] = v;
+          }
+          if (l == 0) r[128] = fast_log(fmaxf(0.25f * (s2 ? p128_b : p128_a), FLT_EPSILON));
+        }
+      }
+      wave_lds_sync();  // the tile is reused by the next frame set
+      continue;
+    }
     // ---- F: mel filterbank on the matrix pipe, one chain per sub-frame ------------------------------------
     float mel[2][4];
 #pragma unroll
@@ -1253,14 +1273,17 @@ bool fast512_eligible(const MelParams& mp, bool any_warp) {
   // Frames that pad to 256 or 128 samples (8 kHz audio, short windows) run as the same 512-point
   // transform of the zero-extended frame: X512[s k] = X_N[k] with s = 512 / N, so the mel taps sit
   // on every s-th bin (fast512_build interleaves zero weights).  Twice the FFT arithmetic the frame
-  // needs, still several times faster than the LDS radix-2 kernel.  The spectrogram needs the N/2+1
-  // bins themselves and stays on the generic kernel for those sizes.
+  // needs, still several times faster than the LDS radix-2 kernel.
   if ((mp.padded != 512 && mp.padded != 256 && mp.padded != 128) || !mp.pow2) return false;
   if (mp.win_len & 1) return false;
   if (mp.kind != SNF_KIND_FBANK && mp.kind != SNF_KIND_MFCC && mp.kind != SNF_KIND_PLP &&
       mp.kind != SNF_KIND_SPECTROGRAM && mp.kind != SNF_KIND_ENERGY)
     return false;
-  if (mp.kind == SNF_KIND_SPECTROGRAM && mp.padded != 512) return false;
+  // (the spectrogram needs the N / 2 + 1 bins themselves: 512-sample frames, or 256-sample frames on the
+  // two-frames-per-transform kernel, whose conditions are those of fast512_dual_eligible)
+  if (mp.kind == SNF_KIND_SPECTROGRAM && mp.padded != 512 &&
+      !(mp.padded == 256 && mp.win_len + mp.win_shift <= 512 && !getenv("SNF_DISABLE_DUAL256")))
+    return false;
   if (mp.kind == SNF_KIND_FBANK && !mp.use_power) return false;
   if (mp.num_bins > kFast512MaxBins) return false;
   if (mp.kind == SNF_KIND_MFCC && mp.num_ceps > 16) return false;
@@ -1271,7 +1294,8 @@ bool fast512_dual_eligible(const MelParams& mp) {
   if (getenv("SNF_DISABLE_DUAL256")) return false;
   // (a pair is fetched as one span of the utterance: at most 512 samples, kernels_fbank512.hip load_span)
   return fast512_eligible(mp, false) && mp.padded == 256 && mp.win_len + mp.win_shift <= 512 &&
-         (mp.kind == SNF_KIND_FBANK || mp.kind == SNF_KIND_MFCC || mp.kind == SNF_KIND_PLP);
+         (mp.kind == SNF_KIND_FBANK || mp.kind == SNF_KIND_MFCC || mp.kind == SNF_KIND_PLP ||
+          mp.kind == SNF_KIND_SPECTROGRAM);
 }
 
 // Builds the packed LDS table blob from the plan's host tables (warp 1.0 mel banks).  `dual`: tables of
@@ -1632,10 +1656,12 @@ int launch_fbank512(const Fast512Params& p, const BatchArgs& b, float* out, int 
     if ((p.win_len + 15) / 16 == 13 && p.win_len + p.win_shift <= 384) {
       if (p.kind == SNF_KIND_FBANK) SNF_DUAL(13, SNF_KIND_FBANK);
       else if (p.kind == SNF_KIND_MFCC) SNF_DUAL(13, SNF_KIND_MFCC);
+      else if (p.kind == SNF_KIND_SPECTROGRAM) SNF_DUAL(13, SNF_KIND_SPECTROGRAM);
       else SNF_DUAL(13, SNF_KIND_PLP);
     } else {
       if (p.kind == SNF_KIND_FBANK) SNF_DUAL(16, SNF_KIND_FBANK);
       else if (p.kind == SNF_KIND_MFCC) SNF_DUAL(16, SNF_KIND_MFCC);
+      else if (p.kind == SNF_KIND_SPECTROGRAM) SNF_DUAL(16, SNF_KIND_SPECTROGRAM);
       else SNF_DUAL(16, SNF_KIND_PLP);
     }
 #undef SNF_DUAL

@@ -709,6 +709,7 @@ def test_fast_kernel_short_frames(gpu, cls, sample_rate, opts, snip_edges):
     (FilterbankProcessor, 8000, dict()),                      # fbank256x2_kernel: two frames per row
     (MfccProcessor, 8000, dict()),
     (PlpProcessor, 8000, dict()),
+    (SpectrogramProcessor, 8000, dict()),
     (MfccProcessor, 16000, dict(frame_length=0.016, frame_shift=0.005)),
     (FilterbankProcessor, 16000, dict()),                     # fbank512_kernel
     (MfccProcessor, 44100, dict()),                           # fbank2048_kernel
@@ -923,8 +924,6 @@ def test_paired_frames_of_unequal_energy(gpu, sample_rate):
     kernel = 'fbank256x2_kernel' if sample_rate == 8000 else 'fbank1024x2_kernel'
     for cls, opts in ((FilterbankProcessor, dict(num_bins=40 if sample_rate > 8000 else 23)), (MfccProcessor, dict()),
                       (SpectrogramProcessor, dict())):
-        if sample_rate == 8000 and cls is SpectrogramProcessor:
-            continue   # (129 bins: the generic kernel, one frame per transform)
         proc = cls(sample_rate=sample_rate, dither=0, **opts)
         feats = proc._process_batch([Audio(w, sample_rate) for w in waves])
         plan = _backend.get_plan(proc._build_options())
@@ -961,12 +960,21 @@ def test_tables_too_large_for_lds_fall_back(gpu):
 
 
 def test_short_frames_spectrogram_and_energy(gpu):
-    """the spectrogram of a 256-sample frame needs its own 129 bins: generic kernel; the frame
-    energy has no spectrum at all: fast kernel"""
+    """the spectrogram of a 256-sample frame needs its own 129 bins: the two-frames-per-transform kernel
+    (round 6; the generic kernel until then, and still for 128-sample frames); the frame energy has no
+    spectrum at all: fast kernel"""
     wave = synth.utterances(5, 1, 6000, 8000)[0]
-    proc = SpectrogramProcessor(sample_rate=8000, dither=0)
+    for opts in (dict(), dict(raw_energy=False), dict(snip_edges=False)):
+        proc = SpectrogramProcessor(sample_rate=8000, dither=0, **opts)
+        got = proc.process(Audio(wave, 8000))
+        assert got.shape[1] == 129
+        assert_close(got.data, _oracle(proc, wave), rtol=1e-4, family='spectrogram')
+        plan = _backend.get_plan(proc._build_options())
+        plan.run([wave])
+        assert plan.kernel_name(1) == 'fbank256x2_kernel'
+    proc = SpectrogramProcessor(sample_rate=8000, frame_length=0.016, frame_shift=0.008, dither=0)   # 128 samples
     got = proc.process(Audio(wave, 8000))
-    assert got.shape[1] == 129
+    assert got.shape[1] == 65
     assert_close(got.data, _oracle(proc, wave), rtol=1e-4, family='spectrogram')
     plan = _backend.get_plan(proc._build_options())
     plan.run([wave])
