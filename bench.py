@@ -642,6 +642,13 @@ def main():
         extra['mfcc13'] = time_plan(
             mfcc_plan, lambda: mfcc_plan.run_device(d_wave.ptr, soff, foff, d_mfcc.ptr),
             total_frames, BYTES_PER_FRAME['mfcc13'])
+        # fbank-80 (a common front end of neural recognisers): banks of 65 ... 128 bins run the 64-bin kernel
+        # twice, over the two halves of the bank (round 6; the generic kernel until then, 7 x slower per frame)
+        p80 = _backend.get_plan(FilterbankProcessor(num_bins=80, dither=0)._build_options())
+        d_o80 = _backend.DeviceBuffer(total_frames * 80 * 4)
+        extra['fbank80'] = time_plan(
+            p80, lambda: p80.run_device(d_wave.ptr, soff, foff, d_o80.ptr), total_frames, 320 + 4 * 80)
+        d_o80.free()
         # the DCT-II of the same plan as an MFMA chain instead of the vector-pipe form that ships (the
         # table layout is chosen when the plan is built: a private plan outside the cache)
         os.environ['SNF_DCT_MFMA'] = '1'

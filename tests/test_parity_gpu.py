@@ -1569,3 +1569,38 @@ def test_adversarial_waveforms(gpu):
         assert module.main() == 0
     finally:
         __import__('sys').argv = sys_argv
+
+
+@pytest.mark.parametrize('opts', [
+    dict(num_bins=80), dict(num_bins=80, use_energy=True), dict(num_bins=80, use_energy=True, htk_compat=True),
+    dict(num_bins=80, use_energy=True, raw_energy=False, snip_edges=False), dict(num_bins=66, low_freq=0),
+    dict(num_bins=100, high_freq=-200, window_type='hamming', use_log_fbank=False),
+    dict(num_bins=128, low_freq=700, vtln_low=800), dict(num_bins=112, low_freq=400, vtln_low=500, frame_length=0.03)])
+def test_wide_filterbanks(gpu, synth_waves, opts):
+    """filterbanks of 65 ... 128 bins (fbank-80 at 16 kHz) run the 64-bin kernel twice, over the two halves of the
+    bank (capi.hip: snf_plan::wide) - until round 6 they fell to the generic kernel; the energy column goes with
+    the half it is adjacent to; VTLN batches of such banks stay on the generic kernel; alone == in a batch"""
+    waves = list(synth_waves)
+    proc = FilterbankProcessor(dither=0, **opts)
+    feats = proc._process_batch([Audio(w, 16000) for w in waves])
+    plan = _backend.get_plan(proc._build_options())
+    assert plan.kernel_name(1) in ('fbank512b_kernel', 'fbank512_kernel')
+    for w, f in zip(waves, feats):
+        want = _oracle(proc, w)
+        assert f.shape == want.shape and f.shape[1] == proc.ndims
+        # (linear mel energies: no logarithm in front of the relative bound, bins 60 dB under the loudest: 2e-4 measured; the fuzzers carry 5e-4 there)
+        assert_close(f.data, want, rtol=1e-4 if proc.use_log_fbank else 5e-4, what=f'{proc.name} {opts}')
+    alone = proc._process_batch([Audio(waves[2], 16000)])[0]
+    assert np.array_equal(alone.data, feats[2].data)
+    warps = [0.9 + 0.05 * i for i in range(len(waves))]
+    try:
+        [_oracle(proc, w, wf) for w, wf in zip(waves, warps)]
+    except RuntimeError:   # (a warped bank of that many bins has an empty bin: a Kaldi-class error on both sides)
+        with pytest.raises(RuntimeError):
+            proc._process_batch([Audio(w, 16000) for w in waves], vtln_warp=warps)
+        return
+    feats = proc._process_batch([Audio(w, 16000) for w in waves], vtln_warp=warps)
+    assert plan.kernel_name(1) == 'mel_features_generic_kernel'
+    for w, wf, f in zip(waves, warps, feats):
+        assert_close(f.data, _oracle(proc, w, wf), rtol=1e-4 if proc.use_log_fbank else 5e-4,
+                     what=f'{proc.name} {opts} warp {wf}')

@@ -28,7 +28,7 @@ def random_case(rng):
         blackman_coeff=float(rng.choice([0.42, 0.42, 0.3])))
     kind = str(rng.choice(['fbank', 'fbank', 'mfcc', 'mfcc', 'plp', 'spectrogram', 'energy']))
     nyquist = sample_rate / 2
-    mel = dict(num_bins=int(rng.integers(8, 65 if sample_rate < 30000 else 100)), low_freq=float(rng.choice([0, 20, 100])),
+    mel = dict(num_bins=int(rng.integers(8, 65 if sample_rate < 16000 else 100)),   # (16 kHz and up: wide banks too) low_freq=float(rng.choice([0, 20, 100])),
                high_freq=float(rng.choice([0, -200, nyquist - 300])),
                vtln_low=float(rng.choice([100, 100, 150])), vtln_high=float(rng.choice([-500, -500, -700])))
     floor = float(rng.choice([0.0, 0.0, 1.0, 1.0e4]))   # (energy_floor: the log-energy column never below its log)

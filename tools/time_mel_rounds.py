@@ -1,3 +1,4 @@
+"""Dev helper: kernel time against the number of mel bins at one sample rate (python tools/time_mel_rounds.py 32000)"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np
@@ -9,9 +10,13 @@ ns = 3 * sr
 base = synth.utterances(0, 20, ns, sr)
 waves = np.ascontiguousarray(np.tile(base, (n_utts // 20, 1)))
 d_wave = _backend.DeviceBuffer(waves.nbytes); d_wave.upload(waves)
-for cls, opts in ((FilterbankProcessor, dict(num_bins=8)), (FilterbankProcessor, dict(num_bins=16)), (FilterbankProcessor, dict(num_bins=23)), (FilterbankProcessor, dict(num_bins=40)), (FilterbankProcessor, dict(num_bins=64)), (MfccProcessor, dict()), (MfccProcessor, dict(num_bins=40))):
+for cls, opts in ((FilterbankProcessor, dict(num_bins=8)), (FilterbankProcessor, dict(num_bins=16)), (FilterbankProcessor, dict(num_bins=23)), (FilterbankProcessor, dict(num_bins=40)), (FilterbankProcessor, dict(num_bins=64)), (FilterbankProcessor, dict(num_bins=80)), (FilterbankProcessor, dict(num_bins=128)), (MfccProcessor, dict()), (MfccProcessor, dict(num_bins=40))):
     proc = cls(sample_rate=sr, dither=0, **opts)
-    plan = _backend.get_plan(proc._build_options())
+    try:
+        plan = _backend.get_plan(proc._build_options())
+    except RuntimeError as err:   # (Kaldi refuses banks with an empty bin)
+        print(cls.__name__, opts, 'refused:', err)
+        continue
     fpu = plan.num_frames(ns)
     soff = np.arange(n_utts + 1, dtype=np.int64) * ns
     foff = np.arange(n_utts + 1, dtype=np.int64) * fpu
