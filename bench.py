@@ -649,6 +649,14 @@ def main():
         extra['fbank80'] = time_plan(
             p80, lambda: p80.run_device(d_wave.ptr, soff, foff, d_o80.ptr), total_frames, 320 + 4 * 80)
         d_o80.free()
+        # Kaldi's "hires" MFCC (40 bins, 40 cepstra): more than the 16 cepstra of the fused form - the filterbank
+        # kernel writes [log energy | log-mel] rows, mfcc_dct_kernel forms the cepstra (round 6; the generic kernel
+        # until then, 14 ms per 2.98 M frames)
+        p4040 = _backend.get_plan(MfccProcessor(num_bins=40, num_ceps=40, dither=0)._build_options())
+        d_o4040 = _backend.DeviceBuffer(total_frames * 40 * 4)
+        extra['mfcc40_hires'] = time_plan(
+            p4040, lambda: p4040.run_device(d_wave.ptr, soff, foff, d_o4040.ptr), total_frames, 320 + 4 * 40)
+        d_o4040.free()
         # the DCT-II of the same plan as an MFMA chain instead of the vector-pipe form that ships (the
         # table layout is chosen when the plan is built: a private plan outside the cache)
         os.environ['SNF_DCT_MFMA'] = '1'

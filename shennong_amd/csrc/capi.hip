@@ -125,6 +125,9 @@ struct snf_plan {
   Fast512Params fp_hi{};
   DevBuf d_fast_tables_hi;
   int wide_offset = 0;
+  // MFCC through the filterbank kernel + mfcc_dct_kernel (more than 16 cepstra, or more than 64 bins)
+  bool mfcc_via_fbank = false;
+  DevBuf d_dct_t;
   // ... and its per-warp-factor tables (VTLN): one blob per warp id, `fp_warp.table_stride` apart
   std::vector<float> h_window, h_dct, h_lifter;
   Fast512Params fp_warp{};
@@ -412,15 +415,30 @@ int build_mel_plan(snf_plan* plan) {
       plan->h_lifter = lifter_h;
     }
   }
-  if (!plan->fast512 && plan->kind == SNF_KIND_FBANK && !plan->banks.empty() && p.padded == 512 &&
-      p.num_bins > kFast512MaxBins && p.num_bins <= 2 * kFast512MaxBins && !getenv("SNF_DISABLE_WIDE512")) {
-    // A filterbank of 65 ... 128 bins (fbank-80 at 16 kHz is a common front end) used to fall to the generic
-    // wave-per-frame kernel, 7 x slower per frame than the 64-bin kernel.  The kernel's matrix-pipe mel chain
-    // holds 16 blocks of 4 bins; a wider bank runs it TWICE, over the lower and the upper half of the bins (twice
-    // the transform arithmetic, still 3.5 x faster than the generic kernel): two parameter sets, the second one
-    // writing behind the columns of the first.  The energy column goes with the half it is adjacent to.
+  // Filterbank plans the 64-bin kernel covers in two launches, and MFCC plans it covers up to the log-mel energies
+  // (round 6; the generic wave-per-frame kernel until then, 7 x slower per frame):
+  //  * a filterbank of 65 ... 128 bins (fbank-80 at 16 kHz is a common front end): the kernel's matrix-pipe mel
+  //    chain holds 16 blocks of 4 bins; a wider bank runs it TWICE, over the lower and the upper half of the bins
+  //    (twice the transform arithmetic, still 3.5 x faster than the generic kernel): two parameter sets, the
+  //    second one writing behind the columns of the first.  The energy column goes with the half it is adjacent to;
+  //  * MFCC with more than 16 cepstra (Kaldi's "hires" MFCC: 40 bins, 40 cepstra) or more than 64 bins: the
+  //    filterbank kernel writes [log energy |] log-mel rows to a scratch, mfcc_dct_kernel forms the cepstra.
+  // -> 0: plan->fp (and fp_hi) are built, 1: not covered, < 0: error
+  auto build_fbank_fast = [&](const MelParams& pf) -> int {
+    if (plan->banks.empty() || pf.padded != 512) return 1;
     const MelBanksHost& mb = plan->banks[0];
-    const int nb = p.num_bins, lo_n = ((nb + 1) / 2 + 3) & ~3, hi_n = nb - lo_n;
+    std::vector<float> none;
+    if (pf.num_bins <= kFast512MaxBins) {
+      if (!fast512_eligible(pf, false)) return 1;
+      std::vector<float> blob;
+      const int rc2 = fast512_build(pf, window, mb, none, none, false, &blob, &plan->fp);
+      if (rc2 != 0) return rc2;
+      if (int rc3 = plan->d_fast_tables.upload(blob, plan->stream)) return rc3;
+      plan->fp.tables = plan->d_fast_tables.as<float>();
+      return 0;
+    }
+    if (pf.num_bins > 2 * kFast512MaxBins || getenv("SNF_DISABLE_WIDE512")) return 1;
+    const int nb = pf.num_bins, lo_n = ((nb + 1) / 2 + 3) & ~3, hi_n = nb - lo_n;
     auto half_of = [&](int first_bin, int count, MelBanksHost* out) {
       out->num_bins = count;
       out->num_fft_bins = mb.num_fft_bins;
@@ -435,22 +453,54 @@ int build_mel_plan(snf_plan* plan) {
     MelBanksHost mb_lo, mb_hi;
     half_of(0, lo_n, &mb_lo);
     half_of(lo_n, hi_n, &mb_hi);
-    MelParams p_lo = p, p_hi = p;
+    MelParams p_lo = pf, p_hi = pf;
     p_lo.num_bins = lo_n;
     p_hi.num_bins = hi_n;
-    const bool energy_first = p.use_energy && !p.htk_compat;   // column 0; otherwise (htk) the last column
-    MelParams& bare = energy_first ? p_hi : p_lo;              // the half that does not write the energy
-    if (p.use_energy) bare.use_energy = bare.need_raw = bare.need_post = 0;
-    std::vector<float> none, blob_lo, blob_hi;
-    if (hi_n >= 3 && fast512_eligible(p_lo, false) && fast512_eligible(p_hi, false) &&
-        fast512_build(p_lo, window, mb_lo, none, none, false, &blob_lo, &plan->fp) == 0 &&
-        fast512_build(p_hi, window, mb_hi, none, none, false, &blob_hi, &plan->fp_hi) == 0) {
-      if ((rc = plan->d_fast_tables.upload(blob_lo, plan->stream))) return rc;
-      if ((rc = plan->d_fast_tables_hi.upload(blob_hi, plan->stream))) return rc;
-      plan->fp.tables = plan->d_fast_tables.as<float>();
-      plan->fp_hi.tables = plan->d_fast_tables_hi.as<float>();
-      plan->wide_offset = lo_n + (energy_first ? 1 : 0);
-      plan->fast512 = plan->wide = true;
+    const bool energy_first = pf.use_energy && !pf.htk_compat;   // column 0; otherwise (htk) the last column
+    MelParams& bare = energy_first ? p_hi : p_lo;                // the half that does not write the energy
+    if (pf.use_energy) bare.use_energy = bare.need_raw = bare.need_post = 0;
+    std::vector<float> blob_lo, blob_hi;
+    if (hi_n < 3 || !fast512_eligible(p_lo, false) || !fast512_eligible(p_hi, false)) return 1;
+    int rc2 = fast512_build(p_lo, window, mb_lo, none, none, false, &blob_lo, &plan->fp);
+    if (rc2 == 0) rc2 = fast512_build(p_hi, window, mb_hi, none, none, false, &blob_hi, &plan->fp_hi);
+    if (rc2 != 0) return rc2;
+    if (int rc3 = plan->d_fast_tables.upload(blob_lo, plan->stream)) return rc3;
+    if (int rc3 = plan->d_fast_tables_hi.upload(blob_hi, plan->stream)) return rc3;
+    plan->fp.tables = plan->d_fast_tables.as<float>();
+    plan->fp_hi.tables = plan->d_fast_tables_hi.as<float>();
+    plan->wide_offset = lo_n + (energy_first ? 1 : 0);
+    plan->wide = true;
+    return 0;
+  };
+  if (!plan->fast512 && plan->kind == SNF_KIND_FBANK && p.num_bins > kFast512MaxBins) {
+    const int rc2 = build_fbank_fast(p);
+    if (rc2 < 0) return rc2;
+    if (rc2 == 0) {
+      plan->fast512 = true;
+      plan->h_window = window;
+    }
+  }
+  if (!plan->fast512 && plan->kind == SNF_KIND_MFCC && !want_fused && !getenv("SNF_DISABLE_MFCC_VIA_FBANK")) {
+    MelParams pf = p;
+    pf.kind = SNF_KIND_FBANK;
+    pf.use_log = 1;
+    pf.use_power = 1;
+    pf.htk_compat = 0;     // (the energy in column 0 of the scratch rows, whatever the cepstra's layout)
+    pf.num_ceps = 0;
+    pf.dct = nullptr;
+    pf.lifter = nullptr;
+    const int rc2 = build_fbank_fast(pf);
+    if (rc2 < 0) return rc2;
+    if (rc2 == 0) {
+      // the DCT matrix transposed, rows of num_ceps rounded up to 16 (mfcc_dct_kernel reads sixteen cepstra at a time)
+      std::vector<float> dct_h, dct_t;
+      make_dct_matrix(o.num_ceps, o.mel.num_bins, &dct_h);
+      const int nc8 = (o.num_ceps + 15) & ~15;
+      dct_t.assign(static_cast<size_t>(o.mel.num_bins) * nc8, 0.0f);
+      for (int c = 0; c < o.num_ceps; ++c)
+        for (int m = 0; m < o.mel.num_bins; ++m) dct_t[static_cast<size_t>(m) * nc8 + c] = dct_h[c * o.mel.num_bins + m];
+      if ((rc = plan->d_dct_t.upload(dct_t, plan->stream))) return rc;
+      plan->fast512 = plan->mfcc_via_fbank = true;
       plan->h_window = window;
     }
   }
@@ -1077,7 +1127,8 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
   }
   bool use_fast = plan->fast512;
   bool use_long = plan->fast2048 || plan->pair1024;  // (per-utterance VTLN warps included: they read the plan's bank tables)
-  if (use_fast && any_warp && plan->wide) use_fast = false;   // (VTLN batches of a wide bank: the generic kernel)
+  if (use_fast && any_warp && (plan->wide || plan->mfcc_via_fbank))
+    use_fast = false;   // (VTLN batches of a wide bank / of a filterbank-first MFCC plan: the generic kernel)
   if (use_fast && any_warp) {
     if ((rc = sync_fast_warp_tables(plan))) return rc;
     use_fast = plan->fast_warps_ok;
@@ -1280,7 +1331,17 @@ int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64
       if ((rc = plan->s_cep.ensure(sizeof(float) * static_cast<size_t>(total_frames) * feat_cols))) return rc;
       feat_out = plan->s_cep.as<float>();
     }
-    if (use_fast) {
+    if (use_fast && plan->mfcc_via_fbank) {
+      // [log energy |] log-mel rows from the filterbank kernel, then DCT / lifter / energy / htk conventions
+      const int nb = plan->o.mel.num_bins, in_cols = nb + (plan->o.use_energy ? 1 : 0);
+      if ((rc = plan->s_mel.ensure(sizeof(float) * static_cast<size_t>(total_frames) * in_cols))) return rc;
+      if ((rc = run_fast(plan->s_mel.as<float>(), in_cols, nullptr))) return rc;
+      if ((rc = launch_mfcc_dct(plan->s_mel.as<float>(), in_cols, nb, plan->o.num_ceps, plan->d_dct_t.as<float>(),
+                                plan->mp.lifter, plan->o.use_energy ? 1 : 0, plan->o.htk_compat ? 1 : 0,
+                                total_frames, feat_out, feat_cols, s)))
+        return rc;
+      if (own_stream) mark_kernel(plan, "mfcc_dct_kernel");
+    } else if (use_fast) {
       if ((rc = run_fast(feat_out, feat_cols, nullptr))) return rc;
     } else if (use_long) {
       if ((rc = run_long(feat_out, feat_cols, nullptr))) return rc;

@@ -273,6 +273,12 @@ void fbank1024x2_tables(const MelParams& mp, const std::vector<float>& window, s
 int launch_fbank1024x2(const MelParams& p, const BatchArgs& b, const float* tables, float* out, int out_cols,
                        double* energy_out, hipStream_t stream);
 
+// MFCC tail behind the filterbank kernels (kernels_dct.hip): DCT, lifter, energy and htk conventions on rows of
+// [log energy |] log-mel energies
+int launch_mfcc_dct(const float* in, int in_cols, int num_bins, int num_ceps, const float* dct_t, const float* lifter,
+                    int use_energy, int htk_compat, int64_t total_frames, float* out, int out_cols,
+                    hipStream_t stream);
+
 struct PitchDevTables {
   int first_lag, last_lag, num_lags, num_states, win_size, win_shift, full_len;
   int ar_max_taps, rs_in_unit, rs_out_unit, rs_max_taps;

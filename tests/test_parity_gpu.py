@@ -1604,3 +1604,32 @@ def test_wide_filterbanks(gpu, synth_waves, opts):
     for w, wf, f in zip(waves, warps, feats):
         assert_close(f.data, _oracle(proc, w, wf), rtol=1e-4 if proc.use_log_fbank else 5e-4,
                      what=f'{proc.name} {opts} warp {wf}')
+
+
+@pytest.mark.parametrize('opts', [
+    dict(num_bins=40, num_ceps=40), dict(num_bins=40, num_ceps=40, use_energy=False),
+    dict(num_bins=40, num_ceps=24, htk_compat=True), dict(num_bins=40, num_ceps=17, htk_compat=True, use_energy=False),
+    dict(num_bins=80, num_ceps=13), dict(num_bins=80, num_ceps=40, raw_energy=False, cepstral_lifter=0.0),
+    dict(num_bins=30, num_ceps=30, snip_edges=False, energy_floor=5.0), dict(num_bins=64, num_ceps=64, low_freq=60)])
+def test_mfcc_through_the_filterbank_kernel(gpu, synth_waves, opts):
+    """MFCC plans with more than 16 cepstra (Kaldi's "hires" MFCC: 40 bins, 40 cepstra) or more than 64 bins: the
+    filterbank kernel writes [log energy |] log-mel rows, mfcc_dct_kernel forms the cepstra (DCT, lifter, c0 :=
+    energy, htk order) - until round 6 the generic kernel took these plans; VTLN batches still do; alone == in a
+    batch, an utterance shorter than a window included (snip_edges = False)"""
+    waves = list(synth_waves) + [synth.utterances(77, 1, 300)[0]]
+    proc = MfccProcessor(dither=0, **opts)
+    feats = proc._process_batch([Audio(w, 16000) for w in waves])
+    plan = _backend.get_plan(proc._build_options())
+    names = {plan.kernel_name(k) for k in range(1, 6)} - {None}
+    assert 'mfcc_dct_kernel' in names and names & {'fbank512b_kernel', 'fbank512_kernel'}, names
+    for w, f in zip(waves, feats):
+        want = _oracle(proc, w)
+        assert f.shape == want.shape
+        assert_close(f.data, want, rtol=1e-4, what=f'{proc.name} {opts}')
+    alone = proc._process_batch([Audio(waves[1], 16000)])[0]
+    assert np.array_equal(alone.data, feats[1].data)
+    warps = [0.9 + 0.04 * i for i in range(len(waves))]
+    feats = proc._process_batch([Audio(w, 16000) for w in waves], vtln_warp=warps)
+    assert plan.kernel_name(1) == 'mel_features_generic_kernel'
+    for w, wf, f in zip(waves, warps, feats):
+        assert_close(f.data, _oracle(proc, w, wf), rtol=1e-4, what=f'{proc.name} {opts} warp {wf}')
