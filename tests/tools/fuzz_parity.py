@@ -38,7 +38,10 @@ def random_case(rng):
                                    use_power=bool(rng.integers(4) > 0), **frame, **mel)
     elif kind == 'mfcc':
         mel['num_bins'] = max(mel['num_bins'], 13)
-        proc = MfccProcessor(num_ceps=int(rng.integers(2, 14)), use_energy=bool(rng.integers(2)), energy_floor=floor,
+        # (one case in three with more than 16 cepstra: the filterbank kernel + mfcc_dct_kernel)
+        many = rng.integers(3) == 0
+        proc = MfccProcessor(num_ceps=int(rng.integers(17, mel['num_bins'] + 1)) if many and mel['num_bins'] > 17
+                             else int(rng.integers(2, 14)), use_energy=bool(rng.integers(2)), energy_floor=floor,
                              raw_energy=bool(rng.integers(2)), htk_compat=bool(rng.integers(2)),
                              cepstral_lifter=float(rng.choice([0, 22])), **frame, **mel)
     elif kind == 'plp':
