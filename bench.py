@@ -210,8 +210,14 @@ def end_to_end(plan, waves, frames_per_utt, chunk=500, reps=3, n_streams=3):
             'utterances_per_chunk': chunk, 'host_to_device_GBps': n_chunks * in_bytes / dt / 1e9,
             'device_to_host_GBps': n_chunks * out_bytes / dt / 1e9, 'finite': bool(np.isfinite(first).all()),
             'streams': n_streams,
+            # the two directions run side by side and the upload carries twice the bytes: it is the bound one
+            # (the `*_GBps` above are each direction's bytes over the WHOLE wall clock, not link rates)
+            'link_floor_ms': max(n_chunks * in_bytes, n_chunks * out_bytes) / 57e9 * 1e3,
             'note': 'page-locked host buffers, %d streams: upload / kernel / download of consecutive '
-                    'chunks overlap; PCIe-inclusive, never the headline value' % n_streams}
+                    'chunks overlap; PCIe-inclusive, never the headline value; host_to_device_GBps / '
+                    'device_to_host_GBps = the bytes of a direction over the whole wall clock (the upload, '
+                    '2 B per sample against 1.6 B per sample of features, is the direction that binds: '
+                    '`link_floor_ms` at 57 GB/s)' % n_streams}
 
 
 # ---- N > 1: the one collective of the job, measured under a watchdog ------------------------------------------
