@@ -257,7 +257,12 @@ int snf_plan_run_batch(snf_plan* plan, const int16_t* wave, const int64_t* sampl
 /* Device-pointer variant: `d_wave`/`d_out` are device buffers on the plan's device; the offsets
    tables and vtln_warp stay host pointers (they are small and are uploaded by the call).
    `stream` is a hipStream_t (NULL = the plan's own stream).  Asynchronous w.r.t. the host when
-   `stream` != NULL; with NULL the call returns after the plan's stream has been synchronised. */
+   `stream` != NULL; with NULL the call returns after the plan's stream has been synchronised.
+   A plan owns scratch in HBM - its offsets and frame tables, the lists of the two-frames-per-transform kernels,
+   the mel / log-mel rows of PLP and of MFCC with more than 16 cepstra, the tracker's buffers: asynchronous
+   calls of ONE plan on DIFFERENT streams must not overlap on the device unless they pass the same offsets
+   tables and the plan writes no intermediate (the 512-sample filterbank / MFCC-13 / spectrogram kernels).  One
+   plan per stream otherwise (what the Python host does for the pieces of a large batch: `Plan._clones`). */
 int snf_plan_run_batch_device(snf_plan* plan, const int16_t* d_wave, const int64_t* sample_offsets,
                               int64_t n_utts, const float* vtln_warp, float* d_out,
                               const int64_t* frame_offsets, void* stream);
